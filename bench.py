@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X sphere tracer.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Metric (BASELINE.json): Mpixels/s, Mandelbulb power-8, 1920x1080, 256 max march steps, uffizi_512.hdr
+environment, in_time = 0.  One "step" = one full frame of the hot path (ray generation, bounding-sphere
+clip, march loop, finite-difference normal, distance AO, prefiltered-env-map shading, gamma, RGBA8 pack)
+with the cube maps already resident in HBM; the frame stays in HBM (the PCIe-inclusive rate is reported
+separately as `d2h_inclusive_mpixels_s`, never as `value`).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the reference's 64 tiles are dealt to the ranks
+interleaved (tile idx mod N), each rank renders its shard, ONE gather over RCCL/xGMI brings the shards to
+rank 0, which scatters them to frame positions.  Per-GPU work shrinks as N grows: "scaling": "strong".
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (k_render): algorithmic HBM bytes per
+launch / its average duration measured with HIP events on the launch stream.  The path is FP32-VALU bound by
+construction, so `roofline.frac` is expected to be ~1 %; the VALU-side figure is reported next
+to it in `valu_roofline`.  `cpu_baseline` = the CPU oracle (a port of the reference's shader to C) on the host
+cores of this box, reported, never the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK_TLANEOPS = 78.6       # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (157.3 TFLOPS only if every op were an FMA)
+
+
+# ---- helpers shared with the CPU-tier tests --------------------------------------------------------
+
+def load_oracle_env(orc):
+    """Oracle-built cube maps of the shipped uffizi_512 + cache files (checker side only)."""
+    import rmdf_amd
+    d = os.path.join(rmdf_amd.DATA_DIR, "latlong_envmaps")
+    rd = lambda n: orc.hdr_decode(open(os.path.join(d, n), "rb").read())
+    return orc.EnvSet.from_latlongs(rd("uffizi_512.hdr"), rd("uffizi_512_cache_pow_1.0.hdr"),
+                                    rd("uffizi_512_cache_pow_8.0.hdr"))
+
+
+def gather_shards(shard, rank, world, dist, out=None):
+    """The single exchange step of the path: gather every rank's packed tile shard on rank 0.
+    shard: (slots, th, tw) int32 tensor.  Returns (world, slots, th, tw) on rank 0, None elsewhere."""
+    import torch
+    if world == 1:
+        return shard.unsqueeze(0)
+    if rank == 0:
+        if out is None:
+            out = torch.empty((world,) + tuple(shard.shape), dtype=shard.dtype, device=shard.device)
+        dist.gather(shard, list(out.unbind(0)), dst=0)
+        return out
+    dist.gather(shard, None, dst=0)
+    return None
+
+
+def max_over_ranks(seconds, dist, device):
+    import torch
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def flops_model(c):
+    """F = 79 I + 11 E + 9 S + 150 H + 30 P  (as-written IEEE op counts)."""
+    return 79 * c["triplex_iters"] + 11 * c["de_evals"] + 9 * c["march_steps"] + 150 * c["hit_pixels"] + 30 * c["pixels"]
+
+
+# ---- the benchmark ----------------------------------------------------------------------------------
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--max-steps", type=int, default=256)
+    ap.add_argument("--time", type=float, default=0.0)
+    ap.add_argument("--scene", type=int, default=2, help="FragmentShader enum (2 = FSMBPower8Shader)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="also compare the frame with the oracle (slow)")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import rmdf_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+        a.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    rmdf_amd.build()
+    w, h, ms, scene = a.width, a.height, a.max_steps, a.scene
+    sr = rmdf_amd.ShaderRenderer(local_rank)
+    sr.load_env_hdr(rmdf_amd.DEFAULT_ENV_HDR)
+    dev_name, cus = sr.device_info()
+    stream = torch.cuda.current_stream(dev)
+    sptr = stream.cuda_stream
+
+    frame = torch.empty((h, w), dtype=torch.int32, device=dev)
+    if world > 1:
+        slots = rmdf_amd.shard_slots(world)
+        shard = torch.zeros((slots, h // 8, w // 8), dtype=torch.int32, device=dev)
+        gathered = torch.empty((world, slots, h // 8, w // 8), dtype=torch.int32, device=dev) if rank == 0 else None
+
+    def step():
+        if world == 1:
+            sr.render_rect_device(scene, w, h, a.time, ms, (0, 0, w, h), d_rgba8=frame.data_ptr(), stream=sptr)
+        else:
+            sr.render_shard_device(scene, w, h, a.time, ms, rank, world, shard.data_ptr(), stream=sptr)
+            g = gather_shards(shard, rank, world, dist, out=gathered)
+            if rank == 0:
+                sr.assemble_shards_device(w, h, world, g.data_ptr(), frame.data_ptr(), stream=sptr)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, dist, dev)
+    ms_per_step = dt / a.steps * 1e3
+    mpix = w * h / 1e6
+    value = mpix / (dt / a.steps)
+
+    # dominant kernel alone: HIP events on the launch stream around each launch (this rank's share)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(a.steps, 100))]
+    for e0, e1 in evs:
+        e0.record(stream)
+        if world == 1:
+            sr.render_rect_device(scene, w, h, a.time, ms, (0, 0, w, h), d_rgba8=frame.data_ptr(), stream=sptr)
+        else:
+            sr.render_shard_device(scene, w, h, a.time, ms, rank, world, shard.data_ptr(), stream=sptr)
+        e1.record(stream)
+    torch.cuda.synchronize(dev)
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
+    kern_ms_min = float(np.min([e0.elapsed_time(e1) for e0, e1 in evs]))
+
+    result = None
+    if rank == 0:
+        # PCIe-inclusive rate (host buffer hand-over as the boundary does it) -- informational
+        host = np.empty(w * h, np.uint32)
+        sr.draw_shader_tile(scene, None, w, h, a.time, host, max_steps=ms)
+        t1 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            sr.draw_shader_tile(scene, None, w, h, a.time, host, max_steps=ms)
+        d2h_rate = mpix / ((time.perf_counter() - t1) / reps)
+
+        env_bytes = 6 * 172 * 172 * 8 + 2 * 6 * 87 * 87 * 8               # padded RGB16F cube maps read once
+        px_this_launch = w * h if world == 1 else len(rmdf_amd.shard_tiles(rank, world)) * (w // 8) * (h // 8)
+        algo_bytes = px_this_launch * 4 + env_bytes                        # RGBA8 store + env read
+        achieved_gbs = algo_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tj) and world == 1:
+            try:
+                t = json.load(open(tj))
+                if t.get("workload") == [scene, w, h, ms]:
+                    traffic = t.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "Mpixels/s, Mandelbulb power-8 1920x1080 @256 steps; 1/2/4/8 GPU",
+            "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "FSMBPower8Shader %dx%d, max_steps %d, in_time %.1f, uffizi_512.hdr env, "
+                                   "full frame -> RGBA8 resident in HBM" % (w, h, ms, a.time),
+                       "scene": scene, "width": w, "height": h, "max_steps": ms,
+                       "parallelism": "1 GPU, one launch per frame" if world == 1 else
+                                      "64 tiles interleaved over %d GPUs + one RCCL gather" % world,
+                       "device": dev_name, "compute_units": cus},
+            "roofline": {"bound": "hbm", "kernel": "k_render<2>", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": round(kern_ms, 4),
+                         "kernel_ms_min": round(kern_ms_min, 4),
+                         "note": "VALU-bound path (SURVEY 8d): HBM fraction is a sanity figure, see valu_roofline"},
+            "d2h_inclusive_mpixels_s": round(d2h_rate, 2),
+        }
+        if not a.no_cpu_baseline or a.check:
+            from oracle import orc
+            env = load_oracle_env(orc)
+            cores = orc.num_processors()
+            tc = time.perf_counter()
+            ref = orc.render(scene, w, h, a.time, ms, env, nthreads=cores, want_f32=False)
+            cpu_dt = time.perf_counter() - tc
+            ctr = ref["counters"]
+            F = flops_model(ctr)
+            if world == 1:
+                result["valu_roofline"] = {"achieved": round(F / (kern_ms * 1e-3) / 1e12, 3), "peak": VALU_PEAK_TLANEOPS,
+                                           "unit": "T lane-ops/s (as-written IEEE ops, no FMA contraction)",
+                                           "frac": round(F / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS, 4),
+                                           "flop_per_frame": F, "counters": ctr}
+            result["cpu_baseline"] = {"value": round(mpix / cpu_dt, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+                                      "sample": "1 full frame %dx%d of the same workload, CPU oracle (C port of fragment.shd), "
+                                                "row segments over all host cores as ConcurrentSegments does" % (w, h)}
+            if a.check:
+                got = frame.cpu().numpy().view(np.uint32)
+                result["check_rgba8_equal"] = bool(np.array_equal(got, ref["rgba8"]))
+        print(json.dumps(result), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    sr.close()
+    return result
+
+
+if __name__ == "__main__":
+    main()

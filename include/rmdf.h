@@ -1,0 +1,173 @@
+/*
+ * rmdf.h -- C ABI of librmdf.so, the MI355X (gfx950) sphere-tracing renderer.
+ *
+ * This is the drop-in boundary for ONE path of blitzcode/ray-marching-distance-
+ * fields: the per-pixel ray march that the reference runs as a GLSL fragment
+ * shader behind `ShaderRendering.drawShaderTile` (ShaderRendering.hs:151-196),
+ * delivered through the host-pointer slot the reference already has for CPU
+ * renderers, `FrameBuffer.fillFrameBuffer` (FrameBuffer.hs:117-158).  Every
+ * entry point cites the reference interface it replaces.  INTEGRATION.md shows
+ * the Haskell `foreign import ccall` binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; the caller owns every host buffer it passes, the
+ *     library owns all device memory; nothing is retained across calls except
+ *     through the rmdf_ctx.
+ *   - every function returns 0 on success or a negative RMDF_E_* code; it never
+ *     throws or aborts across the ABI.  rmdf_last_error() returns the message
+ *     (the `String` of the reference's `Either String` / `ExceptT String`,
+ *     ShaderRendering.hs:63,110; App.hs:246-256).  A failed render leaves the
+ *     previously accumulated frame intact.
+ *   - a ctx is used by one thread at a time (the reference does all GL work on
+ *     its bound main thread, App.hs:287-307).  Host-pointer calls block until
+ *     the output is complete: import them `safe` in Haskell.
+ *   - pixels: little-endian uint32 = bytes R,G,B,A; index px + py*w; row 0 is the
+ *     BOTTOM row (gl_FragCoord origin; FrameBuffer.saveFrameBufferToPNG flips,
+ *     FrameBuffer.hs:222-227).
+ *   - there is no CPU fallback: without a usable HIP device rmdf_create fails
+ *     with RMDF_E_NO_DEVICE.
+ */
+#ifndef RMDF_H
+#define RMDF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rmdf_ctx rmdf_ctx;
+
+/* error codes */
+#define RMDF_OK              0
+#define RMDF_E_INVALID      -1   /* bad argument                                   */
+#define RMDF_E_NO_DEVICE    -2   /* no HIP device / wrong architecture             */
+#define RMDF_E_HIP          -3   /* a HIP runtime call failed                      */
+#define RMDF_E_IO           -4   /* file missing / unreadable / malformed          */
+#define RMDF_E_NO_ENV       -5   /* a cube map the scene samples has not been set  */
+#define RMDF_E_UNSUPPORTED  -6   /* scene not built yet                            */
+#define RMDF_E_NOMEM        -7
+
+/* `data FragmentShader = FSDECornellBoxShader | FSDETestShader | FSMBPower8Shader |
+ * FSMBGeneralShader deriving Enum` (ShaderRendering.hs:46-47) */
+#define RMDF_FS_DE_CORNELL_BOX 0
+#define RMDF_FS_DE_TEST        1
+#define RMDF_FS_MB_POWER8      2
+#define RMDF_FS_MB_GENERAL     3
+
+/* cube-map slots = the shader's samplerCube uniforms (fragment.shd:10-14;
+ * srEnvCubeMaps, ShaderRendering.hs:83-91) */
+#define RMDF_ENV_REFLECTION 0
+#define RMDF_ENV_COS_1      1
+#define RMDF_ENV_COS_8      2
+#define RMDF_ENV_COS_64     3
+#define RMDF_ENV_COS_512    4
+#define RMDF_ENV_SLOTS      5
+
+/* tilesX, tilesY, nTiles (ShaderRendering.hs:49-52) */
+#define RMDF_TILES_X 8
+#define RMDF_TILES_Y 8
+#define RMDF_N_TILES 64
+
+typedef struct {
+    int device;      /* HIP device ordinal                                              */
+    int reserved[7]; /* zero                                                            */
+} rmdf_config;
+
+/* ---- lifetime: withShaderRenderer (ShaderRendering.hs:60-110) --------------------- */
+
+/* Opens the resource bracket: picks the device, creates the stream, uploads the
+ * Cornell-box vertex table (mkCornellBoxVerticesTex, CornellBox.hs:21-46).
+ * cfg may be NULL (device 0). */
+int rmdf_create(rmdf_ctx **out, const rmdf_config *cfg);
+/* Closes the bracket; frees every device object (ResourceT release, :63-99). */
+void rmdf_destroy(rmdf_ctx *ctx);
+/* Message of the last failure on ctx (ctx == NULL: of the last failed rmdf_create). */
+const char *rmdf_last_error(const rmdf_ctx *ctx);
+
+/* ---- environment maps (ShaderRendering.hs:65-91, HDREnvMap.hs) --------------------- */
+
+/* The whole env pipeline of withShaderRenderer for one latlong .hdr file
+ * (ShaderRendering.hs:67-91): load reflMapFn, build any missing
+ * `<name>_cache_pow_<p>.hdr` (p = 1.0, 8.0, 64.0, 512.0) with the device
+ * prefilter (buildPreConvolvedHDREnvMapCache, :131-149), reload the caches,
+ * convert all five maps to cube maps on the device. */
+int rmdf_load_env_hdr(rmdf_ctx *ctx, const char *latlong_hdr_path);
+
+/* latLongHDREnvMapToCubeMap (HDREnvMap.hs:118-163) for one slot: rgb = w*h*3
+ * floats, first scanline first; builds 6 faces of (w div 3)^2 RGB16F texels. */
+int rmdf_set_env_latlong(rmdf_ctx *ctx, int slot, const float *rgb, int w, int h);
+
+/* Upload ready-made faces (the texImage2D RGB16F upload of HDREnvMap.hs:160-161):
+ * faces = 6*face_w*face_w*3 floats, order +X,-X,+Y,-Y,+Z,-Z, row 0 first. */
+int rmdf_set_env_cube(rmdf_ctx *ctx, int slot, const float *faces_rgb, int face_w);
+
+/* Read a slot back as the padded RGB16F array the kernels sample
+ * (6*(W+2)*(W+2)*4 uint16; out may be NULL to query *face_w). */
+int rmdf_get_env_cube_padded(rmdf_ctx *ctx, int slot, uint16_t *out, int *face_w);
+
+/* resizeHDRImage (HDREnvMap.hs:169-195) on the device.  out = dstw * *dsth * 3
+ * floats (may be NULL to query *dsth). */
+int rmdf_resize_latlong(rmdf_ctx *ctx, const float *rgb, int w, int h, int dstw, float *out, int *dsth);
+
+/* cosineConvolveHDREnvMap (HDREnvMap.hs:217-254) on the device: out = w*h*3 floats. */
+int rmdf_prefilter_env(rmdf_ctx *ctx, const float *rgb, int w, int h, float power, float *out);
+
+/* ---- rendering: drawShaderTile (ShaderRendering.hs:151-196) ------------------------ */
+
+/* isTileIdxFirstTile / isTileIdxLastTile (ShaderRendering.hs:54-58) */
+int rmdf_is_tile_idx_first_tile(int idx);
+int rmdf_is_tile_idx_last_tile(int idx);
+
+/* drawShaderTile sr shd tileIdx w h time, delivered through fillFrameBuffer's
+ * `MVector Word32` (FrameBuffer.hs:117-158).
+ *   tile_idx < 0  = `Nothing`: the whole frame.
+ *   tile_idx >= 0 = `Just idx`: tile idx mod 64 of the 8x8 grid, tx = midx mod 8,
+ *                   ty = midx div 8 counted from the bottom (:183-193).
+ * (w, h, time, max_steps) are latched on the first tile of a frame and frozen for
+ * the other 63 (:162-176).  The library keeps the accumulating frame and writes
+ * ALL w*h pixels to out_rgba8 on every call (the PBO is orphaned per call,
+ * FrameBuffer.hs:129,207-213).  max_steps is fragment.shd:634's MAX_STEPS (128 in
+ * the reference; <= 0 selects 128). */
+int rmdf_render_tile(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double time, int max_steps,
+                     uint32_t *out_rgba8);
+
+/* Same, with the extra planes parity tests need (any pointer may be NULL):
+ *   out_rgba_f32  w*h*4 floats, the shader's frag_color before RGBA8 conversion
+ *   out_steps     w*h uint16: bits 0..14 ray_march loop counter at exit
+ *                 (fragment.shd:659-673), bit 15 = hit
+ *   out_iters     w*h uint16: Mandelbulb escape iterations the pixel spent
+ *                 (march + normal + AO distance estimates; 0 for other scenes) */
+int rmdf_render_tile_ex(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double time, int max_steps,
+                        uint32_t *out_rgba8, float *out_rgba_f32, uint16_t *out_steps, uint16_t *out_iters);
+
+/* ---- device-resident forms (benchmarks, multi-GPU; no PCIe in the timed region) ---- */
+
+/* Render the pixel rectangle [x0,x1) x [y0,y1) of a w x h frame into caller-owned
+ * DEVICE buffers laid out as full frames (any may be NULL).  `stream` is a
+ * hipStream_t (NULL = the ctx stream); the call is asynchronous on it. */
+int rmdf_render_rect_device(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps,
+                            int x0, int y0, int x1, int y1,
+                            void *d_rgba8, void *d_rgba_f32, void *d_steps, void *d_iters, void *stream);
+
+/* Multi-GPU sharding of the reference's 64 tiles: rank r of n renders the tiles
+ * with idx mod n == r (interleaved), packed back to back in ascending idx order
+ * into d_packed_rgba8 (tile = (w/8)*(h/8) uint32, rows bottom-up).  Requires
+ * w mod 8 == 0 and h mod 8 == 0. */
+int rmdf_render_shard_device(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps,
+                             int rank, int nranks, void *d_packed_rgba8, void *stream);
+/* Rank 0 after the gather: d_gathered holds the nranks shards back to back (rank
+ * order, each ceil(64/nranks) tile slots); scatter them to frame positions. */
+int rmdf_assemble_shards_device(rmdf_ctx *ctx, int w, int h, int nranks, const void *d_gathered,
+                                void *d_frame_rgba8, void *stream);
+
+/* Block until everything queued on `stream` (NULL = ctx stream) has finished. */
+int rmdf_synchronize(rmdf_ctx *ctx, void *stream);
+
+/* Name of the HIP device the ctx runs on and its compute-unit count. */
+int rmdf_device_info(rmdf_ctx *ctx, char *name, int name_len, int *compute_units);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMDF_H */

@@ -1,0 +1,309 @@
+"""Host-side mirror of the reference's `ShaderRendering` module over librmdf.so.
+
+The reference (Haskell) exposes, for the per-pixel ray-march path,
+
+    withShaderRenderer :: FilePath -> FilePath -> (ShaderRenderer -> IO a) -> IO a
+    drawShaderTile     :: ShaderRenderer -> FragmentShader -> Maybe Int -> Int -> Int -> Double -> IO ()
+    data FragmentShader = FSDECornellBoxShader | FSDETestShader | FSMBPower8Shader | FSMBGeneralShader
+    isTileIdxFirstTile, isTileIdxLastTile :: Int -> Bool          (ShaderRendering.hs:4-11)
+
+and gets CPU-rendered pixels on screen through `FrameBuffer.fillFrameBuffer`
+(FrameBuffer.hs:117-158).  This module keeps those names and argument meanings
+(snake_case) on top of the C ABI in include/rmdf.h; everything is computed by the
+gfx950 kernels in librmdf.so.  There is NO CPU fallback: if the library or a GPU is
+missing, loading / `with_shader_renderer` raises `RmdfError`.
+
+The directory name contains hyphens, so import it with
+    importlib.import_module("ray-marching-distance-fields_amd")
+or through the `rmdf_amd` shim at the repository root.
+"""
+import ctypes as C
+import enum
+import os
+import subprocess
+from contextlib import contextmanager
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librmdf.so")
+CSRC = os.path.join(_HERE, "csrc")
+DATA_DIR = os.path.join(_HERE, "data")
+DEFAULT_ENV_HDR = os.path.join(DATA_DIR, "latlong_envmaps", "uffizi_512.hdr")
+
+TILES_X, TILES_Y, N_TILES = 8, 8, 64          # ShaderRendering.hs:49-52
+ENV_REFLECTION, ENV_COS_1, ENV_COS_8, ENV_COS_64, ENV_COS_512 = range(5)
+
+_ERRORS = {-1: "RMDF_E_INVALID", -2: "RMDF_E_NO_DEVICE", -3: "RMDF_E_HIP", -4: "RMDF_E_IO",
+           -5: "RMDF_E_NO_ENV", -6: "RMDF_E_UNSUPPORTED", -7: "RMDF_E_NOMEM"}
+
+# every symbol include/rmdf.h declares
+ABI_SYMBOLS = (
+    "rmdf_create", "rmdf_destroy", "rmdf_last_error", "rmdf_load_env_hdr", "rmdf_set_env_latlong",
+    "rmdf_set_env_cube", "rmdf_get_env_cube_padded", "rmdf_resize_latlong", "rmdf_prefilter_env",
+    "rmdf_is_tile_idx_first_tile", "rmdf_is_tile_idx_last_tile", "rmdf_render_tile", "rmdf_render_tile_ex",
+    "rmdf_render_rect_device", "rmdf_render_shard_device", "rmdf_assemble_shards_device", "rmdf_synchronize",
+    "rmdf_device_info",
+)
+
+
+class RmdfError(RuntimeError):
+    """The `Left String` / `traceAndThrow` of the reference (ShaderRendering.hs:110)."""
+
+    def __init__(self, code, message):
+        super().__init__("%s (%d): %s" % (_ERRORS.get(code, "RMDF_E_?"), code, message))
+        self.code = code
+
+
+class FragmentShader(enum.IntEnum):
+    """`data FragmentShader`, ShaderRendering.hs:46-47 (Enum order)."""
+    FSDECornellBoxShader = 0
+    FSDETestShader = 1
+    FSMBPower8Shader = 2
+    FSMBGeneralShader = 3
+
+
+def is_tile_idx_first_tile(idx):   # ShaderRendering.hs:57-58
+    return idx % N_TILES == 0
+
+
+def is_tile_idx_last_tile(idx):    # ShaderRendering.hs:54-55
+    return idx % N_TILES == N_TILES - 1
+
+
+def tile_rect(tile_idx, w, h):
+    """Pixel rectangle [x0,x1) x [y0,y1) of tile `tile_idx` (ShaderRendering.hs:183-193); ty counts from the bottom."""
+    midx = tile_idx % N_TILES
+    tx, ty = midx % TILES_X, midx // TILES_X
+    return ((2 * tx * w + 7) // 16, (2 * ty * h + 7) // 16, (2 * (tx + 1) * w + 7) // 16, (2 * (ty + 1) * h + 7) // 16)
+
+
+def build(force=False, verbose=False):
+    """Compile librmdf.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "rmdf.h")]
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        out = None if verbose else subprocess.DEVNULL
+        subprocess.check_call(["make", "-C", CSRC] + (["-B"] if force else []), stdout=out)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen librmdf.so and declare the prototypes.  Raises if the HIP library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RmdfError(-2, "librmdf.so is not built (run __graft_entry__.build() or `make -C %s`); "
+                            "there is no CPU fallback" % CSRC)
+    L = C.CDLL(LIB_PATH)
+    vp, ip = C.c_void_p, C.POINTER(C.c_int)
+    L.rmdf_create.argtypes = [C.POINTER(vp), vp]
+    L.rmdf_destroy.argtypes = [vp]
+    L.rmdf_destroy.restype = None
+    L.rmdf_last_error.argtypes = [vp]
+    L.rmdf_last_error.restype = C.c_char_p
+    L.rmdf_load_env_hdr.argtypes = [vp, C.c_char_p]
+    L.rmdf_set_env_latlong.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int]
+    L.rmdf_set_env_cube.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.rmdf_get_env_cube_padded.argtypes = [vp, C.c_int, vp, ip]
+    L.rmdf_resize_latlong.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, ip]
+    L.rmdf_prefilter_env.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, vp]
+    L.rmdf_is_tile_idx_first_tile.argtypes = [C.c_int]
+    L.rmdf_is_tile_idx_last_tile.argtypes = [C.c_int]
+    L.rmdf_render_tile.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]
+    L.rmdf_render_tile_ex.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp]
+    L.rmdf_render_rect_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int] + [C.c_int] * 4 + [vp] * 5
+    L.rmdf_render_shard_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.rmdf_assemble_shards_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    L.rmdf_synchronize.argtypes = [vp, vp]
+    L.rmdf_device_info.argtypes = [vp, C.c_char_p, C.c_int, ip]
+    _lib = L
+    return L
+
+
+class _Config(C.Structure):
+    _fields_ = [("device", C.c_int), ("reserved", C.c_int * 7)]
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class ShaderRenderer:
+    """The `ShaderRenderer` record (ShaderRendering.hs:36-44): owns the device-side env cube maps,
+    the Cornell geometry table and the accumulating frame."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._ctx = C.c_void_p()
+        cfg = _Config(device=device)
+        rc = self._lib.rmdf_create(C.byref(self._ctx), C.byref(cfg))
+        if rc != 0:
+            raise RmdfError(rc, (self._lib.rmdf_last_error(None) or b"").decode())
+
+    # -- lifetime --------------------------------------------------------------------------
+    def close(self):
+        if self._ctx:
+            self._lib.rmdf_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RmdfError(rc, (self._lib.rmdf_last_error(self._ctx) or b"").decode())
+
+    @property
+    def handle(self):
+        return self._ctx
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus = C.c_int()
+        self._check(self._lib.rmdf_device_info(self._ctx, name, 256, C.byref(cus)))
+        return name.value.decode(), cus.value
+
+    # -- environment maps -------------------------------------------------------------------
+    def load_env_hdr(self, path):
+        """ShaderRendering.hs:67-91 for one latlong .hdr (cache files are built on the GPU if missing)."""
+        self._check(self._lib.rmdf_load_env_hdr(self._ctx, os.fsencode(path)))
+
+    def set_env_latlong(self, slot, rgb):
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        h, w, _ = rgb.shape
+        self._check(self._lib.rmdf_set_env_latlong(self._ctx, slot, rgb.ctypes.data, w, h))
+
+    def set_env_cube(self, slot, faces):
+        faces = np.ascontiguousarray(faces, np.float32)
+        assert faces.ndim == 4 and faces.shape[0] == 6 and faces.shape[1] == faces.shape[2] and faces.shape[3] == 3
+        self._check(self._lib.rmdf_set_env_cube(self._ctx, slot, faces.ctypes.data, faces.shape[1]))
+
+    def get_env_cube_padded(self, slot):
+        w = C.c_int()
+        self._check(self._lib.rmdf_get_env_cube_padded(self._ctx, slot, None, C.byref(w)))
+        out = np.empty((6, w.value + 2, w.value + 2, 4), np.uint16)
+        self._check(self._lib.rmdf_get_env_cube_padded(self._ctx, slot, out.ctypes.data, C.byref(w)))
+        return out
+
+    def resize_latlong(self, rgb, dstw):
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        h, w, _ = rgb.shape
+        dh = C.c_int()
+        self._check(self._lib.rmdf_resize_latlong(self._ctx, rgb.ctypes.data, w, h, dstw, None, C.byref(dh)))
+        out = np.empty((dh.value, dstw, 3), np.float32)
+        self._check(self._lib.rmdf_resize_latlong(self._ctx, rgb.ctypes.data, w, h, dstw, out.ctypes.data, C.byref(dh)))
+        return out
+
+    def prefilter_env(self, rgb, power):
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        h, w, _ = rgb.shape
+        out = np.empty_like(rgb)
+        self._check(self._lib.rmdf_prefilter_env(self._ctx, rgb.ctypes.data, w, h, float(power), out.ctypes.data))
+        return out
+
+    # -- rendering ----------------------------------------------------------------------------
+    def draw_shader_tile(self, shd_enum, tile_idx, w, h, time, fb_vec, max_steps=128):
+        """drawShaderTile sr shdEnum tileIdx w h time, writing into the `MVector Word32` that
+        fillFrameBuffer hands out.  tile_idx None = `Nothing` (whole frame)."""
+        assert fb_vec.dtype == np.uint32 and fb_vec.size == w * h and fb_vec.flags["C_CONTIGUOUS"]
+        self._check(self._lib.rmdf_render_tile(self._ctx, int(shd_enum), -1 if tile_idx is None else int(tile_idx),
+                                               w, h, float(time), max_steps, fb_vec.ctypes.data))
+
+    def render(self, shd_enum, w, h, time, max_steps=128, tile_idx=None, want_f32=True):
+        """Rich form for parity tests: dict(rgba8, rgba_f32, steps, iters), arrays (h, w[, 4]), row 0 = bottom."""
+        rgba8 = np.empty((h, w), np.uint32)
+        f32 = np.empty((h, w, 4), np.float32) if want_f32 else None
+        steps = np.empty((h, w), np.uint16)
+        iters = np.empty((h, w), np.uint16)
+        self._check(self._lib.rmdf_render_tile_ex(self._ctx, int(shd_enum), -1 if tile_idx is None else int(tile_idx),
+                                                  w, h, float(time), max_steps, rgba8.ctypes.data, _ptr(f32),
+                                                  steps.ctypes.data, iters.ctypes.data))
+        return {"rgba8": rgba8, "rgba_f32": f32, "steps": steps, "iters": iters}
+
+    # -- device-resident forms (pointers are plain integers, e.g. torch.Tensor.data_ptr()) -------
+    def render_rect_device(self, shd_enum, w, h, time, max_steps, rect, d_rgba8=0, d_rgba_f32=0, d_steps=0,
+                           d_iters=0, stream=0):
+        x0, y0, x1, y1 = rect
+        self._check(self._lib.rmdf_render_rect_device(self._ctx, int(shd_enum), w, h, float(time), max_steps,
+                                                      x0, y0, x1, y1, d_rgba8 or None, d_rgba_f32 or None,
+                                                      d_steps or None, d_iters or None, stream or None))
+
+    def render_shard_device(self, shd_enum, w, h, time, max_steps, rank, nranks, d_packed_rgba8, stream=0):
+        self._check(self._lib.rmdf_render_shard_device(self._ctx, int(shd_enum), w, h, float(time), max_steps,
+                                                       rank, nranks, d_packed_rgba8, stream or None))
+
+    def assemble_shards_device(self, w, h, nranks, d_gathered, d_frame_rgba8, stream=0):
+        self._check(self._lib.rmdf_assemble_shards_device(self._ctx, w, h, nranks, d_gathered, d_frame_rgba8,
+                                                          stream or None))
+
+    def synchronize(self, stream=0):
+        self._check(self._lib.rmdf_synchronize(self._ctx, stream or None))
+
+
+@contextmanager
+def with_shader_renderer(refl_map_fn=DEFAULT_ENV_HDR, device=0):
+    """withShaderRenderer shdFn reflMapFn (ShaderRendering.hs:60-110) as a bracket.  There is no
+    shader file: the kernels are compiled ahead of time for gfx950.  refl_map_fn=None skips the
+    env-map load (set the cube maps yourself)."""
+    sr = ShaderRenderer(device)
+    try:
+        if refl_map_fn is not None:
+            sr.load_env_hdr(refl_map_fn)
+        yield sr
+    finally:
+        sr.close()
+
+
+class FrameBuffer:
+    """The slice of `FrameBuffer` (FrameBuffer.hs) the boundary needs: a w*h Word32 buffer handed to a
+    filler (fillFrameBuffer, :117-158) and the PNG screenshot (saveFrameBufferToPNG, :215-228)."""
+
+    def __init__(self, w, h):
+        self.w, self.h = w, h
+        self.vec = np.full(w * h, 0xFF000000, np.uint32)     # cleared to opaque black, :109-111
+
+    def fill_frame_buffer(self, f):
+        """fillFrameBuffer fb (\\w h vec -> ...)"""
+        return f(self.w, self.h, self.vec)
+
+    def to_image_rows_top_down(self):
+        """Rows flipped and alpha forced to 0xFF exactly like saveFrameBufferToPNG (:222-227)."""
+        rgba = self.vec.view(np.uint8).reshape(self.h, self.w, 4)[::-1].copy()
+        rgba[..., 3] = 0xFF
+        return rgba
+
+    def save_png(self, fn):
+        from PIL import Image
+        Image.fromarray(self.to_image_rows_top_down(), "RGBA").save(fn)
+
+
+# --- multi-GPU tile sharding: pure index arithmetic, testable without a GPU ------
+
+def shard_tiles(rank, nranks):
+    """Tiles rank `rank` of `nranks` renders: idx = rank, rank+n, ... (interleaved for load balance)."""
+    return list(range(rank, N_TILES, nranks))
+
+
+def shard_slots(nranks):
+    """Slots every rank's packed shard buffer has (the gather needs equal sizes)."""
+    return (N_TILES + nranks - 1) // nranks
+
+
+def assemble_shards_host(gathered, w, h, nranks):
+    """Reference (numpy) statement of rmdf_assemble_shards_device, for the gloo tests.
+    gathered: (nranks, slots, h/8, w/8) uint32."""
+    tw, th = w // 8, h // 8
+    frame = np.zeros((h, w), np.uint32)
+    for r in range(nranks):
+        for slot, idx in enumerate(shard_tiles(r, nranks)):
+            tx, ty = idx % 8, idx // 8
+            frame[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw] = gathered[r, slot]
+    return frame

@@ -1,0 +1,622 @@
+// rmdf_api.cpp -- the C ABI of librmdf.so (include/rmdf.h): host-side counterpart of
+// ShaderRendering.hs (withShaderRenderer / drawShaderTile) for the HIP renderer.
+// No CPU rendering path exists here: every pixel comes from the gfx950 kernels.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rmdf.h"
+#include "rmdf_internal.hpp"
+
+using namespace rmdf;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct CubeSlot {
+    uint2 *d_texels = nullptr;
+    int    W = 0;
+};
+
+}  // namespace
+
+struct rmdf_ctx {
+    int          device = 0;
+    hipStream_t  stream = nullptr;
+    float       *d_cornell = nullptr;
+    CubeSlot     env[RMDF_ENV_SLOTS];
+    // frame latched on the first tile (ShaderRendering.hs:162-176)
+    int          w = 0, h = 0, max_steps = 128;
+    float        time = 0.0f;
+    bool         latched = false;
+    // accumulating frame (device)
+    uint32_t    *d_rgba8 = nullptr;
+    float4      *d_rgba_f32 = nullptr;
+    uint16_t    *d_steps = nullptr;
+    uint16_t    *d_iters = nullptr;
+    size_t       cap_px = 0;
+    std::string  err;
+    char         dev_name[256] = { 0 };
+    int          cus = 0;
+};
+
+namespace {
+
+int fail(rmdf_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(ctx, RMDF_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+// one IEEE rounding per operation on the host too (this file is built with -ffp-contract=off)
+struct hv3 { float x, y, z; };
+inline float hdot(hv3 a, hv3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline hv3 hnormalize(hv3 a)
+{
+    float s = 1.0f / sqrtf(hdot(a, a));
+    return hv3{ a.x * s, a.y * s, a.z * s };
+}
+inline hv3 hcross(hv3 a, hv3 b) { return hv3{ a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+
+// camera block of main() (fragment.shd:883-902) + lookat (829-838), evaluated once per
+// frame on the host instead of once per pixel; sinf/cosf/tanf are the host libm's
+void host_camera(int scene, float time, float cam[12])
+{
+    hv3 c;
+    if (scene == RMDF_FS_DE_CORNELL_BOX) {
+        c = hv3{ sinf(time / 2.0f) * 0.4f, cosf(time / 2.0f) * 0.4f, -2.0f };
+    } else {
+        c = hv3{ sinf(time / 3.0f), cosf(time / 4.0f), cosf(time / 3.0f) };
+        hv3 nrm = hnormalize(c);
+        c = hv3{ nrm.x * 2.414213562373095f, nrm.y * 2.414213562373095f, nrm.z * 2.414213562373095f };
+    }
+    hv3 zaxis = hnormalize(hv3{ c.x - 0.0f, c.y - 0.0f, c.z - 0.0f });
+    hv3 xaxis = hnormalize(hcross(hv3{ 0.0f, 1.0f, 0.0f }, zaxis));
+    hv3 yaxis = hcross(zaxis, xaxis);
+    cam[0] = xaxis.x; cam[1] = xaxis.y; cam[2] = xaxis.z;
+    cam[3] = yaxis.x; cam[4] = yaxis.y; cam[5] = yaxis.z;
+    cam[6] = zaxis.x; cam[7] = zaxis.y; cam[8] = zaxis.z;
+    cam[9] = c.x; cam[10] = c.y; cam[11] = c.z;
+}
+
+float host_fov_xs()
+{
+    float hfov = (45.0f * 1.5f) * 0.017453292519943295f;   // radians(45.0 * 1.5)
+    return tanf(hfov / 2.0f);
+}
+
+// ---- Cornell box geometry, CornellBox.hs:48-129 (data) and :21-46 (triangulation) ----
+const float kCornellQuads[64][3] = {
+    { 552.8f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 559.2f }, { 549.6f, 0.0f, 559.2f },
+    { 556.0f, 548.8f, 0.0f }, { 556.0f, 548.8f, 559.2f }, { 0.0f, 548.8f, 559.2f }, { 0.0f, 548.8f, 0.0f },
+    { 549.6f, 0.0f, 559.2f }, { 0.0f, 0.0f, 559.2f }, { 0.0f, 548.8f, 559.2f }, { 556.0f, 548.8f, 559.2f },
+    { 0.0f, 0.0f, 559.2f }, { 0.0f, 0.0f, 0.0f }, { 0.0f, 548.8f, 0.0f }, { 0.0f, 548.8f, 559.2f },
+    { 552.8f, 0.0f, 0.0f }, { 549.6f, 0.0f, 559.2f }, { 556.0f, 548.8f, 559.2f }, { 556.0f, 548.8f, 0.0f },
+    { 343.0f, 548.8f - 0.1f, 227.0f }, { 343.0f, 548.8f - 0.1f, 332.0f }, { 213.0f, 548.8f - 0.1f, 332.0f }, { 213.0f, 548.8f - 0.1f, 227.0f },
+    { 130.0f, 165.0f, 65.0f }, { 82.0f, 165.0f, 225.0f }, { 240.0f, 165.0f, 272.0f }, { 290.0f, 165.0f, 114.0f },
+    { 290.0f, 0.0f, 114.0f }, { 290.0f, 165.0f, 114.0f }, { 240.0f, 165.0f, 272.0f }, { 240.0f, 0.0f, 272.0f },
+    { 130.0f, 0.0f, 65.0f }, { 130.0f, 165.0f, 65.0f }, { 290.0f, 165.0f, 114.0f }, { 290.0f, 0.0f, 114.0f },
+    { 82.0f, 0.0f, 225.0f }, { 82.0f, 165.0f, 225.0f }, { 130.0f, 165.0f, 65.0f }, { 130.0f, 0.0f, 65.0f },
+    { 240.0f, 0.0f, 272.0f }, { 240.0f, 165.0f, 272.0f }, { 82.0f, 165.0f, 225.0f }, { 82.0f, 0.0f, 225.0f },
+    { 423.0f, 330.0f, 247.0f }, { 265.0f, 330.0f, 296.0f }, { 314.0f, 330.0f, 456.0f }, { 472.0f, 330.0f, 406.0f },
+    { 423.0f, 0.0f, 247.0f }, { 423.0f, 330.0f, 247.0f }, { 472.0f, 330.0f, 406.0f }, { 472.0f, 0.0f, 406.0f },
+    { 472.0f, 0.0f, 406.0f }, { 472.0f, 330.0f, 406.0f }, { 314.0f, 330.0f, 456.0f }, { 314.0f, 0.0f, 456.0f },
+    { 314.0f, 0.0f, 456.0f }, { 314.0f, 330.0f, 456.0f }, { 265.0f, 330.0f, 296.0f }, { 265.0f, 0.0f, 296.0f },
+    { 265.0f, 0.0f, 296.0f }, { 265.0f, 330.0f, 296.0f }, { 423.0f, 330.0f, 247.0f }, { 423.0f, 0.0f, 247.0f },
+};
+
+void cornell_triangles(float out[96 * 3])
+{
+    const float to_unit = 559.2f / 2.0f;
+    const float scale = 1.0f / (sqrtf(2.0f * 2.0f + 2.0f * 2.0f + 2.0f * 2.0f) / 2.0f) * 0.99f;
+    static const int order[6] = { 0, 1, 3, 3, 1, 2 };   // (q0,q1,q3),(q3,q1,q2)
+    for (int q = 0; q < 16; q++)
+        for (int k = 0; k < 6; k++)
+            for (int a = 0; a < 3; a++)
+                out[(q * 6 + k) * 3 + a] = (kCornellQuads[q * 4 + order[k]][a] / to_unit - 1.0f) * scale;
+}
+
+int ensure_frame(rmdf_ctx *ctx, int w, int h)
+{
+    size_t npx = (size_t)w * (size_t)h;
+    if (npx <= ctx->cap_px && ctx->d_rgba8) return RMDF_OK;
+    if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
+    if (ctx->d_rgba_f32) (void)hipFree(ctx->d_rgba_f32);
+    if (ctx->d_steps) (void)hipFree(ctx->d_steps);
+    if (ctx->d_iters) (void)hipFree(ctx->d_iters);
+    ctx->d_rgba8 = nullptr; ctx->d_rgba_f32 = nullptr; ctx->d_steps = nullptr; ctx->d_iters = nullptr;
+    ctx->cap_px = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_rgba8, npx * 4));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_rgba_f32, npx * 16));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_steps, npx * 2));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_iters, npx * 2));
+    ctx->cap_px = npx;
+    return RMDF_OK;
+}
+
+// resizeFrameBuffer clears the new texture to opaque black (FrameBuffer.hs:109-111)
+int clear_frame(rmdf_ctx *ctx, int w, int h)
+{
+    size_t npx = (size_t)w * (size_t)h;
+    HIP_TRY(ctx, launch_fill_u32(ctx->d_rgba8, 0xff000000u, npx, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_rgba_f32, 0, npx * 16, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_steps, 0, npx * 2, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_iters, 0, npx * 2, ctx->stream));
+    return RMDF_OK;
+}
+
+int fill_params(rmdf_ctx *ctx, int scene, int w, int h, float time, int max_steps, FrameParams &p)
+{
+    if (scene != RMDF_FS_MB_POWER8 && scene != RMDF_FS_DE_CORNELL_BOX) {
+        if (scene == RMDF_FS_DE_TEST || scene == RMDF_FS_MB_GENERAL)
+            return fail(ctx, RMDF_E_UNSUPPORTED, "scene not built yet (FSDETestShader / FSMBGeneralShader)");
+        return fail(ctx, RMDF_E_INVALID, "unknown FragmentShader value");
+    }
+    if (w <= 0 || h <= 0 || w > 32768 || h > 32768) return fail(ctx, RMDF_E_INVALID, "bad frame size");
+    if (max_steps > 32767) return fail(ctx, RMDF_E_INVALID, "max_steps > 32767");
+    for (int s = RMDF_ENV_REFLECTION; s <= RMDF_ENV_COS_8; s++)
+        if (!ctx->env[s].d_texels)
+            return fail(ctx, RMDF_E_NO_ENV, "environment cube map slot " + std::to_string(s) + " not set");
+    memset(&p, 0, sizeof p);
+    host_camera(scene, time, p.cam);
+    p.fov_xs = host_fov_xs();
+    p.wf = (float)w; p.hf = (float)h; p.aspect = p.wf / p.hf;
+    p.w = w; p.h = h;
+    p.max_steps = max_steps <= 0 ? 128 : max_steps;
+    p.env_refl = CubeDev{ ctx->env[RMDF_ENV_REFLECTION].d_texels, ctx->env[RMDF_ENV_REFLECTION].W };
+    p.env_cos1 = CubeDev{ ctx->env[RMDF_ENV_COS_1].d_texels, ctx->env[RMDF_ENV_COS_1].W };
+    p.env_cos8 = CubeDev{ ctx->env[RMDF_ENV_COS_8].d_texels, ctx->env[RMDF_ENV_COS_8].W };
+    p.cornell = ctx->d_cornell;
+    return RMDF_OK;
+}
+
+bool read_file(const char *path, std::vector<uint8_t> &out)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (n < 0) { fclose(f); return false; }
+    out.resize((size_t)n);
+    size_t got = n ? fread(out.data(), 1, (size_t)n, f) : 0;
+    fclose(f);
+    return got == (size_t)n;
+}
+
+bool file_exists(const std::string &p)
+{
+    FILE *f = fopen(p.c_str(), "rb");
+    if (!f) return false;
+    fclose(f);
+    return true;
+}
+
+// Radiance RGBE <-> float as JuicyPixels does it (third-party arithmetic behind
+// JP.readImage / JP.saveRadianceImage, HDREnvMap.hs:33, ShaderRendering.hs:147)
+void rgbe_to_float(const uint8_t *p, float *rgb)
+{
+    float f = ldexpf(1.0f, (int)p[3] - (128 + 8));
+    rgb[0] = ((float)p[0] + 0.5f) * f;
+    rgb[1] = ((float)p[1] + 0.5f) * f;
+    rgb[2] = ((float)p[2] + 0.5f) * f;
+}
+
+void float_to_rgbe(const float *rgb, uint8_t *p)
+{
+    float d = rgb[0];
+    if (rgb[1] > d) d = rgb[1];
+    if (rgb[2] > d) d = rgb[2];
+    if (!(d > 1e-32f)) { p[0] = p[1] = p[2] = p[3] = 0; return; }
+    int e;
+    float sig = frexpf(d, &e);
+    float coeff = sig * 255.9999f / d;
+    p[0] = (uint8_t)(int)(rgb[0] * coeff);
+    p[1] = (uint8_t)(int)(rgb[1] * coeff);
+    p[2] = (uint8_t)(int)(rgb[2] * coeff);
+    p[3] = (uint8_t)(e + 128);
+}
+
+// loadHDRImage (HDREnvMap.hs:31-52): flat or new-style-RLE Radiance files
+bool decode_hdr(const std::vector<uint8_t> &file, int &w, int &h, std::vector<float> &rgb, std::string &why)
+{
+    size_t pos = 0, len = file.size();
+    bool blank = false;
+    while (pos < len) {                        // header lines up to the empty line
+        size_t eol = pos;
+        while (eol < len && file[eol] != '\n') eol++;
+        if (eol >= len) { why = "truncated header"; return false; }
+        bool empty = (eol == pos);
+        pos = eol + 1;
+        if (empty) { blank = true; break; }
+    }
+    if (!blank) { why = "no header terminator"; return false; }
+    size_t eol = pos;
+    while (eol < len && file[eol] != '\n') eol++;
+    if (eol >= len || eol - pos > 100) { why = "no resolution line"; return false; }
+    std::string line((const char *)&file[pos], eol - pos);
+    if (sscanf(line.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) { why = "unsupported resolution line '" + line + "'"; return false; }
+    pos = eol + 1;
+    rgb.resize((size_t)w * h * 3);
+    std::vector<uint8_t> scan((size_t)w * 4);
+    for (int y = 0; y < h; y++) {
+        if (pos + 4 <= len && w >= 8 && w < 32768 && file[pos] == 2 && file[pos + 1] == 2 &&
+            ((file[pos + 2] << 8) | file[pos + 3]) == w) {
+            pos += 4;
+            for (int ch = 0; ch < 4; ch++) {
+                int x = 0;
+                while (x < w) {
+                    if (pos >= len) { why = "truncated RLE scanline"; return false; }
+                    int cnt = file[pos++];
+                    if (cnt > 128) {
+                        cnt -= 128;
+                        if (pos >= len || x + cnt > w) { why = "bad RLE run"; return false; }
+                        uint8_t v = file[pos++];
+                        for (int k = 0; k < cnt; k++) scan[(size_t)(x++) * 4 + ch] = v;
+                    } else {
+                        if (cnt == 0 || pos + cnt > len || x + cnt > w) { why = "bad RLE literal"; return false; }
+                        for (int k = 0; k < cnt; k++) scan[(size_t)(x++) * 4 + ch] = file[pos++];
+                    }
+                }
+            }
+        } else {
+            if (pos + (size_t)w * 4 > len) { why = "truncated pixel data"; return false; }
+            memcpy(scan.data(), &file[pos], (size_t)w * 4);
+            pos += (size_t)w * 4;
+        }
+        for (int x = 0; x < w; x++) rgbe_to_float(&scan[(size_t)x * 4], &rgb[((size_t)y * w + x) * 3]);
+    }
+    return true;
+}
+
+bool write_hdr(const std::string &path, const std::vector<float> &rgb, int w, int h)
+{
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    fprintf(f, "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n", h, w);
+    std::vector<uint8_t> px((size_t)w * h * 4);
+    for (size_t i = 0; i < (size_t)w * h; i++) float_to_rgbe(&rgb[i * 3], &px[i * 4]);
+    bool ok = fwrite(px.data(), 1, px.size(), f) == px.size();
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) remove(path.c_str());            // removeFile on failure, ShaderRendering.hs:146-148
+    return ok;
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+int set_env_from_device_faces(rmdf_ctx *ctx, int slot, const float *d_faces, int W)
+{
+    uint2 *d_padded = nullptr;
+    size_t n = (size_t)6 * (W + 2) * (W + 2);
+    HIP_TRY(ctx, hipMalloc((void **)&d_padded, n * sizeof(uint2)));
+    hipError_t e = launch_cube_upload(d_faces, W, d_padded, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(d_padded); return fail(ctx, RMDF_E_HIP, std::string("cube upload: ") + hipGetErrorString(e)); }
+    if (ctx->env[slot].d_texels) (void)hipFree(ctx->env[slot].d_texels);
+    ctx->env[slot].d_texels = d_padded;
+    ctx->env[slot].W = W;
+    return RMDF_OK;
+}
+
+int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double time, int max_steps,
+                  uint32_t *out_rgba8, float *out_rgba_f32, uint16_t *out_steps, uint16_t *out_iters)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool whole = tile_idx < 0;
+    const bool first = whole || rmdf_is_tile_idx_first_tile(tile_idx);
+    // latch on the first tile (ShaderRendering.hs:162-176).  A size change in the middle
+    // of a tiled frame re-latches (the reference would resize its FBO texture and clear it).
+    if (first || !ctx->latched || w != ctx->w || h != ctx->h) {
+        FrameParams probe;
+        int rc = fill_params(ctx, scene, w, h, (float)time, max_steps, probe);
+        if (rc != RMDF_OK) return rc;
+        const bool resized = (w != ctx->w || h != ctx->h || !ctx->d_rgba8);
+        rc = ensure_frame(ctx, w, h);
+        if (rc != RMDF_OK) return rc;
+        if (resized) { rc = clear_frame(ctx, w, h); if (rc != RMDF_OK) return rc; }
+        ctx->w = w; ctx->h = h; ctx->time = (float)time; ctx->max_steps = max_steps <= 0 ? 128 : max_steps;
+        ctx->latched = true;
+    }
+    FrameParams p;
+    int rc = fill_params(ctx, scene, ctx->w, ctx->h, ctx->time, ctx->max_steps, p);
+    if (rc != RMDF_OK) return rc;
+    if (whole) { p.x0 = 0; p.y0 = 0; p.x1 = ctx->w; p.y1 = ctx->h; }
+    else tile_rect_host(tile_idx, ctx->w, ctx->h, &p.x0, &p.y0, &p.x1, &p.y1);
+    p.rgba8 = ctx->d_rgba8; p.rgba_f32 = ctx->d_rgba_f32; p.steps = ctx->d_steps; p.iters = ctx->d_iters;
+    HIP_TRY(ctx, launch_render(scene, p, ctx->stream));
+    const size_t npx = (size_t)ctx->w * ctx->h;
+    if (out_rgba8) HIP_TRY(ctx, hipMemcpyAsync(out_rgba8, ctx->d_rgba8, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_rgba_f32) HIP_TRY(ctx, hipMemcpyAsync(out_rgba_f32, ctx->d_rgba_f32, npx * 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_steps) HIP_TRY(ctx, hipMemcpyAsync(out_steps, ctx->d_steps, npx * 2, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_iters) HIP_TRY(ctx, hipMemcpyAsync(out_iters, ctx->d_iters, npx * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RMDF_OK;
+}
+
+}  // namespace
+
+namespace rmdf {
+void tile_rect_host(int tile_idx, int w, int h, int *x0, int *y0, int *x1, int *y1)
+{
+    // ShaderRendering.hs:183-193, centre-inside rasterisation (see rmdf_kernels.hip)
+    int midx = tile_idx % 64;
+    int tx = midx % 8, ty = midx / 8;
+    *x0 = (2 * tx * w + 7) / 16;
+    *x1 = (2 * (tx + 1) * w + 7) / 16;
+    *y0 = (2 * ty * h + 7) / 16;
+    *y1 = (2 * (ty + 1) * h + 7) / 16;
+}
+}  // namespace rmdf
+
+extern "C" {
+
+int rmdf_create(rmdf_ctx **out, const rmdf_config *cfg)
+{
+    if (!out) return fail(nullptr, RMDF_E_INVALID, "null out pointer");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, RMDF_E_NO_DEVICE, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0"));
+    int dev = cfg ? cfg->device : 0;
+    if (dev < 0 || dev >= ndev) return fail(nullptr, RMDF_E_INVALID, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return fail(nullptr, RMDF_E_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, RMDF_E_NO_DEVICE, std::string("librmdf is built for gfx950 only, found ") + prop.gcnArchName);
+    rmdf_ctx *ctx = new (std::nothrow) rmdf_ctx();
+    if (!ctx) return fail(nullptr, RMDF_E_NOMEM, "out of host memory");
+    ctx->device = dev;
+    ctx->cus = prop.multiProcessorCount;
+    snprintf(ctx->dev_name, sizeof ctx->dev_name, "%s (%s)", prop.name, prop.gcnArchName);
+    float tri[96 * 3];
+    cornell_triangles(tri);
+    if ((e = hipSetDevice(dev)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipMalloc((void **)&ctx->d_cornell, sizeof tri)) != hipSuccess ||
+        (e = hipMemcpy(ctx->d_cornell, tri, sizeof tri, hipMemcpyHostToDevice)) != hipSuccess) {
+        std::string msg = std::string("device init: ") + hipGetErrorString(e);
+        rmdf_destroy(ctx);
+        return fail(nullptr, RMDF_E_HIP, msg);
+    }
+    *out = ctx;
+    return RMDF_OK;
+}
+
+void rmdf_destroy(rmdf_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &s : ctx->env) if (s.d_texels) (void)hipFree(s.d_texels);
+    if (ctx->d_cornell) (void)hipFree(ctx->d_cornell);
+    if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
+    if (ctx->d_rgba_f32) (void)hipFree(ctx->d_rgba_f32);
+    if (ctx->d_steps) (void)hipFree(ctx->d_steps);
+    if (ctx->d_iters) (void)hipFree(ctx->d_iters);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *rmdf_last_error(const rmdf_ctx *ctx)
+{
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int rmdf_is_tile_idx_first_tile(int idx) { return idx % RMDF_N_TILES == 0; }
+int rmdf_is_tile_idx_last_tile(int idx) { return idx % RMDF_N_TILES == RMDF_N_TILES - 1; }
+
+int rmdf_set_env_cube(rmdf_ctx *ctx, int slot, const float *faces_rgb, int face_w)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (slot < 0 || slot >= RMDF_ENV_SLOTS || !faces_rgb || face_w < 1 || face_w > 8192)
+        return fail(ctx, RMDF_E_INVALID, "rmdf_set_env_cube: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf faces;
+    size_t bytes = (size_t)6 * face_w * face_w * 3 * sizeof(float);
+    HIP_TRY(ctx, hipMalloc(&faces.p, bytes));
+    HIP_TRY(ctx, hipMemcpyAsync(faces.p, faces_rgb, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return set_env_from_device_faces(ctx, slot, (const float *)faces.p, face_w);
+}
+
+int rmdf_set_env_latlong(rmdf_ctx *ctx, int slot, const float *rgb, int w, int h)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (slot < 0 || slot >= RMDF_ENV_SLOTS || !rgb || w < 6 || h < 2 || w > 65536 || h > 32768)
+        return fail(ctx, RMDF_E_INVALID, "rmdf_set_env_latlong: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int cw = w / 3;
+    DevBuf ll, faces;
+    size_t ll_bytes = (size_t)w * h * 3 * sizeof(float), f_bytes = (size_t)6 * cw * cw * 3 * sizeof(float);
+    HIP_TRY(ctx, hipMalloc(&ll.p, ll_bytes));
+    HIP_TRY(ctx, hipMalloc(&faces.p, f_bytes));
+    HIP_TRY(ctx, hipMemcpyAsync(ll.p, rgb, ll_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, launch_latlong_to_cube((const float *)ll.p, w, h, (float *)faces.p, ctx->stream));
+    return set_env_from_device_faces(ctx, slot, (const float *)faces.p, cw);
+}
+
+int rmdf_get_env_cube_padded(rmdf_ctx *ctx, int slot, uint16_t *out, int *face_w)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (slot < 0 || slot >= RMDF_ENV_SLOTS) return fail(ctx, RMDF_E_INVALID, "bad slot");
+    if (!ctx->env[slot].d_texels) return fail(ctx, RMDF_E_NO_ENV, "slot not set");
+    const int W = ctx->env[slot].W;
+    if (face_w) *face_w = W;
+    if (!out) return RMDF_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->env[slot].d_texels, (size_t)6 * (W + 2) * (W + 2) * 8, hipMemcpyDeviceToHost));
+    return RMDF_OK;
+}
+
+int rmdf_resize_latlong(rmdf_ctx *ctx, const float *rgb, int w, int h, int dstw, float *out, int *dsth)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!rgb || w < 2 || h < 2 || dstw < 1 || !dsth) return fail(ctx, RMDF_E_INVALID, "rmdf_resize_latlong: bad argument");
+    // dsth = round (srch / srcw * dstw) in Float, Haskell round = half-to-even (HDREnvMap.hs:173)
+    const int dh = (int)rintf((float)h / (float)w * (float)dstw);
+    *dsth = dh;
+    if (!out) return RMDF_OK;
+    if (dh < 1) return fail(ctx, RMDF_E_INVALID, "destination height < 1");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf src, dst;
+    size_t sb = (size_t)w * h * 12, db = (size_t)dstw * dh * 12;
+    HIP_TRY(ctx, hipMalloc(&src.p, sb));
+    HIP_TRY(ctx, hipMalloc(&dst.p, db));
+    HIP_TRY(ctx, hipMemcpyAsync(src.p, rgb, sb, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, launch_resize_latlong((const float *)src.p, w, h, dstw, dh, (float *)dst.p, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(out, dst.p, db, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RMDF_OK;
+}
+
+int rmdf_prefilter_env(rmdf_ctx *ctx, const float *rgb, int w, int h, float power, float *out)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!rgb || !out || w < 2 || h < 2 || w > 640) return fail(ctx, RMDF_E_INVALID, "rmdf_prefilter_env: bad argument (2 <= w <= 640)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf src, dst;
+    size_t b = (size_t)w * h * 12;
+    HIP_TRY(ctx, hipMalloc(&src.p, b));
+    HIP_TRY(ctx, hipMalloc(&dst.p, b));
+    HIP_TRY(ctx, hipMemcpyAsync(src.p, rgb, b, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, launch_prefilter((const float *)src.p, w, h, power, (float *)dst.p, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(out, dst.p, b, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RMDF_OK;
+}
+
+int rmdf_load_env_hdr(rmdf_ctx *ctx, const char *path)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!path) return fail(ctx, RMDF_E_INVALID, "null path");
+    std::vector<uint8_t> file;
+    if (!read_file(path, file)) return fail(ctx, RMDF_E_IO, std::string("cannot read ") + path);
+    int w = 0, h = 0;
+    std::vector<float> refl;
+    std::string why;
+    if (!decode_hdr(file, w, h, refl, why)) return fail(ctx, RMDF_E_IO, std::string(path) + ": " + why);
+    // powers / cache file names, ShaderRendering.hs:71-75 (`show pow` of a Float: "1.0")
+    static const struct { int slot; const char *suffix; float power; } kPow[4] = {
+        { RMDF_ENV_COS_1, "1.0", 1.0f }, { RMDF_ENV_COS_8, "8.0", 8.0f },
+        { RMDF_ENV_COS_64, "64.0", 64.0f }, { RMDF_ENV_COS_512, "512.0", 512.0f } };
+    std::string stem(path);
+    size_t dot = stem.find_last_of('.'), slash = stem.find_last_of('/');
+    if (dot != std::string::npos && (slash == std::string::npos || dot > slash)) stem = stem.substr(0, dot);
+    std::vector<float> resized;
+    int rw = 256, rh = 0;
+    for (const auto &pw : kPow) {
+        std::string fn = stem + "_cache_pow_" + pw.suffix + ".hdr";
+        if (!file_exists(fn)) {
+            // buildPreConvolvedHDREnvMapCache, ShaderRendering.hs:131-149
+            if (resized.empty()) {
+                int rc = rmdf_resize_latlong(ctx, refl.data(), w, h, rw, nullptr, &rh);
+                if (rc != RMDF_OK) return rc;
+                resized.resize((size_t)rw * rh * 3);
+                rc = rmdf_resize_latlong(ctx, refl.data(), w, h, rw, resized.data(), &rh);
+                if (rc != RMDF_OK) return rc;
+            }
+            std::vector<float> conv((size_t)rw * rh * 3);
+            int rc = rmdf_prefilter_env(ctx, resized.data(), rw, rh, pw.power, conv.data());
+            if (rc != RMDF_OK) return rc;
+            if (!write_hdr(fn, conv, rw, rh)) return fail(ctx, RMDF_E_IO, "cannot write cache file " + fn);
+        }
+        std::vector<uint8_t> cf;
+        if (!read_file(fn.c_str(), cf)) return fail(ctx, RMDF_E_IO, "cannot read cache file " + fn);
+        int cw = 0, chh = 0;
+        std::vector<float> cimg;
+        if (!decode_hdr(cf, cw, chh, cimg, why)) return fail(ctx, RMDF_E_IO, fn + ": " + why);
+        int rc = rmdf_set_env_latlong(ctx, pw.slot, cimg.data(), cw, chh);
+        if (rc != RMDF_OK) return rc;
+    }
+    return rmdf_set_env_latlong(ctx, RMDF_ENV_REFLECTION, refl.data(), w, h);
+}
+
+int rmdf_render_tile(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double time, int max_steps,
+                     uint32_t *out_rgba8)
+{
+    return render_common(ctx, scene, tile_idx, w, h, time, max_steps, out_rgba8, nullptr, nullptr, nullptr);
+}
+
+int rmdf_render_tile_ex(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double time, int max_steps,
+                        uint32_t *out_rgba8, float *out_rgba_f32, uint16_t *out_steps, uint16_t *out_iters)
+{
+    return render_common(ctx, scene, tile_idx, w, h, time, max_steps, out_rgba8, out_rgba_f32, out_steps, out_iters);
+}
+
+int rmdf_render_rect_device(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps,
+                            int x0, int y0, int x1, int y1,
+                            void *d_rgba8, void *d_rgba_f32, void *d_steps, void *d_iters, void *stream)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    FrameParams p;
+    int rc = fill_params(ctx, scene, w, h, (float)time, max_steps, p);
+    if (rc != RMDF_OK) return rc;
+    if (x0 < 0 || y0 < 0 || x1 > w || y1 > h || x0 > x1 || y0 > y1) return fail(ctx, RMDF_E_INVALID, "bad rectangle");
+    p.x0 = x0; p.y0 = y0; p.x1 = x1; p.y1 = y1;
+    p.rgba8 = (uint32_t *)d_rgba8; p.rgba_f32 = (float4 *)d_rgba_f32; p.steps = (uint16_t *)d_steps; p.iters = (uint16_t *)d_iters;
+    HIP_TRY(ctx, launch_render(scene, p, stream ? (hipStream_t)stream : ctx->stream));
+    return RMDF_OK;
+}
+
+int rmdf_render_shard_device(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps,
+                             int rank, int nranks, void *d_packed_rgba8, void *stream)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks || !d_packed_rgba8)
+        return fail(ctx, RMDF_E_INVALID, "rmdf_render_shard_device: bad rank / nranks / buffer");
+    if (w % 8 || h % 8) return fail(ctx, RMDF_E_INVALID, "tile sharding needs w and h divisible by 8");
+    FrameParams p;
+    int rc = fill_params(ctx, scene, w, h, (float)time, max_steps, p);
+    if (rc != RMDF_OK) return rc;
+    p.n_shard_tiles = (RMDF_N_TILES - rank + nranks - 1) / nranks;   // tiles idx = rank, rank+n, ...
+    p.shard_first = rank; p.shard_stride = nranks;
+    p.rgba8 = (uint32_t *)d_packed_rgba8;
+    HIP_TRY(ctx, launch_render(scene, p, stream ? (hipStream_t)stream : ctx->stream));
+    return RMDF_OK;
+}
+
+int rmdf_assemble_shards_device(rmdf_ctx *ctx, int w, int h, int nranks, const void *d_gathered,
+                                void *d_frame_rgba8, void *stream)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (nranks < 1 || nranks > 64 || !d_gathered || !d_frame_rgba8 || w % 8 || h % 8 || w <= 0 || h <= 0)
+        return fail(ctx, RMDF_E_INVALID, "rmdf_assemble_shards_device: bad argument");
+    HIP_TRY(ctx, launch_assemble_shards((const uint32_t *)d_gathered, (uint32_t *)d_frame_rgba8, w, h, nranks,
+                                        stream ? (hipStream_t)stream : ctx->stream));
+    return RMDF_OK;
+}
+
+int rmdf_synchronize(rmdf_ctx *ctx, void *stream)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    HIP_TRY(ctx, hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
+    return RMDF_OK;
+}
+
+int rmdf_device_info(rmdf_ctx *ctx, char *name, int name_len, int *compute_units)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s", ctx->dev_name);
+    if (compute_units) *compute_units = ctx->cus;
+    return RMDF_OK;
+}
+
+}  // extern "C"

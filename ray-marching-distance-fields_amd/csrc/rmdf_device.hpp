@@ -1,0 +1,326 @@
+// rmdf_device.hpp -- per-ray device arithmetic for the gfx950 sphere tracer.
+//
+// Semantics restated from the reference's fragment shader (fragment.shd, cited
+// per function).  float32 throughout, one IEEE rounding per written operation:
+// this file MUST be compiled with -ffp-contract=off and without fast-math, so
+// that step counts and escape-iteration counts are reproducible bit for bit.
+// GLSL built-ins whose precision GLSL leaves open are pinned in DESIGN.md
+// ("spec pins"): inversesqrt = 1/sqrt (both correctly rounded), pow(r,7) =
+// multiply chain, log/exp = fixed-order fdlibm-style float algorithms.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace rmdf {
+
+struct v3 { float x, y, z; };
+
+__device__ __forceinline__ v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+
+// GLSL min/max/clamp: min(x,y) = y < x ? y : x; max(x,y) = x < y ? y : x
+__device__ __forceinline__ float gmin(float x, float y) { return (y < x) ? y : x; }
+__device__ __forceinline__ float gmax(float x, float y) { return (x < y) ? y : x; }
+__device__ __forceinline__ float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
+
+__device__ __forceinline__ float dot3(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float length3(v3 a) { return sqrtf(dot3(a, a)); }
+__device__ __forceinline__ float rsqrt_ieee(float x) { return 1.0f / sqrtf(x); }
+__device__ __forceinline__ v3 normalize3(v3 a)
+{
+    float s = rsqrt_ieee(dot3(a, a));
+    return mk3(a.x * s, a.y * s, a.z * s);
+}
+__device__ __forceinline__ v3 sub3(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 add3(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 reflect3(v3 i, v3 n)
+{
+    float k = 2.0f * dot3(n, i);
+    return mk3(i.x - k * n.x, i.y - k * n.y, i.z - k * n.z);
+}
+
+// log(x), fixed operation order; < 1 ulp
+__device__ __forceinline__ float log_pinned(float x)
+{
+    const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
+    const float Lg1 = 0.66666662693f, Lg2 = 0.40000972152f, Lg3 = 0.28498786688f, Lg4 = 0.24279078841f;
+    int32_t ix = __float_as_int(x);
+    int32_t k = 0;
+    if (ix < 0x00800000) {
+        if ((ix & 0x7fffffff) == 0) return -__builtin_inff();
+        if (ix < 0) return __builtin_nanf("");
+        k = -25;
+        x = x * 33554432.0f;
+        ix = __float_as_int(x);
+    }
+    if (ix >= 0x7f800000) return x + x;
+    k += (ix >> 23) - 127;
+    ix &= 0x007fffff;
+    int32_t i = (ix + 0x4afb20) & 0x800000;
+    x = __int_as_float(ix | (i ^ 0x3f800000));
+    k += (i >> 23);
+    float f = x - 1.0f;
+    float s = f / (2.0f + f);
+    float dk = (float)k;
+    float z = s * s;
+    float w = z * z;
+    float t1 = w * (Lg2 + w * Lg4);
+    float t2 = z * (Lg1 + w * Lg3);
+    float R = t2 + t1;
+    float hfsq = (0.5f * f) * f;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+// exp(x), fixed operation order; x < -87 -> 0, x > 88.5 -> inf
+__device__ __forceinline__ float exp_pinned(float x)
+{
+    const float ln2_hi = 6.9314575195e-01f, ln2_lo = 1.4286067653e-06f, invln2 = 1.4426950216e+00f;
+    const float P1 = 1.6666625440e-1f, P2 = -2.7667332906e-3f;
+    if (x != x) return x;
+    if (x > 88.5f) return __builtin_inff();
+    if (x < -87.0f) return 0.0f;
+    float kf = x * invln2 + ((x < 0.0f) ? -0.5f : 0.5f);
+    int32_t k = (int32_t)kf;
+    float t = (float)k;
+    float hi = x - t * ln2_hi;
+    float lo = t * ln2_lo;
+    float r = hi - lo;
+    float tt = r * r;
+    float c = r - tt * (P1 + tt * P2);
+    float y = 1.0f - ((lo - (r * c) / (2.0f - c)) - hi);
+    int32_t k1 = k / 2, k2 = k - k1;
+    y = y * __int_as_float((k1 + 127) << 23);
+    y = y * __int_as_float((k2 + 127) << 23);
+    return y;
+}
+
+// pow(x,y) = exp(y*log(x)); x <= 0 or NaN -> 0 (GLSL leaves it undefined)
+__device__ __forceinline__ float pow_pinned(float x, float y)
+{
+    if (!(x > 0.0f)) return 0.0f;
+    return exp_pinned(y * log_pinned(x));
+}
+
+// ---- distance estimators ---------------------------------------------------------
+
+// fragment.shd:74-99
+__device__ __forceinline__ v3 triplex_pow8(v3 w)
+{
+    float x = w.x; float x2 = x * x; float x4 = x2 * x2;
+    float y = w.y; float y2 = y * y; float y4 = y2 * y2;
+    float z = w.z; float z2 = z * z; float z4 = z2 * z2;
+
+    float k3 = y2 + x2;
+    float k2 = rsqrt_ieee(k3 * k3 * k3 * k3 * k3 * k3 * k3);
+    float k1 = y4 + z4 + x4 - 6.0f * z2 * x2 - 6.0f * y2 * z2 + 2.0f * x2 * y2;
+    float k4 = y2 - z2 + x2;
+
+    return mk3(-8.0f * z * k4 * (y4 * y4 - 28.0f * y4 * y2 * x2 + 70.0f * y4 * x4 - 28.0f * y2 * x2 * x4 + x4 * x4) * k1 * k2,
+               64.0f * y * z * x * (y2 - x2) * k4 * (y4 - 6.0f * y2 * x2 + x4) * k1 * k2,
+               -16.0f * z2 * k3 * k4 * k4 + k1 * k1);
+}
+
+// fragment.shd:101-158 (POWER8); iters counts the iterations that ran triplex_pow8
+__device__ __forceinline__ float de_mandelbulb8(v3 pos, unsigned &iters)
+{
+    pos = mk3(pos.z, pos.x, pos.y);
+    v3 w = pos;
+    float dr = 1.0f;
+    float r = 0.0f;
+    for (int i = 0; i < 25; i++) {
+        r = length3(w);
+        if (r > 4.0f) break;
+        w = triplex_pow8(w);
+        w = add3(w, pos);
+        float r2 = r * r, r4 = r2 * r2, r7 = (r4 * r2) * r;
+        dr = r7 * 8.0f * dr + 1.0f;
+        iters++;
+    }
+    return 0.5f * log_pinned(r) * r / dr;
+}
+
+// fragment.shd:312-321
+__device__ __forceinline__ float line_seg_min_dist_sq(v3 a, v3 b, v3 p)
+{
+    v3 ab = sub3(b, a);
+    float len_sq = dot3(ab, ab);
+    float t = dot3(sub3(p, a), ab) / len_sq;
+    t = gclamp(t, 0.0f, 1.0f);
+    v3 proj = mk3(a.x + t * ab.x, a.y + t * ab.y, a.z + t * ab.z);
+    v3 d = sub3(p, proj);
+    return dot3(d, d);
+}
+
+// fragment.shd:348-372 (compute_barycentric 323-346 inlined)
+__device__ __forceinline__ float de_triangle(v3 pos, v3 v0, v3 v1, v3 v2)
+{
+    v3 e0 = sub3(v2, v0);
+    v3 e1 = sub3(v1, v0);
+    v3 e2 = sub3(pos, v0);
+    float dot00 = dot3(e0, e0);
+    float dot01 = dot3(e0, e1);
+    float dot02 = dot3(e0, e2);
+    float dot11 = dot3(e1, e1);
+    float dot12 = dot3(e1, e2);
+    float inv_denom = 1.0f / (dot00 * dot11 - dot01 * dot01);
+    float u = (dot11 * dot02 - dot01 * dot12) * inv_denom;
+    float v = (dot00 * dot12 - dot01 * dot02) * inv_denom;
+    if ((u >= 0.0f) && (v >= 0.0f) && (u + v < 1.0f)) {
+        float k = 1.0f - (u + v);
+        v3 pp = mk3(v2.x * u + v1.x * v + v0.x * k,
+                    v2.y * u + v1.y * v + v0.y * k,
+                    v2.z * u + v1.z * v + v0.z * k);
+        return length3(sub3(pos, pp));
+    }
+    return sqrtf(gmin(line_seg_min_dist_sq(v0, v1, pos),
+                      gmin(line_seg_min_dist_sq(v0, v2, pos), line_seg_min_dist_sq(v1, v2, pos))));
+}
+
+// fragment.shd:374-411; tri = 96 vertices (wave-uniform -> scalar loads)
+__device__ __forceinline__ float de_cornell_box(v3 pos, const float *__restrict__ tri)
+{
+    float dist = 999.0f;
+    for (int i = 0; i < 32; i++) {
+        const float *t = tri + i * 9;
+        dist = gmin(dist, de_triangle(pos, mk3(t[0], t[1], t[2]), mk3(t[3], t[4], t[5]), mk3(t[6], t[7], t[8])));
+    }
+    return dist;
+}
+
+// fragment.shd:694-719
+__device__ __forceinline__ float fresnel_conductor(float cosi, float eta, float k)
+{
+    float tmp = (eta * eta + k * k) * cosi * cosi;
+    float r_parallel_2 = (tmp - (2.0f * eta * cosi) + 1.0f) / (tmp + (2.0f * eta * cosi) + 1.0f);
+    float tmp_f = eta * eta + k * k;
+    float r_perpend_2 = (tmp_f - (2.0f * eta * cosi) + cosi * cosi) / (tmp_f + (2.0f * eta * cosi) + cosi * cosi);
+    return (r_parallel_2 + r_perpend_2) / 2.0f;
+}
+
+// fragment.shd:595-616, spherePos = 0
+__device__ __forceinline__ bool ray_sphere(v3 origin, v3 dir, float R, float &tmin, float &tmax)
+{
+    v3 rs = mk3(0.0f - origin.x, 0.0f - origin.y, 0.0f - origin.z);
+    float t = dot3(dir, rs);
+    float a = dot3(rs, rs) - t * t;
+    float r2 = R * R;
+    if (a > r2) return false;
+    float h = sqrtf(r2 - a);
+    tmin = t - h;
+    tmax = t + h;
+    return true;
+}
+
+// ---- samplerCube: RGB16F texels, min NEAREST / mag LINEAR, seamless (padded) -------
+
+struct CubeDev {
+    const uint2 *texels;   // 6 * (W+2)^2 texels of 4 halfs (r,g,b,0)
+    int W;
+};
+
+__device__ __forceinline__ void cube_coords(v3 r, int &face, float &sc, float &tc, float &ma)
+{
+    float ax = fabsf(r.x), ay = fabsf(r.y), az = fabsf(r.z);
+    if (ax >= ay && ax >= az) {
+        if (r.x > 0.0f) { face = 0; sc = -r.z; tc = -r.y; ma = r.x; }
+        else            { face = 1; sc =  r.z; tc = -r.y; ma = r.x; }
+    } else if (ay >= az) {
+        if (r.y > 0.0f) { face = 2; sc =  r.x; tc =  r.z; ma = r.y; }
+        else            { face = 3; sc =  r.x; tc = -r.z; ma = r.y; }
+    } else {
+        if (r.z > 0.0f) { face = 4; sc =  r.x; tc = -r.y; ma = r.z; }
+        else            { face = 5; sc = -r.x; tc = -r.y; ma = r.z; }
+    }
+}
+
+__device__ __forceinline__ void cube_project(int face, v3 q, float &sc, float &tc, float &ma)
+{
+    switch (face) {
+    case 0:  sc = -q.z; tc = -q.y; ma = q.x; break;
+    case 1:  sc =  q.z; tc = -q.y; ma = q.x; break;
+    case 2:  sc =  q.x; tc =  q.z; ma = q.y; break;
+    case 3:  sc =  q.x; tc = -q.z; ma = q.y; break;
+    case 4:  sc =  q.x; tc = -q.y; ma = q.z; break;
+    default: sc = -q.x; tc = -q.y; ma = q.z; break;
+    }
+}
+
+__device__ __forceinline__ float cube_texcoord(float c, float ama, float W) { return (0.5f * (c / ama + 1.0f)) * W; }
+
+__device__ __forceinline__ v3 texel_rgb(uint2 t)
+{
+    __half2 rg = *reinterpret_cast<__half2 *>(&t.x);
+    __half2 b0 = *reinterpret_cast<__half2 *>(&t.y);
+    return mk3(__low2float(rg), __high2float(rg), __low2float(b0));
+}
+
+__device__ __forceinline__ v3 cube_fetch_nearest(const CubeDev &c, int face, float u, float v)
+{
+    float Wm1 = (float)(c.W - 1);
+    float fi = floorf(u), fj = floorf(v);
+    if (!(fi >= 0.0f)) fi = 0.0f;
+    if (fi > Wm1) fi = Wm1;
+    if (!(fj >= 0.0f)) fj = 0.0f;
+    if (fj > Wm1) fj = Wm1;
+    int P = c.W + 2;
+    return texel_rgb(c.texels[(face * P + ((int)fj + 1)) * P + ((int)fi + 1)]);
+}
+
+__device__ __forceinline__ v3 cube_fetch_linear(const CubeDev &c, int face, float u, float v)
+{
+    float Wm1 = (float)(c.W - 1);
+    float ub = u - 0.5f, vb = v - 0.5f;
+    float fi = floorf(ub), fj = floorf(vb);
+    if (!(fi >= -1.0f)) fi = -1.0f;
+    if (fi > Wm1) fi = Wm1;
+    if (!(fj >= -1.0f)) fj = -1.0f;
+    if (fj > Wm1) fj = Wm1;
+    float fu = ub - fi, fv = vb - fj;
+    float gu = 1.0f - fu, gv = 1.0f - fv;
+    int P = c.W + 2;
+    const uint2 *row0 = c.texels + (face * P + ((int)fj + 1)) * P + ((int)fi + 1);
+    v3 t00 = texel_rgb(row0[0]), t10 = texel_rgb(row0[1]);
+    v3 t01 = texel_rgb(row0[P]), t11 = texel_rgb(row0[P + 1]);
+    v3 o;
+    o.x = (t00.x * gu + t10.x * fu) * gv + (t01.x * gu + t11.x * fu) * fv;
+    o.y = (t00.y * gu + t10.y * fu) * gv + (t01.y * gu + t11.y * fu) * fv;
+    o.z = (t00.z * gu + t10.z * fu) * gv + (t01.z * gu + t11.z * fu) * fv;
+    return o;
+}
+
+// texture(samplerCube, r) inside a 2x2 quad; rh / rv = the same expression in the
+// horizontal / vertical quad neighbour, valid_* = that neighbour evaluated it.
+__device__ __forceinline__ v3 cube_texture(const CubeDev &c, v3 r, bool valid_h, v3 rh, bool valid_v, v3 rv)
+{
+    int face; float sc, tc, ma;
+    cube_coords(r, face, sc, tc, ma);
+    float W = (float)c.W, ama = fabsf(ma);
+    float u = cube_texcoord(sc, ama, W), v = cube_texcoord(tc, ama, W);
+    bool linear = false;
+    if (valid_h && valid_v) {
+        float sh, th, mh, sv, tv, mv;
+        cube_project(face, rh, sh, th, mh);
+        cube_project(face, rv, sv, tv, mv);
+        bool pos = (face & 1) == 0;
+        bool okh = pos ? (mh > 0.0f) : (mh < 0.0f);
+        bool okv = pos ? (mv > 0.0f) : (mv < 0.0f);
+        if (okh && okv) {
+            float amh = fabsf(mh), amv = fabsf(mv);
+            float dux = cube_texcoord(sh, amh, W) - u, dvx = cube_texcoord(th, amh, W) - v;
+            float duy = cube_texcoord(sv, amv, W) - u, dvy = cube_texcoord(tv, amv, W) - v;
+            float rx = dux * dux + dvx * dvx;
+            float ry = duy * duy + dvy * dvy;
+            linear = (rx <= 1.0f) && (ry <= 1.0f);
+        }
+    }
+    return linear ? cube_fetch_linear(c, face, u, v) : cube_fetch_nearest(c, face, u, v);
+}
+
+__device__ __forceinline__ uint32_t to_unorm8(float g)
+{
+    if (!(g == g)) return 0u;
+    return (uint32_t)rintf(gclamp(g, 0.0f, 1.0f) * 255.0f);
+}
+
+}  // namespace rmdf

@@ -1,0 +1,46 @@
+// rmdf_internal.hpp -- structures shared by the C-ABI host code and the kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rmdf_device.hpp"
+
+namespace rmdf {
+
+// Everything one frame's kernels need; passed by value (kernarg segment).
+struct FrameParams {
+    // camera block of main() (fragment.shd:883-902) computed once on the host:
+    // xaxis, yaxis, zaxis, eye of lookat() (829-838)
+    float cam[12];
+    float fov_xs;             // tan(radians(67.5)/2), fragment.shd:866-867
+    float wf, hf, aspect;     // in_screen_wdh, in_screen_hgt, wdh/hgt
+    int   w, h;
+    int   max_steps;          // fragment.shd:634
+    // pixel rectangle to produce (single-rect mode, n_shard_tiles == 0)
+    int   x0, y0, x1, y1;
+    // tile-shard mode: blockIdx.z = slot; tile idx = shard_first + slot*shard_stride
+    int   n_shard_tiles, shard_first, shard_stride;
+    // outputs: element (px,py) lives at out_base + (px-ox) + (py-oy)*pitch, where for
+    // single-rect mode ox=oy=0,pitch=w and for shard mode the slot's packed tile
+    CubeDev env_refl, env_cos1, env_cos8;
+    const float *cornell;     // 96 vertices
+    uint32_t *rgba8;
+    float4   *rgba_f32;
+    uint16_t *steps;
+    uint16_t *iters;
+};
+
+// tile idx -> pixel rectangle (ShaderRendering.hs:183-193), host copy in rmdf_api.cpp
+void tile_rect_host(int tile_idx, int w, int h, int *x0, int *y0, int *x1, int *y1);
+
+// kernels / launchers implemented in rmdf_kernels.hip
+hipError_t launch_render(int scene, const FrameParams &p, hipStream_t stream);
+hipError_t launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t stream);
+hipError_t launch_cube_upload(const float *d_faces_f32, int W, uint2 *d_padded, hipStream_t stream);
+hipError_t launch_latlong_to_cube(const float *d_latlong, int w, int h, float *d_faces_f32, hipStream_t stream);
+hipError_t launch_resize_latlong(const float *d_src, int sw, int sh, int dstw, int dsth, float *d_out, hipStream_t stream);
+hipError_t launch_prefilter(const float *d_src, int w, int h, float power, float *d_out, hipStream_t stream);
+hipError_t launch_assemble_shards(const uint32_t *d_gathered, uint32_t *d_frame, int w, int h, int nranks, hipStream_t stream);
+
+}  // namespace rmdf

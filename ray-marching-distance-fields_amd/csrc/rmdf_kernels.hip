@@ -1,0 +1,504 @@
+// rmdf_kernels.hip -- gfx950 kernels of the sphere tracer and its env-map data prep.
+//
+// Compile with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fast-math).
+// Geometry of the render kernel: one 64-lane wavefront = one 8x8 pixel packet
+// (16 GL-style 2x2 quads, 4 consecutive lanes = one quad so that the quad
+// neighbours needed by the cube-map min/mag decision are lane^1 and lane^2),
+// one 256-thread workgroup = a 32x8 pixel strip.  No MFMA: the path is scalar
+// per ray.  See DESIGN.md for the roofline that bounds it.
+#include "rmdf_internal.hpp"
+
+namespace rmdf {
+
+// ------------------------------------------------------------------------------------
+// tile -> pixel rectangle, ShaderRendering.hs:183-193 (centre-inside rasterisation of
+// the NDC rect; exact when 8 divides w and h)
+// ------------------------------------------------------------------------------------
+__host__ __device__ inline void tile_rect(int tile_idx, int w, int h, int &x0, int &y0, int &x1, int &y1)
+{
+    int midx = tile_idx % 64;
+    int tx = midx % 8, ty = midx / 8;
+    // pixel centre x+0.5 in [tx*w/8, (tx+1)*w/8)  <=>  x in [ceil(tx*w/8 - 0.5), ceil((tx+1)*w/8 - 0.5))
+    x0 = (2 * tx * w + 7) / 16;        // ceil((2*tx*w - 8) / 16) = floor((2*tx*w + 7) / 16)
+    x1 = (2 * (tx + 1) * w + 7) / 16;
+    y0 = (2 * ty * h + 7) / 16;
+    y1 = (2 * (ty + 1) * h + 7) / 16;
+}
+
+template <typename T>
+__device__ __forceinline__ T shfl_xor_w(T v, int mask) { return __shfl_xor(v, mask, 64); }
+
+__device__ __forceinline__ v3 shfl_xor3(v3 a, int mask)
+{
+    return mk3(__shfl_xor(a.x, mask, 64), __shfl_xor(a.y, mask, 64), __shfl_xor(a.z, mask, 64));
+}
+
+template <int SCENE>
+__device__ __forceinline__ float distance_estimator(v3 pos, const FrameParams &p, unsigned &iters)
+{
+    if (SCENE == 2) return de_mandelbulb8(pos, iters);
+    else            return de_cornell_box(pos, p.cornell);
+}
+
+template <int SCENE>
+__device__ __forceinline__ float bsphere_r() { return SCENE == 2 ? 1.15f : (SCENE == 3 ? 1.5f : 1.0f); }
+
+// ------------------------------------------------------------------------------------
+// v1 render kernel: per-lane nested loops (march loop around the DE loop)
+// ------------------------------------------------------------------------------------
+template <int SCENE>
+__global__ __launch_bounds__(256) void k_render(const FrameParams p)
+{
+    // rectangle of this launch / shard slot
+    int rx0, ry0, rx1, ry1, pitch, ox, oy;
+    size_t obase;
+    if (p.n_shard_tiles > 0) {
+        int slot = blockIdx.z;
+        tile_rect(p.shard_first + slot * p.shard_stride, p.w, p.h, rx0, ry0, rx1, ry1);
+        pitch = rx1 - rx0; ox = rx0; oy = ry0;
+        obase = (size_t)slot * (size_t)(p.w / 8) * (size_t)(p.h / 8);
+    } else {
+        rx0 = p.x0; ry0 = p.y0; rx1 = p.x1; ry1 = p.y1;
+        pitch = p.w; ox = 0; oy = 0; obase = 0;
+    }
+    // GL quads are aligned to even window coordinates: helper pixels outside the
+    // rectangle are computed (not written) so that derivatives match a full-frame render
+    const int ex0 = rx0 & ~1, ey0 = ry0 & ~1;
+    const int ex1 = (rx1 + 1) & ~1, ey1 = (ry1 + 1) & ~1;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lx = (lane & 1) | (((lane >> 2) & 3) << 1);
+    const int ly = ((lane >> 1) & 1) | (((lane >> 4) & 3) << 1);
+    const int px = ex0 + blockIdx.x * 32 + wave * 8 + lx;
+    const int py = ey0 + blockIdx.y * 8 + ly;
+    const bool active = (px < ex1) && (py < ey1);
+
+    // generate_ray, perspective branch (fragment.shd:840-871)
+    const float ndcx = ((float)px + 0.5f) / p.wf * 2.0f - 1.0f;
+    const float ndcy = ((float)py + 0.5f) / p.hf * 2.0f - 1.0f;
+    const v3 dcam = normalize3(mk3(ndcx * p.fov_xs, ndcy * p.fov_xs / p.aspect, -1.0f));
+    const v3 dir = mk3(p.cam[0] * dcam.x + p.cam[3] * dcam.y + p.cam[6] * dcam.z,
+                       p.cam[1] * dcam.x + p.cam[4] * dcam.y + p.cam[7] * dcam.z,
+                       p.cam[2] * dcam.x + p.cam[5] * dcam.y + p.cam[8] * dcam.z);
+    const v3 origin = mk3(p.cam[9], p.cam[10], p.cam[11]);
+
+    // ray_march (fragment.shd:618-676)
+    bool hit = false;
+    int steps = 0;
+    unsigned iters = 0;
+    float t = 0.0f;
+    float tmin, tmax;
+    if (active && ray_sphere(origin, dir, bsphere_r<SCENE>(), tmin, tmax)) {
+        t = gmax(0.0f, tmin);
+        for (steps = 0; steps < p.max_steps; steps++) {
+            v3 pos = mk3(origin.x + t * dir.x, origin.y + t * dir.y, origin.z + t * dir.z);
+            float dist = distance_estimator<SCENE>(pos, p, iters);
+            t += dist;
+            if (t > tmax) break;
+            if (dist < 0.001f) { hit = true; break; }
+        }
+    }
+
+    // render_ray hit branch up to the texture lookups (fragment.shd:743-799)
+    v3 n = mk3(0.0f, 0.0f, 0.0f), refl = mk3(0.0f, 0.0f, 0.0f);
+    float ao = 0.0f, fresnel = 0.0f;
+    if (hit) {
+        v3 isec = mk3(origin.x + dir.x * t, origin.y + dir.y * t, origin.z + dir.z * t);
+        v3 np = mk3(isec.x - dir.x * 0.00001f, isec.y - dir.y * 0.00001f, isec.z - dir.z * 0.00001f);
+        const float eps = 0.00001f;
+        float d0 = distance_estimator<SCENE>(np, p, iters);
+        float dx = distance_estimator<SCENE>(mk3(np.x - eps, np.y - 0.0f, np.z - 0.0f), p, iters);
+        float dy = distance_estimator<SCENE>(mk3(np.x - 0.0f, np.y - eps, np.z - 0.0f), p, iters);
+        float dz = distance_estimator<SCENE>(mk3(np.x - 0.0f, np.y - 0.0f, np.z - eps), p, iters);
+        n = normalize3(mk3(d0 - dx, d0 - dy, d0 - dz));
+        // distance_ao (fragment.shd:542-591)
+        float occl = 0.0f;
+        if (SCENE != 0) {
+            const float w0 = 0.5f, e0 = 0.016f, w1 = 0.25f, e1 = 0.081f;
+            occl += w0 * gclamp(1.0f - distance_estimator<SCENE>(mk3(isec.x + n.x * e0, isec.y + n.y * e0, isec.z + n.z * e0), p, iters) / e0, 0.0f, 1.0f);
+            occl += w1 * gclamp(1.0f - distance_estimator<SCENE>(mk3(isec.x + n.x * e1, isec.y + n.y * e1, isec.z + n.z * e1), p, iters) / e1, 0.0f, 1.0f);
+            occl = 1.0f - occl;
+            occl -= 0.29f;
+            occl *= 3.5f;
+            occl *= occl;
+            ao = gclamp(occl, 0.0f, 1.0f);
+        } else {
+            const float wt[4] = { 0.1f, 0.2f, 0.125f, 0.0625f }, dl[4] = { 0.1f, 0.2f, 0.4f, 0.5f };
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                occl += wt[k] * gclamp(1.0f - distance_estimator<SCENE>(mk3(isec.x + n.x * dl[k], isec.y + n.y * dl[k], isec.z + n.z * dl[k]), p, iters) / dl[k], 0.0f, 1.0f);
+            ao = 1.0f - occl;
+        }
+        fresnel = fresnel_conductor(dot3(mk3(-dir.x, -dir.y, -dir.z), n), 0.4f, 0.8f);
+        refl = reflect3(dir, n);
+    }
+
+    // quad neighbours (lane^1 = horizontal, lane^2 = vertical)
+    const int hit_i = hit ? 1 : 0;
+    const bool hit_h = shfl_xor_w(hit_i, 1) != 0, hit_v = shfl_xor_w(hit_i, 2) != 0;
+    const v3 n_h = shfl_xor3(n, 1), n_v = shfl_xor3(n, 2);
+    const v3 refl_h = shfl_xor3(refl, 1), refl_v = shfl_xor3(refl, 2);
+    const v3 dir_h = shfl_xor3(dir, 1), dir_v = shfl_xor3(dir, 2);
+
+    v3 color;
+    if (hit) {
+        // fragment.shd:799-810
+        v3 t1 = cube_texture(p.env_cos1, n, hit_h, n_h, hit_v, n_v);
+        v3 t8 = cube_texture(p.env_cos8, refl, hit_h, refl_h, hit_v, refl_v);
+        v3 tr = cube_texture(p.env_refl, refl, hit_h, refl_h, hit_v, refl_v);
+        const float diff_weight = 0.5f, spec_weight = 1.0f - 0.5f, npl = (8.0f + 2.0f) / 2.0f;
+        color.x = (t1.x * 1.0f * diff_weight + t8.x * 0.8f * npl * fresnel * spec_weight + tr.x * spec_weight * fresnel * 0.1f) * 3.0f * ao;
+        color.y = (t1.y * 0.8f * diff_weight + t8.y * 0.8f * npl * fresnel * spec_weight + tr.y * spec_weight * fresnel * 0.1f) * 3.0f * ao;
+        color.z = (t1.z * 0.8f * diff_weight + t8.z * 1.0f * npl * fresnel * spec_weight + tr.z * spec_weight * fresnel * 0.1f) * 3.0f * ao;
+    } else {
+        // fragment.shd:823
+        color = cube_texture(p.env_refl, dir, true, dir_h, true, dir_v);
+    }
+
+    // fragment.shd:959-960 and the RGBA8 conversion of the colour attachment
+    const float inv_gamma = 1.0f / 2.2f;
+    const float gr = pow_pinned(color.x, inv_gamma), gg = pow_pinned(color.y, inv_gamma), gb = pow_pinned(color.z, inv_gamma);
+    if (active && px >= rx0 && px < rx1 && py >= ry0 && py < ry1) {
+        const size_t idx = obase + (size_t)(px - ox) + (size_t)(py - oy) * (size_t)pitch;
+        if (p.rgba8) p.rgba8[idx] = to_unorm8(gr) | (to_unorm8(gg) << 8) | (to_unorm8(gb) << 16) | 0xff000000u;
+        if (p.rgba_f32) p.rgba_f32[idx] = make_float4(gr, gg, gb, 1.0f);
+        if (p.steps) p.steps[idx] = (uint16_t)(steps | (hit_i << 15));
+        if (p.iters) p.iters[idx] = (uint16_t)(iters > 65535u ? 65535u : iters);
+    }
+}
+
+hipError_t launch_render(int scene, const FrameParams &p, hipStream_t stream)
+{
+    int rx0, ry0, rx1, ry1, nz = 1;
+    if (p.n_shard_tiles > 0) {
+        // all tiles have the same size when 8 | w and 8 | h (required in shard mode)
+        // a tile may start and end on odd coordinates: up to one helper column/row per side
+        rx0 = 0; ry0 = 0; rx1 = p.w / 8 + 2; ry1 = p.h / 8 + 2;
+        nz = p.n_shard_tiles;
+    } else {
+        rx0 = p.x0; ry0 = p.y0; rx1 = p.x1; ry1 = p.y1;
+    }
+    const int ex0 = rx0 & ~1, ey0 = ry0 & ~1, ex1 = (rx1 + 1) & ~1, ey1 = (ry1 + 1) & ~1;
+    if (ex1 <= ex0 || ey1 <= ey0) return hipSuccess;
+    dim3 grid((ex1 - ex0 + 31) / 32, (ey1 - ey0 + 7) / 8, nz), block(256);
+    if (scene == 2)      hipLaunchKernelGGL(k_render<2>, grid, block, 0, stream, p);
+    else if (scene == 0) hipLaunchKernelGGL(k_render<0>, grid, block, 0, stream, p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// small utility kernels
+// ------------------------------------------------------------------------------------
+__global__ void k_fill_u32(uint32_t *dst, uint32_t value, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = value;
+}
+
+hipError_t launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, stream, dst, value, n);
+    return hipGetLastError();
+}
+
+// After the gather: shard r holds tiles r, r+n, r+2n, ... in slots 0,1,2,...; every
+// rank's shard has ceil(64/n) slots.  One thread per frame pixel (coalesced writes).
+__global__ void k_assemble_shards(const uint32_t *__restrict__ gathered, uint32_t *__restrict__ frame,
+                                  int w, int h, int nranks)
+{
+    const int tw = w / 8, th = h / 8;
+    const int slots = (64 + nranks - 1) / nranks;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)w * h, stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        int px = (int)(i % w), py = (int)(i / w);
+        int tx = px / tw, ty = py / th;
+        int idx = tx + ty * 8;
+        int rank = idx % nranks, slot = idx / nranks;
+        size_t src = ((size_t)rank * slots + slot) * (size_t)tw * th + (size_t)(px - tx * tw) + (size_t)(py - ty * th) * tw;
+        frame[i] = gathered[src];
+    }
+}
+
+hipError_t launch_assemble_shards(const uint32_t *d_gathered, uint32_t *d_frame, int w, int h, int nranks, hipStream_t stream)
+{
+    size_t n = (size_t)w * h;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_assemble_shards, dim3(blocks), dim3(256), 0, stream, d_gathered, d_frame, w, h, nranks);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// RGB16F upload with seamless border (the texImage2D RGB16F of HDREnvMap.hs:160-161 +
+// GL_TEXTURE_CUBE_MAP_SEAMLESS, :126).  Border rule: DESIGN.md "spec pins".
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void cube_int_dir(int face, int W, int cw, int ch, int d[3])
+{
+    switch (face) {
+    case 0:  d[0] =  W;  d[1] = -ch; d[2] = -cw; break;
+    case 1:  d[0] = -W;  d[1] = -ch; d[2] =  cw; break;
+    case 2:  d[0] =  cw; d[1] =  W;  d[2] =  ch; break;
+    case 3:  d[0] =  cw; d[1] = -W;  d[2] = -ch; break;
+    case 4:  d[0] =  cw; d[1] = -ch; d[2] =  W;  break;
+    default: d[0] = -cw; d[1] = -ch; d[2] = -W;  break;
+    }
+}
+
+// texel (x,y) of `face` with exactly one coordinate out of range by one -> the texel
+// adjacent across the cube edge
+__device__ __forceinline__ void cube_fold(int face, int W, int x, int y, int &nf, int &nx, int &ny)
+{
+    int d[3];
+    cube_int_dir(face, W, 2 * x + 1 - W, 2 * y + 1 - W, d);
+    int major = face >> 1;
+    int over = -1;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        if (a != (face >> 1) && over < 0 && (d[a] > W || d[a] < -W)) over = a;
+    if (over >= 0) {
+        int keep = (d[major] > 0) ? W - 1 : -(W - 1);
+        int nd[3] = { d[0], d[1], d[2] };
+        nd[over] = (d[over] > 0) ? W : -W;
+        nd[major] = keep;
+        d[0] = nd[0]; d[1] = nd[1]; d[2] = nd[2];
+        major = over;
+    }
+    int f = major * 2 + (d[major] > 0 ? 0 : 1);
+    int cw, ch;
+    switch (f) {
+    case 0:  ch = -d[1]; cw = -d[2]; break;
+    case 1:  ch = -d[1]; cw =  d[2]; break;
+    case 2:  cw =  d[0]; ch =  d[2]; break;
+    case 3:  cw =  d[0]; ch = -d[2]; break;
+    case 4:  cw =  d[0]; ch = -d[1]; break;
+    default: cw = -d[0]; ch = -d[1]; break;
+    }
+    nf = f; nx = (cw + W - 1) / 2; ny = (ch + W - 1) / 2;
+}
+
+__device__ __forceinline__ __half src_half(const float *faces, int W, int f, int x, int y, int k)
+{
+    return __float2half_rn(faces[(((size_t)f * W + y) * W + x) * 3 + k]);
+}
+
+__global__ void k_cube_upload(const float *__restrict__ faces, int W, uint2 *__restrict__ padded)
+{
+    const int P = W + 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 6 * P * P) return;
+    const int X = i % P, Y = (i / P) % P, f = i / (P * P);
+    const int x = X - 1, y = Y - 1;
+    const bool ox = (x < 0 || x >= W), oy = (y < 0 || y >= W);
+    __half c[3];
+    if (!ox && !oy) {
+        for (int k = 0; k < 3; k++) c[k] = src_half(faces, W, f, x, y, k);
+    } else if (ox != oy) {
+        int nf, nx, ny;
+        cube_fold(f, W, x, y, nf, nx, ny);
+        for (int k = 0; k < 3; k++) c[k] = src_half(faces, W, nf, nx, ny, k);
+    } else {
+        const int cx = x < 0 ? 0 : W - 1, cy = y < 0 ? 0 : W - 1;
+        int f1, x1, y1, f2, x2, y2;
+        cube_fold(f, W, x, cy, f1, x1, y1);
+        cube_fold(f, W, cx, y, f2, x2, y2);
+        for (int k = 0; k < 3; k++) {
+            float a = __half2float(src_half(faces, W, f, cx, cy, k));
+            float b = __half2float(src_half(faces, W, f1, x1, y1, k));
+            float cc = __half2float(src_half(faces, W, f2, x2, y2, k));
+            c[k] = __float2half_rn(((a + b) + cc) / 3.0f);
+        }
+    }
+    uint2 t;
+    t.x = (uint32_t)__half_as_ushort(c[0]) | ((uint32_t)__half_as_ushort(c[1]) << 16);
+    t.y = (uint32_t)__half_as_ushort(c[2]);
+    padded[i] = t;
+}
+
+hipError_t launch_cube_upload(const float *d_faces_f32, int W, uint2 *d_padded, hipStream_t stream)
+{
+    const int n = 6 * (W + 2) * (W + 2);
+    hipLaunchKernelGGL(k_cube_upload, dim3((n + 255) / 256), dim3(256), 0, stream, d_faces_f32, W, d_padded);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// latLongHDREnvMapToCubeMap (HDREnvMap.hs:118-163) on the device: one thread per texel.
+// acosf / atanf are the device libm's (the reference calls glibc's through GHC), so
+// this kernel is tolerance-checked, not bit-checked.
+// ------------------------------------------------------------------------------------
+#define RMDF_PI_F 3.14159265358979323846f
+
+// pixelAtBilinear, HDREnvMap.hs:91-113 (keeps the `mod (w-1)` / `min (h-1)` quirks)
+__device__ __forceinline__ v3 pixel_at_bilinear(const float *__restrict__ img, int w, int h, float u, float v)
+{
+    const float upx = u * ((float)w - 1.0f), upy = v * ((float)h - 1.0f);
+    const int x = (int)floorf(upx), y = (int)floorf(upy);
+    const int m = w - 1;
+    int xp1 = (x + 1) % m;
+    if (xp1 < 0) xp1 += m;
+    const int yp1 = (y + 1 < h - 1) ? y + 1 : h - 1;
+    const float ur = upx - (float)x, vr = upy - (float)y;
+    const float uo = 1.0f - ur, vo = 1.0f - vr;
+    const float *a = img + ((size_t)x + (size_t)y * w) * 3, *b = img + ((size_t)xp1 + (size_t)y * w) * 3;
+    const float *c = img + ((size_t)x + (size_t)yp1 * w) * 3, *d = img + ((size_t)xp1 + (size_t)yp1 * w) * 3;
+    return mk3((a[0] * uo + b[0] * ur) * vo + (c[0] * uo + d[0] * ur) * vr,
+               (a[1] * uo + b[1] * ur) * vo + (c[1] * uo + d[1] * ur) * vr,
+               (a[2] * uo + b[2] * ur) * vo + (c[2] * uo + d[2] * ur) * vr);
+}
+
+// GHC's class-default RealFloat atan2 (Float has no specialised one)
+__device__ float hs_atan2f(float y, float x)
+{
+    if (x > 0.0f) return atanf(y / x);
+    if (x == 0.0f && y > 0.0f) return RMDF_PI_F / 2.0f;
+    if (x < 0.0f && y > 0.0f) return RMDF_PI_F + atanf(y / x);
+    if ((x <= 0.0f && y < 0.0f) || (x < 0.0f && y == 0.0f && signbit(y)) ||
+        (x == 0.0f && signbit(x) && y == 0.0f && signbit(y))) {
+        // -atan2 (-y) x : one level of recursion suffices (-y > 0 or -y == +0)
+        const float ny = -y;
+        if (x == 0.0f && ny > 0.0f) return -(RMDF_PI_F / 2.0f);
+        if (x < 0.0f && ny > 0.0f) return -(RMDF_PI_F + atanf(ny / x));
+        if (ny == 0.0f && (x < 0.0f || (x == 0.0f && signbit(x)))) return -RMDF_PI_F;
+        return -ny;
+    }
+    if (y == 0.0f && (x < 0.0f || (x == 0.0f && signbit(x)))) return RMDF_PI_F;
+    if (x == 0.0f && y == 0.0f) return y;
+    return x + y;
+}
+
+__global__ void k_latlong_to_cube(const float *__restrict__ latlong, int w, int h, int cw, float *__restrict__ faces)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 6 * cw * cw) return;
+    const int x = i % cw, y = (i / cw) % cw, face = i / (cw * cw);
+    // cubeMapPixelToDir, HDREnvMap.hs:76-87
+    const float vw = ((float)x + 0.5f) / (float)cw * 2.0f - 1.0f;
+    const float vh = ((float)y + 0.5f) / (float)cw * 2.0f - 1.0f;
+    v3 d;
+    switch (face) {
+    case 0:  d = mk3(1.0f, -vh, -vw); break;
+    case 1:  d = mk3(-1.0f, -vh, vw); break;
+    case 2:  d = mk3(vw, 1.0f, vh); break;
+    case 3:  d = mk3(vw, -1.0f, -vh); break;
+    case 4:  d = mk3(vw, -vh, 1.0f); break;
+    default: d = mk3(-vw, -vh, -1.0f); break;
+    }
+    // Linear.normalize: unchanged if |l| or |1-l| <= 1e-6
+    const float l = d.x * d.x + d.y * d.y + d.z * d.z;
+    if (!(fabsf(l) <= 1e-6f || fabsf(1.0f - l) <= 1e-6f)) {
+        const float s = sqrtf(l);
+        d = mk3(d.x / s, d.y / s, d.z / s);
+    }
+    // worldToLocal (CoordTransf.hs:46-50), cartesianToSpherical (35-44)
+    const v3 loc = mk3((d.x * 1.0f + d.y * 0.0f) + d.z * 0.0f,
+                       (d.x * 0.0f + d.y * 0.0f) + d.z * -1.0f,
+                       (d.x * 0.0f + d.y * 1.0f) + d.z * 0.0f);
+    float cz = loc.z;
+    if (cz > 1.0f) cz = 1.0f;
+    if (cz < -1.0f) cz = -1.0f;
+    const float theta = acosf(cz);
+    const float p2 = hs_atan2f(loc.y, loc.x);
+    const float p1 = (p2 < 0.0f) ? p2 + 2.0f * RMDF_PI_F : p2;
+    const float phi = (p1 == 2.0f * RMDF_PI_F) ? 0.0f : p1;
+    // sphericalToEnvironmentUV (CoordTransf.hs:60-70)
+    const float q1 = phi + RMDF_PI_F / 2.0f;
+    const float q2 = (q1 > 2.0f * RMDF_PI_F) ? q1 - 2.0f * RMDF_PI_F : q1;
+    const float q3 = 2.0f * RMDF_PI_F - q2;
+    const float u = q3 / (RMDF_PI_F * 2.0f), v = theta / RMDF_PI_F;
+    const v3 c = pixel_at_bilinear(latlong, w, h, u, v);
+    faces[(size_t)i * 3 + 0] = c.x; faces[(size_t)i * 3 + 1] = c.y; faces[(size_t)i * 3 + 2] = c.z;
+}
+
+hipError_t launch_latlong_to_cube(const float *d_latlong, int w, int h, float *d_faces_f32, hipStream_t stream)
+{
+    const int cw = w / 3, n = 6 * cw * cw;
+    if (n <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_latlong_to_cube, dim3((n + 255) / 256), dim3(256), 0, stream, d_latlong, w, h, cw, d_faces_f32);
+    return hipGetLastError();
+}
+
+// resizeHDRImage (HDREnvMap.hs:169-195): one thread per destination pixel
+__global__ void k_resize_latlong(const float *__restrict__ src, int sw, int sh, int dstw, int dsth, float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dstw * dsth) return;
+    const int dx = i % dstw, dy = i / dstw;
+    const float scale = (float)sw / (float)dstw;
+    const int taps = (int)ceilf(scale);
+    const float ntaps = (float)(taps * taps);
+    const float step = scale / (float)taps;
+    const float srcx1 = (float)dx * scale, srcy1 = (float)dy * scale;
+    float ar = 0.0f, ag = 0.0f, ab = 0.0f;
+    for (int y = 0; y < taps; y++)
+        for (int x = 0; x < taps; x++) {
+            const float sx = srcx1 + (float)x * step, sy = srcy1 + (float)y * step;
+            const v3 c = pixel_at_bilinear(src, sw, sh, sx / ((float)sw - 1.0f), sy / ((float)sh - 1.0f));
+            ar = ar + c.x; ag = ag + c.y; ab = ab + c.z;
+        }
+    out[(size_t)i * 3 + 0] = ar / ntaps; out[(size_t)i * 3 + 1] = ag / ntaps; out[(size_t)i * 3 + 2] = ab / ntaps;
+}
+
+hipError_t launch_resize_latlong(const float *d_src, int sw, int sh, int dstw, int dsth, float *d_out, hipStream_t stream)
+{
+    const int n = dstw * dsth;
+    if (n <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_resize_latlong, dim3((n + 255) / 256), dim3(256), 0, stream, d_src, sw, sh, dstw, dsth, d_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// cosineConvolveHDREnvMap (HDREnvMap.hs:217-254): O(n^4).  One lane per destination
+// texel, summing over the source in the reference's order (y outer, x inner) so the
+// float accumulation matches; one 64-lane wave = 64 consecutive dstx of one row.  The
+// source row and the per-row cos/sin are wave-uniform (scalar loads); the
+// cos|phiL - phi_x| table is staged in LDS transposed so lanes read consecutive words.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_prefilter(const float *__restrict__ src, int w, int h, float power,
+                                                  float *__restrict__ out)
+{
+    extern __shared__ float lut[];            // [w][64]: lut[x*64 + lane] = cos|phiL(lane) - phi(x)|
+    const int lane = threadIdx.x;
+    const int dx = blockIdx.x * 64 + lane, dy = blockIdx.y;
+    const int dxc = dx < w ? dx : w - 1;
+    const float theta_l = (float)dy / (float)(h - 1) * RMDF_PI_F;
+    const float lc = cosf(theta_l), ls = sinf(theta_l);
+    const float phi_l = (float)dxc / (float)(w - 1) * 2.0f * RMDF_PI_F;
+    for (int x = 0; x < w; x++) lut[x * 64 + lane] = cosf(fabsf(phi_l - (float)x / (float)(w - 1) * 2.0f * RMDF_PI_F));
+    float ar = 0.0f, ag = 0.0f, ab = 0.0f, n = 0.0f;
+    for (int y = 0; y < h; y++) {
+        const float th = (float)y / (float)(h - 1) * RMDF_PI_F;
+        const float pc = cosf(th), ps = sinf(th);
+        const float *row = src + (size_t)y * w * 3;
+        for (int x = 0; x < w; x++) {
+            const float cos_angle = lc * pc + ls * ps * lut[x * 64 + lane];
+            if (cos_angle > 0.0f) {
+                const float fac = ps * powf(cos_angle, power);
+                ar = ar + row[x * 3] * fac; ag = ag + row[x * 3 + 1] * fac; ab = ab + row[x * 3 + 2] * fac;
+                n = n + 1.0f;
+            }
+        }
+    }
+    if (dx < w) {
+        float *o = out + ((size_t)dx + (size_t)dy * w) * 3;
+        o[0] = ar / n; o[1] = ag / n; o[2] = ab / n;
+    }
+}
+
+hipError_t launch_prefilter(const float *d_src, int w, int h, float power, float *d_out, hipStream_t stream)
+{
+    if (w < 2 || h < 2) return hipErrorInvalidValue;
+    const size_t lds = (size_t)w * 64 * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute((const void *)k_prefilter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_prefilter, dim3((w + 63) / 64, h), dim3(64), lds, stream, d_src, w, h, power, d_out);
+    return hipGetLastError();
+}
+
+}  // namespace rmdf

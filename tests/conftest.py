@@ -1,0 +1,74 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (test infrastructure)."""
+    from oracle import orc as _orc
+    _orc.build()
+    return _orc
+
+
+@pytest.fixture(scope="session")
+def rmdf():
+    import rmdf_amd
+    return rmdf_amd
+
+
+@pytest.fixture(scope="session")
+def env_latlongs(orc, rmdf):
+    """uffizi_512 + its committed pre-convolved caches, decoded by the oracle."""
+    d = os.path.join(rmdf.DATA_DIR, "latlong_envmaps")
+    rd = lambda n: orc.hdr_decode(open(os.path.join(d, n), "rb").read())
+    return {"refl": rd("uffizi_512.hdr"), "cos1": rd("uffizi_512_cache_pow_1.0.hdr"),
+            "cos8": rd("uffizi_512_cache_pow_8.0.hdr")}
+
+
+@pytest.fixture(scope="session")
+def env_faces(orc, env_latlongs):
+    """Oracle-built float32 cube faces (the input both sides share in strict parity tests)."""
+    return {k: orc.latlong_to_cube(v) for k, v in env_latlongs.items()}
+
+
+@pytest.fixture(scope="session")
+def env_oracle(orc, env_faces):
+    return orc.EnvSet(*(orc.cube_pad_f16(env_faces[k]) for k in ("refl", "cos1", "cos8")))
+
+
+@pytest.fixture(scope="session")
+def sr(rmdf, env_faces):
+    """A ShaderRenderer on cuda:0 whose cube maps were uploaded from the oracle-built faces."""
+    rmdf.build()
+    r = rmdf.ShaderRenderer(0)
+    r.set_env_cube(rmdf.ENV_REFLECTION, env_faces["refl"])
+    r.set_env_cube(rmdf.ENV_COS_1, env_faces["cos1"])
+    r.set_env_cube(rmdf.ENV_COS_8, env_faces["cos8"])
+    yield r
+    r.close()
+
+
+def rel_err(a, b, floor=1e-6):
+    """max relative error with an absolute floor; NaN matches NaN, inf matches inf."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    both_nan = np.isnan(a) & np.isnan(b)
+    same_inf = np.isinf(a) & (a == b)
+    with np.errstate(invalid="ignore"):
+        e = np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), floor)
+    e = np.where(both_nan | same_inf, 0.0, e)
+    e = np.where(np.isnan(e), np.inf, e)
+    return e

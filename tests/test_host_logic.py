@@ -1,0 +1,128 @@
+"""CPU tier: host-side logic of the boundary (tile rectangles, shard bookkeeping) and the N>1 gather path
+exercised with world_size-2 gloo processes."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_tile_rect_matches_the_ndc_quad(rmdf):
+    """drawShaderTile's NDC rect [-1+2tx/8, -1+2(tx+1)/8] (ShaderRendering.hs:183-193) rasterised by pixel
+    centres, in float64, for sizes that 8 does and does not divide."""
+    for (w, h) in ((1920, 1080), (1280, 720), (64, 36), (100, 50), (37, 19), (8, 8)):
+        cover = np.zeros((h, w), int)
+        for idx in (0, 7, 8, 27, 63, 64 + 5):
+            midx = idx % 64
+            tx, ty = midx % 8, midx // 8
+            x0n, x1n = -1 + tx / 8 * 2, -1 + (tx + 1) / 8 * 2
+            y0n, y1n = -1 + ty / 8 * 2, -1 + (ty + 1) / 8 * 2
+            xs = (np.arange(w) + 0.5) / w * 2 - 1
+            ys = (np.arange(h) + 0.5) / h * 2 - 1
+            inx = np.nonzero((xs >= x0n) & (xs < x1n))[0]
+            iny = np.nonzero((ys >= y0n) & (ys < y1n))[0]
+            x0, y0, x1, y1 = rmdf.tile_rect(idx, w, h)
+            assert (x0, x1) == ((inx[0], inx[-1] + 1) if len(inx) else (x0, x0))
+            assert (y0, y1) == ((iny[0], iny[-1] + 1) if len(iny) else (y0, y0))
+        for idx in range(64):
+            x0, y0, x1, y1 = rmdf.tile_rect(idx, w, h)
+            cover[y0:y1, x0:x1] += 1
+        assert (cover == 1).all()
+
+
+def test_shard_bookkeeping(rmdf):
+    for n in (1, 2, 3, 4, 8, 64):
+        tiles = [rmdf.shard_tiles(r, n) for r in range(n)]
+        assert sorted(sum(tiles, [])) == list(range(64))          # a partition of the 64 tiles
+        assert max(len(t) for t in tiles) == rmdf.shard_slots(n)
+        assert max(len(t) for t in tiles) - min(len(t) for t in tiles) <= 1
+    # interleaving: neighbouring tiles go to different ranks (load balance)
+    assert rmdf.shard_tiles(1, 8) == [1, 9, 17, 25, 33, 41, 49, 57]
+
+
+def test_assemble_shards_host(rmdf):
+    w, h, n = 64, 32, 3
+    tw, th = w // 8, h // 8
+    frame = np.arange(w * h, dtype=np.uint32).reshape(h, w)
+    gathered = np.zeros((n, rmdf.shard_slots(n), th, tw), np.uint32)
+    for r in range(n):
+        for slot, idx in enumerate(rmdf.shard_tiles(r, n)):
+            tx, ty = idx % 8, idx // 8
+            gathered[r, slot] = frame[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw]
+    assert np.array_equal(rmdf.assemble_shards_host(gathered, w, h, n), frame)
+
+
+def test_framebuffer_slot(rmdf):
+    fb = rmdf.FrameBuffer(4, 3)
+    assert (fb.vec == 0xFF000000).all()
+
+    def filler(w, h, vec):
+        vec[:] = np.arange(w * h, dtype=np.uint32) << 8          # green ramp, alpha 0 like Fractal2D
+        return "done"
+    assert fb.fill_frame_buffer(filler) == "done"
+    img = fb.to_image_rows_top_down()
+    assert img.shape == (3, 4, 4) and (img[..., 3] == 255).all()  # alpha forced to 0xFF
+    assert img[0, 0, 1] == 8 and img[2, 0, 1] == 0                # row 0 of the buffer is the bottom row
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    import rmdf_amd
+    from oracle import orc
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w, h = 64, 32
+
+        def render_shard(rank_, n_):
+            # stand-in for the HIP shard render on the CPU tier: the ORACLE renders this rank's tiles
+            env = bench.load_oracle_env(orc)
+            out = np.zeros((rmdf_amd.shard_slots(n_), h // 8, w // 8), np.uint32)
+            for slot, idx in enumerate(rmdf_amd.shard_tiles(rank_, n_)):
+                x0, y0, x1, y1 = rmdf_amd.tile_rect(idx, w, h)
+                r = orc.render(orc.SCENE_MB_POWER8, w, h, 0.0, 64, env, rect=(x0, y0, x1, y1), nthreads=2)
+                out[slot] = r["rgba8"][y0:y1, x0:x1]
+            return torch.from_numpy(out.view(np.int32))
+        shard = render_shard(rank, world)
+        gathered = bench.gather_shards(shard, rank, world, dist)
+        if rank == 0:
+            frame = rmdf_amd.assemble_shards_host(gathered.numpy().view(np.uint32), w, h, world)
+            env = bench.load_oracle_env(orc)
+            full = orc.render(orc.SCENE_MB_POWER8, w, h, 0.0, 64, env, nthreads=2)["rgba8"]
+            q.put(bool(np.array_equal(frame, full)))
+        t = bench.max_over_ranks(float(rank + 1), dist, torch.device("cpu"))
+        if rank == 1:
+            q.put(t == float(world))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gather_reassembles_the_frame():
+    """world_size 2 over gloo: each rank produces its interleaved tile shard, ONE gather at frame end, rank 0
+    scatters tiles to frame positions -> identical to a single-process full-frame render."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    results = [q.get(timeout=10), q.get(timeout=10)]
+    assert results == [True, True]
