@@ -115,8 +115,11 @@ def main():
     sr = rmdf_amd.ShaderRenderer(local_rank)
     sr.load_env_hdr(rmdf_amd.DEFAULT_ENV_HDR)
     dev_name, cus = sr.device_info()
-    stream = torch.cuda.current_stream(dev)
+    # a dedicated (non-null) HIP stream: kernels, RCCL calls and the timing events all go on it
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
     sptr = stream.cuda_stream
+    assert sptr != 0
 
     frame = torch.empty((h, w), dtype=torch.int32, device=dev)
     if world > 1:

@@ -72,6 +72,7 @@ def test_tiled_frame_equals_full_frame(sr, rmdf):
     ignored on the other 63 (ShaderRendering.hs:162-176); every call returns the whole accumulated frame."""
     w, h = 120, 72                      # 72/8 = 9: odd tile rows -> helper pixels across tile edges
     full = sr.render(2, w, h, 1.0, max_steps=256)
+    old = sr.render(2, w, h, 2.5, max_steps=256)          # what the accumulating frame holds before tiling starts
     fb = rmdf.FrameBuffer(w, h)
     for idx in range(64):
         sr.draw_shader_tile(rmdf.FragmentShader.FSMBPower8Shader, idx, w, h, 1.0 if idx == 0 else 99.0 + idx, fb.vec, max_steps=256)
@@ -80,7 +81,7 @@ def test_tiled_frame_equals_full_frame(sr, rmdf):
             x0, y0, x1, y1 = rmdf.tile_rect(10, w, h)
             assert np.array_equal(part[y0:y1, x0:x1], full["rgba8"][y0:y1, x0:x1])
             x0, y0, x1, y1 = rmdf.tile_rect(63, w, h)
-            assert (part[y0:y1, x0:x1] == 0xFF000000).all()            # not rendered yet: cleared to opaque black
+            assert np.array_equal(part[y0:y1, x0:x1], old["rgba8"][y0:y1, x0:x1])   # not re-rendered yet
     assert np.array_equal(fb.vec.reshape(h, w), full["rgba8"])
     # a new frame (tile 64 = first tile again) re-latches the time
     sr.draw_shader_tile(2, 64, w, h, 2.5, fb.vec, max_steps=256)
@@ -123,7 +124,9 @@ def test_device_resident_and_shard_paths(sr, rmdf):
     import torch
     w, h, ms = 256, 144, 256
     dev = torch.device("cuda", 0)
-    s = torch.cuda.current_stream(dev).cuda_stream
+    ts = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(ts)
+    s = ts.cuda_stream
     full = torch.zeros((h, w), dtype=torch.int32, device=dev)
     sr.render_rect_device(2, w, h, 0.0, ms, (0, 0, w, h), d_rgba8=full.data_ptr(), stream=s)
     torch.cuda.synchronize()
@@ -189,3 +192,22 @@ def test_gpu_env_pipeline_vs_oracle(sr, rmdf, orc, env_latlongs, env_faces):
     for p in (1.0, 8.0, 64.0):
         e = rel_err(sr.prefilter_env(tiny, p), orc.cosine_convolve(tiny, p))
         assert e.max() < 2e-5, (p, e.max())
+
+
+def test_fresh_frame_is_cleared_to_opaque_black(rmdf, env_faces):
+    """resizeFrameBuffer clears the new texture to (0,0,0,1) (FrameBuffer.hs:109-111): tiles that have not been
+    drawn yet read 0xFF000000."""
+    fresh = rmdf.ShaderRenderer(0)
+    try:
+        for slot, k in ((rmdf.ENV_REFLECTION, "refl"), (rmdf.ENV_COS_1, "cos1"), (rmdf.ENV_COS_8, "cos8")):
+            fresh.set_env_cube(slot, env_faces[k])
+        w, h = 64, 40
+        fb = rmdf.FrameBuffer(w, h)
+        fresh.draw_shader_tile(2, 27, w, h, 0.0, fb.vec, max_steps=64)       # a middle tile first
+        img = fb.vec.reshape(h, w)
+        x0, y0, x1, y1 = rmdf.tile_rect(27, w, h)
+        mask = np.ones((h, w), bool)
+        mask[y0:y1, x0:x1] = False
+        assert (img[mask] == 0xFF000000).all() and (img[~mask] != 0xFF000000).any()
+    finally:
+        fresh.close()

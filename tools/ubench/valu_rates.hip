@@ -1,0 +1,102 @@
+// valu_rates.hip -- VALU issue-rate microbenchmark for gfx950 (measurement tool, not product code).
+// Each kernel runs REPS x 64 independent-chain instructions per wave; prints wave-instructions/cycle/SIMD
+// at several occupancies.  Build: hipcc --offload-arch=gfx950 -O2 valu_rates.hip -o valu_rates
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#define REPS 4096
+
+#define CHAIN8(OP)                                                             \
+    asm volatile(OP " %0, %0, %8\n\t" OP " %1, %1, %8\n\t" OP " %2, %2, %8\n\t" \
+                 OP " %3, %3, %8\n\t" OP " %4, %4, %8\n\t" OP " %5, %5, %8\n\t" \
+                 OP " %6, %6, %8\n\t" OP " %7, %7, %8"                          \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+
+#define UN8(OP)                                                                \
+    asm volatile(OP " %0, %0\n\t" OP " %1, %1\n\t" OP " %2, %2\n\t" OP " %3, %3\n\t" \
+                 OP " %4, %4\n\t" OP " %5, %5\n\t" OP " %6, %6\n\t" OP " %7, %7"     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+
+template <int K>
+__global__ void k_scalar(float *out, float c)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    for (int i = 0; i < REPS; i++) {
+        if (K == 0) { CHAIN8("v_mul_f32") }
+        if (K == 1) { CHAIN8("v_add_f32") }
+        if (K == 2) { asm volatile("v_fma_f32 %0, %0, %8, %8\n\tv_fma_f32 %1, %1, %8, %8\n\tv_fma_f32 %2, %2, %8, %8\n\tv_fma_f32 %3, %3, %8, %8\n\t"
+                                   "v_fma_f32 %4, %4, %8, %8\n\tv_fma_f32 %5, %5, %8, %8\n\tv_fma_f32 %6, %6, %8, %8\n\tv_fma_f32 %7, %7, %8, %8"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c)); }
+        if (K == 3) { UN8("v_sqrt_f32") }
+        if (K == 4) { UN8("v_rcp_f32") }
+        if (K == 5) { UN8("v_rsq_f32") }
+        if (K == 6) { UN8("v_log_f32") }
+        if (K == 7) { CHAIN8("v_max_f32") }
+        if (K == 8) { asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n\tv_cndmask_b32 %1, %1, %8, vcc\n\tv_cndmask_b32 %2, %2, %8, vcc\n\tv_cndmask_b32 %3, %3, %8, vcc\n\t"
+                                   "v_cndmask_b32 %4, %4, %8, vcc\n\tv_cndmask_b32 %5, %5, %8, vcc\n\tv_cndmask_b32 %6, %6, %8, vcc\n\tv_cndmask_b32 %7, %7, %8, vcc"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c) : "vcc"); }
+        if (K == 9) { // dependent chain of v_mul (latency)
+            asm volatile("v_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\t"
+                         "v_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1" : "+v"(a0) : "v"(c)); }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+template <int K>
+__global__ void k_packed(float *out, float cc)
+{
+    float2_t a0 = { (float)threadIdx.x, 1 }, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float2_t c = { cc, cc };
+    for (int i = 0; i < REPS; i++) {
+        if (K == 0) { CHAIN8("v_pk_mul_f32") }
+        if (K == 1) { CHAIN8("v_pk_add_f32") }
+        if (K == 2) { asm volatile("v_pk_fma_f32 %0, %0, %8, %8\n\tv_pk_fma_f32 %1, %1, %8, %8\n\tv_pk_fma_f32 %2, %2, %8, %8\n\tv_pk_fma_f32 %3, %3, %8, %8\n\t"
+                                   "v_pk_fma_f32 %4, %4, %8, %8\n\tv_pk_fma_f32 %5, %5, %8, %8\n\tv_pk_fma_f32 %6, %6, %8, %8\n\tv_pk_fma_f32 %7, %7, %8, %8"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c)); }
+    }
+    float2_t s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y;
+}
+
+template <typename F>
+static void run(const char *name, F launch, int ops_per_instr)
+{
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount;
+    float *out;
+    hipMalloc(&out, (size_t)cus * 32 * 64 * 4 * 2);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    printf("%-14s", name);
+    for (int wps : { 1, 2, 4, 8 }) {               // waves per SIMD
+        const int blocks = cus * wps, threads = 256; // 4 waves per block -> one per SIMD
+        launch(blocks, threads, out);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        launch(blocks, threads, out);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        double winstr = (double)blocks * 4 * REPS * 8;
+        double per_simd_per_s = winstr / (cus * 4.0) / (ms * 1e-3);
+        printf("  wps%d: %6.3f ms %6.2f Ginstr/s/SIMD (%5.1f Tlaneops/s)", wps, ms, per_simd_per_s / 1e9,
+               winstr * 64 * ops_per_instr / (ms * 1e-3) / 1e12);
+    }
+    printf("\n");
+    hipFree(out);
+}
+
+int main()
+{
+#define S(K, NAME) run(NAME, [](int b, int t, float *o) { hipLaunchKernelGGL(k_scalar<K>, dim3(b), dim3(t), 0, 0, o, 1.0001f); }, 1)
+#define P(K, NAME) run(NAME, [](int b, int t, float *o) { hipLaunchKernelGGL(k_packed<K>, dim3(b), dim3(t), 0, 0, o, 1.0001f); }, 2)
+    S(0, "v_mul_f32"); S(1, "v_add_f32"); S(2, "v_fma_f32"); P(0, "v_pk_mul_f32"); P(1, "v_pk_add_f32"); P(2, "v_pk_fma_f32");
+    S(3, "v_sqrt_f32"); S(4, "v_rcp_f32"); S(5, "v_rsq_f32"); S(6, "v_log_f32"); S(7, "v_max_f32"); S(8, "v_cndmask"); S(9, "dep v_mul");
+    return 0;
+}
