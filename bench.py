@@ -112,7 +112,7 @@ def main():
 
     rmdf_amd.build()
     w, h, ms, scene = a.width, a.height, a.max_steps, a.scene
-    sr = rmdf_amd.ShaderRenderer(local_rank)
+    sr = rmdf_amd.ShaderRenderer(local_rank, flags=int(os.environ.get("RMDF_FLAGS", "0")))
     sr.load_env_hdr(rmdf_amd.DEFAULT_ENV_HDR)
     dev_name, cus = sr.device_info()
     # a dedicated (non-null) HIP stream: kernels, RCCL calls and the timing events all go on it

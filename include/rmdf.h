@@ -69,9 +69,14 @@ typedef struct rmdf_ctx rmdf_ctx;
 #define RMDF_TILES_Y 8
 #define RMDF_N_TILES 64
 
+/* rmdf_config.reserved[0] flags */
+#define RMDF_FLAG_NESTED_LOOPS 1   /* Mandelbulb: single nested-loop kernel (k_render<2>)                  */
+#define RMDF_FLAG_FLAT_MARCH   2   /* Mandelbulb: flattened march kernel + shade kernel (rmdf_march.hip)   */
+/* neither bit set = the library's default (currently the fastest measured: nested loops) */
+
 typedef struct {
     int device;      /* HIP device ordinal                                              */
-    int reserved[7]; /* zero                                                            */
+    int reserved[7]; /* [0] = RMDF_FLAG_* bits, rest zero                               */
 } rmdf_config;
 
 /* ---- lifetime: withShaderRenderer (ShaderRendering.hs:60-110) --------------------- */
@@ -160,6 +165,12 @@ int rmdf_render_shard_device(rmdf_ctx *ctx, int scene, int w, int h, double time
  * order, each ceil(64/nranks) tile slots); scatter them to frame positions. */
 int rmdf_assemble_shards_device(rmdf_ctx *ctx, int w, int h, int nranks, const void *d_gathered,
                                 void *d_frame_rgba8, void *stream);
+
+/* Measurement aid: per-wave counters of the Mandelbulb march kernel.  enable != 0 switches collection on
+ * (off: frees the buffer); out (may be NULL) receives 16 uint64 per wave for the launches since the last read:
+ * iteration passes, march-tail passes, shade-tail passes, refill rounds, sum of iterating lanes over iteration
+ * passes, sum of waiting lanes over march tails, begin / end timestamps (100 MHz s_memrealtime ticks). */
+int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_waves);
 
 /* Block until everything queued on `stream` (NULL = ctx stream) has finished. */
 int rmdf_synchronize(rmdf_ctx *ctx, void *stream);

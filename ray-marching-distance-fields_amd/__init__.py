@@ -33,6 +33,7 @@ DEFAULT_ENV_HDR = os.path.join(DATA_DIR, "latlong_envmaps", "uffizi_512.hdr")
 
 TILES_X, TILES_Y, N_TILES = 8, 8, 64          # ShaderRendering.hs:49-52
 ENV_REFLECTION, ENV_COS_1, ENV_COS_8, ENV_COS_64, ENV_COS_512 = range(5)
+FLAG_NESTED_LOOPS, FLAG_FLAT_MARCH = 1, 2     # rmdf.h RMDF_FLAG_*
 
 _ERRORS = {-1: "RMDF_E_INVALID", -2: "RMDF_E_NO_DEVICE", -3: "RMDF_E_HIP", -4: "RMDF_E_IO",
            -5: "RMDF_E_NO_ENV", -6: "RMDF_E_UNSUPPORTED", -7: "RMDF_E_NOMEM"}
@@ -43,7 +44,7 @@ ABI_SYMBOLS = (
     "rmdf_set_env_cube", "rmdf_get_env_cube_padded", "rmdf_resize_latlong", "rmdf_prefilter_env",
     "rmdf_is_tile_idx_first_tile", "rmdf_is_tile_idx_last_tile", "rmdf_render_tile", "rmdf_render_tile_ex",
     "rmdf_render_rect_device", "rmdf_render_shard_device", "rmdf_assemble_shards_device", "rmdf_synchronize",
-    "rmdf_device_info",
+    "rmdf_device_info", "rmdf_debug_march_stats",
 )
 
 
@@ -121,6 +122,7 @@ def load_library():
     L.rmdf_assemble_shards_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.rmdf_synchronize.argtypes = [vp, vp]
     L.rmdf_device_info.argtypes = [vp, C.c_char_p, C.c_int, ip]
+    L.rmdf_debug_march_stats.argtypes = [vp, C.c_int, vp, C.c_int]
     _lib = L
     return L
 
@@ -137,10 +139,11 @@ class ShaderRenderer:
     """The `ShaderRenderer` record (ShaderRendering.hs:36-44): owns the device-side env cube maps,
     the Cornell geometry table and the accumulating frame."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, flags=0):
         self._lib = load_library()
         self._ctx = C.c_void_p()
         cfg = _Config(device=device)
+        cfg.reserved[0] = flags
         rc = self._lib.rmdf_create(C.byref(self._ctx), C.byref(cfg))
         if rc != 0:
             raise RmdfError(rc, (self._lib.rmdf_last_error(None) or b"").decode())
@@ -243,6 +246,12 @@ class ShaderRenderer:
     def assemble_shards_device(self, w, h, nranks, d_gathered, d_frame_rgba8, stream=0):
         self._check(self._lib.rmdf_assemble_shards_device(self._ctx, w, h, nranks, d_gathered, d_frame_rgba8,
                                                           stream or None))
+
+    def debug_march_stats(self, enable=True, read_waves=0):
+        """Per-wave counters of the march kernel (see rmdf.h); returns (n, 8) uint64 or None."""
+        out = np.zeros((read_waves, 16), np.uint64) if read_waves else None
+        self._check(self._lib.rmdf_debug_march_stats(self._ctx, int(enable), _ptr(out), read_waves))
+        return out
 
     def synchronize(self, stream=0):
         self._check(self._lib.rmdf_synchronize(self._ctx, stream or None))

@@ -41,6 +41,13 @@ struct rmdf_ctx {
     uint16_t    *d_steps = nullptr;
     uint16_t    *d_iters = nullptr;
     size_t       cap_px = 0;
+    // G-buffer + work counter of the two-kernel Mandelbulb path
+    float4      *d_gbuf_nao = nullptr;
+    unsigned    *d_gbuf_meta = nullptr;
+    int         *d_work_counter = nullptr;
+    unsigned long long *d_dbg = nullptr;   // per-wave march diagnostics (rmdf_debug_march_stats)
+    size_t       gbuf_cap = 0;
+    int          flags = 0;            // rmdf_config.reserved[0]
     std::string  err;
     char         dev_name[256] = { 0 };
     int          cus = 0;
@@ -158,6 +165,32 @@ int clear_frame(rmdf_ctx *ctx, int w, int h)
     return RMDF_OK;
 }
 
+int ensure_gbuf(rmdf_ctx *ctx, int w, int h)
+{
+    const size_t gw = (size_t)((w + 1) & ~1), gh = (size_t)((h + 1) & ~1);
+    const size_t need = gw * gh;
+    if (!ctx->d_work_counter) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_work_counter, 256));
+    if (need <= ctx->gbuf_cap) return RMDF_OK;
+    if (ctx->d_gbuf_nao) (void)hipFree(ctx->d_gbuf_nao);
+    if (ctx->d_gbuf_meta) (void)hipFree(ctx->d_gbuf_meta);
+    ctx->d_gbuf_nao = nullptr; ctx->d_gbuf_meta = nullptr; ctx->gbuf_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_gbuf_nao, need * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_gbuf_meta, need * sizeof(unsigned)));
+    ctx->gbuf_cap = need;
+    return RMDF_OK;
+}
+
+// scene dispatch: the Mandelbulb has two schedules of the same per-ray arithmetic; the default is the
+// fastest measured one, the other stays selectable for A/B measurements and tests
+int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t stream)
+{
+    if (scene == RMDF_FS_MB_POWER8 && (ctx->flags & RMDF_FLAG_FLAT_MARCH))
+        HIP_TRY(ctx, launch_render_mb8(p, stream, ctx->cus));
+    else
+        HIP_TRY(ctx, launch_render(scene, p, stream));
+    return RMDF_OK;
+}
+
 int fill_params(rmdf_ctx *ctx, int scene, int w, int h, float time, int max_steps, FrameParams &p)
 {
     if (scene != RMDF_FS_MB_POWER8 && scene != RMDF_FS_DE_CORNELL_BOX) {
@@ -180,6 +213,11 @@ int fill_params(rmdf_ctx *ctx, int scene, int w, int h, float time, int max_step
     p.env_cos1 = CubeDev{ ctx->env[RMDF_ENV_COS_1].d_texels, ctx->env[RMDF_ENV_COS_1].W };
     p.env_cos8 = CubeDev{ ctx->env[RMDF_ENV_COS_8].d_texels, ctx->env[RMDF_ENV_COS_8].W };
     p.cornell = ctx->d_cornell;
+    int rc = ensure_gbuf(ctx, w, h);
+    if (rc != RMDF_OK) return rc;
+    p.gbuf_nao = ctx->d_gbuf_nao; p.gbuf_meta = ctx->d_gbuf_meta; p.gw = (w + 1) & ~1;
+    p.work_counter = ctx->d_work_counter;
+    p.dbg = ctx->d_dbg;
     return RMDF_OK;
 }
 
@@ -340,7 +378,8 @@ int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double t
     if (whole) { p.x0 = 0; p.y0 = 0; p.x1 = ctx->w; p.y1 = ctx->h; }
     else tile_rect_host(tile_idx, ctx->w, ctx->h, &p.x0, &p.y0, &p.x1, &p.y1);
     p.rgba8 = ctx->d_rgba8; p.rgba_f32 = ctx->d_rgba_f32; p.steps = ctx->d_steps; p.iters = ctx->d_iters;
-    HIP_TRY(ctx, launch_render(scene, p, ctx->stream));
+    rc = launch_scene(ctx, scene, p, ctx->stream);
+    if (rc != RMDF_OK) return rc;
     const size_t npx = (size_t)ctx->w * ctx->h;
     if (out_rgba8) HIP_TRY(ctx, hipMemcpyAsync(out_rgba8, ctx->d_rgba8, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (out_rgba_f32) HIP_TRY(ctx, hipMemcpyAsync(out_rgba_f32, ctx->d_rgba_f32, npx * 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -385,6 +424,7 @@ int rmdf_create(rmdf_ctx **out, const rmdf_config *cfg)
     rmdf_ctx *ctx = new (std::nothrow) rmdf_ctx();
     if (!ctx) return fail(nullptr, RMDF_E_NOMEM, "out of host memory");
     ctx->device = dev;
+    ctx->flags = cfg ? cfg->reserved[0] : 0;
     ctx->cus = prop.multiProcessorCount;
     snprintf(ctx->dev_name, sizeof ctx->dev_name, "%s (%s)", prop.name, prop.gcnArchName);
     float tri[96 * 3];
@@ -412,6 +452,10 @@ void rmdf_destroy(rmdf_ctx *ctx)
     if (ctx->d_rgba_f32) (void)hipFree(ctx->d_rgba_f32);
     if (ctx->d_steps) (void)hipFree(ctx->d_steps);
     if (ctx->d_iters) (void)hipFree(ctx->d_iters);
+    if (ctx->d_gbuf_nao) (void)hipFree(ctx->d_gbuf_nao);
+    if (ctx->d_gbuf_meta) (void)hipFree(ctx->d_gbuf_meta);
+    if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
+    if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -572,8 +616,7 @@ int rmdf_render_rect_device(rmdf_ctx *ctx, int scene, int w, int h, double time,
     if (x0 < 0 || y0 < 0 || x1 > w || y1 > h || x0 > x1 || y0 > y1) return fail(ctx, RMDF_E_INVALID, "bad rectangle");
     p.x0 = x0; p.y0 = y0; p.x1 = x1; p.y1 = y1;
     p.rgba8 = (uint32_t *)d_rgba8; p.rgba_f32 = (float4 *)d_rgba_f32; p.steps = (uint16_t *)d_steps; p.iters = (uint16_t *)d_iters;
-    HIP_TRY(ctx, launch_render(scene, p, stream ? (hipStream_t)stream : ctx->stream));
-    return RMDF_OK;
+    return launch_scene(ctx, scene, p, stream ? (hipStream_t)stream : ctx->stream);
 }
 
 int rmdf_render_shard_device(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps,
@@ -589,8 +632,7 @@ int rmdf_render_shard_device(rmdf_ctx *ctx, int scene, int w, int h, double time
     p.n_shard_tiles = (RMDF_N_TILES - rank + nranks - 1) / nranks;   // tiles idx = rank, rank+n, ...
     p.shard_first = rank; p.shard_stride = nranks;
     p.rgba8 = (uint32_t *)d_packed_rgba8;
-    HIP_TRY(ctx, launch_render(scene, p, stream ? (hipStream_t)stream : ctx->stream));
-    return RMDF_OK;
+    return launch_scene(ctx, scene, p, stream ? (hipStream_t)stream : ctx->stream);
 }
 
 int rmdf_assemble_shards_device(rmdf_ctx *ctx, int w, int h, int nranks, const void *d_gathered,
@@ -601,6 +643,26 @@ int rmdf_assemble_shards_device(rmdf_ctx *ctx, int w, int h, int nranks, const v
         return fail(ctx, RMDF_E_INVALID, "rmdf_assemble_shards_device: bad argument");
     HIP_TRY(ctx, launch_assemble_shards((const uint32_t *)d_gathered, (uint32_t *)d_frame_rgba8, w, h, nranks,
                                         stream ? (hipStream_t)stream : ctx->stream));
+    return RMDF_OK;
+}
+
+int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_waves)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    const size_t cap = 8192;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (enable && !ctx->d_dbg) {
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_dbg, cap * 16 * sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMemset(ctx->d_dbg, 0, cap * 16 * sizeof(unsigned long long)));
+    }
+    if (out && ctx->d_dbg) {
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        size_t n = (size_t)(max_waves < 0 ? 0 : max_waves);
+        if (n > cap) n = cap;
+        HIP_TRY(ctx, hipMemcpy(out, ctx->d_dbg, n * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemset(ctx->d_dbg, 0, cap * 16 * sizeof(unsigned long long)));
+    }
+    if (!enable && ctx->d_dbg) { (void)hipFree(ctx->d_dbg); ctx->d_dbg = nullptr; }
     return RMDF_OK;
 }
 

@@ -25,8 +25,61 @@ __device__ __forceinline__ float gmax(float x, float y) { return (x < y) ? y : x
 __device__ __forceinline__ float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
 
 __device__ __forceinline__ float dot3(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-__device__ __forceinline__ float length3(v3 a) { return sqrtf(dot3(a, a)); }
-__device__ __forceinline__ float rsqrt_ieee(float x) { return 1.0f / sqrtf(x); }
+
+// Correctly rounded sqrt / reciprocal in a handful of instructions.  hipcc's own expansion of sqrtf(x)
+// and 1.0f/x is correctly rounded for every input but spends ~17 / ~14 VALU slots on scaling and
+// special-case fix-ups.  For 2^-100 <= |x| <= 2^100 the short "core" sequences below return the SAME
+// bits (checked for all 2^32 inputs on gfx950: tools/ubench/exact_math.hip and the gpu test
+// test_exact_math_exhaustive); anything outside that range, zero, inf and NaN take the compiler's path.
+__device__ __forceinline__ bool in_core_range(float x)
+{
+    // 2^-100 <= |x| <= 2^100 as one unsigned compare on the exponent field (NaN, inf, 0, subnormals fail)
+    return ((__float_as_uint(x) & 0x7fffffffu) - 0x0d800000u) <= (0x71800000u - 0x0d800000u);
+}
+__device__ __forceinline__ float sqrt_core(float x)        // x in [2^-100, 2^100]
+{
+    float s = __builtin_amdgcn_sqrtf(x);                                  // <= 1 ulp
+    const float s_dn = __int_as_float(__float_as_int(s) - 1), s_up = __int_as_float(__float_as_int(s) + 1);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    s = (r_dn <= 0.0f) ? s_dn : s;
+    s = (r_up > 0.0f) ? s_up : s;
+    return s;
+}
+__device__ __forceinline__ float rcp_core(float x)         // |x| in [2^-100, 2^100]
+{
+    const float y0 = __builtin_amdgcn_rcpf(x);                            // <= 1 ulp
+    const float e = __builtin_fmaf(-x, y0, 1.0f);
+    return __builtin_fmaf(e, y0, y0);
+}
+// The core sequence runs unconditionally; only when some lane of the wave is out of range (rare: the
+// branch is wave-uniform) are those lanes recomputed with the compiler's expansion.
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+    float s = sqrt_core(x);
+    const bool bad = !in_core_range(x) || (x < 0.0f);
+    if (__builtin_expect(__ballot(bad) != 0ull, 0)) { if (bad) s = sqrtf(x); }
+    return s;
+}
+__device__ __forceinline__ float rcp_rn(float x)
+{
+    float y = rcp_core(x);
+    const bool bad = !in_core_range(x);
+    if (__builtin_expect(__ballot(bad) != 0ull, 0)) { if (bad) y = 1.0f / x; }
+    return y;
+}
+// a / b for operands whose range is known at the call site: |b| in [2^-40, 2^40], a = 0 or |a| in
+// [2^-40, 2^40] (no range test).  y = RN(1/b); q0 = RN(a*y); q1 = RN(q0 + (a - b*q0)*y) is the correctly
+// rounded quotient (Markstein); checked against the compiler's division in test_exact_math_exhaustive.
+__device__ __forceinline__ float div_known_range(float a, float b)
+{
+    const float y = rcp_core(b);
+    const float q0 = a * y;
+    const float r0 = __builtin_fmaf(-b, q0, a);
+    return __builtin_fmaf(r0, y, q0);
+}
+
+__device__ __forceinline__ float length3(v3 a) { return sqrt_rn(dot3(a, a)); }
+__device__ __forceinline__ float rsqrt_ieee(float x) { return rcp_rn(sqrt_rn(x)); }   // inversesqrt := 1/sqrt, two roundings
 __device__ __forceinline__ v3 normalize3(v3 a)
 {
     float s = rsqrt_ieee(dot3(a, a));
@@ -61,7 +114,7 @@ __device__ __forceinline__ float log_pinned(float x)
     x = __int_as_float(ix | (i ^ 0x3f800000));
     k += (i >> 23);
     float f = x - 1.0f;
-    float s = f / (2.0f + f);
+    float s = div_known_range(f, 2.0f + f);   // f in [-0.293, 0.415], 2+f in [1.70, 2.42]: the IEEE quotient
     float dk = (float)k;
     float z = s * s;
     float w = z * z;

@@ -29,6 +29,15 @@ struct FrameParams {
     float4   *rgba_f32;
     uint16_t *steps;
     uint16_t *iters;
+    // two-kernel Mandelbulb path (rmdf_march.hip): G-buffer written by k_march_mb8, read by k_shade.
+    // Indexed px + py*gw over the frame padded to even dimensions (helper pixels of odd sizes).
+    float4   *gbuf_nao;       // normal.xyz, ao (hit pixels only)
+    unsigned *gbuf_meta;      // bits 0..14 steps, bit 15 hit, bits 16..31 escape iterations (saturated)
+    int       gw;
+    int      *work_counter;   // zeroed before every march launch
+    int       total_items, items_per_shard_tile;
+    int       tail_t, shade_t, refill_t, chunk;
+    unsigned long long *dbg;  // optional per-wave counters of k_march_mb8 (8 x u64 per wave), may be null   // scheduling thresholds of k_march_mb8 (see rmdf_march.hip)
 };
 
 // tile idx -> pixel rectangle (ShaderRendering.hs:183-193), host copy in rmdf_api.cpp
@@ -36,6 +45,7 @@ void tile_rect_host(int tile_idx, int w, int h, int *x0, int *y0, int *x1, int *
 
 // kernels / launchers implemented in rmdf_kernels.hip
 hipError_t launch_render(int scene, const FrameParams &p, hipStream_t stream);
+hipError_t launch_render_mb8(const FrameParams &p, hipStream_t stream, int num_cus);
 hipError_t launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t stream);
 hipError_t launch_cube_upload(const float *d_faces_f32, int W, uint2 *d_padded, hipStream_t stream);
 hipError_t launch_latlong_to_cube(const float *d_latlong, int w, int h, float *d_faces_f32, hipStream_t stream);

@@ -211,3 +211,21 @@ def test_fresh_frame_is_cleared_to_opaque_black(rmdf, env_faces):
         assert (img[mask] == 0xFF000000).all() and (img[~mask] != 0xFF000000).any()
     finally:
         fresh.close()
+
+
+def test_both_mandelbulb_schedules_agree(sr_alt, sr, orc, env_oracle, rmdf):
+    """The nested-loop kernel and the flattened march + shade pair are two independent schedules of the same
+    per-ray arithmetic: both must match the oracle, hence each other, bit for bit (tiles and shards too)."""
+    for (w, h, t, ms) in ((64, 36, 0.0, 256), (250, 130, 2.5, 64), (33, 17, 1.0, 256), (480, 270, 7.0, 256)):
+        a = sr_alt.render(2, w, h, t, max_steps=ms)
+        b = sr.render(2, w, h, t, max_steps=ms)
+        assert_frame_parity(a, orc.render(2, w, h, t, ms, env_oracle), "alt %dx%d" % (w, h))
+        for k in ("rgba8", "steps", "iters"):
+            assert np.array_equal(a[k], b[k])
+        assert np.array_equal(a["rgba_f32"].view(np.uint32), b["rgba_f32"].view(np.uint32))
+    w, h = 120, 72
+    full = sr.render(2, w, h, 1.0, max_steps=256)["rgba8"]
+    fb = rmdf.FrameBuffer(w, h)
+    for idx in range(64):
+        sr_alt.draw_shader_tile(2, idx, w, h, 1.0, fb.vec, max_steps=256)
+    assert np.array_equal(fb.vec.reshape(h, w), full)

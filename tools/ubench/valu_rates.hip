@@ -6,7 +6,7 @@
 #include <stdlib.h>
 #include <vector>
 
-#define REPS 4096
+#define REPS 32768
 
 #define CHAIN8(OP)                                                             \
     asm volatile(OP " %0, %0, %8\n\t" OP " %1, %1, %8\n\t" OP " %2, %2, %8\n\t" \
@@ -22,6 +22,7 @@
 template <int K>
 __global__ void k_scalar(float *out, float c)
 {
+    float c2 = c * 0.5f; unsigned long long msk = 0x5555555555555555ull + (unsigned long long)(c > 2.0f);
     float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     for (int i = 0; i < REPS; i++) {
         if (K == 0) { CHAIN8("v_mul_f32") }
@@ -37,6 +38,37 @@ __global__ void k_scalar(float *out, float c)
         if (K == 8) { asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n\tv_cndmask_b32 %1, %1, %8, vcc\n\tv_cndmask_b32 %2, %2, %8, vcc\n\tv_cndmask_b32 %3, %3, %8, vcc\n\t"
                                    "v_cndmask_b32 %4, %4, %8, vcc\n\tv_cndmask_b32 %5, %5, %8, vcc\n\tv_cndmask_b32 %6, %6, %8, vcc\n\tv_cndmask_b32 %7, %7, %8, vcc"
                                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c) : "vcc"); }
+        if (K == 10) { asm volatile("v_cndmask_b32_e64 %0, %0, %8, %9\n\tv_cndmask_b32_e64 %1, %1, %8, %9\n\tv_cndmask_b32_e64 %2, %2, %8, %9\n\tv_cndmask_b32_e64 %3, %3, %8, %9\n\t"
+                                   "v_cndmask_b32_e64 %4, %4, %8, %9\n\tv_cndmask_b32_e64 %5, %5, %8, %9\n\tv_cndmask_b32_e64 %6, %6, %8, %9\n\tv_cndmask_b32_e64 %7, %7, %8, %9"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "s"(msk)); }
+        if (K == 11) { asm volatile("v_cmp_lt_f32 vcc, %0, %8\n\tv_cmp_lt_f32 vcc, %1, %8\n\tv_cmp_lt_f32 vcc, %2, %8\n\tv_cmp_lt_f32 vcc, %3, %8\n\t"
+                                   "v_cmp_lt_f32 vcc, %4, %8\n\tv_cmp_lt_f32 vcc, %5, %8\n\tv_cmp_lt_f32 vcc, %6, %8\n\tv_cmp_lt_f32 vcc, %7, %8"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c) : "vcc"); }
+        if (K == 12) { asm volatile("v_fma_f32 %0, %0, %8, %9\n\tv_fma_f32 %1, %1, %8, %9\n\tv_fma_f32 %2, %2, %8, %9\n\tv_fma_f32 %3, %3, %8, %9\n\t"
+                                   "v_fma_f32 %4, %4, %8, %9\n\tv_fma_f32 %5, %5, %8, %9\n\tv_fma_f32 %6, %6, %8, %9\n\tv_fma_f32 %7, %7, %8, %9"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(c2)); }
+        if (K == 13) { asm volatile("v_fmac_f32 %0, %8, %9\n\tv_fmac_f32 %1, %8, %9\n\tv_fmac_f32 %2, %8, %9\n\tv_fmac_f32 %3, %8, %9\n\t"
+                                   "v_fmac_f32 %4, %8, %9\n\tv_fmac_f32 %5, %8, %9\n\tv_fmac_f32 %6, %8, %9\n\tv_fmac_f32 %7, %8, %9"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(c2)); }
+        if (K == 14) { CHAIN8("v_add_u32") }
+        if (K == 15) { asm volatile("v_mul_f32 %0, %1, %2\n\tv_mul_f32 %1, %2, %3\n\tv_mul_f32 %2, %3, %4\n\tv_mul_f32 %3, %4, %5\n\t"
+                                   "v_mul_f32 %4, %5, %6\n\tv_mul_f32 %5, %6, %7\n\tv_mul_f32 %6, %7, %0\n\tv_mul_f32 %7, %0, %1"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)); }
+        if (K == 16) { asm volatile("v_cmp_lt_f32 vcc, %0, %4\n\tv_cndmask_b32 %0, %0, %4, vcc\n\tv_cmp_lt_f32 vcc, %1, %4\n\tv_cndmask_b32 %1, %1, %4, vcc\n\t"
+                                   "v_cmp_lt_f32 vcc, %2, %4\n\tv_cndmask_b32 %2, %2, %4, vcc\n\tv_cmp_lt_f32 vcc, %3, %4\n\tv_cndmask_b32 %3, %3, %4, vcc"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c) : "vcc"); }
+        if (K == 17) { asm volatile("v_cmp_lt_f32 s[20:21], %0, %4\n\tv_cndmask_b32_e64 %0, %0, %4, s[20:21]\n\tv_cmp_lt_f32 s[22:23], %1, %4\n\tv_cndmask_b32_e64 %1, %1, %4, s[22:23]\n\t"
+                                   "v_cmp_lt_f32 s[24:25], %2, %4\n\tv_cndmask_b32_e64 %2, %2, %4, s[24:25]\n\tv_cmp_lt_f32 s[26:27], %3, %4\n\tv_cndmask_b32_e64 %3, %3, %4, s[26:27]"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c) : "s20","s21","s22","s23","s24","s25","s26","s27"); }
+        if (K == 18) { asm volatile("v_cmp_lt_f32 vcc, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_mul_f32 %2, %2, %4\n\tv_cndmask_b32 %0, %0, %4, vcc\n\tv_mul_f32 %3, %3, %4\n\tv_mul_f32 %1, %1, %4\n\t"
+                                   "v_mul_f32 %2, %2, %4\n\tv_mul_f32 %3, %3, %4"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c) : "vcc"); }
+        if (K == 19) { asm volatile("v_min_f32 %0, %0, %4\n\tv_min_f32 %1, %1, %4\n\tv_min_f32 %2, %2, %4\n\tv_min_f32 %3, %3, %4\n\t"
+                                   "v_min_f32 %0, %0, %4\n\tv_min_f32 %1, %1, %4\n\tv_min_f32 %2, %2, %4\n\tv_min_f32 %3, %3, %4"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c)); }
+        if (K == 20) { asm volatile("v_sub_f32 %0, %0, %4\n\tv_sub_f32 %1, %1, %4\n\tv_sub_f32 %2, %2, %4\n\tv_sub_f32 %3, %3, %4\n\t"
+                                   "v_mul_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_mul_f32 %2, %2, %4\n\tv_mul_f32 %3, %3, %4"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c)); }
         if (K == 9) { // dependent chain of v_mul (latency)
             asm volatile("v_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\t"
                          "v_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1" : "+v"(a0) : "v"(c)); }
@@ -73,7 +105,7 @@ static void run(const char *name, F launch, int ops_per_instr)
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     printf("%-14s", name);
-    for (int wps : { 1, 2, 4, 8 }) {               // waves per SIMD
+    for (int wps : { 1, 2, 4 }) {               // waves per SIMD
         const int blocks = cus * wps, threads = 256; // 4 waves per block -> one per SIMD
         launch(blocks, threads, out);
         hipDeviceSynchronize();
@@ -97,6 +129,6 @@ int main()
 #define S(K, NAME) run(NAME, [](int b, int t, float *o) { hipLaunchKernelGGL(k_scalar<K>, dim3(b), dim3(t), 0, 0, o, 1.0001f); }, 1)
 #define P(K, NAME) run(NAME, [](int b, int t, float *o) { hipLaunchKernelGGL(k_packed<K>, dim3(b), dim3(t), 0, 0, o, 1.0001f); }, 2)
     S(0, "v_mul_f32"); S(1, "v_add_f32"); S(2, "v_fma_f32"); P(0, "v_pk_mul_f32"); P(1, "v_pk_add_f32"); P(2, "v_pk_fma_f32");
-    S(3, "v_sqrt_f32"); S(4, "v_rcp_f32"); S(5, "v_rsq_f32"); S(6, "v_log_f32"); S(7, "v_max_f32"); S(8, "v_cndmask"); S(9, "dep v_mul");
+    S(3, "v_sqrt_f32"); S(4, "v_rcp_f32"); S(5, "v_rsq_f32"); S(6, "v_log_f32"); S(7, "v_max_f32"); S(8, "v_cndmask vcc"); S(10, "v_cndmask e64"); S(11, "v_cmp_lt_f32"); S(12, "v_fma 3src"); S(13, "v_fmac_f32"); S(14, "v_add_u32"); S(15, "v_mul 2vsrc"); S(9, "dep v_mul"); S(16, "cmp+cnd vcc"); S(17, "cmp+cnd sgpr"); S(18, "cmp,2mul,cnd,4mul"); S(19, "v_min_f32"); S(20, "sub/mul mix");
     return 0;
 }
