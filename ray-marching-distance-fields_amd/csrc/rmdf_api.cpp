@@ -45,6 +45,12 @@ struct rmdf_ctx {
     float4      *d_gbuf_nao = nullptr;
     unsigned    *d_gbuf_meta = nullptr;
     int         *d_work_counter = nullptr;
+    // cost-ordered dispatch state of the nested-loop kernel (previous frame's per-strip costs)
+    unsigned    *d_block_cost = nullptr, *d_block_order = nullptr;
+    int          order_cap = 0, order_n = 0;
+    int          order_key[8] = { -1, 0, 0, 0, 0, 0, 0, 0 };
+    hipStream_t  order_stream = nullptr;
+    bool         order_valid = false;
     unsigned long long *d_dbg = nullptr;   // per-wave march diagnostics (rmdf_debug_march_stats)
     size_t       gbuf_cap = 0;
     int          flags = 0;            // rmdf_config.reserved[0]
@@ -184,10 +190,42 @@ int ensure_gbuf(rmdf_ctx *ctx, int w, int h)
 // fastest measured one, the other stays selectable for A/B measurements and tests
 int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t stream)
 {
-    if (scene == RMDF_FS_MB_POWER8 && (ctx->flags & RMDF_FLAG_FLAT_MARCH))
+    if (scene == RMDF_FS_MB_POWER8 && ctx->d_dbg && getenv("RMDF_NESTED_STATS")) {
+        HIP_TRY(ctx, launch_march_stats(p, stream));
+        return RMDF_OK;
+    }
+    if (scene == RMDF_FS_MB_POWER8 && (ctx->flags & RMDF_FLAG_FLAT_MARCH)) {
         HIP_TRY(ctx, launch_render_mb8(p, stream, ctx->cus));
-    else
-        HIP_TRY(ctx, launch_render(scene, p, stream));
+        return RMDF_OK;
+    }
+    // Nested-loop kernel.  Its run time is set by the strips that hold the longest rays (a 226-step ray is a
+    // ~0.4 ms serial chain), so large launches dispatch the strips that were most expensive in the previous
+    // frame of the same configuration first (temporal coherence; `time` is deliberately not part of the key).
+    // The table only permutes which workgroup renders which strip: the image does not depend on it.
+    FrameParams q = p;
+    const int nblk = render_grid_blocks(p);
+    const bool want = (p.n_shard_tiles == 0) && nblk >= 1024 && !(ctx->flags & RMDF_FLAG_RASTER_ORDER);
+    if (want) {
+        if (nblk > ctx->order_cap) {
+            if (ctx->d_block_cost) (void)hipFree(ctx->d_block_cost);
+            if (ctx->d_block_order) (void)hipFree(ctx->d_block_order);
+            ctx->d_block_cost = ctx->d_block_order = nullptr; ctx->order_cap = 0; ctx->order_valid = false;
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->d_block_cost, (size_t)nblk * 4));
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->d_block_order, (size_t)nblk * 4));
+            ctx->order_cap = nblk;
+        }
+        const int key[8] = { scene, p.w, p.h, p.x0, p.y0, p.x1, p.y1, p.max_steps };
+        const bool same = ctx->order_valid && ctx->order_stream == stream && ctx->order_n == nblk &&
+                          memcmp(key, ctx->order_key, sizeof key) == 0;
+        q.block_cost = ctx->d_block_cost;
+        q.block_order = same ? ctx->d_block_order : nullptr;
+        HIP_TRY(ctx, launch_render(scene, q, stream));
+        HIP_TRY(ctx, launch_order_blocks(ctx->d_block_cost, nblk, ctx->d_block_order, stream));
+        memcpy(ctx->order_key, key, sizeof key);
+        ctx->order_n = nblk; ctx->order_stream = stream; ctx->order_valid = true;
+    } else {
+        HIP_TRY(ctx, launch_render(scene, q, stream));
+    }
     return RMDF_OK;
 }
 
@@ -456,6 +494,8 @@ void rmdf_destroy(rmdf_ctx *ctx)
     if (ctx->d_gbuf_meta) (void)hipFree(ctx->d_gbuf_meta);
     if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
     if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
+    if (ctx->d_block_cost) (void)hipFree(ctx->d_block_cost);
+    if (ctx->d_block_order) (void)hipFree(ctx->d_block_order);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -193,6 +193,26 @@ __device__ __forceinline__ float de_mandelbulb8(v3 pos, unsigned &iters)
     return 0.5f * log_pinned(r) * r / dr;
 }
 
+// same, counting wave-level inner passes and the lanes active in them (measurement builds only)
+__device__ __forceinline__ float de_mandelbulb8_dbg(v3 pos, unsigned &iters, unsigned long long &passes, unsigned long long &lanes)
+{
+    pos = mk3(pos.z, pos.x, pos.y);
+    v3 w = pos;
+    float dr = 1.0f;
+    float r = 0.0f;
+    for (int i = 0; i < 25; i++) {
+        passes++; lanes += __popcll(__ballot(true));
+        r = length3(w);
+        if (r > 4.0f) break;
+        w = triplex_pow8(w);
+        w = add3(w, pos);
+        float r2 = r * r, r4 = r2 * r2, r7 = (r4 * r2) * r;
+        dr = r7 * 8.0f * dr + 1.0f;
+        iters++;
+    }
+    return 0.5f * log_pinned(r) * r / dr;
+}
+
 // fragment.shd:312-321
 __device__ __forceinline__ float line_seg_min_dist_sq(v3 a, v3 b, v3 p)
 {

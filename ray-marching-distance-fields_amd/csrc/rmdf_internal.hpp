@@ -36,7 +36,11 @@ struct FrameParams {
     int       gw;
     int      *work_counter;   // zeroed before every march launch
     int       total_items, items_per_shard_tile;
-    int       tail_t, shade_t, refill_t, chunk;
+    int       tail_t, shade_t, refill_t, chunk, pool_low;
+    // cost-ordered dispatch of the nested-loop kernel (see DESIGN.md 'critical path'): block b renders
+    // strip order[b] (null = raster order) and writes its cost (max escape iterations of a pixel) to cost[]
+    const unsigned *block_order;
+    unsigned *block_cost;
     unsigned long long *dbg;  // optional per-wave counters of k_march_mb8 (8 x u64 per wave), may be null   // scheduling thresholds of k_march_mb8 (see rmdf_march.hip)
 };
 
@@ -45,7 +49,11 @@ void tile_rect_host(int tile_idx, int w, int h, int *x0, int *y0, int *x1, int *
 
 // kernels / launchers implemented in rmdf_kernels.hip
 hipError_t launch_render(int scene, const FrameParams &p, hipStream_t stream);
+hipError_t launch_march_stats(const FrameParams &p, hipStream_t stream);
+int render_grid_blocks(const FrameParams &p);   // number of 32x8 strips launch_render() uses for p
+hipError_t launch_order_blocks(const unsigned *d_cost, int n, unsigned *d_order, hipStream_t stream);
 hipError_t launch_render_mb8(const FrameParams &p, hipStream_t stream, int num_cus);
+hipError_t launch_march_pool(const FrameParams &p, int blocks, hipStream_t stream);   // rmdf_pool.hip
 hipError_t launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t stream);
 hipError_t launch_cube_upload(const float *d_faces_f32, int W, uint2 *d_padded, hipStream_t stream);
 hipError_t launch_latlong_to_cube(const float *d_latlong, int w, int h, float *d_faces_f32, hipStream_t stream);

@@ -69,9 +69,14 @@ __global__ __launch_bounds__(256) void k_render(const FrameParams p)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lx = (lane & 1) | (((lane >> 2) & 3) << 1);
     const int ly = ((lane >> 1) & 1) | (((lane >> 4) & 3) << 1);
-    const int px = ex0 + blockIdx.x * 32 + wave * 8 + lx;
-    const int py = ey0 + blockIdx.y * 8 + ly;
+    // strip handled by this workgroup: raster order, or most expensive first (block_order)
+    unsigned strip = blockIdx.y * gridDim.x + blockIdx.x;
+    if (p.block_order) strip = p.block_order[strip];
+    const int bx = strip % gridDim.x, by = strip / gridDim.x;
+    const int px = ex0 + bx * 32 + wave * 8 + lx;
+    const int py = ey0 + by * 8 + ly;
     const bool active = (px < ex1) && (py < ey1);
+    const unsigned long long dbg_t0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     // generate_ray, perspective branch (fragment.shd:840-871)
     const float ndcx = ((float)px + 0.5f) / p.wf * 2.0f - 1.0f;
@@ -165,6 +170,130 @@ __global__ __launch_bounds__(256) void k_render(const FrameParams p)
         if (p.steps) p.steps[idx] = (uint16_t)(steps | (hit_i << 15));
         if (p.iters) p.iters[idx] = (uint16_t)(iters > 65535u ? 65535u : iters);
     }
+    if (p.block_cost) {
+        // cost of the strip = the largest escape-iteration total of one of its pixels (proxy of its longest
+        // serial chain); only steers next frame's dispatch order, never the image
+        __shared__ unsigned s_cost;
+        if (threadIdx.x == 0) s_cost = 0u;
+        __syncthreads();
+        unsigned c = iters + (unsigned)steps;
+        for (int o = 32; o > 0; o >>= 1) { const unsigned v = __shfl_xor(c, o, 64); c = v > c ? v : c; }
+        if (lane == 0) atomicMax(&s_cost, c);
+        __syncthreads();
+        if (threadIdx.x == 0) p.block_cost[(size_t)blockIdx.z * gridDim.x * gridDim.y + strip] = s_cost;
+    }
+    if (p.dbg && lane == 0) {
+        const unsigned wid = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+        if (wid < 8192u * 2u) { p.dbg[wid * 8 + 6] = dbg_t0; p.dbg[wid * 8 + 7] = __builtin_amdgcn_s_memrealtime(); p.dbg[wid * 8] = (unsigned long long)steps; }
+    }
+}
+
+// measurement aid: the march loop of k_render<2> alone, with wave-level divergence counters
+__global__ __launch_bounds__(256) void k_march_stats(const FrameParams p)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lx = (lane & 1) | (((lane >> 2) & 3) << 1);
+    const int ly = ((lane >> 1) & 1) | (((lane >> 4) & 3) << 1);
+    const int px = blockIdx.x * 32 + wave * 8 + lx, py = blockIdx.y * 8 + ly;
+    const bool active = (px < p.w) && (py < p.h);
+    const float ndcx = ((float)px + 0.5f) / p.wf * 2.0f - 1.0f;
+    const float ndcy = ((float)py + 0.5f) / p.hf * 2.0f - 1.0f;
+    const v3 dcam = normalize3(mk3(ndcx * p.fov_xs, ndcy * p.fov_xs / p.aspect, -1.0f));
+    const v3 dir = mk3(p.cam[0] * dcam.x + p.cam[3] * dcam.y + p.cam[6] * dcam.z,
+                       p.cam[1] * dcam.x + p.cam[4] * dcam.y + p.cam[7] * dcam.z,
+                       p.cam[2] * dcam.x + p.cam[5] * dcam.y + p.cam[8] * dcam.z);
+    const v3 origin = mk3(p.cam[9], p.cam[10], p.cam[11]);
+    unsigned long long passes = 0, lanes = 0, wsteps = 0, wlanes = 0;
+    unsigned iters = 0;
+    float t = 0.0f, tmin, tmax;
+    int steps = 0;
+    bool hit = false;
+    if (active && ray_sphere(origin, dir, 1.15f, tmin, tmax)) {
+        t = gmax(0.0f, tmin);
+        for (steps = 0; steps < p.max_steps; steps++) {
+            wsteps++; wlanes += __popcll(__ballot(true));
+            v3 pos = mk3(origin.x + t * dir.x, origin.y + t * dir.y, origin.z + t * dir.z);
+            float dist = de_mandelbulb8_dbg(pos, iters, passes, lanes);
+            t += dist;
+            if (t > tmax) break;
+            if (dist < 0.001f) { hit = true; break; }
+        }
+    }
+    // wave totals: every lane counted the passes it took part in; the wave-level count is the max
+    unsigned long long wp = passes, ws = wsteps;
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long a = __shfl_xor(wp, o, 64), b = __shfl_xor(ws, o, 64);
+        wp = a > wp ? a : wp; ws = b > ws ? b : ws;
+    }
+    unsigned long long li = iters, lh = hit ? 1 : 0, lst = (unsigned long long)(steps);
+    for (int o = 32; o > 0; o >>= 1) { li += __shfl_xor(li, o, 64); lh += __shfl_xor(lh, o, 64); lst += __shfl_xor(lst, o, 64); }
+    if (lane == 0 && p.dbg) {
+        atomicAdd(&p.dbg[0], wp);       // wave-level inner passes (max over lanes is a lower bound of the true count)
+        atomicAdd(&p.dbg[1], li);       // lane iterations
+        atomicAdd(&p.dbg[2], ws);       // wave-level march steps
+        atomicAdd(&p.dbg[3], lst);      // lane steps (sum of loop counters)
+        atomicAdd(&p.dbg[4], lh);
+        atomicAdd(&p.dbg[5], 1ull);
+    }
+}
+
+hipError_t launch_march_stats(const FrameParams &p, hipStream_t stream)
+{
+    dim3 grid((p.w + 31) / 32, (p.h + 7) / 8), block(256);
+    hipLaunchKernelGGL(k_march_stats, grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+static void render_grid(const FrameParams &p, dim3 &grid)
+{
+    int rx0, ry0, rx1, ry1, nz = 1;
+    if (p.n_shard_tiles > 0) {
+        rx0 = 0; ry0 = 0; rx1 = p.w / 8 + 2; ry1 = p.h / 8 + 2;
+        nz = p.n_shard_tiles;
+    } else {
+        rx0 = p.x0; ry0 = p.y0; rx1 = p.x1; ry1 = p.y1;
+    }
+    const int ex0 = rx0 & ~1, ey0 = ry0 & ~1, ex1 = (rx1 + 1) & ~1, ey1 = (ry1 + 1) & ~1;
+    if (ex1 <= ex0 || ey1 <= ey0) { grid = dim3(0, 0, 0); return; }
+    grid = dim3((ex1 - ex0 + 31) / 32, (ey1 - ey0 + 7) / 8, nz);
+}
+
+int render_grid_blocks(const FrameParams &p)
+{
+    dim3 g;
+    render_grid(p, g);
+    return (int)(g.x * g.y * g.z);
+}
+
+// Counting sort of the strips by descending cost (256 logarithmic-ish bins): order[rank] = strip.
+// One workgroup; ~n/1024 elements per thread.  Longest-processing-time-first dispatch needs no exact order.
+__global__ __launch_bounds__(1024) void k_order_blocks(const unsigned *__restrict__ cost, int n, unsigned *__restrict__ order)
+{
+    __shared__ unsigned hist[256], base[256];
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0u;
+    __syncthreads();
+    auto bin_of = [](unsigned c) -> unsigned {
+        // 8 sub-bins per power of two: monotone in c, 0..255
+        if (c < 8u) return c;
+        const int e = 31 - __builtin_clz(c);              // >= 3
+        const unsigned b = (unsigned)(e - 2) * 8u + ((c >> (e - 3)) & 7u);
+        return b > 255u ? 255u : b;
+    };
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[bin_of(cost[i])], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        unsigned acc = 0u;
+        for (int b = 255; b >= 0; b--) { base[b] = acc; acc += hist[b]; }   // descending cost
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) order[atomicAdd(&base[bin_of(cost[i])], 1u)] = (unsigned)i;
+}
+
+hipError_t launch_order_blocks(const unsigned *d_cost, int n, unsigned *d_order, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, stream, d_cost, n, d_order);
+    return hipGetLastError();
 }
 
 hipError_t launch_render(int scene, const FrameParams &p, hipStream_t stream)
