@@ -251,6 +251,7 @@ int fill_params(rmdf_ctx *ctx, int scene, int w, int h, float time, int max_step
     p.env_cos1 = CubeDev{ ctx->env[RMDF_ENV_COS_1].d_texels, ctx->env[RMDF_ENV_COS_1].W };
     p.env_cos8 = CubeDev{ ctx->env[RMDF_ENV_COS_8].d_texels, ctx->env[RMDF_ENV_COS_8].W };
     p.cornell = ctx->d_cornell;
+    { static int skip = -1; if (skip < 0) { const char *e = getenv("RMDF_DBG_SKIP"); skip = e ? atoi(e) : 0; } p.dbg_skip = skip; }
     int rc = ensure_gbuf(ctx, w, h);
     if (rc != RMDF_OK) return rc;
     p.gbuf_nao = ctx->d_gbuf_nao; p.gbuf_meta = ctx->d_gbuf_meta; p.gw = (w + 1) & ~1;

@@ -39,6 +39,7 @@ struct FrameParams {
     int       tail_t, shade_t, refill_t, chunk, pool_low;
     // cost-ordered dispatch of the nested-loop kernel (see DESIGN.md 'critical path'): block b renders
     // strip order[b] (null = raster order) and writes its cost (max escape iterations of a pixel) to cost[]
+    int dbg_skip;             // measurement knob: 1 = skip normal/AO + shading of k_render, 2 = skip only normal/AO
     const unsigned *block_order;
     unsigned *block_cost;
     unsigned long long *dbg;  // optional per-wave counters of k_march_mb8 (8 x u64 per wave), may be null   // scheduling thresholds of k_march_mb8 (see rmdf_march.hip)

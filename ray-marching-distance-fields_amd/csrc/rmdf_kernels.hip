@@ -6,6 +6,8 @@
 // neighbours needed by the cube-map min/mag decision are lane^1 and lane^2),
 // one 256-thread workgroup = a 32x8 pixel strip.  No MFMA: the path is scalar
 // per ray.  See DESIGN.md for the roofline that bounds it.
+#include <stdlib.h>
+
 #include "rmdf_internal.hpp"
 
 namespace rmdf {
@@ -107,7 +109,8 @@ __global__ __launch_bounds__(256) void k_render(const FrameParams p)
     // render_ray hit branch up to the texture lookups (fragment.shd:743-799)
     v3 n = mk3(0.0f, 0.0f, 0.0f), refl = mk3(0.0f, 0.0f, 0.0f);
     float ao = 0.0f, fresnel = 0.0f;
-    if (hit) {
+    if (hit && p.dbg_skip != 0) { n = mk3(0.0f, 1.0f, 0.0f); ao = 1.0f; refl = reflect3(dir, n); fresnel = 0.5f; }
+    if (hit && p.dbg_skip == 0) {
         v3 isec = mk3(origin.x + dir.x * t, origin.y + dir.y * t, origin.z + dir.z * t);
         v3 np = mk3(isec.x - dir.x * 0.00001f, isec.y - dir.y * 0.00001f, isec.z - dir.z * 0.00001f);
         const float eps = 0.00001f;
@@ -146,7 +149,9 @@ __global__ __launch_bounds__(256) void k_render(const FrameParams p)
     const v3 dir_h = shfl_xor3(dir, 1), dir_v = shfl_xor3(dir, 2);
 
     v3 color;
-    if (hit) {
+    if (p.dbg_skip == 1) {
+        color = mk3(t, (float)steps, 0.0f);
+    } else if (hit) {
         // fragment.shd:799-810
         v3 t1 = cube_texture(p.env_cos1, n, hit_h, n_h, hit_v, n_v);
         v3 t8 = cube_texture(p.env_cos8, refl, hit_h, refl_h, hit_v, refl_v);
@@ -163,12 +168,29 @@ __global__ __launch_bounds__(256) void k_render(const FrameParams p)
     // fragment.shd:959-960 and the RGBA8 conversion of the colour attachment
     const float inv_gamma = 1.0f / 2.2f;
     const float gr = pow_pinned(color.x, inv_gamma), gg = pow_pinned(color.y, inv_gamma), gb = pow_pinned(color.z, inv_gamma);
-    if (active && px >= rx0 && px < rx1 && py >= ry0 && py < ry1) {
-        const size_t idx = obase + (size_t)(px - ox) + (size_t)(py - oy) * (size_t)pitch;
-        if (p.rgba8) p.rgba8[idx] = to_unorm8(gr) | (to_unorm8(gg) << 8) | (to_unorm8(gb) << 16) | 0xff000000u;
-        if (p.rgba_f32) p.rgba_f32[idx] = make_float4(gr, gg, gb, 1.0f);
-        if (p.steps) p.steps[idx] = (uint16_t)(steps | (hit_i << 15));
-        if (p.iters) p.iters[idx] = (uint16_t)(iters > 65535u ? 65535u : iters);
+    // Stage the 32x8 strip in LDS so that every store instruction writes whole 128-byte lines (a wave's own
+    // 8x8 packet would write 32-byte pieces of 8 different rows).  Thread t stores pixel (t % 32, t / 32).
+    __shared__ uint32_t s_rgba8[8][32];
+    __shared__ float4   s_f32[8][32];
+    __shared__ uint32_t s_meta[8][32];
+    {
+        const int sx = wave * 8 + lx;
+        s_rgba8[ly][sx] = to_unorm8(gr) | (to_unorm8(gg) << 8) | (to_unorm8(gb) << 16) | 0xff000000u;
+        if (p.rgba_f32) s_f32[ly][sx] = make_float4(gr, gg, gb, 1.0f);
+        s_meta[ly][sx] = (uint32_t)(steps | (hit_i << 15)) | ((iters > 65535u ? 65535u : iters) << 16);
+    }
+    __syncthreads();
+    {
+        const int ox_ = threadIdx.x & 31, oy_ = threadIdx.x >> 5;
+        const int qx = ex0 + bx * 32 + ox_, qy = ey0 + by * 8 + oy_;
+        if (qx >= rx0 && qx < rx1 && qy >= ry0 && qy < ry1) {
+            const size_t idx = obase + (size_t)(qx - ox) + (size_t)(qy - oy) * (size_t)pitch;
+            if (p.rgba8) p.rgba8[idx] = s_rgba8[oy_][ox_];
+            if (p.rgba_f32) p.rgba_f32[idx] = s_f32[oy_][ox_];
+            const uint32_t m = s_meta[oy_][ox_];
+            if (p.steps) p.steps[idx] = (uint16_t)(m & 0xffffu);
+            if (p.iters) p.iters[idx] = (uint16_t)(m >> 16);
+        }
     }
     if (p.block_cost) {
         // cost of the strip = the largest escape-iteration total of one of its pixels (proxy of its longest
@@ -310,8 +332,11 @@ hipError_t launch_render(int scene, const FrameParams &p, hipStream_t stream)
     const int ex0 = rx0 & ~1, ey0 = ry0 & ~1, ex1 = (rx1 + 1) & ~1, ey1 = (ry1 + 1) & ~1;
     if (ex1 <= ex0 || ey1 <= ey0) return hipSuccess;
     dim3 grid((ex1 - ex0 + 31) / 32, (ey1 - ey0 + 7) / 8, nz), block(256);
-    if (scene == 2)      hipLaunchKernelGGL(k_render<2>, grid, block, 0, stream, p);
-    else if (scene == 0) hipLaunchKernelGGL(k_render<0>, grid, block, 0, stream, p);
+    // RMDF_OCC_LDS (measurement knob): dynamic LDS bytes per workgroup, only to cap waves per SIMD
+    static int occ_lds = -1;
+    if (occ_lds < 0) { const char *e = getenv("RMDF_OCC_LDS"); occ_lds = e ? atoi(e) : 0; }
+    if (scene == 2)      hipLaunchKernelGGL(k_render<2>, grid, block, occ_lds, stream, p);
+    else if (scene == 0) hipLaunchKernelGGL(k_render<0>, grid, block, occ_lds, stream, p);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
