@@ -98,10 +98,26 @@ def test_determinism(sr):
     assert np.array_equal(a["rgba_f32"].view(np.uint32), b["rgba_f32"].view(np.uint32))
 
 
-def test_full_size_properties(sr, orc, env_oracle, rmdf):
-    """BASELINE.json's full size (1920x1080 @256): size-independent properties + sampled rows vs the oracle."""
+def test_full_size_properties(sr, orc, env_oracle, rmdf, env_faces):
+    """BASELINE.json's full size (1920x1080 @256): size-independent properties + sampled rows vs the oracle.
+    The second frame of the same configuration is dispatched in cost order: it must equal the
+    first (raster order) and a renderer with RMDF_FLAG_RASTER_ORDER bit for bit."""
     w, h, ms = 1920, 1080, 256
-    got = sr.render(2, w, h, 0.0, max_steps=ms)
+    first = sr.render(2, w, h, 0.0, max_steps=ms)
+    got = sr.render(2, w, h, 0.0, max_steps=ms)              # cost-ordered dispatch from the first frame's costs
+    moved = sr.render(2, w, h, 0.05, max_steps=ms)           # order table from t = 0 applied to another view
+    raster = rmdf.ShaderRenderer(0, flags=rmdf.FLAG_RASTER_ORDER)
+    try:
+        for slot, k in ((rmdf.ENV_REFLECTION, "refl"), (rmdf.ENV_COS_1, "cos1"), (rmdf.ENV_COS_8, "cos8")):
+            raster.set_env_cube(slot, env_faces[k])
+        ref0 = raster.render(2, w, h, 0.0, max_steps=ms)
+        ref1 = raster.render(2, w, h, 0.05, max_steps=ms)
+    finally:
+        raster.close()
+    for a, b in ((first, got), (got, ref0), (moved, ref1)):
+        for k in ("rgba8", "steps", "iters"):
+            assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a["rgba_f32"].view(np.uint32), b["rgba_f32"].view(np.uint32))
     hit = (got["steps"] >> 15).astype(bool)
     assert abs(hit.mean() - 0.593) < 0.01                               # SURVEY.md section 6 workload statistics
     assert (got["rgba8"] >> 24 == 0xFF).all()                           # alpha = 1 everywhere
