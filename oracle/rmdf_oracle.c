@@ -772,9 +772,10 @@ static void shade_pixel(const render_job *j, const px_state q[4], int k, float r
                       + t8[c] * spec_col[c] * npl * s->fresnel * spec_weight
                       + tr[c] * spec_weight * s->fresnel * 0.1f) * 3.0f * s->ao;
     } else {
-        /* fragment.shd:823; `dir` is computed in uniform control flow, so the
-         * neighbours' value is always defined */
-        cube_texture(&f->env_reflection, s->dir, 1, sh->dir, 1, sv->dir, rgb);
+        /* fragment.shd:823.  The lookup sits in the miss branch: a quad neighbour that took the hit
+         * branch leaves the derivative undefined (GLSL non-uniform control flow) -> pinned as minified,
+         * which is also what the reference shader does on SwiftShader (tests/test_oracle_vs_glsl.py) */
+        cube_texture(&f->env_reflection, s->dir, !sh->hit, sh->dir, !sv->hit, sv->dir, rgb);
     }
 }
 

@@ -7,18 +7,23 @@
  * ConcurrentSegments.hs).  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may load this library; the product (librmdf.so) never does.
  *
- * PARITY STATUS: the reference ships no tests, golden vectors or fixtures
- * (SURVEY.md section 4), its device code is GLSL 3.30 (no GL driver here) and
- * its host code is Haskell (no GHC here), so the reference itself cannot be
- * run in this container: **parity unpinned** by the reference's own vectors.
- * What pins this oracle instead:  (1) analytic known-answer tests
- * (tests/test_oracle_kat.py), (2) a statistical cross-check against the
- * reference's fragment.shd executed -- after a mechanical GLSL-ES patch -- on
- * the SwiftShader GLES3 software rasteriser found in this container
- * (tests/golden/make_swiftshader_vectors.py; vectors committed under
- * tests/golden/).  GLSL leaves inversesqrt/pow/log precision, FMA
- * contraction, f16 texel rounding and LOD selection implementation-defined;
- * every such choice is pinned below and listed in DESIGN.md ("spec pins").
+ * PARITY STATUS.  The reference ships no tests, golden vectors or fixtures
+ *  and its host code is Haskell (no GHC here), so nothing of
+ * the reference's own pins this file: the CPU paths restated here (HDREnvMap,
+ * CoordTransf, Fractal2D, the JuicyPixels / linear arithmetic behind them) are
+ * **parity unpinned**.  The shader path IS pinned against outputs of the
+ * reference itself run in the build container: fragment.shd, mechanically patched
+ * for GLSL ES, executed on the SwiftShader GLES3 software rasteriser
+ * (tests/golden/make_swiftshader_vectors.py wrote tests/golden/swiftshader_*.npz;
+ * tests/test_oracle_vs_glsl.py): hit masks identical and march step counts
+ * identical on every pixel of 7 frames, background colour equal to ~1e-6, surface
+ * colour statistically (the shader differentiates a fractal with eps = 1e-5 in
+ * float32, so two correct implementations agree only in distribution).  Further
+ * pins: analytic known-answer tests (tests/test_oracle_kat.py) and committed
+ * golden frames of this oracle (tests/golden/make_fixtures.py).  GLSL leaves
+ * inversesqrt/pow/log precision, FMA contraction, f16 texel rounding and LOD
+ * selection implementation-defined; every such choice is pinned below and listed
+ * in DESIGN.md ("spec pins").
  *
  * All arithmetic is IEEE-754 binary32, round-to-nearest-even, one rounding per
  * written operation (compile with -ffp-contract=off), left-to-right

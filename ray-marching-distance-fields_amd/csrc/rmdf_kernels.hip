@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_render(const FrameParams p)
         color.z = (t1.z * 0.8f * diff_weight + t8.z * 1.0f * npl * fresnel * spec_weight + tr.z * spec_weight * fresnel * 0.1f) * 3.0f * ao;
     } else {
         // fragment.shd:823
-        color = cube_texture(p.env_refl, dir, true, dir_h, true, dir_v);
+        color = cube_texture(p.env_refl, dir, !hit_h, dir_h, !hit_v, dir_v);   // neighbours in the hit branch: undefined derivative -> minified
     }
 
     // fragment.shd:959-960 and the RGBA8 conversion of the colour attachment

@@ -1,0 +1,64 @@
+"""CPU tier, parity tier B: the CPU oracle against the REFERENCE's own fragment.shd executed on SwiftShader
+(GLES 3.0 software rasteriser) -- vectors made by tests/golden/make_swiftshader_vectors.py in the build container
+(the reference cannot travel; only the resulting images are committed).
+
+What this pins, with an actual execution of the reference shader:
+  * the hit mask: identical, every pixel, every case;
+  * the march step count of every ray: identical (<= 3 pixels per frame may differ by one step -- SwiftShader's
+    inversesqrt / log are approximations, so a ray that ends within an ulp of MIN_DIST can flip);
+  * the background colour (one cube-map lookup, gamma): equal to ~1e-6 wherever both sides magnify; the min/mag
+    decision itself is implementation-defined near rho = 1, so low-resolution frames are checked statistically;
+  * the surface colour statistically: the shader differentiates a fractal distance field with eps = 1e-5 in float32
+    (fragment.shd:466), so normals -- hence colours -- of two correct implementations agree only in distribution
+    (SURVEY.md H1).  Bars below are ~3x looser than the observed values.
+"""
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLD
+
+CASES = sorted(glob.glob(os.path.join(GOLD, "swiftshader_s*_*.npz")))
+
+
+def _parse(fn):
+    m = re.match(r"swiftshader_s(\d)_(\d+)x(\d+)_t(\d+)p(\d+)_m(\d+)\.npz", os.path.basename(fn))
+    return int(m.group(1)), int(m.group(2)), int(m.group(3)), float(m.group(4) + "." + m.group(5)), int(m.group(6))
+
+
+def _rel(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return (np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-6)).max(axis=-1)
+
+
+@pytest.mark.parametrize("fn", CASES, ids=[os.path.basename(c)[:-4] for c in CASES])
+def test_oracle_matches_reference_shader_on_swiftshader(orc, env_oracle, fn):
+    scene, w, h, t, ms = _parse(fn)
+    g = np.load(fn)
+    r = orc.render(scene, w, h, t, ms, env_oracle)
+    hit = (r["steps"] >> 15).astype(bool)
+    steps = (r["steps"] & 0x7FFF).astype(int)
+    assert np.array_equal(hit, g["hit"])                                   # hit mask: identical
+    dsteps = np.abs(steps - g["steps"].astype(int))
+    assert (dsteps > 0).sum() <= 3 and dsteps.max() <= 1                   # march length: identical (see docstring)
+    rgb = r["rgba_f32"][..., :3]
+    rel = _rel(rgb, g["rgb16"].astype(np.float32))
+    # quads in which every pixel missed: the lookup derivative is well defined on both sides
+    miss_quads = ~hit.reshape(h // 2, 2, w // 2, 2).any(axis=(1, 3))
+    bg = np.repeat(np.repeat(miss_quads, 2, axis=0), 2, axis=1)
+    assert np.median(rel[bg]) < 1e-3                                        # float16 storage: ~5e-4 quantisation
+    if w >= 320:                                                            # magnified everywhere: rho << 1
+        assert rel[bg].max() < 2e-3
+        rows = np.concatenate([rgb[:8], rgb[-8:]])
+        rows_bg = np.concatenate([bg[:8], bg[-8:]])
+        assert _rel(rows, g["rows_f32"])[rows_bg].max() < 1e-5              # float32 copy of 16 rows: tight
+    else:
+        assert (rel[bg] < 2e-3).mean() > 0.6                                # rho ~ 1: filter choice may differ
+    surf = rel[hit]
+    assert np.median(surf) < 5e-3
+    assert (surf < 1e-2).mean() > 0.80
+    assert (surf < 0.2).mean() > 0.97
+    assert abs(rgb.mean() - g["rgb16"].astype(np.float64).mean()) < 2e-3    # no systematic brightness shift

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Timings of the secondary BASELINE.json configurations (device-resident unless noted)."""
+import os, sys, time, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import rmdf_amd
+from oracle import orc
+
+dev = torch.device("cuda", 0)
+stream = torch.cuda.Stream(dev); torch.cuda.set_stream(stream); sp = stream.cuda_stream
+sr = rmdf_amd.ShaderRenderer(0)
+sr.load_env_hdr(rmdf_amd.DEFAULT_ENV_HDR)
+out = {}
+
+def time_render(scene, w, h, ms, t=0.0, n=50):
+    frame = torch.empty((h, w), dtype=torch.int32, device=dev)
+    for _ in range(5):
+        sr.render_rect_device(scene, w, h, t, ms, (0, 0, w, h), d_rgba8=frame.data_ptr(), stream=sp)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(n):
+        sr.render_rect_device(scene, w, h, t, ms, (0, 0, w, h), d_rgba8=frame.data_ptr(), stream=sp)
+    e1.record(stream); torch.cuda.synchronize()
+    ms_ = e0.elapsed_time(e1) / n
+    return ms_, w * h / 1e6 / (ms_ * 1e-3)
+
+m, r = time_render(0, 1280, 720, 128)
+out["C2 CornellBox 1280x720/128"] = {"ms": round(m, 4), "Mpixels/s": round(r, 1)}
+m, r = time_render(2, 1920, 1080, 256)
+out["C3 Mandelbulb 1920x1080/256"] = {"ms": round(m, 4), "Mpixels/s": round(r, 1)}
+m, r = time_render(2, 7680, 4320, 256, n=5)
+out["C4 Mandelbulb 7680x4320 rays (4 rays/px of 3840x2160), 1 GPU, no resolve"] = {"ms": round(m, 3), "Mrays/s": round(r, 1)}
+# C5: env prefilter: synthetic 2048x1024 latlong -> resize 256 -> 4 powers (host buffers in/out, PCIe included)
+rng = np.random.RandomState(0)
+big = np.exp(rng.uniform(-3, 3, (1024, 2048, 3))).astype(np.float32)
+t0 = time.perf_counter(); small = sr.resize_latlong(big, 256); t1 = time.perf_counter()
+ts = []
+for p in (1.0, 8.0, 64.0, 512.0):
+    ta = time.perf_counter(); sr.prefilter_env(small, p); ts.append(time.perf_counter() - ta)
+out["C5 prefilter 2048x1024 -> 256x128, powers 1/8/64/512 (host in/out)"] = {
+    "resize_ms": round((t1 - t0) * 1e3, 2), "per_power_ms": [round(x * 1e3, 2) for x in ts],
+    "G pair-terms/s": round(4 * (256 * 128) ** 2 / sum(ts) / 1e9, 1)}
+# CPU baselines of the same (oracle = C port, threading as the reference: one thread per power / row segments)
+tc = time.perf_counter(); orc.cosine_convolve(small, 8.0, nthreads=1); c1 = time.perf_counter() - tc
+tc = time.perf_counter(); orc.cosine_convolve(small, 8.0, nthreads=0); call = time.perf_counter() - tc
+out["C5 CPU oracle cosine_convolve 256x128 power 8"] = {"1 thread s": round(c1, 2), "all cores s": round(call, 3), "cores": orc.num_processors()}
+tc = time.perf_counter(); orc.julia_animated(512, 512, 0, 0.0); j = time.perf_counter() - tc
+out["C1 CPU oracle julia 512x512"] = {"ms": round(j * 1e3, 2), "Mpixels/s": round(0.262144 / j, 1), "cores": orc.num_processors()}
+print(json.dumps(out, indent=1))
+sr.close()
