@@ -49,11 +49,13 @@ def lib():
         L = C.CDLL(_LIB)
         fp, ip, u8p = C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p
         L.orc_fov_xs.restype = C.c_float
-        for n in ("orc_logf", "orc_expf"):
+        for n in ("orc_logf", "orc_expf", "orc_sinf", "orc_cosf", "orc_acosf", "orc_general_power"):
             getattr(L, n).restype = C.c_float
             getattr(L, n).argtypes = [C.c_float]
-        L.orc_powf.restype = C.c_float
-        L.orc_powf.argtypes = [C.c_float, C.c_float]
+        for n in ("orc_powf", "orc_atan2f"):
+            getattr(L, n).restype = C.c_float
+            getattr(L, n).argtypes = [C.c_float, C.c_float]
+        L.orc_triplex_pow.argtypes = [fp, C.c_float, fp]
         L.orc_de.restype = C.c_float
         L.orc_de.argtypes = [C.c_int, C.c_float, fp]
         L.orc_fresnel_conductor.restype = C.c_float
@@ -96,6 +98,17 @@ def _f3(v):
 def logf(x): return lib().orc_logf(float(x))
 def expf(x): return lib().orc_expf(float(x))
 def powf(x, y): return lib().orc_powf(float(x), float(y))
+def sinf(x): return lib().orc_sinf(float(x))
+def cosf(x): return lib().orc_cosf(float(x))
+def acosf(x): return lib().orc_acosf(float(x))
+def atan2f(y, x): return lib().orc_atan2f(float(y), float(x))
+def general_power(t): return lib().orc_general_power(float(t))
+
+
+def triplex_pow(w, power):
+    out = (C.c_float * 3)()
+    lib().orc_triplex_pow(_f3(w), float(power), out)
+    return np.array(out[:], dtype=np.float32)
 def de(scene, pos, time=0.0): return lib().orc_de(scene, float(time), _f3(pos))
 def fresnel_conductor(cosi, eta, k): return lib().orc_fresnel_conductor(cosi, eta, k)
 def fov_xs(): return lib().orc_fov_xs()

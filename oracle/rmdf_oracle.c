@@ -128,6 +128,169 @@ static float rm_powf(float x, float y)
     return rm_expf(y * rm_logf(x));
 }
 
+
+/* ---- pinned sin / cos / acos / atan (scenes FSMBGeneralShader and FSDETestShader) ----
+ * fdlibm-style float algorithms with a fixed operation order, < 2 ulp on the ranges the shader uses.
+ * Argument reduction: x - k*(pi/2) with a 4-part constant whose leading parts have <= 11 significant
+ * bits, so k*c is exact for |k| < 2^13 (|x| < ~1.2e4; beyond that the result is pinned to the same
+ * formula, merely less accurate). */
+static void rm_rem_pio2(float x, float *r, int *q)
+{
+    const float invpio2 = 0.6366197466850281f;
+    const float c1 = 1.5703125f, c2 = 4.837512969970703e-4f, c3 = 7.549533620476723e-8f, c4 = 2.5633440682570896e-12f;
+    float kf = rintf(x * invpio2);
+    *q = (int)kf;
+    float t = x - kf * c1;
+    t = t - kf * c2;
+    t = t - kf * c3;
+    t = t - kf * c4;
+    *r = t;
+}
+static float rm_ksin(float x)
+{
+    const float S1 = -1.6666667163e-01f, S2 = 8.3333337680e-03f, S3 = -1.9841270114e-04f, S4 = 2.7557314297e-06f,
+                S5 = -2.5050759689e-08f, S6 = 1.5896910177e-10f;
+    float z = x * x;
+    float v = z * x;
+    float r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    return x + v * (S1 + z * r);
+}
+static float rm_kcos(float x)
+{
+    const float C1 = 4.1666667908e-02f, C2 = -1.3888889225e-03f, C3 = 2.4801587642e-05f, C4 = -2.7557314297e-07f,
+                C5 = 2.0875723372e-09f, C6 = -1.1359647598e-11f;
+    float z = x * x;
+    float r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    return 1.0f - (0.5f * z - z * r);
+}
+static float rm_sinf(float x)
+{
+    if (!(fabsf(x) <= 3.4e38f)) return x - x;      /* inf, NaN -> NaN */
+    float r; int q;
+    rm_rem_pio2(x, &r, &q);
+    switch (q & 3) {
+    case 0:  return rm_ksin(r);
+    case 1:  return rm_kcos(r);
+    case 2:  return -rm_ksin(r);
+    default: return -rm_kcos(r);
+    }
+}
+static float rm_cosf(float x)
+{
+    if (!(fabsf(x) <= 3.4e38f)) return x - x;
+    float r; int q;
+    rm_rem_pio2(x, &r, &q);
+    switch (q & 3) {
+    case 0:  return rm_kcos(r);
+    case 1:  return -rm_ksin(r);
+    case 2:  return -rm_kcos(r);
+    default: return rm_ksin(r);
+    }
+}
+static float rm_acosf(float x)
+{
+    const float pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f, pi = 3.1415925026e+00f;
+    const float pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f,
+                pS4 = 7.9153501429e-04f, pS5 = 3.4793309169e-05f;
+    const float qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f, qS3 = -6.8828397989e-01f, qS4 = 7.7038154006e-02f;
+    float ax = fabsf(x);
+    if (!(ax <= 1.0f)) return (x - x) / (x - x);            /* |x| > 1 or NaN -> NaN */
+    if (ax == 1.0f) return (x > 0.0f) ? 0.0f : pi + 2.0f * pio2_lo;
+    if (ax < 0.5f) {
+        if (ax <= 1.4901161e-8f) return pio2_hi + pio2_lo;   /* 2^-26 */
+        float z = x * x;
+        float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        float r = p / q;
+        return pio2_hi - (x - (pio2_lo - x * r));
+    } else if (x < 0.0f) {
+        float z = (1.0f + x) * 0.5f;
+        float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        float s = sqrtf(z);
+        float r = p / q;
+        float w = r * s - pio2_lo;
+        return pi - 2.0f * (s + w);
+    } else {
+        float z = (1.0f - x) * 0.5f;
+        float s = sqrtf(z);
+        float df = u2f(f2u(s) & 0xfffff000u);
+        float c = (z - df * df) / (s + df);
+        float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        float r = p / q;
+        float w = r * s + c;
+        return 2.0f * (df + w);
+    }
+}
+static float rm_atanf(float x)
+{
+    static const float atanhi[4] = { 4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f };
+    static const float atanlo[4] = { 5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f };
+    static const float aT[11] = { 3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f,
+                                  9.0908870101e-02f, -7.6918758452e-02f, 6.6610731184e-02f, -5.8335702866e-02f,
+                                  4.9768779427e-02f, -3.6531571299e-02f, 1.6285819933e-02f };
+    if (x != x) return x;
+    float ax = fabsf(x);
+    int neg = (f2u(x) >> 31) != 0;
+    int id;
+    float t;
+    if (ax >= 67108864.0f) {                                /* 2^26 */
+        float z = atanhi[3] + atanlo[3];
+        return neg ? -z : z;
+    }
+    if (ax < 0.4375f) {
+        if (ax < 2.44140625e-4f) return x;                   /* 2^-12 */
+        id = -1; t = x;
+    } else if (ax < 1.1875f) {
+        if (ax < 0.6875f) { id = 0; t = (2.0f * ax - 1.0f) / (2.0f + ax); }
+        else              { id = 1; t = (ax - 1.0f) / (ax + 1.0f); }
+    } else {
+        if (ax < 2.4375f) { id = 2; t = (ax - 1.5f) / (1.0f + 1.5f * ax); }
+        else              { id = 3; t = -1.0f / ax; }
+    }
+    float z = t * t;
+    float w = z * z;
+    float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+    float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+    if (id < 0) return t - t * (s1 + s2);
+    float zz = atanhi[id] - ((t * (s1 + s2) - atanlo[id]) - t);
+    return neg ? -zz : zz;
+}
+/* GLSL atan(y, x) */
+static float rm_atan2f(float y, float x)
+{
+    const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f, pio2 = 1.5707963705e+00f;
+    if (x != x || y != y) return x + y;
+    int m = (int)((f2u(y) >> 31) | ((f2u(x) >> 30) & 2u));   /* 2*sign(x) + sign(y) */
+    float ax = fabsf(x), ay = fabsf(y);
+    if (ay == 0.0f) {
+        switch (m) { case 0: case 1: return y; case 2: return pi; default: return -pi; }
+    }
+    if (ax == 0.0f) return (m & 1) ? -pio2 : pio2;
+    if (ax == INFINITY) {
+        if (ay == INFINITY) {
+            switch (m) { case 0: return 0.25f * pi; case 1: return -0.25f * pi; case 2: return 0.75f * pi; default: return -0.75f * pi; }
+        }
+        switch (m) { case 0: return 0.0f; case 1: return -0.0f; case 2: return pi; default: return -pi; }
+    }
+    if (ay == INFINITY) return (m & 1) ? -pio2 : pio2;
+    float z = rm_atanf(ay / ax);                              /* |y/x| */
+    switch (m) {
+    case 0:  return z;
+    case 1:  return -z;
+    case 2:  return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+    }
+}
+/* GLSL mod(x, y) = x - y*floor(x/y) */
+static inline float rm_mod(float x, float y) { return x - y * floorf(x / y); }
+
+float orc_sinf(float x) { return rm_sinf(x); }
+float orc_cosf(float x) { return rm_cosf(x); }
+float orc_acosf(float x) { return rm_acosf(x); }
+float orc_atan2f(float y, float x) { return rm_atan2f(y, x); }
+
 float orc_logf(float x) { return rm_logf(x); }
 float orc_expf(float x) { return rm_expf(x); }
 float orc_powf(float x, float y) { return rm_powf(x, y); }
@@ -164,6 +327,7 @@ typedef struct {
     float    time;
     const float *cornell;    /* 96*3 */
     uint64_t de_evals, triplex_iters;
+    float    power;          /* FSMBGeneralShader: fragment.shd:116-119 */
 } de_ctx;
 
 /* fragment.shd:101-158 with POWER8: pow(r, power-1) pinned as the multiply chain
@@ -186,6 +350,78 @@ static float de_mandelbulb8(v3 pos, de_ctx *c)
         c->triplex_iters++;
     }
     return 0.5f * rm_logf(r) * r / dr;      /* :157 */
+}
+
+
+/* fragment.shd:116-119: the animated power of FSMBGeneralShader, uniform per frame */
+static float general_power(float time)
+{
+    float pow_offs = rm_mod(time / 2.0f, 9.0f);
+    if (pow_offs > 4.5f) pow_offs = 9.0f - pow_offs;
+    return pow_offs + 2.0f;
+}
+float orc_general_power(float time) { return general_power(time); }
+
+/* fragment.shd:42-72 */
+static v3 triplex_pow(v3 w, float power)
+{
+    float r = rm_length(w);
+    float theta = rm_acosf(w.z / r);
+    float phi = rm_atan2f(w.y, w.x);
+    float zr = rm_powf(r, power);
+    theta = theta * power;
+    phi = phi * power;
+    float st = rm_sinf(theta), ct = rm_cosf(theta), sp = rm_sinf(phi), cp = rm_cosf(phi);
+    return V3(zr * (st * cp), zr * (st * sp), zr * ct);
+}
+
+void orc_triplex_pow(const float w[3], float power, float out[3])
+{
+    v3 r = triplex_pow(V3(w[0], w[1], w[2]), power);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+/* fragment.shd:101-158 without POWER8 */
+static float de_mandelbulb_general(v3 pos, de_ctx *c)
+{
+    const float bailout = 4.0f;
+    const float power = c->power;
+    pos = V3(pos.z, pos.x, pos.y);
+    v3 w = pos;
+    float dr = 1.0f;
+    float r = 0.0f;
+    for (int i = 0; i < 25; i++) {
+        r = rm_length(w);
+        if (r > bailout) break;
+        w = triplex_pow(w, power);
+        w = rm_add(w, pos);
+        dr = rm_powf(r, power - 1.0f) * power * dr + 1.0f;
+        c->triplex_iters++;
+    }
+    return 0.5f * rm_logf(r) * r / dr;
+}
+
+/* fragment.shd:21-33, 413-418, 447-456 */
+static inline float length2(float x, float y) { return sqrtf(x * x + y * y); }
+static float de_torus(v3 p, float size, float r) { return length2(length2(p.x, p.y) - size, p.z) - r; }
+static float de_rounded_box(v3 p, v3 b, float r)
+{
+    v3 q = V3(rm_max(fabsf(p.x) - b.x, 0.0f), rm_max(fabsf(p.y) - b.y, 0.0f), rm_max(fabsf(p.z) - b.z, 0.0f));
+    return rm_length(q) - r;
+}
+static float smin(float a, float b, float k)
+{
+    float res = rm_expf(-k * a) + rm_expf(-k * b);
+    return -rm_logf(res) / k;
+}
+static float de_test_scene(v3 pos)
+{
+    float d_sphere = rm_length(pos) - 0.4f;
+    float d_torus = smin(smin(de_torus(pos, 0.85f, 0.1f), de_torus(V3(pos.z, pos.x, pos.y), 0.85f, 0.1f), 64.0f),
+                         de_torus(V3(pos.y, pos.z, pos.x), 0.85f, 0.1f), 64.0f);
+    float d_box = smin(smin(de_rounded_box(pos, V3(0.8f, 0.06f, 0.06f), 0.03f), de_rounded_box(pos, V3(0.06f, 0.8f, 0.06f), 0.03f), 64.0f),
+                       de_rounded_box(pos, V3(0.06f, 0.06f, 0.8f), 0.03f), 64.0f);
+    return smin(d_box, rm_min(d_sphere, d_torus), 64.0f);
 }
 
 /* fragment.shd:312-321 */
@@ -253,7 +489,8 @@ static float distance_estimator(v3 pos, de_ctx *c)
     switch (c->scene) {
     case ORC_SCENE_MB_POWER8: return de_mandelbulb8(pos, c);
     case ORC_SCENE_CORNELL:   return de_cornell_box(pos, c);
-    default:                  return NAN; /* scenes 1 and 3: not restated yet */
+    case ORC_SCENE_MB_GENERAL: return de_mandelbulb_general(pos, c);
+    default:                  return de_test_scene(pos);
     }
 }
 
@@ -316,7 +553,7 @@ static const float *cornell_table(void)
 
 float orc_de(int scene, float time, const float pos[3])
 {
-    de_ctx c = { scene, time, cornell_table(), 0, 0 };
+    de_ctx c = { scene, time, cornell_table(), 0, 0, general_power(time) };
     return distance_estimator(V3(pos[0], pos[1], pos[2]), &c);
 }
 
@@ -730,7 +967,7 @@ static v3 generate_ray_dir(const render_job *j, int px, int py)
 static void trace_pixel(render_job *j, int px, int py, px_state *s)
 {
     const orc_frame *f = j->f;
-    de_ctx c = { f->scene, f->time, cornell_table(), 0, 0 };
+    de_ctx c = { f->scene, f->time, cornell_table(), 0, 0, general_power(f->time) };
     v3 origin = V3(j->cam[9], j->cam[10], j->cam[11]);
     uint64_t march_steps = 0;
     float t = 0.0f;
@@ -867,7 +1104,7 @@ int orc_render(const orc_frame *f, int x0, int y0, int x1, int y1, float *rgba_f
                uint16_t *steps, uint16_t *iters, orc_counters *ctr, int nthreads)
 {
     if (!f || f->w <= 0 || f->h <= 0 || f->max_steps < 0 || f->max_steps > 32767) return -1;
-    if (f->scene != ORC_SCENE_MB_POWER8 && f->scene != ORC_SCENE_CORNELL) return -2;
+    if (f->scene < 0 || f->scene > 3) return -2;
     if (x0 < 0 || y0 < 0 || x1 > f->w || y1 > f->h || x0 > x1 || y0 > y1) return -3;
     render_job *jobs = (render_job *)calloc(256, sizeof(render_job));
     if (!jobs) return -4;

@@ -98,6 +98,7 @@ float orc_sinf(float x);
 float orc_cosf(float x);
 float orc_acosf(float x);
 float orc_atan2f(float y, float x);
+float orc_general_power(float time);   /* fragment.shd:116-119 */
 float orc_fresnel_conductor(float cosi, float eta, float k);
 int   orc_ray_sphere(const float o[3], const float d[3], float R, float *tmin, float *tmax);
 /* texture(samplerCube, dir) with an explicit filter choice (0 NEAREST, 1 LINEAR) */

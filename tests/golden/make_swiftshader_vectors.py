@@ -198,7 +198,8 @@ class GLES:
 
 
 CASES = [(2, 96, 54, 0.0, 128), (2, 96, 54, 2.5, 256), (2, 192, 108, 0.0, 256), (2, 480, 270, 0.0, 256),
-         (0, 96, 54, 0.0, 128), (0, 128, 72, 1.0, 128), (0, 320, 180, 0.0, 128)]
+         (0, 96, 54, 0.0, 128), (0, 128, 72, 1.0, 128), (0, 320, 180, 0.0, 128),
+         (1, 96, 54, 0.0, 128), (1, 320, 180, 3.0, 128), (3, 96, 54, 0.0, 128), (3, 320, 180, 3.0, 128), (3, 160, 90, 11.0, 128)]
 
 
 def main():
