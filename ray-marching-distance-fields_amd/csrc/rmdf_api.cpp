@@ -231,11 +231,8 @@ int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t str
 
 int fill_params(rmdf_ctx *ctx, int scene, int w, int h, float time, int max_steps, FrameParams &p)
 {
-    if (scene != RMDF_FS_MB_POWER8 && scene != RMDF_FS_DE_CORNELL_BOX) {
-        if (scene == RMDF_FS_DE_TEST || scene == RMDF_FS_MB_GENERAL)
-            return fail(ctx, RMDF_E_UNSUPPORTED, "scene not built yet (FSDETestShader / FSMBGeneralShader)");
+    if (scene < RMDF_FS_DE_CORNELL_BOX || scene > RMDF_FS_MB_GENERAL)
         return fail(ctx, RMDF_E_INVALID, "unknown FragmentShader value");
-    }
     if (w <= 0 || h <= 0 || w > 32768 || h > 32768) return fail(ctx, RMDF_E_INVALID, "bad frame size");
     if (max_steps > 32767) return fail(ctx, RMDF_E_INVALID, "max_steps > 32767");
     for (int s = RMDF_ENV_REFLECTION; s <= RMDF_ENV_COS_8; s++)
@@ -244,6 +241,13 @@ int fill_params(rmdf_ctx *ctx, int scene, int w, int h, float time, int max_step
     memset(&p, 0, sizeof p);
     host_camera(scene, time, p.cam);
     p.fov_xs = host_fov_xs();
+    {
+        // fragment.shd:116-119: pow_offs = mod(in_time / 2, 9); if (pow_offs > 4.5) pow_offs = 9 - pow_offs; power = pow_offs + 2
+        const float a = time / 2.0f;
+        float pow_offs = a - 9.0f * floorf(a / 9.0f);
+        if (pow_offs > 4.5f) pow_offs = 9.0f - pow_offs;
+        p.power = pow_offs + 2.0f;
+    }
     p.wf = (float)w; p.hf = (float)h; p.aspect = p.wf / p.hf;
     p.w = w; p.h = h;
     p.max_steps = max_steps <= 0 ? 128 : max_steps;

@@ -193,6 +193,194 @@ __device__ __forceinline__ float de_mandelbulb8(v3 pos, unsigned &iters)
     return 0.5f * log_pinned(r) * r / dr;
 }
 
+// ---- pinned sin / cos / acos / atan / mod (FSMBGeneralShader, FSDETestShader) ------------------------
+// fdlibm-style float algorithms, fixed operation order, identical to the oracle's restatement
+__device__ __forceinline__ void rem_pio2_pinned(float x, float &r, int &q)
+{
+    const float invpio2 = 0.6366197466850281f;
+    const float c1 = 1.5703125f, c2 = 4.837512969970703e-4f, c3 = 7.549533620476723e-8f, c4 = 2.5633440682570896e-12f;
+    const float kf = rintf(x * invpio2);
+    q = (int)kf;
+    float t = x - kf * c1;
+    t = t - kf * c2;
+    t = t - kf * c3;
+    t = t - kf * c4;
+    r = t;
+}
+__device__ __forceinline__ float ksin_pinned(float x)
+{
+    const float S1 = -1.6666667163e-01f, S2 = 8.3333337680e-03f, S3 = -1.9841270114e-04f, S4 = 2.7557314297e-06f,
+                S5 = -2.5050759689e-08f, S6 = 1.5896910177e-10f;
+    const float z = x * x;
+    const float v = z * x;
+    const float r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    return x + v * (S1 + z * r);
+}
+__device__ __forceinline__ float kcos_pinned(float x)
+{
+    const float C1 = 4.1666667908e-02f, C2 = -1.3888889225e-03f, C3 = 2.4801587642e-05f, C4 = -2.7557314297e-07f,
+                C5 = 2.0875723372e-09f, C6 = -1.1359647598e-11f;
+    const float z = x * x;
+    const float r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    return 1.0f - (0.5f * z - z * r);
+}
+// sin and cos of the same argument share the reduction (the shader always needs both)
+__device__ __forceinline__ void sincos_pinned(float x, float &s, float &c)
+{
+    if (!(fabsf(x) <= 3.4e38f)) { s = x - x; c = x - x; return; }
+    float r; int q;
+    rem_pio2_pinned(x, r, q);
+    const float ks = ksin_pinned(r), kc = kcos_pinned(r);
+    switch (q & 3) {
+    case 0:  s = ks;  c = kc;  break;
+    case 1:  s = kc;  c = -ks; break;
+    case 2:  s = -ks; c = -kc; break;
+    default: s = -kc; c = ks;  break;
+    }
+}
+__device__ __forceinline__ float acos_pinned(float x)
+{
+    const float pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f, pi = 3.1415925026e+00f;
+    const float pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f,
+                pS4 = 7.9153501429e-04f, pS5 = 3.4793309169e-05f;
+    const float qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f, qS3 = -6.8828397989e-01f, qS4 = 7.7038154006e-02f;
+    const float ax = fabsf(x);
+    if (!(ax <= 1.0f)) return (x - x) / (x - x);
+    if (ax == 1.0f) return (x > 0.0f) ? 0.0f : pi + 2.0f * pio2_lo;
+    if (ax < 0.5f) {
+        if (ax <= 1.4901161e-8f) return pio2_hi + pio2_lo;
+        const float z = x * x;
+        const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const float r = p / q;
+        return pio2_hi - (x - (pio2_lo - x * r));
+    } else if (x < 0.0f) {
+        const float z = (1.0f + x) * 0.5f;
+        const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const float s = sqrt_rn(z);
+        const float r = p / q;
+        const float w = r * s - pio2_lo;
+        return pi - 2.0f * (s + w);
+    } else {
+        const float z = (1.0f - x) * 0.5f;
+        const float s = sqrt_rn(z);
+        const float df = __uint_as_float(__float_as_uint(s) & 0xfffff000u);
+        const float c = (z - df * df) / (s + df);
+        const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const float r = p / q;
+        const float w = r * s + c;
+        return 2.0f * (df + w);
+    }
+}
+__device__ __forceinline__ float atan_pinned(float x)
+{
+    const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
+                aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
+                aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+    if (x != x) return x;
+    const float ax = fabsf(x);
+    const bool neg = (__float_as_uint(x) >> 31) != 0u;
+    float hi = 0.0f, lo = 0.0f, t;
+    bool small = false;
+    if (ax >= 67108864.0f) {
+        const float z = 1.5707962513e+00f + 7.5497894159e-08f;
+        return neg ? -z : z;
+    }
+    if (ax < 0.4375f) {
+        if (ax < 2.44140625e-4f) return x;
+        small = true; t = x;
+    } else if (ax < 1.1875f) {
+        if (ax < 0.6875f) { hi = 4.6364760399e-01f; lo = 5.0121582440e-09f; t = (2.0f * ax - 1.0f) / (2.0f + ax); }
+        else              { hi = 7.8539812565e-01f; lo = 3.7748947079e-08f; t = (ax - 1.0f) / (ax + 1.0f); }
+    } else {
+        if (ax < 2.4375f) { hi = 9.8279368877e-01f; lo = 3.4473217170e-08f; t = (ax - 1.5f) / (1.0f + 1.5f * ax); }
+        else              { hi = 1.5707962513e+00f; lo = 7.5497894159e-08f; t = -1.0f / ax; }
+    }
+    const float z = t * t;
+    const float w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    if (small) return t - t * (s1 + s2);
+    const float zz = hi - ((t * (s1 + s2) - lo) - t);
+    return neg ? -zz : zz;
+}
+// GLSL atan(y, x)
+__device__ __forceinline__ float atan2_pinned(float y, float x)
+{
+    const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f, pio2 = 1.5707963705e+00f;
+    const float inf = __builtin_inff();
+    if (x != x || y != y) return x + y;
+    const int m = (int)((__float_as_uint(y) >> 31) | ((__float_as_uint(x) >> 30) & 2u));
+    const float ax = fabsf(x), ay = fabsf(y);
+    if (ay == 0.0f) return (m < 2) ? y : ((m == 2) ? pi : -pi);
+    if (ax == 0.0f) return (m & 1) ? -pio2 : pio2;
+    if (ax == inf) {
+        if (ay == inf) return (m == 0) ? 0.25f * pi : (m == 1) ? -0.25f * pi : (m == 2) ? 0.75f * pi : -0.75f * pi;
+        return (m == 0) ? 0.0f : (m == 1) ? -0.0f : (m == 2) ? pi : -pi;
+    }
+    if (ay == inf) return (m & 1) ? -pio2 : pio2;
+    const float z = atan_pinned(ay / ax);
+    return (m == 0) ? z : (m == 1) ? -z : (m == 2) ? pi - (z - pi_lo) : (z - pi_lo) - pi;
+}
+
+// fragment.shd:42-72
+__device__ __forceinline__ v3 triplex_pow_general(v3 w, float power)
+{
+    const float r = length3(w);
+    float theta = acos_pinned(w.z / r);
+    float phi = atan2_pinned(w.y, w.x);
+    const float zr = pow_pinned(r, power);
+    theta = theta * power;
+    phi = phi * power;
+    float st, ct, sp, cp;
+    sincos_pinned(theta, st, ct);
+    sincos_pinned(phi, sp, cp);
+    return mk3(zr * (st * cp), zr * (st * sp), zr * ct);
+}
+
+// fragment.shd:101-158 without POWER8; power = fragment.shd:116-119, uniform per frame
+__device__ __forceinline__ float de_mandelbulb_general(v3 pos, float power, unsigned &iters)
+{
+    pos = mk3(pos.z, pos.x, pos.y);
+    v3 w = pos;
+    float dr = 1.0f;
+    float r = 0.0f;
+    for (int i = 0; i < 25; i++) {
+        r = length3(w);
+        if (r > 4.0f) break;
+        w = triplex_pow_general(w, power);
+        w = add3(w, pos);
+        dr = pow_pinned(r, power - 1.0f) * power * dr + 1.0f;
+        iters++;
+    }
+    return 0.5f * log_pinned(r) * r / dr;
+}
+
+// fragment.shd:21-33, 413-418, 447-456
+__device__ __forceinline__ float length2_(float x, float y) { return sqrt_rn(x * x + y * y); }
+__device__ __forceinline__ float de_torus(v3 p, float size, float r) { return length2_(length2_(p.x, p.y) - size, p.z) - r; }
+__device__ __forceinline__ float de_rounded_box(v3 p, v3 b, float r)
+{
+    return length3(mk3(gmax(fabsf(p.x) - b.x, 0.0f), gmax(fabsf(p.y) - b.y, 0.0f), gmax(fabsf(p.z) - b.z, 0.0f))) - r;
+}
+__device__ __forceinline__ float smin_exp(float a, float b, float k)
+{
+    const float res = exp_pinned(-k * a) + exp_pinned(-k * b);
+    return -log_pinned(res) / k;
+}
+__device__ __forceinline__ float de_test_scene(v3 pos)
+{
+    const float d_sphere = length3(pos) - 0.4f;
+    const float d_torus = smin_exp(smin_exp(de_torus(pos, 0.85f, 0.1f), de_torus(mk3(pos.z, pos.x, pos.y), 0.85f, 0.1f), 64.0f),
+                                   de_torus(mk3(pos.y, pos.z, pos.x), 0.85f, 0.1f), 64.0f);
+    const float d_box = smin_exp(smin_exp(de_rounded_box(pos, mk3(0.8f, 0.06f, 0.06f), 0.03f),
+                                          de_rounded_box(pos, mk3(0.06f, 0.8f, 0.06f), 0.03f), 64.0f),
+                                 de_rounded_box(pos, mk3(0.06f, 0.06f, 0.8f), 0.03f), 64.0f);
+    return smin_exp(d_box, gmin(d_sphere, d_torus), 64.0f);
+}
+
 // same, counting wave-level inner passes and the lanes active in them (measurement builds only)
 __device__ __forceinline__ float de_mandelbulb8_dbg(v3 pos, unsigned &iters, unsigned long long &passes, unsigned long long &lanes)
 {

@@ -14,6 +14,7 @@ struct FrameParams {
     // xaxis, yaxis, zaxis, eye of lookat() (829-838)
     float cam[12];
     float fov_xs;             // tan(radians(67.5)/2), fragment.shd:866-867
+    float power;              // FSMBGeneralShader: animated power (fragment.shd:116-119), uniform per frame
     float wf, hf, aspect;     // in_screen_wdh, in_screen_hgt, wdh/hgt
     int   w, h;
     int   max_steps;          // fragment.shd:634

@@ -38,8 +38,10 @@ __device__ __forceinline__ v3 shfl_xor3(v3 a, int mask)
 template <int SCENE>
 __device__ __forceinline__ float distance_estimator(v3 pos, const FrameParams &p, unsigned &iters)
 {
-    if (SCENE == 2) return de_mandelbulb8(pos, iters);
-    else            return de_cornell_box(pos, p.cornell);
+    if (SCENE == 2)      return de_mandelbulb8(pos, iters);
+    else if (SCENE == 3) return de_mandelbulb_general(pos, p.power, iters);
+    else if (SCENE == 1) return de_test_scene(pos);
+    else                 return de_cornell_box(pos, p.cornell);
 }
 
 template <int SCENE>
@@ -337,6 +339,8 @@ hipError_t launch_render(int scene, const FrameParams &p, hipStream_t stream)
     if (occ_lds < 0) { const char *e = getenv("RMDF_OCC_LDS"); occ_lds = e ? atoi(e) : 0; }
     if (scene == 2)      hipLaunchKernelGGL(k_render<2>, grid, block, occ_lds, stream, p);
     else if (scene == 0) hipLaunchKernelGGL(k_render<0>, grid, block, occ_lds, stream, p);
+    else if (scene == 1) hipLaunchKernelGGL(k_render<1>, grid, block, occ_lds, stream, p);
+    else if (scene == 3) hipLaunchKernelGGL(k_render<3>, grid, block, occ_lds, stream, p);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

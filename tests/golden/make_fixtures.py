@@ -34,7 +34,8 @@ RENDER_CASES = [(scene, w, h, t, ms)
                 for (w, h) in ((64, 36),)
                 for t in (0.0, 1.0, 2.5, 7.0)] + \
                [(orc.SCENE_MB_POWER8, 256, 144, 0.0, 256), (orc.SCENE_CORNELL, 256, 144, 0.0, 128),
-                (orc.SCENE_MB_POWER8, 64, 36, 0.0, 128)]
+                (orc.SCENE_MB_POWER8, 64, 36, 0.0, 128)] + \
+               [(scene, 64, 36, t, 128) for scene in (orc.SCENE_DETEST, orc.SCENE_MB_GENERAL) for t in (0.0, 2.5, 11.0)]
 
 
 def cache_name(power):

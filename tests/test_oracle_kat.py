@@ -348,3 +348,49 @@ def test_mandelbrot_known_points(orc):
     # smooth = iter - log2(ln|z|^2) with |z|^2 in (16, ~(16 + 2.5)^2]  ->  1.47 .. 2.55 iterations lower
     d = (g.astype(int) - sm.astype(int))[g < 255]
     assert (d >= 0).all() and (d <= int(2.6 * 255 / 40) + 1).all()
+
+
+# ---- pinned trigonometry of the general-power variants (fragment.shd:42-72, 116-119) ------------------
+
+def test_pinned_trig_accuracy(orc):
+    rng = np.random.RandomState(21)
+    xs = rng.uniform(-25, 25, 8000).astype(np.float32)                  # theta*power, phi*power <= pi*6.5
+    s = np.array([orc.sinf(x) for x in xs], np.float32)
+    c = np.array([orc.cosf(x) for x in xs], np.float32)
+    assert np.abs(s - np.sin(xs.astype(np.float64))).max() < 1.5e-7
+    assert np.abs(c - np.cos(xs.astype(np.float64))).max() < 1.5e-7
+    xa = np.concatenate([rng.uniform(-1, 1, 8000), [-1.0, 1.0, 0.0, 0.5, -0.5, 1e-9]]).astype(np.float32)
+    a = np.array([orc.acosf(x) for x in xa], np.float32)
+    assert ulp_diff(a, np.arccos(xa.astype(np.float64)).astype(np.float32)).max() <= 1
+    yy, xx = rng.normal(size=8000).astype(np.float32), rng.normal(size=8000).astype(np.float32)
+    t = np.array([orc.atan2f(y, x) for y, x in zip(yy, xx)], np.float32)
+    assert ulp_diff(t, np.arctan2(yy.astype(np.float64), xx.astype(np.float64)).astype(np.float32)).max() <= 1
+    assert orc.atan2f(0.0, -1.0) == np.float32(np.pi) and orc.atan2f(1.0, 0.0) == np.float32(np.pi / 2)
+    assert math.isnan(orc.acosf(1.5)) and math.isnan(orc.sinf(math.inf))
+
+
+def test_general_power_schedule(orc):
+    """fragment.shd:116-119: triangle wave 2 .. 6.5 .. 2 with period 18 s"""
+    for t, p in ((0.0, 2.0), (1.0, 2.5), (9.0, 6.5), (10.0, 6.0), (18.0, 2.0), (20.0, 3.0), (27.0, 6.5)):
+        assert abs(orc.general_power(t) - p) < 1e-6
+
+
+def test_general_triplex_pow_matches_power8_closed_form(orc):
+    """triplex_pow(w, 8) (spherical form, pinned trig) and triplex_pow8(w) (closed form) describe the same map."""
+    rng = np.random.RandomState(8)
+    for _ in range(300):
+        w = rng.uniform(-1.2, 1.2, 3).astype(np.float32)
+        a, b = orc.triplex_pow(w, 8.0).astype(np.float64), orc.triplex_pow8(w).astype(np.float64)
+        assert np.abs(a - b).max() / max(1e-9, np.abs(b).max()) < 3e-5
+
+
+def test_de_test_scene_known_points(orc):
+    """FSDETestShader (fragment.shd:447-456): far from the tori and boxes the exponential smooth-min collapses to the
+    nearest primitive; at the origin that is the sphere of radius 0.4."""
+    assert abs(orc.de(orc.SCENE_DETEST, [0.0, 0.0, 0.0]) - (-0.4)) < 2e-3
+    assert abs(orc.de(orc.SCENE_DETEST, [0.3, 0.3, 0.3]) - (math.sqrt(0.27) - 0.4)) < 2e-3
+    # on the x axis at 0.9 the box arm along x (half-length 0.8, rounding 0.03 + 0.06) and the tori compete; the
+    # value must be a lower bound of the true distance and within the smooth-min blending width log(n)/64
+    d = orc.de(orc.SCENE_DETEST, [0.9, 0.0, 0.0])
+    true = min(0.9 - 0.8 - 0.03, abs(0.9 - 0.85) - 0.1)      # box end cap vs. the two tori through (0.85, 0, 0)
+    assert true - math.log(6) / 64 - 1e-3 <= d <= true + 1e-3
