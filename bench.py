@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--max-steps", type=int, default=256)
     ap.add_argument("--time", type=float, default=0.0)
     ap.add_argument("--scene", type=int, default=2, help="FragmentShader enum (2 = FSMBPower8Shader)")
+    ap.add_argument("--supersample", type=int, default=0, help="mip levels of super-sampling: rays = (w<<L) x (h<<L), "
+                    "resolved on the GPU before the gather (BASELINE config 4: --width 3840 --height 2160 --supersample 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also compare the frame with the oracle (slow)")
     a = ap.parse_args()
@@ -121,17 +123,41 @@ def main():
     sptr = stream.cuda_stream
     assert sptr != 0
 
+    L = a.supersample
+    rw, rh = w << L, h << L                                   # ray grid
     frame = torch.empty((h, w), dtype=torch.int32, device=dev)
-    if world > 1:
+    if world == 1:
+        big = torch.empty((rh, rw), dtype=torch.int32, device=dev) if L else frame
+        tmp = torch.empty((rh // 2, rw // 2), dtype=torch.int32, device=dev) if L > 1 else None
+    else:
         slots = rmdf_amd.shard_slots(world)
         shard = torch.zeros((slots, h // 8, w // 8), dtype=torch.int32, device=dev)
+        big = torch.zeros((slots, rh // 8, rw // 8), dtype=torch.int32, device=dev) if L else shard
+        tmp = torch.empty((slots, rh // 16, rw // 16), dtype=torch.int32, device=dev) if L > 1 else None
         gathered = torch.empty((world, slots, h // 8, w // 8), dtype=torch.int32, device=dev) if rank == 0 else None
 
-    def step():
+    def resolve(src, sw, sh, dst):
+        """`L` box-filter levels from src (sw x sh) into dst, ping-ponging through tmp"""
+        cur, cw, ch = src, sw, sh
+        for lvl in range(L):
+            out = dst if lvl == L - 1 else (tmp if cur is not tmp else src)
+            sr.resolve_box2_device(cur.data_ptr(), cw, ch, out.data_ptr(), stream=sptr)
+            cur, cw, ch = out, cw // 2, ch // 2
+
+    def render_only():
         if world == 1:
-            sr.render_rect_device(scene, w, h, a.time, ms, (0, 0, w, h), d_rgba8=frame.data_ptr(), stream=sptr)
+            sr.render_rect_device(scene, rw, rh, a.time, ms, (0, 0, rw, rh), d_rgba8=big.data_ptr(), stream=sptr)
         else:
-            sr.render_shard_device(scene, w, h, a.time, ms, rank, world, shard.data_ptr(), stream=sptr)
+            sr.render_shard_device(scene, rw, rh, a.time, ms, rank, world, big.data_ptr(), stream=sptr)
+
+    def step():
+        render_only()
+        if world == 1:
+            if L:
+                resolve(big, rw, rh, frame)
+        else:
+            if L:
+                resolve(big, rw // 8, slots * (rh // 8), shard)
             g = gather_shards(shard, rank, world, dist, out=gathered)
             if rank == 0:
                 sr.assemble_shards_device(w, h, world, g.data_ptr(), frame.data_ptr(), stream=sptr)
@@ -157,10 +183,7 @@ def main():
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(a.steps, 100))]
     for e0, e1 in evs:
         e0.record(stream)
-        if world == 1:
-            sr.render_rect_device(scene, w, h, a.time, ms, (0, 0, w, h), d_rgba8=frame.data_ptr(), stream=sptr)
-        else:
-            sr.render_shard_device(scene, w, h, a.time, ms, rank, world, shard.data_ptr(), stream=sptr)
+        render_only()
         e1.record(stream)
     torch.cuda.synchronize(dev)
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
@@ -170,20 +193,26 @@ def main():
     if rank == 0:
         # PCIe-inclusive rate (host buffer hand-over as the boundary does it) -- informational
         host = np.empty(w * h, np.uint32)
-        sr.draw_shader_tile(scene, None, w, h, a.time, host, max_steps=ms)
+        if L == 0:
+            sr.draw_shader_tile(scene, None, w, h, a.time, host, max_steps=ms)
+        else:
+            sr.render_supersampled(scene, w, h, L, a.time, max_steps=ms)
         t1 = time.perf_counter()
         reps = 5
         for _ in range(reps):
-            sr.draw_shader_tile(scene, None, w, h, a.time, host, max_steps=ms)
+            if L == 0:
+                sr.draw_shader_tile(scene, None, w, h, a.time, host, max_steps=ms)
+            else:
+                sr.render_supersampled(scene, w, h, L, a.time, max_steps=ms)
         d2h_rate = mpix / ((time.perf_counter() - t1) / reps)
 
         env_bytes = 6 * 172 * 172 * 8 + 2 * 6 * 87 * 87 * 8               # padded RGB16F cube maps read once
-        px_this_launch = w * h if world == 1 else len(rmdf_amd.shard_tiles(rank, world)) * (w // 8) * (h // 8)
+        px_this_launch = rw * rh if world == 1 else len(rmdf_amd.shard_tiles(rank, world)) * (rw // 8) * (rh // 8)
         algo_bytes = px_this_launch * 4 + env_bytes                        # RGBA8 store + env read
         achieved_gbs = algo_bytes / (kern_ms * 1e-3) / 1e9
         traffic = None
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tj) and world == 1:
+        if os.path.exists(tj) and world == 1 and L == 0:
             try:
                 t = json.load(open(tj))
                 if t.get("workload") == [scene, w, h, ms]:
@@ -195,8 +224,9 @@ def main():
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "FSMBPower8Shader %dx%d, max_steps %d, in_time %.1f, uffizi_512.hdr env, "
-                                   "full frame -> RGBA8 resident in HBM" % (w, h, ms, a.time),
+            "config": {"workload": "FragmentShader %d (2 = FSMBPower8Shader) %dx%d%s, max_steps %d, in_time %.1f, uffizi_512.hdr env, "
+                                   "full frame -> RGBA8 resident in HBM" % (scene, w, h, (" x %d rays/px, box-resolved on the GPU" % (4 ** L)) if L else "", ms, a.time),
+                       "supersample_levels": L, "mrays_per_s": round(value * 4 ** L, 2),
                        "scene": scene, "width": w, "height": h, "max_steps": ms,
                        "parallelism": "1 GPU, one launch per frame" if world == 1 else
                                       "64 tiles interleaved over %d GPUs + one RCCL gather" % world,
@@ -208,7 +238,7 @@ def main():
                          "note": "VALU-bound path (SURVEY 8d): HBM fraction is a sanity figure, see valu_roofline"},
             "d2h_inclusive_mpixels_s": round(d2h_rate, 2),
         }
-        if not a.no_cpu_baseline or a.check:
+        if (not a.no_cpu_baseline or a.check) and L == 0:
             from oracle import orc
             env = load_oracle_env(orc)
             cores = orc.num_processors()

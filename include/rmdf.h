@@ -167,6 +167,16 @@ int rmdf_render_shard_device(rmdf_ctx *ctx, int scene, int w, int h, double time
 int rmdf_assemble_shards_device(rmdf_ctx *ctx, int w, int h, int nranks, const void *d_gathered,
                                 void *d_frame_rgba8, void *stream);
 
+/* Super-sampling (the viewer's frame-buffer scale, App.hs:105-106,124-133, shown through the mip chain that
+ * glGenerateMipmap builds, FrameBuffer.hs:153-154,187-195).  rmdf_resolve_box2_device: one mip level of an RGBA8
+ * image on the device: 2x2 box per channel, (a+b+c+d+2)>>2; sw, sh even; dst = (sw/2)*(sh/2) uint32.  It also
+ * works on a packed tile shard (tiles stacked: width w/8, height slots*h/8).
+ * rmdf_render_supersampled: render scene at (w<<levels) x (h<<levels), resolve `levels` times, copy the w x h
+ * result to the host buffer. */
+int rmdf_resolve_box2_device(rmdf_ctx *ctx, const void *d_src_rgba8, int sw, int sh, void *d_dst_rgba8, void *stream);
+int rmdf_render_supersampled(rmdf_ctx *ctx, int scene, int w, int h, int levels, double time, int max_steps,
+                             uint32_t *out_rgba8);
+
 /* Measurement aid: per-wave counters of the Mandelbulb march kernel.  enable != 0 switches collection on
  * (off: frees the buffer); out (may be NULL) receives 16 uint64 per wave for the launches since the last read:
  * iteration passes, march-tail passes, shade-tail passes, refill rounds, sum of iterating lanes over iteration

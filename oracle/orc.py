@@ -85,6 +85,7 @@ def lib():
         L.orc_triplex_pow8.argtypes = [fp, fp]
         L.orc_cornell_vertices.argtypes = [fp]
         L.orc_build_test_latlong.argtypes = [C.c_void_p]
+        L.orc_resolve_box2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -254,6 +255,15 @@ def mandelbrot(w, h, smooth):
     fb = np.empty((h, w), np.uint32)
     lib().orc_mandelbrot(w, h, fb.ctypes.data, int(smooth))
     return fb
+
+
+def resolve_box2(src):
+    src = np.ascontiguousarray(src, np.uint32)
+    sh, sw = src.shape
+    dst = np.empty((sh // 2, sw // 2), np.uint32)
+    if lib().orc_resolve_box2(src.ctypes.data, sw, sh, dst.ctypes.data) != 0:
+        raise ValueError("resolve needs even sizes")
+    return dst
 
 
 # ---- the renderer -------------------------------------------------------------------

@@ -1582,3 +1582,28 @@ void orc_mandelbrot(int w, int h, uint32_t *fb, int smooth)
             fb[(size_t)px + (size_t)py * w] = iter_to_green(val);
         }
 }
+
+/* ============================================================================
+ * 9. Super-sampling resolve: one level of the RGBA8 mip chain that
+ *    fillFrameBuffer / drawIntoFrameBuffer build with glGenerateMipmap
+ *    (FrameBuffer.hs:153-154,187-195) -- 2x2 box filter per channel; the rounding
+ *    of the 8-bit average is driver-defined, pinned as round-half-up
+ *    ((a+b+c+d+2) >> 2).  Even source sizes only.
+ * ==========================================================================*/
+int orc_resolve_box2(const uint32_t *src, int sw, int sh, uint32_t *dst)
+{
+    if (sw <= 0 || sh <= 0 || (sw & 1) || (sh & 1)) return -1;
+    int dw = sw / 2, dh = sh / 2;
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            const uint32_t a = src[(size_t)(2 * y) * sw + 2 * x], b = src[(size_t)(2 * y) * sw + 2 * x + 1];
+            const uint32_t c = src[(size_t)(2 * y + 1) * sw + 2 * x], d = src[(size_t)(2 * y + 1) * sw + 2 * x + 1];
+            uint32_t o = 0;
+            for (int k = 0; k < 4; k++) {
+                const uint32_t sum = ((a >> (8 * k)) & 255u) + ((b >> (8 * k)) & 255u) + ((c >> (8 * k)) & 255u) + ((d >> (8 * k)) & 255u);
+                o |= ((sum + 2u) >> 2) << (8 * k);
+            }
+            dst[(size_t)y * dw + x] = o;
+        }
+    return 0;
+}

@@ -136,6 +136,9 @@ void orc_julia_animated(int w, int h, uint32_t *fb, int smooth, double tick, int
 void orc_mandelbrot(int w, int h, uint32_t *fb, int smooth);
 int  orc_make_n_segments(int nseg, int low, int high, int *out_pairs /* 2*nseg ints */);
 
+/* one glGenerateMipmap level of an RGBA8 frame (FrameBuffer.hs:153-154): 2x2 box, round-half-up */
+int  orc_resolve_box2(const uint32_t *src, int sw, int sh, uint32_t *dst);
+
 int  orc_num_processors(void);
 
 #ifdef __cplusplus

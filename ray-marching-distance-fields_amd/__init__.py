@@ -44,7 +44,7 @@ ABI_SYMBOLS = (
     "rmdf_set_env_cube", "rmdf_get_env_cube_padded", "rmdf_resize_latlong", "rmdf_prefilter_env",
     "rmdf_is_tile_idx_first_tile", "rmdf_is_tile_idx_last_tile", "rmdf_render_tile", "rmdf_render_tile_ex",
     "rmdf_render_rect_device", "rmdf_render_shard_device", "rmdf_assemble_shards_device", "rmdf_synchronize",
-    "rmdf_device_info", "rmdf_debug_march_stats",
+    "rmdf_device_info", "rmdf_debug_march_stats", "rmdf_resolve_box2_device", "rmdf_render_supersampled",
 )
 
 
@@ -123,6 +123,8 @@ def load_library():
     L.rmdf_synchronize.argtypes = [vp, vp]
     L.rmdf_device_info.argtypes = [vp, C.c_char_p, C.c_int, ip]
     L.rmdf_debug_march_stats.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.rmdf_resolve_box2_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+    L.rmdf_render_supersampled.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]
     _lib = L
     return L
 
@@ -246,6 +248,16 @@ class ShaderRenderer:
     def assemble_shards_device(self, w, h, nranks, d_gathered, d_frame_rgba8, stream=0):
         self._check(self._lib.rmdf_assemble_shards_device(self._ctx, w, h, nranks, d_gathered, d_frame_rgba8,
                                                           stream or None))
+
+    def resolve_box2_device(self, d_src, sw, sh, d_dst, stream=0):
+        self._check(self._lib.rmdf_resolve_box2_device(self._ctx, d_src, sw, sh, d_dst, stream or None))
+
+    def render_supersampled(self, shd_enum, w, h, levels, time, max_steps=128):
+        """Frame-buffer scale 2**levels (App.hs:105-106) + mip-chain resolve: returns (h, w) uint32."""
+        out = np.empty((h, w), np.uint32)
+        self._check(self._lib.rmdf_render_supersampled(self._ctx, int(shd_enum), w, h, levels, float(time), max_steps,
+                                                       out.ctypes.data))
+        return out
 
     def debug_march_stats(self, enable=True, read_waves=0):
         """Per-wave counters of the march kernel (see rmdf.h); returns (n, 8) uint64 or None."""

@@ -691,6 +691,46 @@ int rmdf_assemble_shards_device(rmdf_ctx *ctx, int w, int h, int nranks, const v
     return RMDF_OK;
 }
 
+int rmdf_resolve_box2_device(rmdf_ctx *ctx, const void *d_src_rgba8, int sw, int sh, void *d_dst_rgba8, void *stream)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!d_src_rgba8 || !d_dst_rgba8 || sw <= 0 || sh <= 0 || (sw & 1) || (sh & 1))
+        return fail(ctx, RMDF_E_INVALID, "rmdf_resolve_box2_device: needs even, positive source sizes");
+    HIP_TRY(ctx, launch_resolve_box2((const uint32_t *)d_src_rgba8, sw, sh, (uint32_t *)d_dst_rgba8,
+                                     stream ? (hipStream_t)stream : ctx->stream));
+    return RMDF_OK;
+}
+
+int rmdf_render_supersampled(rmdf_ctx *ctx, int scene, int w, int h, int levels, double time, int max_steps,
+                             uint32_t *out_rgba8)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!out_rgba8 || levels < 0 || levels > 3 || w <= 0 || h <= 0)
+        return fail(ctx, RMDF_E_INVALID, "rmdf_render_supersampled: bad argument (levels 0..3)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int sw = w << levels, sh = h << levels;
+    FrameParams p;
+    int rc = fill_params(ctx, scene, sw, sh, (float)time, max_steps, p);
+    if (rc != RMDF_OK) return rc;
+    DevBuf a, b;
+    HIP_TRY(ctx, hipMalloc(&a.p, (size_t)sw * sh * 4));
+    if (levels > 0) HIP_TRY(ctx, hipMalloc(&b.p, (size_t)(sw / 2) * (sh / 2) * 4));
+    p.x0 = 0; p.y0 = 0; p.x1 = sw; p.y1 = sh;
+    p.rgba8 = (uint32_t *)a.p;
+    rc = launch_scene(ctx, scene, p, ctx->stream);
+    if (rc != RMDF_OK) return rc;
+    void *cur = a.p, *other = b.p;
+    int cw = sw, ch = sh;
+    for (int l = 0; l < levels; l++) {
+        HIP_TRY(ctx, launch_resolve_box2((const uint32_t *)cur, cw, ch, (uint32_t *)other, ctx->stream));
+        void *t = cur; cur = other; other = t;
+        cw /= 2; ch /= 2;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(out_rgba8, cur, (size_t)w * h * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RMDF_OK;
+}
+
 int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_waves)
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");

@@ -393,6 +393,30 @@ hipError_t launch_assemble_shards(const uint32_t *d_gathered, uint32_t *d_frame,
 }
 
 // ------------------------------------------------------------------------------------
+// Super-sampling resolve: one glGenerateMipmap level of the RGBA8 frame (FrameBuffer.hs:153-154,187-195):
+// 2x2 box per channel, (a+b+c+d+2)>>2.  One lane per destination pixel; each lane reads two 8-byte
+// pairs (coalesced 512 B per wave-row) and writes 4 bytes.
+// ------------------------------------------------------------------------------------
+__global__ void k_resolve_box2(const uint2 *__restrict__ src, int dw, int dh, uint32_t *__restrict__ dst)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= dw || y >= dh) return;
+    const uint2 top = src[(size_t)(2 * y) * dw + x], bot = src[(size_t)(2 * y + 1) * dw + x];
+    // per-channel sums without carries between channels: split even / odd bytes
+    const uint32_t lo = (top.x & 0x00ff00ffu) + (top.y & 0x00ff00ffu) + (bot.x & 0x00ff00ffu) + (bot.y & 0x00ff00ffu) + 0x00020002u;
+    const uint32_t hi = ((top.x >> 8) & 0x00ff00ffu) + ((top.y >> 8) & 0x00ff00ffu) + ((bot.x >> 8) & 0x00ff00ffu) + ((bot.y >> 8) & 0x00ff00ffu) + 0x00020002u;
+    dst[(size_t)y * dw + x] = ((lo >> 2) & 0x00ff00ffu) | (((hi >> 2) & 0x00ff00ffu) << 8);
+}
+
+hipError_t launch_resolve_box2(const uint32_t *d_src, int sw, int sh, uint32_t *d_dst, hipStream_t stream)
+{
+    const int dw = sw / 2, dh = sh / 2;
+    if (dw <= 0 || dh <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_resolve_box2, dim3((dw + 255) / 256, dh), dim3(256), 0, stream, (const uint2 *)d_src, dw, dh, d_dst);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
 // RGB16F upload with seamless border (the texImage2D RGB16F of HDREnvMap.hs:160-161 +
 // GL_TEXTURE_CUBE_MAP_SEAMLESS, :126).  Border rule: DESIGN.md "spec pins".
 // ------------------------------------------------------------------------------------

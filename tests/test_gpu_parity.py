@@ -243,3 +243,33 @@ def test_both_mandelbulb_schedules_agree(sr_alt, sr, orc, env_oracle, rmdf):
     for idx in range(64):
         sr_alt.draw_shader_tile(2, idx, w, h, 1.0, fb.vec, max_steps=256)
     assert np.array_equal(fb.vec.reshape(h, w), full)
+
+
+def test_supersample_resolve(sr, orc, rmdf):
+    """Frame-buffer scale 2 and 4 (App.hs:105-106) resolved through the RGBA8 mip chain (FrameBuffer.hs:153-154):
+    GPU resolve == oracle resolve of the GPU's own high-resolution frame, bit for bit; alpha stays opaque; the packed
+    shard form resolves to the same pixels."""
+    import torch
+    w, h, ms = 96, 54, 64
+    hi2 = sr.render(2, 2 * w, 2 * h, 0.0, max_steps=ms)["rgba8"]
+    got2 = sr.render_supersampled(2, w, h, 1, 0.0, max_steps=ms)
+    assert np.array_equal(got2, orc.resolve_box2(hi2))
+    hi4 = sr.render(2, 4 * w, 4 * h, 0.0, max_steps=ms)["rgba8"]
+    got4 = sr.render_supersampled(2, w, h, 2, 0.0, max_steps=ms)
+    assert np.array_equal(got4, orc.resolve_box2(orc.resolve_box2(hi4)))
+    assert (got4 >> 24 == 0xFF).all()
+    assert np.array_equal(sr.render_supersampled(2, w, h, 0, 0.0, max_steps=ms), sr.render(2, w, h, 0.0, max_steps=ms)["rgba8"])
+    # shard form: W = 128, H = 64 output, 2x2 rays per pixel, 3 ranks
+    W, H, n = 128, 64, 3
+    dev = torch.device("cuda", 0)
+    ts = torch.cuda.Stream(dev); torch.cuda.set_stream(ts); s = ts.cuda_stream
+    slots = rmdf.shard_slots(n)
+    gathered = torch.zeros((n, slots, H // 8, W // 8), dtype=torch.int32, device=dev)
+    for r in range(n):
+        big = torch.zeros((slots, 2 * H // 8, 2 * W // 8), dtype=torch.int32, device=dev)
+        sr.render_shard_device(2, 2 * W, 2 * H, 0.0, ms, r, n, big.data_ptr(), stream=s)
+        sr.resolve_box2_device(big.data_ptr(), 2 * W // 8, slots * 2 * H // 8, gathered[r].data_ptr(), stream=s)
+    frame = torch.zeros((H, W), dtype=torch.int32, device=dev)
+    sr.assemble_shards_device(W, H, n, gathered.data_ptr(), frame.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy().view(np.uint32), sr.render_supersampled(2, W, H, 1, 0.0, max_steps=ms))

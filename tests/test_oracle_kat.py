@@ -394,3 +394,15 @@ def test_de_test_scene_known_points(orc):
     d = orc.de(orc.SCENE_DETEST, [0.9, 0.0, 0.0])
     true = min(0.9 - 0.8 - 0.03, abs(0.9 - 0.85) - 0.1)      # box end cap vs. the two tori through (0.85, 0, 0)
     assert true - math.log(6) / 64 - 1e-3 <= d <= true + 1e-3
+
+
+def test_resolve_box2(orc):
+    rng = np.random.RandomState(3)
+    src = rng.randint(0, 2**32, (6, 8), dtype=np.uint64).astype(np.uint32)
+    got = orc.resolve_box2(src)
+    b = src.view(np.uint8).reshape(6, 8, 4).astype(np.int64)
+    ref = ((b[0::2, 0::2] + b[0::2, 1::2] + b[1::2, 0::2] + b[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    assert np.array_equal(got.view(np.uint8).reshape(3, 4, 4), ref)
+    assert np.array_equal(orc.resolve_box2(np.full((4, 4), 0xFF102030, np.uint32)), np.full((2, 2), 0xFF102030, np.uint32))
+    with pytest.raises(ValueError):
+        orc.resolve_box2(np.zeros((3, 4), np.uint32))
