@@ -45,6 +45,7 @@ struct rmdf_ctx {
     float4      *d_gbuf_nao = nullptr;
     unsigned    *d_gbuf_meta = nullptr;
     int         *d_work_counter = nullptr;
+    int         *d_hit_list = nullptr;
     // cost-ordered dispatch state of the nested-loop kernel (previous frame's per-strip costs)
     unsigned    *d_block_cost = nullptr, *d_block_order = nullptr;
     int          order_cap = 0, order_n = 0;
@@ -179,9 +180,11 @@ int ensure_gbuf(rmdf_ctx *ctx, int w, int h)
     if (need <= ctx->gbuf_cap) return RMDF_OK;
     if (ctx->d_gbuf_nao) (void)hipFree(ctx->d_gbuf_nao);
     if (ctx->d_gbuf_meta) (void)hipFree(ctx->d_gbuf_meta);
-    ctx->d_gbuf_nao = nullptr; ctx->d_gbuf_meta = nullptr; ctx->gbuf_cap = 0;
+    if (ctx->d_hit_list) (void)hipFree(ctx->d_hit_list);
+    ctx->d_gbuf_nao = nullptr; ctx->d_gbuf_meta = nullptr; ctx->d_hit_list = nullptr; ctx->gbuf_cap = 0;
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_gbuf_nao, need * sizeof(float4)));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_gbuf_meta, need * sizeof(unsigned)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_hit_list, need * sizeof(int)));
     ctx->gbuf_cap = need;
     return RMDF_OK;
 }
@@ -192,6 +195,10 @@ int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t str
 {
     if (scene == RMDF_FS_MB_POWER8 && ctx->d_dbg && getenv("RMDF_NESTED_STATS")) {
         HIP_TRY(ctx, launch_march_stats(p, stream));
+        return RMDF_OK;
+    }
+    if (ctx->flags & RMDF_FLAG_PIPELINE) {
+        HIP_TRY(ctx, launch_render_pipeline(scene, p, stream, ctx->cus));
         return RMDF_OK;
     }
     if (scene == RMDF_FS_MB_POWER8 && (ctx->flags & RMDF_FLAG_FLAT_MARCH)) {
@@ -219,6 +226,7 @@ int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t str
                           memcmp(key, ctx->order_key, sizeof key) == 0;
         q.block_cost = ctx->d_block_cost;
         q.block_order = same ? ctx->d_block_order : nullptr;
+        { static int ps = -1; if (ps < 0) { const char *e = getenv("RMDF_PRIO_STRIPS"); ps = e ? atoi(e) : 256; } q.prio_strips = ps; }
         HIP_TRY(ctx, launch_render(scene, q, stream));
         HIP_TRY(ctx, launch_order_blocks(ctx->d_block_cost, nblk, ctx->d_block_order, stream));
         memcpy(ctx->order_key, key, sizeof key);
@@ -260,6 +268,9 @@ int fill_params(rmdf_ctx *ctx, int scene, int w, int h, float time, int max_step
     if (rc != RMDF_OK) return rc;
     p.gbuf_nao = ctx->d_gbuf_nao; p.gbuf_meta = ctx->d_gbuf_meta; p.gw = (w + 1) & ~1;
     p.work_counter = ctx->d_work_counter;
+    p.hit_count = ctx->d_work_counter + 1;
+    p.hit_list = ctx->d_hit_list;
+    p.tile_order = nullptr;
     p.dbg = ctx->d_dbg;
     return RMDF_OK;
 }
@@ -497,6 +508,7 @@ void rmdf_destroy(rmdf_ctx *ctx)
     if (ctx->d_iters) (void)hipFree(ctx->d_iters);
     if (ctx->d_gbuf_nao) (void)hipFree(ctx->d_gbuf_nao);
     if (ctx->d_gbuf_meta) (void)hipFree(ctx->d_gbuf_meta);
+    if (ctx->d_hit_list) (void)hipFree(ctx->d_hit_list);
     if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
     if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
     if (ctx->d_block_cost) (void)hipFree(ctx->d_block_cost);

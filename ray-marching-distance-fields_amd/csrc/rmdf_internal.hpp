@@ -36,11 +36,15 @@ struct FrameParams {
     unsigned *gbuf_meta;      // bits 0..14 steps, bit 15 hit, bits 16..31 escape iterations (saturated)
     int       gw;
     int      *work_counter;   // zeroed before every march launch
+    int      *hit_count;      // = work_counter + 1 (rmdf_pipeline.hip): entries in hit_list
+    int      *hit_list;       // G-buffer indices of the hit pixels, filled by k_march_refill
+    const unsigned *tile_order;   // optional dispatch order of the 8x8 tiles (rmdf_pipeline.hip)
     int       total_items, items_per_shard_tile;
     int       tail_t, shade_t, refill_t, chunk, pool_low;
     // cost-ordered dispatch of the nested-loop kernel (see DESIGN.md 'critical path'): block b renders
     // strip order[b] (null = raster order) and writes its cost (max escape iterations of a pixel) to cost[]
     int dbg_skip;             // measurement knob: 1 = skip normal/AO + shading of k_render, 2 = skip only normal/AO
+    int prio_strips;          // the first prio_strips workgroups of an ordered launch raise their wave priority
     const unsigned *block_order;
     unsigned *block_cost;
     unsigned long long *dbg;  // optional per-wave counters of k_march_mb8 (8 x u64 per wave), may be null   // scheduling thresholds of k_march_mb8 (see rmdf_march.hip)
@@ -55,6 +59,7 @@ hipError_t launch_march_stats(const FrameParams &p, hipStream_t stream);
 int render_grid_blocks(const FrameParams &p);   // number of 32x8 strips launch_render() uses for p
 hipError_t launch_order_blocks(const unsigned *d_cost, int n, unsigned *d_order, hipStream_t stream);
 hipError_t launch_render_mb8(const FrameParams &p, hipStream_t stream, int num_cus);
+hipError_t launch_render_pipeline(int scene, const FrameParams &p, hipStream_t stream, int num_cus);   // rmdf_pipeline.hip
 hipError_t launch_march_pool(const FrameParams &p, int blocks, hipStream_t stream);   // rmdf_pool.hip
 hipError_t launch_resolve_box2(const uint32_t *d_src, int sw, int sh, uint32_t *d_dst, hipStream_t stream);
 hipError_t launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t stream);

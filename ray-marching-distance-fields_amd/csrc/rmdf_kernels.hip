@@ -75,7 +75,12 @@ __global__ __launch_bounds__(256) void k_render(const FrameParams p)
     const int ly = ((lane >> 1) & 1) | (((lane >> 4) & 3) << 1);
     // strip handled by this workgroup: raster order, or most expensive first (block_order)
     unsigned strip = blockIdx.y * gridDim.x + blockIdx.x;
-    if (p.block_order) strip = p.block_order[strip];
+    if (p.block_order) {
+        // the first workgroups carry last frame's most expensive strips: the launch cannot end before their
+        // longest ray has finished its serial chain, so let their waves win the issue arbitration on the SIMD
+        if (strip < (unsigned)p.prio_strips) __builtin_amdgcn_s_setprio(3);
+        strip = p.block_order[strip];
+    }
     const int bx = strip % gridDim.x, by = strip / gridDim.x;
     const int px = ex0 + bx * 32 + wave * 8 + lx;
     const int py = ey0 + by * 8 + ly;

@@ -397,6 +397,13 @@ __global__ __launch_bounds__(256) void k_shade(const FrameParams p)
     }
 }
 
+hipError_t launch_shade(const FrameParams &p, int ew, int eh, int nz, hipStream_t stream)
+{
+    dim3 grid((ew + 31) / 32, (eh + 7) / 8, nz);
+    hipLaunchKernelGGL(k_shade, grid, dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_render_mb8(const FrameParams &p_in, hipStream_t stream, int num_cus)
 {
     FrameParams p = p_in;
@@ -445,9 +452,7 @@ hipError_t launch_render_mb8(const FrameParams &p_in, hipStream_t stream, int nu
         e = hipGetLastError();
     }
     if (e != hipSuccess) return e;
-    dim3 grid((ew + 31) / 32, (eh + 7) / 8, nz);
-    hipLaunchKernelGGL(k_shade, grid, dim3(256), 0, stream, p);
-    return hipGetLastError();
+    return launch_shade(p, ew, eh, nz, stream);
 }
 
 }  // namespace rmdf

@@ -73,6 +73,18 @@ def sr_alt(rmdf, env_faces):
     r.close()
 
 
+@pytest.fixture(scope="session")
+def sr_pipe(rmdf, env_faces):
+    """The three-kernel schedule (RMDF_FLAG_PIPELINE)."""
+    rmdf.build()
+    r = rmdf.ShaderRenderer(0, flags=rmdf.FLAG_PIPELINE)
+    r.set_env_cube(rmdf.ENV_REFLECTION, env_faces["refl"])
+    r.set_env_cube(rmdf.ENV_COS_1, env_faces["cos1"])
+    r.set_env_cube(rmdf.ENV_COS_8, env_faces["cos8"])
+    yield r
+    r.close()
+
+
 def rel_err(a, b, floor=1e-6):
     """max relative error with an absolute floor; NaN matches NaN, inf matches inf."""
     a = np.asarray(a, np.float64)

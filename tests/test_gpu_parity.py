@@ -273,3 +273,22 @@ def test_supersample_resolve(sr, orc, rmdf):
     sr.assemble_shards_device(W, H, n, gathered.data_ptr(), frame.data_ptr(), stream=s)
     torch.cuda.synchronize()
     assert np.array_equal(frame.cpu().numpy().view(np.uint32), sr.render_supersampled(2, W, H, 1, 0.0, max_steps=ms))
+
+
+@pytest.mark.parametrize("scene,ms", [(2, 256), (0, 128), (1, 128), (3, 128)])
+def test_pipeline_schedule_agrees(sr_pipe, sr, orc, env_oracle, rmdf, scene, ms):
+    """march-with-refill + normal/AO on the hit list + shade: a third schedule of the same arithmetic, all scenes."""
+    for (w, h, t) in ((64, 36, 0.0), (250, 130, 2.5), (33, 17, 1.0), (480, 270, 7.0)):
+        a = sr_pipe.render(scene, w, h, t, max_steps=ms)
+        if w <= 250:
+            assert_frame_parity(a, orc.render(scene, w, h, t, ms, env_oracle), "pipeline s%d %dx%d" % (scene, w, h))
+        b = sr.render(scene, w, h, t, max_steps=ms)
+        for k in ("rgba8", "steps", "iters"):
+            assert np.array_equal(a[k], b[k]), (k, w, h)
+        assert np.array_equal(a["rgba_f32"].view(np.uint32), b["rgba_f32"].view(np.uint32))
+    w, h = 120, 72
+    full = sr.render(scene, w, h, 1.0, max_steps=ms)["rgba8"]
+    fb = rmdf.FrameBuffer(w, h)
+    for idx in range(64):
+        sr_pipe.draw_shader_tile(scene, idx, w, h, 1.0, fb.vec, max_steps=ms)
+    assert np.array_equal(fb.vec.reshape(h, w), full)
