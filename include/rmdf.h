@@ -178,6 +178,11 @@ int rmdf_resolve_box2_device(rmdf_ctx *ctx, const void *d_src_rgba8, int sw, int
 int rmdf_render_supersampled(rmdf_ctx *ctx, int scene, int w, int h, int levels, double time, int max_steps,
                              uint32_t *out_rgba8);
 
+/* Self-test of the kernels' short correctly-rounded sequences (sqrt, reciprocal, 1/sqrt, and the known-range
+ * division inside log) against the compiler's IEEE expansions for ALL 2^32 float inputs on the device.
+ * mismatches[0..3] = sqrt, reciprocal, log, 1/sqrt; all must be 0 (about one second of GPU time). */
+int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[4]);
+
 /* Measurement aid: per-wave counters of the Mandelbulb march kernel.  enable != 0 switches collection on
  * (off: frees the buffer); out (may be NULL) receives 16 uint64 per wave for the launches since the last read:
  * iteration passes, march-tail passes, shade-tail passes, refill rounds, sum of iterating lanes over iteration

@@ -45,6 +45,7 @@ ABI_SYMBOLS = (
     "rmdf_is_tile_idx_first_tile", "rmdf_is_tile_idx_last_tile", "rmdf_render_tile", "rmdf_render_tile_ex",
     "rmdf_render_rect_device", "rmdf_render_shard_device", "rmdf_assemble_shards_device", "rmdf_synchronize",
     "rmdf_device_info", "rmdf_debug_march_stats", "rmdf_resolve_box2_device", "rmdf_render_supersampled",
+    "rmdf_selftest_exact_math",
 )
 
 
@@ -123,6 +124,7 @@ def load_library():
     L.rmdf_synchronize.argtypes = [vp, vp]
     L.rmdf_device_info.argtypes = [vp, C.c_char_p, C.c_int, ip]
     L.rmdf_debug_march_stats.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.rmdf_selftest_exact_math.argtypes = [vp, vp]
     L.rmdf_resolve_box2_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     L.rmdf_render_supersampled.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]
     _lib = L
@@ -257,6 +259,12 @@ class ShaderRenderer:
         out = np.empty((h, w), np.uint32)
         self._check(self._lib.rmdf_render_supersampled(self._ctx, int(shd_enum), w, h, levels, float(time), max_steps,
                                                        out.ctypes.data))
+        return out
+
+    def selftest_exact_math(self):
+        """Mismatch counts (sqrt, rcp, log, rsqrt) of the short exact sequences vs the compiler's, all 2^32 inputs."""
+        out = np.zeros(4, np.uint64)
+        self._check(self._lib.rmdf_selftest_exact_math(self._ctx, out.ctypes.data))
         return out
 
     def debug_march_stats(self, enable=True, read_waves=0):

@@ -743,6 +743,20 @@ int rmdf_render_supersampled(rmdf_ctx *ctx, int scene, int w, int h, int levels,
     return RMDF_OK;
 }
 
+int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[4])
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!mismatches) return fail(ctx, RMDF_E_INVALID, "null output");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf d;
+    HIP_TRY(ctx, hipMalloc(&d.p, 4 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(d.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, launch_selftest_exact_math((unsigned long long *)d.p, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(mismatches, d.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RMDF_OK;
+}
+
 int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_waves)
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");

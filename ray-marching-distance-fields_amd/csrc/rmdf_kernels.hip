@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_march_stats(const FrameParams p)
         for (steps = 0; steps < p.max_steps; steps++) {
             wsteps++; wlanes += __popcll(__ballot(true));
             v3 pos = mk3(origin.x + t * dir.x, origin.y + t * dir.y, origin.z + t * dir.z);
-            float dist = de_mandelbulb8_dbg(pos, iters, passes, lanes);
+            float dist = de_mandelbulb8_dbg(pos, iters, passes, lanes, p.dbg ? p.dbg + 8 : nullptr);
             t += dist;
             if (t > tmax) break;
             if (dist < 0.001f) { hit = true; break; }
@@ -347,6 +347,63 @@ hipError_t launch_render(int scene, const FrameParams &p, hipStream_t stream)
     else if (scene == 1) hipLaunchKernelGGL(k_render<1>, grid, block, occ_lds, stream, p);
     else if (scene == 3) hipLaunchKernelGGL(k_render<3>, grid, block, occ_lds, stream, p);
     else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// Self-test of the short correctly-rounded sequences of rmdf_device.hpp against hipcc's own IEEE expansions,
+// over ALL 2^32 float bit patterns: sqrt_rn vs sqrtf, rcp_rn vs 1.0f/x, log_pinned (whose internal quotient uses
+// div_known_range) vs the same algorithm with the compiler's division.  counts[k] = number of differing inputs
+// (NaN results compare equal to NaN).  ~1 s on an MI355X.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float log_ref_division(float x)
+{
+    const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
+    const float Lg1 = 0.66666662693f, Lg2 = 0.40000972152f, Lg3 = 0.28498786688f, Lg4 = 0.24279078841f;
+    int32_t ix = __float_as_int(x);
+    int32_t k = 0;
+    if (ix < 0x00800000) {
+        if ((ix & 0x7fffffff) == 0) return -__builtin_inff();
+        if (ix < 0) return __builtin_nanf("");
+        k = -25; x = x * 33554432.0f; ix = __float_as_int(x);
+    }
+    if (ix >= 0x7f800000) return x + x;
+    k += (ix >> 23) - 127;
+    ix &= 0x007fffff;
+    const int32_t i = (ix + 0x4afb20) & 0x800000;
+    x = __int_as_float(ix | (i ^ 0x3f800000));
+    k += (i >> 23);
+    const float f = x - 1.0f;
+    const float s = f / (2.0f + f);
+    const float dk = (float)k;
+    const float z = s * s, w = z * z;
+    const float t1 = w * (Lg2 + w * Lg4), t2 = z * (Lg1 + w * Lg3);
+    const float R = t2 + t1;
+    const float hfsq = (0.5f * f) * f;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+__global__ void k_selftest_exact_math(unsigned long long *counts)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (uint64_t i = tid; i < (1ull << 32); i += stride) {
+        const float x = __uint_as_float((uint32_t)i);
+        const float a0 = sqrt_rn(x), b0 = sqrtf(x);
+        const float a1 = rcp_rn(x), b1 = 1.0f / x;
+        const float a2 = log_pinned(x), b2 = log_ref_division(x);
+        const float a3 = rsqrt_ieee(x), b3 = 1.0f / sqrtf(x);
+        c0 += !((__float_as_uint(a0) == __float_as_uint(b0)) || (a0 != a0 && b0 != b0));
+        c1 += !((__float_as_uint(a1) == __float_as_uint(b1)) || (a1 != a1 && b1 != b1));
+        c2 += !((__float_as_uint(a2) == __float_as_uint(b2)) || (a2 != a2 && b2 != b2));
+        c3 += !((__float_as_uint(a3) == __float_as_uint(b3)) || (a3 != a3 && b3 != b3));
+    }
+    atomicAdd(&counts[0], c0); atomicAdd(&counts[1], c1); atomicAdd(&counts[2], c2); atomicAdd(&counts[3], c3);
+}
+
+hipError_t launch_selftest_exact_math(unsigned long long *d_counts, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_selftest_exact_math, dim3(8192), dim3(256), 0, stream, d_counts);
     return hipGetLastError();
 }
 

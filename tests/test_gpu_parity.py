@@ -292,3 +292,12 @@ def test_pipeline_schedule_agrees(sr_pipe, sr, orc, env_oracle, rmdf, scene, ms)
     for idx in range(64):
         sr_pipe.draw_shader_tile(scene, idx, w, h, 1.0, fb.vec, max_steps=ms)
     assert np.array_equal(fb.vec.reshape(h, w), full)
+
+
+def test_exact_math_exhaustive(sr, orc):
+    """The kernels replace hipcc's ~17/14-instruction sqrtf / division expansions by short sequences
+    (rmdf_device.hpp: sqrt_rn, rcp_rn, div_known_range inside log_pinned).  They must return the SAME bits: checked
+    on the device for all 2^32 float inputs.  The compiler's own sqrtf / division are then tied to the host's IEEE
+    arithmetic (what the oracle runs on) through sampled comparisons of the functions built from them."""
+    mism = sr.selftest_exact_math()
+    assert mism.tolist() == [0, 0, 0, 0], mism
