@@ -56,7 +56,8 @@ __device__ __forceinline__ float rcp_core(float x)         // |x| in [2^-100, 2^
 __device__ __forceinline__ float sqrt_rn(float x)
 {
     float s = sqrt_core(x);
-    const bool bad = !in_core_range(x) || (x < 0.0f);
+    // one unsigned compare on the raw bits: negative numbers have the sign bit set and fall out of range too
+    const bool bad = (__float_as_uint(x) - 0x0d800000u) > (0x71800000u - 0x0d800000u);
     if (__builtin_expect(__ballot(bad) != 0ull, 0)) { if (bad) s = sqrtf(x); }
     return s;
 }
@@ -79,7 +80,14 @@ __device__ __forceinline__ float div_known_range(float a, float b)
 }
 
 __device__ __forceinline__ float length3(v3 a) { return sqrt_rn(dot3(a, a)); }
-__device__ __forceinline__ float rsqrt_ieee(float x) { return rcp_rn(sqrt_rn(x)); }   // inversesqrt := 1/sqrt, two roundings
+// inversesqrt := 1/sqrt, two roundings.  If x is in the core range so is sqrt(x) (2^-50 .. 2^50): one range test.
+__device__ __forceinline__ float rsqrt_ieee(float x)
+{
+    float y = rcp_core(sqrt_core(x));
+    const bool bad = (__float_as_uint(x) - 0x0d800000u) > (0x71800000u - 0x0d800000u);
+    if (__builtin_expect(__ballot(bad) != 0ull, 0)) { if (bad) y = 1.0f / sqrtf(x); }
+    return y;
+}
 __device__ __forceinline__ v3 normalize3(v3 a)
 {
     float s = rsqrt_ieee(dot3(a, a));
