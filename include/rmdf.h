@@ -180,8 +180,9 @@ int rmdf_render_supersampled(rmdf_ctx *ctx, int scene, int w, int h, int levels,
 
 /* Self-test of the kernels' short correctly-rounded sequences (sqrt, reciprocal, 1/sqrt, and the known-range
  * division inside log) against the compiler's IEEE expansions for ALL 2^32 float inputs on the device.
- * mismatches[0..3] = sqrt, reciprocal, log, 1/sqrt; all must be 0 (about one second of GPU time). */
-int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[4]);
+ * mismatches[0..3] = sqrt, reciprocal, log, 1/sqrt; mismatches[4] = the table-driven division of the Cornell
+ * distance estimator against the compiler's for every numerator and each of its 96 divisors.  All must be 0. */
+int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[5]);
 
 /* Measurement aid: per-wave counters of the Mandelbulb march kernel.  enable != 0 switches collection on
  * (off: frees the buffer); out (may be NULL) receives 16 uint64 per wave for the launches since the last read:

@@ -263,7 +263,7 @@ class ShaderRenderer:
 
     def selftest_exact_math(self):
         """Mismatch counts (sqrt, rcp, log, rsqrt) of the short exact sequences vs the compiler's, all 2^32 inputs."""
-        out = np.zeros(4, np.uint64)
+        out = np.zeros(5, np.uint64)
         self._check(self._lib.rmdf_selftest_exact_math(self._ctx, out.ctypes.data))
         return out
 

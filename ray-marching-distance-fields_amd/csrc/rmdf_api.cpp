@@ -30,6 +30,7 @@ struct rmdf_ctx {
     int          device = 0;
     hipStream_t  stream = nullptr;
     float       *d_cornell = nullptr;
+    float       *d_cornell_tab = nullptr;
     CubeSlot     env[RMDF_ENV_SLOTS];
     // frame latched on the first tile (ShaderRendering.hs:162-176)
     int          w = 0, h = 0, max_steps = 128;
@@ -141,6 +142,28 @@ void cornell_triangles(float out[96 * 3])
         for (int k = 0; k < 6; k++)
             for (int a = 0; a < 3; a++)
                 out[(q * 6 + k) * 3 + a] = (kCornellQuads[q * 4 + order[k]][a] / to_unit - 1.0f) * scale;
+}
+
+// per-triangle constants of de_cornell_box_table: the operation order of de_triangle / line_seg_min_dist_sq
+// (fragment.shd:312-372), evaluated once here instead of once per lane and distance estimate
+void cornell_table(const float tri[96 * 3], float tab[32 * CORNELL_STRIDE])
+{
+    for (int i = 0; i < 32; i++) {
+        const float *v0 = tri + i * 9, *v1 = v0 + 3, *v2 = v0 + 6;
+        float *t = tab + i * CORNELL_STRIDE;
+        for (int k = 0; k < 9; k++) t[k] = v0[k];
+        hv3 e0{ v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2] }, e1{ v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2] };
+        hv3 e12{ v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2] };
+        const float dot00 = hdot(e0, e0), dot01 = hdot(e0, e1), dot11 = hdot(e1, e1);
+        t[9] = e0.x; t[10] = e0.y; t[11] = e0.z; t[12] = e1.x; t[13] = e1.y; t[14] = e1.z;
+        t[15] = dot00; t[16] = dot01; t[17] = dot11;
+        t[18] = 1.0f / (dot00 * dot11 - dot01 * dot01);
+        t[19] = e12.x; t[20] = e12.y; t[21] = e12.z;
+        const float len12 = hdot(e12, e12);
+        t[22] = len12;
+        t[23] = 1.0f / dot00; t[24] = 1.0f / dot11; t[25] = 1.0f / len12;
+        t[26] = t[27] = 0.0f;
+    }
 }
 
 int ensure_frame(rmdf_ctx *ctx, int w, int h)
@@ -263,6 +286,7 @@ int fill_params(rmdf_ctx *ctx, int scene, int w, int h, float time, int max_step
     p.env_cos1 = CubeDev{ ctx->env[RMDF_ENV_COS_1].d_texels, ctx->env[RMDF_ENV_COS_1].W };
     p.env_cos8 = CubeDev{ ctx->env[RMDF_ENV_COS_8].d_texels, ctx->env[RMDF_ENV_COS_8].W };
     p.cornell = ctx->d_cornell;
+    p.cornell_tab = ctx->d_cornell_tab;
     { static int skip = -1; if (skip < 0) { const char *e = getenv("RMDF_DBG_SKIP"); skip = e ? atoi(e) : 0; } p.dbg_skip = skip; }
     int rc = ensure_gbuf(ctx, w, h);
     if (rc != RMDF_OK) return rc;
@@ -483,10 +507,14 @@ int rmdf_create(rmdf_ctx **out, const rmdf_config *cfg)
     snprintf(ctx->dev_name, sizeof ctx->dev_name, "%s (%s)", prop.name, prop.gcnArchName);
     float tri[96 * 3];
     cornell_triangles(tri);
+    float tab[32 * CORNELL_STRIDE];
+    cornell_table(tri, tab);
     if ((e = hipSetDevice(dev)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc((void **)&ctx->d_cornell, sizeof tri)) != hipSuccess ||
-        (e = hipMemcpy(ctx->d_cornell, tri, sizeof tri, hipMemcpyHostToDevice)) != hipSuccess) {
+        (e = hipMemcpy(ctx->d_cornell, tri, sizeof tri, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMalloc((void **)&ctx->d_cornell_tab, sizeof tab)) != hipSuccess ||
+        (e = hipMemcpy(ctx->d_cornell_tab, tab, sizeof tab, hipMemcpyHostToDevice)) != hipSuccess) {
         std::string msg = std::string("device init: ") + hipGetErrorString(e);
         rmdf_destroy(ctx);
         return fail(nullptr, RMDF_E_HIP, msg);
@@ -502,6 +530,7 @@ void rmdf_destroy(rmdf_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &s : ctx->env) if (s.d_texels) (void)hipFree(s.d_texels);
     if (ctx->d_cornell) (void)hipFree(ctx->d_cornell);
+    if (ctx->d_cornell_tab) (void)hipFree(ctx->d_cornell_tab);
     if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
     if (ctx->d_rgba_f32) (void)hipFree(ctx->d_rgba_f32);
     if (ctx->d_steps) (void)hipFree(ctx->d_steps);
@@ -743,16 +772,16 @@ int rmdf_render_supersampled(rmdf_ctx *ctx, int scene, int w, int h, int levels,
     return RMDF_OK;
 }
 
-int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[4])
+int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[5])
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
     if (!mismatches) return fail(ctx, RMDF_E_INVALID, "null output");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf d;
-    HIP_TRY(ctx, hipMalloc(&d.p, 4 * sizeof(unsigned long long)));
-    HIP_TRY(ctx, hipMemsetAsync(d.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
-    HIP_TRY(ctx, launch_selftest_exact_math((unsigned long long *)d.p, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(mismatches, d.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMalloc(&d.p, 8 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(d.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, launch_selftest_exact_math((unsigned long long *)d.p, ctx->d_cornell_tab, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(mismatches, d.p, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RMDF_OK;
 }

@@ -467,6 +467,66 @@ __device__ __forceinline__ float de_cornell_box(v3 pos, const float *__restrict_
     return dist;
 }
 
+// ---- the same distance with everything that depends only on the triangle taken from a table -----------------
+// Per triangle (CORNELL_STRIDE floats, computed on the host with the operation order of de_triangle, so every
+// entry has the bits the kernel would have computed): v0, v1, v2, e0 = v2-v0, e1 = v1-v0, dot00, dot01, dot11,
+// inv_denom, e12 = v2-v1, len12 = dot(e12,e12), and the correctly rounded reciprocals of the three squared edge
+// lengths.  Bit-identical to de_cornell_box because
+//   * x / len is replaced by q1 = fma(fma(-len, q0, x), y, q0), q0 = x*y, y = RN(1/len): the correctly rounded
+//     quotient for these 96 divisors (checked for every numerator bit pattern by rmdf_selftest_exact_math); numerators
+//     outside 2^-60..2^60 (zeros included) take the compiler's division;
+//   * min over sqrt(x_i) = sqrt(min over x_i): correctly rounded sqrt is monotone, and 999 = sqrt(998001) exactly.
+#define CORNELL_STRIDE 28
+__device__ __forceinline__ float div_by_table(float x, float len, float rlen)
+{
+    const float q0 = x * rlen;
+    const float r0 = __builtin_fmaf(-len, q0, x);
+    float q = __builtin_fmaf(r0, rlen, q0);
+    const unsigned ax = __float_as_uint(x) & 0x7fffffffu;
+    const bool bad = (ax - 0x21800000u) > (0x5d800000u - 0x21800000u);   // |x| outside 2^-60 .. 2^60 (zeros too: sign of -0/len)
+    if (__builtin_expect(__ballot(bad) != 0ull, 0)) { if (bad) q = x / len; }
+    return q;
+}
+__device__ __forceinline__ float seg_dist_sq_table(v3 a, v3 ab, float len, float rlen, v3 pa, v3 p)
+{
+    // line_seg_min_dist_sq (fragment.shd:312-321) with ab, len_sq from the table and pa = p - a
+    float t = div_by_table(dot3(pa, ab), len, rlen);
+    t = gclamp(t, 0.0f, 1.0f);
+    const v3 proj = mk3(a.x + t * ab.x, a.y + t * ab.y, a.z + t * ab.z);
+    const v3 d = sub3(p, proj);
+    return dot3(d, d);
+}
+__device__ __forceinline__ float de_cornell_box_table(v3 pos, const float *__restrict__ tab)
+{
+    float dist2 = 998001.0f;                                   // 999^2
+    for (int i = 0; i < 32; i++) {
+        const float *t = tab + i * CORNELL_STRIDE;
+        const v3 v0 = mk3(t[0], t[1], t[2]), v1 = mk3(t[3], t[4], t[5]), v2 = mk3(t[6], t[7], t[8]);
+        const v3 e0 = mk3(t[9], t[10], t[11]), e1 = mk3(t[12], t[13], t[14]);
+        const float dot00 = t[15], dot01 = t[16], dot11 = t[17], inv_denom = t[18];
+        const v3 e12 = mk3(t[19], t[20], t[21]);
+        const float len12 = t[22], r00 = t[23], r11 = t[24], r12 = t[25];
+        const v3 e2 = sub3(pos, v0);
+        const float dot02 = dot3(e0, e2), dot12 = dot3(e1, e2);
+        const float u = (dot11 * dot02 - dot01 * dot12) * inv_denom;
+        const float v = (dot00 * dot12 - dot01 * dot02) * inv_denom;
+        float x;
+        if ((u >= 0.0f) && (v >= 0.0f) && (u + v < 1.0f)) {
+            const float k = 1.0f - (u + v);
+            const v3 pp = mk3(v2.x * u + v1.x * v + v0.x * k, v2.y * u + v1.y * v + v0.y * k, v2.z * u + v1.z * v + v0.z * k);
+            const v3 d = sub3(pos, pp);
+            x = dot3(d, d);
+        } else {
+            const float s01 = seg_dist_sq_table(v0, e1, dot11, r11, e2, pos);                 // segment v0 v1: ab = e1
+            const float s02 = seg_dist_sq_table(v0, e0, dot00, r00, e2, pos);                 // segment v0 v2: ab = e0
+            const float s12 = seg_dist_sq_table(v1, e12, len12, r12, sub3(pos, v1), pos);     // segment v1 v2
+            x = gmin(s01, gmin(s02, s12));
+        }
+        dist2 = (x < dist2) ? x : dist2;
+    }
+    return sqrt_rn(dist2);
+}
+
 // fragment.shd:694-719
 __device__ __forceinline__ float fresnel_conductor(float cosi, float eta, float k)
 {

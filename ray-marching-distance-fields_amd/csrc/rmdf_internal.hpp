@@ -26,6 +26,7 @@ struct FrameParams {
     // single-rect mode ox=oy=0,pitch=w and for shard mode the slot's packed tile
     CubeDev env_refl, env_cos1, env_cos8;
     const float *cornell;     // 96 vertices
+    const float *cornell_tab; // 32 x CORNELL_STRIDE per-triangle constants (rmdf_device.hpp: de_cornell_box_table)
     uint32_t *rgba8;
     float4   *rgba_f32;
     uint16_t *steps;
@@ -62,7 +63,7 @@ hipError_t launch_render_mb8(const FrameParams &p, hipStream_t stream, int num_c
 hipError_t launch_render_pipeline(int scene, const FrameParams &p, hipStream_t stream, int num_cus);   // rmdf_pipeline.hip
 hipError_t launch_march_pool(const FrameParams &p, int blocks, hipStream_t stream);   // rmdf_pool.hip
 hipError_t launch_resolve_box2(const uint32_t *d_src, int sw, int sh, uint32_t *d_dst, hipStream_t stream);
-hipError_t launch_selftest_exact_math(unsigned long long *d_counts, hipStream_t stream);
+hipError_t launch_selftest_exact_math(unsigned long long *d_counts, const float *d_cornell_tab, hipStream_t stream);
 hipError_t launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t stream);
 hipError_t launch_cube_upload(const float *d_faces_f32, int W, uint2 *d_padded, hipStream_t stream);
 hipError_t launch_latlong_to_cube(const float *d_latlong, int w, int h, float *d_faces_f32, hipStream_t stream);

@@ -41,7 +41,7 @@ __device__ __forceinline__ float distance_estimator(v3 pos, const FrameParams &p
     if (SCENE == 2)      return de_mandelbulb8(pos, iters);
     else if (SCENE == 3) return de_mandelbulb_general(pos, p.power, iters);
     else if (SCENE == 1) return de_test_scene(pos);
-    else                 return de_cornell_box(pos, p.cornell);
+    else                 return de_cornell_box_table(pos, p.cornell_tab);
 }
 
 template <int SCENE>
@@ -383,6 +383,23 @@ __device__ __forceinline__ float log_ref_division(float x)
     return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
 }
 
+// div_by_table against the compiler's division: every numerator bit pattern x the 96 Cornell divisors
+__global__ void k_selftest_cornell_div(unsigned long long *counts, const float *__restrict__ tab)
+{
+    const int tri = blockIdx.y / 3, which = blockIdx.y % 3;
+    const float *t = tab + tri * CORNELL_STRIDE;
+    const float len = which == 0 ? t[15] : which == 1 ? t[17] : t[22];
+    const float rlen = which == 0 ? t[23] : which == 1 ? t[24] : t[25];
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long c = 0;
+    for (uint64_t i = tid; i < (1ull << 32); i += stride) {
+        const float x = __uint_as_float((uint32_t)i);
+        const float a = div_by_table(x, len, rlen), b = x / len;
+        c += !((__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b));
+    }
+    if (c) atomicAdd(&counts[4], c);
+}
+
 __global__ void k_selftest_exact_math(unsigned long long *counts)
 {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
@@ -401,9 +418,10 @@ __global__ void k_selftest_exact_math(unsigned long long *counts)
     atomicAdd(&counts[0], c0); atomicAdd(&counts[1], c1); atomicAdd(&counts[2], c2); atomicAdd(&counts[3], c3);
 }
 
-hipError_t launch_selftest_exact_math(unsigned long long *d_counts, hipStream_t stream)
+hipError_t launch_selftest_exact_math(unsigned long long *d_counts, const float *d_cornell_tab, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_selftest_exact_math, dim3(8192), dim3(256), 0, stream, d_counts);
+    hipLaunchKernelGGL(k_selftest_cornell_div, dim3(256, 96), dim3(256), 0, stream, d_counts, d_cornell_tab);
     return hipGetLastError();
 }
 
