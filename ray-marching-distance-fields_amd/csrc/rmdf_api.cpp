@@ -620,7 +620,7 @@ int rmdf_resize_latlong(rmdf_ctx *ctx, const float *rgb, int w, int h, int dstw,
 int rmdf_prefilter_env(rmdf_ctx *ctx, const float *rgb, int w, int h, float power, float *out)
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
-    if (!rgb || !out || w < 2 || h < 2 || w > 640) return fail(ctx, RMDF_E_INVALID, "rmdf_prefilter_env: bad argument (2 <= w <= 640)");
+    if (!rgb || !out || w < 2 || h < 2 || w > 600) return fail(ctx, RMDF_E_INVALID, "rmdf_prefilter_env: bad argument (2 <= w <= 600)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf src, dst;
     size_t b = (size_t)w * h * 12;

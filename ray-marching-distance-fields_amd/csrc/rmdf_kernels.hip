@@ -715,51 +715,83 @@ hipError_t launch_resize_latlong(const float *d_src, int sw, int sh, int dstw, i
 }
 
 // ------------------------------------------------------------------------------------
-// cosineConvolveHDREnvMap (HDREnvMap.hs:217-254): O(n^4).  One lane per destination
-// texel, summing over the source in the reference's order (y outer, x inner) so the
-// float accumulation matches; one 64-lane wave = 64 consecutive dstx of one row.  The
-// source row and the per-row cos/sin are wave-uniform (scalar loads); the
-// cos|phiL - phi_x| table is staged in LDS transposed so lanes read consecutive words.
+// cosineConvolveHDREnvMap (HDREnvMap.hs:217-254): O(n^4) -- every destination texel sums sin(theta)*cos^p over
+// all source texels with a positive cosine.  Workgroup = 64 destination columns x 8 row groups (512 threads):
+// lane = destination column dx, wave g sums the source rows [g*h/8, (g+1)*h/8) in the reference's order (y outer,
+// x inner); the 8 partial sums are added in row order, so the result differs from a single serial sum only by the
+// re-association at 7 points (tolerance parity).  The source row and per-row cos/sin are wave-uniform
+// (scalar loads); cos|phiL - phi_x| is staged once per workgroup in LDS, transposed so lanes read consecutive
+// words.  LOG2P >= 0: power = 2^LOG2P <= 8 by repeated squaring (the reference's 1 and 8); -1: powf (64, 512, any other).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_prefilter(const float *__restrict__ src, int w, int h, float power,
-                                                  float *__restrict__ out)
+template <int LOG2P>
+__global__ __launch_bounds__(512) void k_prefilter(const float *__restrict__ src, int w, int h, float power,
+                                                   float *__restrict__ out)
 {
-    extern __shared__ float lut[];            // [w][64]: lut[x*64 + lane] = cos|phiL(lane) - phi(x)|
-    const int lane = threadIdx.x;
+    extern __shared__ float lut[];            // [w][64]: lut[x*64 + lane] = cos|phiL(lane) - phi(x)|, then 8x64x4 partials
+    float *part = lut + (size_t)w * 64;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int dx = blockIdx.x * 64 + lane, dy = blockIdx.y;
     const int dxc = dx < w ? dx : w - 1;
     const float theta_l = (float)dy / (float)(h - 1) * RMDF_PI_F;
     const float lc = cosf(theta_l), ls = sinf(theta_l);
     const float phi_l = (float)dxc / (float)(w - 1) * 2.0f * RMDF_PI_F;
-    for (int x = 0; x < w; x++) lut[x * 64 + lane] = cosf(fabsf(phi_l - (float)x / (float)(w - 1) * 2.0f * RMDF_PI_F));
+    for (int x = g; x < w; x += 8) lut[x * 64 + lane] = cosf(fabsf(phi_l - (float)x / (float)(w - 1) * 2.0f * RMDF_PI_F));
+    __syncthreads();
     float ar = 0.0f, ag = 0.0f, ab = 0.0f, n = 0.0f;
-    for (int y = 0; y < h; y++) {
+    const int y0 = (int)((long long)g * h / 8), y1 = (int)((long long)(g + 1) * h / 8);
+    for (int y = y0; y < y1; y++) {
         const float th = (float)y / (float)(h - 1) * RMDF_PI_F;
         const float pc = cosf(th), ps = sinf(th);
         const float *row = src + (size_t)y * w * 3;
         for (int x = 0; x < w; x++) {
             const float cos_angle = lc * pc + ls * ps * lut[x * 64 + lane];
             if (cos_angle > 0.0f) {
-                const float fac = ps * powf(cos_angle, power);
+                float cp;
+                if (LOG2P >= 0) {
+                    cp = cos_angle;
+#pragma unroll
+                    for (int k = 0; k < LOG2P; k++) cp = cp * cp;
+                } else {
+                    cp = powf(cos_angle, power);
+                }
+                const float fac = ps * cp;
                 ar = ar + row[x * 3] * fac; ag = ag + row[x * 3 + 1] * fac; ab = ab + row[x * 3 + 2] * fac;
                 n = n + 1.0f;
             }
         }
     }
-    if (dx < w) {
+    float *pp = part + (g * 64 + lane) * 4;
+    pp[0] = ar; pp[1] = ag; pp[2] = ab; pp[3] = n;
+    __syncthreads();
+    if (g == 0 && dx < w) {
+        float sr = 0.0f, sg = 0.0f, sb = 0.0f, sn = 0.0f;
+        for (int k = 0; k < 8; k++) {
+            const float *q = part + (k * 64 + lane) * 4;
+            sr = sr + q[0]; sg = sg + q[1]; sb = sb + q[2]; sn = sn + q[3];
+        }
         float *o = out + ((size_t)dx + (size_t)dy * w) * 3;
-        o[0] = ar / n; o[1] = ag / n; o[2] = ab / n;
+        o[0] = sr / sn; o[1] = sg / sn; o[2] = sb / sn;
     }
 }
 
 hipError_t launch_prefilter(const float *d_src, int w, int h, float power, float *d_out, hipStream_t stream)
 {
     if (w < 2 || h < 2) return hipErrorInvalidValue;
-    const size_t lds = (size_t)w * 64 * sizeof(float);
+    const size_t lds = (size_t)w * 64 * sizeof(float) + 8 * 64 * 4 * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute((const void *)k_prefilter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int log2p = -1;
+    // repeated squaring doubles the relative rounding error per step: fine up to 2^3 (<= 5e-7), not for 64 / 512
+    for (int k = 0; k <= 3; k++) if (power == (float)(1 << k)) log2p = k;
+    const void *fn = log2p == 0 ? (const void *)k_prefilter<0> : log2p == 3 ? (const void *)k_prefilter<3> :
+                     log2p == 6 ? (const void *)k_prefilter<6> : log2p == 9 ? (const void *)k_prefilter<9> : (const void *)k_prefilter<-1>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_prefilter, dim3((w + 63) / 64, h), dim3(64), lds, stream, d_src, w, h, power, d_out);
+    dim3 grid((w + 63) / 64, h), block(512);
+    if (log2p == 0)      hipLaunchKernelGGL(k_prefilter<0>, grid, block, lds, stream, d_src, w, h, power, d_out);
+    else if (log2p == 3) hipLaunchKernelGGL(k_prefilter<3>, grid, block, lds, stream, d_src, w, h, power, d_out);
+    else if (log2p == 6) hipLaunchKernelGGL(k_prefilter<6>, grid, block, lds, stream, d_src, w, h, power, d_out);
+    else if (log2p == 9) hipLaunchKernelGGL(k_prefilter<9>, grid, block, lds, stream, d_src, w, h, power, d_out);
+    else                 hipLaunchKernelGGL(k_prefilter<-1>, grid, block, lds, stream, d_src, w, h, power, d_out);
     return hipGetLastError();
 }
 
