@@ -73,6 +73,7 @@ typedef struct rmdf_ctx rmdf_ctx;
 #define RMDF_FLAG_NESTED_LOOPS 1   /* Mandelbulb: single nested-loop kernel (k_render<2>)                  */
 #define RMDF_FLAG_FLAT_MARCH   2   /* Mandelbulb: flattened march kernel + shade kernel (rmdf_march.hip)   */
 #define RMDF_FLAG_PIPELINE     8   /* all scenes: march-with-refill + normal/AO-on-hit-list + shade kernels (rmdf_pipeline.hip) */
+#define RMDF_FLAG_NO_MERGE     16   /* nested-loop kernel: do NOT pool the last rays of a workgroup's four packets in one wave */
 #define RMDF_FLAG_RASTER_ORDER 4   /* nested-loop kernel: always dispatch strips in raster order (no cost feedback) */
 /* neither bit set = the library's default (currently the fastest measured: nested loops) */
 

@@ -33,7 +33,7 @@ DEFAULT_ENV_HDR = os.path.join(DATA_DIR, "latlong_envmaps", "uffizi_512.hdr")
 
 TILES_X, TILES_Y, N_TILES = 8, 8, 64          # ShaderRendering.hs:49-52
 ENV_REFLECTION, ENV_COS_1, ENV_COS_8, ENV_COS_64, ENV_COS_512 = range(5)
-FLAG_NESTED_LOOPS, FLAG_FLAT_MARCH, FLAG_RASTER_ORDER, FLAG_PIPELINE = 1, 2, 4, 8     # rmdf.h RMDF_FLAG_*
+FLAG_NESTED_LOOPS, FLAG_FLAT_MARCH, FLAG_RASTER_ORDER, FLAG_PIPELINE, FLAG_NO_MERGE = 1, 2, 4, 8, 16   # rmdf.h RMDF_FLAG_*
 
 _ERRORS = {-1: "RMDF_E_INVALID", -2: "RMDF_E_NO_DEVICE", -3: "RMDF_E_HIP", -4: "RMDF_E_IO",
            -5: "RMDF_E_NO_ENV", -6: "RMDF_E_UNSUPPORTED", -7: "RMDF_E_NOMEM"}

@@ -45,6 +45,7 @@ struct FrameParams {
     // cost-ordered dispatch of the nested-loop kernel (see DESIGN.md 'critical path'): block b renders
     // strip order[b] (null = raster order) and writes its cost (max escape iterations of a pixel) to cost[]
     int dbg_skip;             // measurement knob: 1 = skip normal/AO + shading of k_render, 2 = skip only normal/AO
+    int merge_stragglers;     // k_render: pool the last rays of a workgroup's four packets in one wave (MERGE variant)
     int prio_strips;          // the first prio_strips workgroups of an ordered launch raise their wave priority
     const unsigned *block_order;
     unsigned *block_cost;

@@ -50,7 +50,17 @@ __device__ __forceinline__ float bsphere_r() { return SCENE == 2 ? 1.15f : (SCEN
 // ------------------------------------------------------------------------------------
 // v1 render kernel: per-lane nested loops (march loop around the DE loop)
 // ------------------------------------------------------------------------------------
-template <int SCENE>
+// MERGE = true: the four waves of a workgroup pool their last few rays.  A packet's march loop keeps running until
+// its slowest ray is done, and 29 % of all iteration passes of the headline frame run with <= 16 of 64 lanes.  So
+// the first wave of a workgroup that is down to <= MERGE_T active rays becomes the "host"; every other wave that
+// gets down to MERGE_T hands its remaining rays (strip pixel, t, steps, iterations) over through an LDS mailbox and
+// leaves the march; the host adopts them into its idle lanes and marches everything to the end.  Rays never wait:
+// they march in their own wave until handed over, then in the host.  Handed-over rays are all late, near-surface
+// rays with similar escape-iteration counts, so the packet coherence the nested loop lives on is kept.  Results go
+// through an LDS table indexed by strip pixel; ray arithmetic is untouched (bit-identical output).
+#define MERGE_T 32
+
+template <int SCENE, bool MERGE>
 __global__ __launch_bounds__(256) void k_render(const FrameParams p)
 {
     // rectangle of this launch / shard slot
@@ -102,15 +112,131 @@ __global__ __launch_bounds__(256) void k_render(const FrameParams p)
     unsigned iters = 0;
     float t = 0.0f;
     float tmin, tmax;
-    if (active && ray_sphere(origin, dir, bsphere_r<SCENE>(), tmin, tmax)) {
-        t = gmax(0.0f, tmin);
-        for (steps = 0; steps < p.max_steps; steps++) {
-            v3 pos = mk3(origin.x + t * dir.x, origin.y + t * dir.y, origin.z + t * dir.z);
-            float dist = distance_estimator<SCENE>(pos, p, iters);
-            t += dist;
-            if (t > tmax) break;
-            if (dist < 0.001f) { hit = true; break; }
+    if (!MERGE) {
+        if (active && ray_sphere(origin, dir, bsphere_r<SCENE>(), tmin, tmax)) {
+            t = gmax(0.0f, tmin);
+            for (steps = 0; steps < p.max_steps; steps++) {
+                v3 pos = mk3(origin.x + t * dir.x, origin.y + t * dir.y, origin.z + t * dir.z);
+                float dist = distance_estimator<SCENE>(pos, p, iters);
+                t += dist;
+                if (t > tmax) break;
+                if (dist < 0.001f) { hit = true; break; }
+            }
         }
+    } else {
+        __shared__ int    s_host, s_nreported;
+        __shared__ int    s_mb_n[4], s_mb_ready[4];
+        __shared__ float4 s_mb[4][MERGE_T];
+        __shared__ float4 s_res[256];          // per strip pixel: t, steps | hit << 15, iterations
+        if (threadIdx.x == 0) { s_host = -1; s_nreported = 0; }
+        if (threadIdx.x < 4) { s_mb_ready[threadIdx.x] = 0; s_mb_n[threadIdx.x] = 0; }
+        const int my_sp = ly * 32 + wave * 8 + lx;
+        s_res[my_sp] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        __syncthreads();
+
+        // the ray this lane is marching right now (its own, or an adopted one when this wave is the host)
+        bool act = false;
+        int cur_sp = my_sp, st = 0;
+        unsigned it = 0;
+        float dx = dir.x, dy = dir.y, dz = dir.z, tt = 0.0f, tmx = 0.0f;
+        if (active && ray_sphere(origin, dir, bsphere_r<SCENE>(), tmin, tmax) && p.max_steps > 0) {
+            tt = gmax(0.0f, tmin); tmx = tmax; act = true;
+        }
+        bool is_host = false;
+        unsigned taken = 0u, cursor = 0u;      // per-mailbox: fully adopted flag, entries adopted so far (8 bits each)
+        const int merge_t = p.merge_stragglers < MERGE_T ? p.merge_stragglers : MERGE_T;
+        for (;;) {
+            unsigned long long am = __ballot(act);
+            int n_act = __popcll(am);
+            if (!is_host) {
+                if (n_act == 0) {
+                    if (lane == 0) __hip_atomic_fetch_add(&s_nreported, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    break;
+                }
+                if (n_act <= merge_t) {
+                    int h = 0;
+                    if (lane == 0) h = atomicCAS(&s_host, -1, wave);
+                    h = __builtin_amdgcn_readfirstlane(h);
+                    if (h == -1) {
+                        is_host = true;
+                    } else {
+                        if (act) {
+                            const int r = __builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0));
+                            s_mb[wave][r] = make_float4(__int_as_float(cur_sp), tt, __int_as_float(st), __uint_as_float(it));
+                        }
+                        if (lane == 0) {
+                            s_mb_n[wave] = n_act;
+                            __hip_atomic_store(&s_mb_ready[wave], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(&s_nreported, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        act = false;
+                        break;
+                    }
+                }
+            }
+            if (is_host) {
+                // adopt what the other waves have handed over so far, as far as idle lanes allow
+                for (int w = 0; w < 4; w++) {
+                    if (w == wave || ((taken >> w) & 1u)) continue;
+                    if (__hip_atomic_load(&s_mb_ready[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) continue;
+                    const int n = s_mb_n[w], first = (int)((cursor >> (8 * w)) & 255u);
+                    const unsigned long long idle = __ballot(!act);
+                    const int n_idle = __popcll(idle);
+                    const int r = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0));
+                    const int take = (n - first) < n_idle ? (n - first) : n_idle;
+                    if (!act && r < take) {
+                        const float4 e = s_mb[w][first + r];
+                        cur_sp = __float_as_int(e.x); tt = e.y; st = __float_as_int(e.z); it = __float_as_uint(e.w);
+                        const int qx = ex0 + bx * 32 + (cur_sp & 31), qy = ey0 + by * 8 + (cur_sp >> 5);
+                        const float nx_ = ((float)qx + 0.5f) / p.wf * 2.0f - 1.0f, ny_ = ((float)qy + 0.5f) / p.hf * 2.0f - 1.0f;
+                        const v3 dc = normalize3(mk3(nx_ * p.fov_xs, ny_ * p.fov_xs / p.aspect, -1.0f));
+                        dx = p.cam[0] * dc.x + p.cam[3] * dc.y + p.cam[6] * dc.z;
+                        dy = p.cam[1] * dc.x + p.cam[4] * dc.y + p.cam[7] * dc.z;
+                        dz = p.cam[2] * dc.x + p.cam[5] * dc.y + p.cam[8] * dc.z;
+                        float tmin2;
+                        (void)ray_sphere(origin, mk3(dx, dy, dz), bsphere_r<SCENE>(), tmin2, tmx);
+                        act = true;
+                    }
+                    cursor += (unsigned)take << (8 * w);
+                    if (first + take >= n) taken |= 1u << w;
+                }
+                am = __ballot(act);
+                n_act = __popcll(am);
+                if (n_act == 0) {
+                    // nothing to march: done once the three other waves have left their march and all mail is taken
+                    bool all = __hip_atomic_load(&s_nreported, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 3;
+                    if (all) {
+                        for (int w = 0; w < 4; w++)
+                            if (w != wave && !((taken >> w) & 1u) &&
+                                __hip_atomic_load(&s_mb_ready[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) all = false;
+                    }
+                    if (all) break;
+                    __builtin_amdgcn_s_sleep(4);
+                    continue;
+                }
+            }
+            // one march step (fragment.shd:661-672) for the rays in flight
+            if (act) {
+                const v3 pos = mk3(origin.x + tt * dx, origin.y + tt * dy, origin.z + tt * dz);
+                const float dist = distance_estimator<SCENE>(pos, p, it);
+                tt += dist;
+                const bool out = tt > tmx;
+                const bool h2 = !out && (dist < 0.001f);
+                bool done = out || h2;
+                if (!done) { st++; done = st >= p.max_steps; }
+                if (done) {
+                    s_res[cur_sp] = make_float4(tt, __int_as_float(st | (h2 ? 0x8000 : 0)), __uint_as_float(it), 0.0f);
+                    act = false;
+                }
+            }
+        }
+        __syncthreads();
+        const float4 rr = s_res[my_sp];
+        t = rr.x;
+        const int sb = __float_as_int(rr.y);
+        steps = sb & 0x7fff;
+        hit = (sb >> 15) != 0;
+        iters = __float_as_uint(rr.z);
     }
 
     // render_ray hit branch up to the texture lookups (fragment.shd:743-799)
@@ -342,10 +468,11 @@ hipError_t launch_render(int scene, const FrameParams &p, hipStream_t stream)
     // RMDF_OCC_LDS (measurement knob): dynamic LDS bytes per workgroup, only to cap waves per SIMD
     static int occ_lds = -1;
     if (occ_lds < 0) { const char *e = getenv("RMDF_OCC_LDS"); occ_lds = e ? atoi(e) : 0; }
-    if (scene == 2)      hipLaunchKernelGGL(k_render<2>, grid, block, occ_lds, stream, p);
-    else if (scene == 0) hipLaunchKernelGGL(k_render<0>, grid, block, occ_lds, stream, p);
-    else if (scene == 1) hipLaunchKernelGGL(k_render<1>, grid, block, occ_lds, stream, p);
-    else if (scene == 3) hipLaunchKernelGGL(k_render<3>, grid, block, occ_lds, stream, p);
+    const bool merge = p.merge_stragglers != 0;
+    if (scene == 2)      { if (merge) hipLaunchKernelGGL((k_render<2, true>), grid, block, occ_lds, stream, p); else hipLaunchKernelGGL((k_render<2, false>), grid, block, occ_lds, stream, p); }
+    else if (scene == 0) { if (merge) hipLaunchKernelGGL((k_render<0, true>), grid, block, occ_lds, stream, p); else hipLaunchKernelGGL((k_render<0, false>), grid, block, occ_lds, stream, p); }
+    else if (scene == 1) { if (merge) hipLaunchKernelGGL((k_render<1, true>), grid, block, occ_lds, stream, p); else hipLaunchKernelGGL((k_render<1, false>), grid, block, occ_lds, stream, p); }
+    else if (scene == 3) { if (merge) hipLaunchKernelGGL((k_render<3, true>), grid, block, occ_lds, stream, p); else hipLaunchKernelGGL((k_render<3, false>), grid, block, occ_lds, stream, p); }
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

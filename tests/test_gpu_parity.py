@@ -305,3 +305,19 @@ def test_exact_math_exhaustive(sr, orc):
     arithmetic (what the oracle runs on) through sampled comparisons of the functions built from them."""
     mism = sr.selftest_exact_math()
     assert mism.tolist() == [0, 0, 0, 0, 0], mism
+
+
+def test_straggler_pooling_is_invisible(rmdf, sr, env_faces):
+    """The default power-8 kernel pools the last rays of a workgroup's four packets in one wave; a
+    renderer with RMDF_FLAG_NO_MERGE must produce the same bits; forcing the pooling on for the other scenes too."""
+    plain = rmdf.ShaderRenderer(0, flags=rmdf.FLAG_NO_MERGE)
+    try:
+        for slot, k in ((rmdf.ENV_REFLECTION, "refl"), (rmdf.ENV_COS_1, "cos1"), (rmdf.ENV_COS_8, "cos8")):
+            plain.set_env_cube(slot, env_faces[k])
+        for (w, h, t, ms) in ((480, 270, 0.0, 256), (250, 130, 2.5, 64), (33, 17, 1.0, 256), (1280, 720, 7.0, 256)):
+            a, b = sr.render(2, w, h, t, max_steps=ms), plain.render(2, w, h, t, max_steps=ms)
+            for k in ("rgba8", "steps", "iters"):
+                assert np.array_equal(a[k], b[k]), (k, w, h)
+            assert np.array_equal(a["rgba_f32"].view(np.uint32), b["rgba_f32"].view(np.uint32))
+    finally:
+        plain.close()
