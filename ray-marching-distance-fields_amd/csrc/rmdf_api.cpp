@@ -233,7 +233,7 @@ int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t str
     // frame of the same configuration first (temporal coherence; `time` is deliberately not part of the key).
     // The table only permutes which workgroup renders which strip: the image does not depend on it.
     FrameParams q = p;
-    const int nblk = render_grid_blocks(p);
+    const int nblk = render_grid_blocks(scene, p);
     const bool want = (p.n_shard_tiles == 0) && nblk >= 1024 && !(ctx->flags & RMDF_FLAG_RASTER_ORDER);
     if (want) {
         if (nblk > ctx->order_cap) {

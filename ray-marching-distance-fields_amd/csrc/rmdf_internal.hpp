@@ -58,7 +58,7 @@ void tile_rect_host(int tile_idx, int w, int h, int *x0, int *y0, int *x1, int *
 // kernels / launchers implemented in rmdf_kernels.hip
 hipError_t launch_render(int scene, const FrameParams &p, hipStream_t stream);
 hipError_t launch_march_stats(const FrameParams &p, hipStream_t stream);
-int render_grid_blocks(const FrameParams &p);   // number of 32x8 strips launch_render() uses for p
+int render_grid_blocks(int scene, const FrameParams &p);   // number of 32x8 strips launch_render() uses for p
 hipError_t launch_order_blocks(const unsigned *d_cost, int n, unsigned *d_order, hipStream_t stream);
 hipError_t launch_render_mb8(const FrameParams &p, hipStream_t stream, int num_cus);
 hipError_t launch_render_pipeline(int scene, const FrameParams &p, hipStream_t stream, int num_cus);   // rmdf_pipeline.hip

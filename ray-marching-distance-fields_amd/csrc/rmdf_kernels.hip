@@ -60,8 +60,8 @@ __device__ __forceinline__ float bsphere_r() { return SCENE == 2 ? 1.15f : (SCEN
 // through an LDS table indexed by strip pixel; ray arithmetic is untouched (bit-identical output).
 #define MERGE_T 32
 
-template <int SCENE, bool MERGE>
-__global__ __launch_bounds__(256) void k_render(const FrameParams p)
+template <int SCENE, bool MERGE, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
 {
     // rectangle of this launch / shard slot
     int rx0, ry0, rx1, ry1, pitch, ox, oy;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_render(const FrameParams p)
         strip = p.block_order[strip];
     }
     const int bx = strip % gridDim.x, by = strip / gridDim.x;
-    const int px = ex0 + bx * 32 + wave * 8 + lx;
+    const int px = ex0 + bx * (WPB * 8) + wave * 8 + lx;
     const int py = ey0 + by * 8 + ly;
     const bool active = (px < ex1) && (py < ey1);
     const unsigned long long dbg_t0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -125,12 +125,12 @@ __global__ __launch_bounds__(256) void k_render(const FrameParams p)
         }
     } else {
         __shared__ int    s_host, s_nreported;
-        __shared__ int    s_mb_n[4], s_mb_ready[4];
-        __shared__ float4 s_mb[4][MERGE_T];
-        __shared__ float4 s_res[256];          // per strip pixel: t, steps | hit << 15, iterations
+        __shared__ int    s_mb_n[WPB], s_mb_ready[WPB];
+        __shared__ float4 s_mb[WPB][MERGE_T];
+        __shared__ float4 s_res[WPB * 64];          // per strip pixel: t, steps | hit << 15, iterations
         if (threadIdx.x == 0) { s_host = -1; s_nreported = 0; }
-        if (threadIdx.x < 4) { s_mb_ready[threadIdx.x] = 0; s_mb_n[threadIdx.x] = 0; }
-        const int my_sp = ly * 32 + wave * 8 + lx;
+        if (threadIdx.x < WPB) { s_mb_ready[threadIdx.x] = 0; s_mb_n[threadIdx.x] = 0; }
+        const int my_sp = ly * (WPB * 8) + wave * 8 + lx;
         s_res[my_sp] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         __syncthreads();
 
@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256) void k_render(const FrameParams p)
             tt = gmax(0.0f, tmin); tmx = tmax; act = true;
         }
         bool is_host = false;
-        unsigned taken = 0u, cursor = 0u;      // per-mailbox: fully adopted flag, entries adopted so far (8 bits each)
+        unsigned taken = 0u;
+        unsigned long long cursor = 0ull;      // per-mailbox: fully adopted flag, entries adopted so far (8 bits each)
         const int merge_t = p.merge_stragglers < MERGE_T ? p.merge_stragglers : MERGE_T;
         for (;;) {
             unsigned long long am = __ballot(act);
@@ -176,10 +177,10 @@ __global__ __launch_bounds__(256) void k_render(const FrameParams p)
             }
             if (is_host) {
                 // adopt what the other waves have handed over so far, as far as idle lanes allow
-                for (int w = 0; w < 4; w++) {
+                for (int w = 0; w < WPB; w++) {
                     if (w == wave || ((taken >> w) & 1u)) continue;
                     if (__hip_atomic_load(&s_mb_ready[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) continue;
-                    const int n = s_mb_n[w], first = (int)((cursor >> (8 * w)) & 255u);
+                    const int n = s_mb_n[w], first = (int)((cursor >> (8 * w)) & 255ull);
                     const unsigned long long idle = __ballot(!act);
                     const int n_idle = __popcll(idle);
                     const int r = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0));
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void k_render(const FrameParams p)
                     if (!act && r < take) {
                         const float4 e = s_mb[w][first + r];
                         cur_sp = __float_as_int(e.x); tt = e.y; st = __float_as_int(e.z); it = __float_as_uint(e.w);
-                        const int qx = ex0 + bx * 32 + (cur_sp & 31), qy = ey0 + by * 8 + (cur_sp >> 5);
+                        const int qx = ex0 + bx * (WPB * 8) + (cur_sp % (WPB * 8)), qy = ey0 + by * 8 + (cur_sp / (WPB * 8));
                         const float nx_ = ((float)qx + 0.5f) / p.wf * 2.0f - 1.0f, ny_ = ((float)qy + 0.5f) / p.hf * 2.0f - 1.0f;
                         const v3 dc = normalize3(mk3(nx_ * p.fov_xs, ny_ * p.fov_xs / p.aspect, -1.0f));
                         dx = p.cam[0] * dc.x + p.cam[3] * dc.y + p.cam[6] * dc.z;
@@ -197,16 +198,16 @@ __global__ __launch_bounds__(256) void k_render(const FrameParams p)
                         (void)ray_sphere(origin, mk3(dx, dy, dz), bsphere_r<SCENE>(), tmin2, tmx);
                         act = true;
                     }
-                    cursor += (unsigned)take << (8 * w);
+                    cursor += (unsigned long long)take << (8 * w);
                     if (first + take >= n) taken |= 1u << w;
                 }
                 am = __ballot(act);
                 n_act = __popcll(am);
                 if (n_act == 0) {
                     // nothing to march: done once the three other waves have left their march and all mail is taken
-                    bool all = __hip_atomic_load(&s_nreported, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 3;
+                    bool all = __hip_atomic_load(&s_nreported, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == WPB - 1;
                     if (all) {
-                        for (int w = 0; w < 4; w++)
+                        for (int w = 0; w < WPB; w++)
                             if (w != wave && !((taken >> w) & 1u) &&
                                 __hip_atomic_load(&s_mb_ready[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) all = false;
                     }
@@ -303,9 +304,9 @@ __global__ __launch_bounds__(256) void k_render(const FrameParams p)
     const float gr = pow_pinned(color.x, inv_gamma), gg = pow_pinned(color.y, inv_gamma), gb = pow_pinned(color.z, inv_gamma);
     // Stage the 32x8 strip in LDS so that every store instruction writes whole 128-byte lines (a wave's own
     // 8x8 packet would write 32-byte pieces of 8 different rows).  Thread t stores pixel (t % 32, t / 32).
-    __shared__ uint32_t s_rgba8[8][32];
-    __shared__ float4   s_f32[8][32];
-    __shared__ uint32_t s_meta[8][32];
+    __shared__ uint32_t s_rgba8[8][WPB * 8];
+    __shared__ float4   s_f32[8][WPB * 8];
+    __shared__ uint32_t s_meta[8][WPB * 8];
     {
         const int sx = wave * 8 + lx;
         s_rgba8[ly][sx] = to_unorm8(gr) | (to_unorm8(gg) << 8) | (to_unorm8(gb) << 16) | 0xff000000u;
@@ -314,8 +315,8 @@ __global__ __launch_bounds__(256) void k_render(const FrameParams p)
     }
     __syncthreads();
     {
-        const int ox_ = threadIdx.x & 31, oy_ = threadIdx.x >> 5;
-        const int qx = ex0 + bx * 32 + ox_, qy = ey0 + by * 8 + oy_;
+        const int ox_ = threadIdx.x % (WPB * 8), oy_ = threadIdx.x / (WPB * 8);
+        const int qx = ex0 + bx * (WPB * 8) + ox_, qy = ey0 + by * 8 + oy_;
         if (qx >= rx0 && qx < rx1 && qy >= ry0 && qy < ry1) {
             const size_t idx = obase + (size_t)(qx - ox) + (size_t)(qy - oy) * (size_t)pitch;
             if (p.rgba8) p.rgba8[idx] = s_rgba8[oy_][ox_];
@@ -399,7 +400,15 @@ hipError_t launch_march_stats(const FrameParams &p, hipStream_t stream)
     return hipGetLastError();
 }
 
-static void render_grid(const FrameParams &p, dim3 &grid)
+static int render_wpb(int scene)
+{
+    // waves per workgroup of k_render: RMDF_WPB (measurement knob) for the power-8 scene, 4 elsewhere
+    static int wpb = 0;
+    if (!wpb) { const char *e = getenv("RMDF_WPB"); wpb = (e && atoi(e) == 8) ? 8 : 4; }
+    return scene == 2 ? wpb : 4;
+}
+
+static void render_grid(const FrameParams &p, dim3 &grid, int wpb)
 {
     int rx0, ry0, rx1, ry1, nz = 1;
     if (p.n_shard_tiles > 0) {
@@ -410,13 +419,13 @@ static void render_grid(const FrameParams &p, dim3 &grid)
     }
     const int ex0 = rx0 & ~1, ey0 = ry0 & ~1, ex1 = (rx1 + 1) & ~1, ey1 = (ry1 + 1) & ~1;
     if (ex1 <= ex0 || ey1 <= ey0) { grid = dim3(0, 0, 0); return; }
-    grid = dim3((ex1 - ex0 + 31) / 32, (ey1 - ey0 + 7) / 8, nz);
+    grid = dim3((ex1 - ex0 + wpb * 8 - 1) / (wpb * 8), (ey1 - ey0 + 7) / 8, nz);
 }
 
-int render_grid_blocks(const FrameParams &p)
+int render_grid_blocks(int scene, const FrameParams &p)
 {
     dim3 g;
-    render_grid(p, g);
+    render_grid(p, g, render_wpb(scene));
     return (int)(g.x * g.y * g.z);
 }
 
@@ -464,16 +473,22 @@ hipError_t launch_render(int scene, const FrameParams &p, hipStream_t stream)
     }
     const int ex0 = rx0 & ~1, ey0 = ry0 & ~1, ex1 = (rx1 + 1) & ~1, ey1 = (ry1 + 1) & ~1;
     if (ex1 <= ex0 || ey1 <= ey0) return hipSuccess;
-    dim3 grid((ex1 - ex0 + 31) / 32, (ey1 - ey0 + 7) / 8, nz), block(256);
+    const int wpb = render_wpb(scene);
+    dim3 grid((ex1 - ex0 + wpb * 8 - 1) / (wpb * 8), (ey1 - ey0 + 7) / 8, nz);
     // RMDF_OCC_LDS (measurement knob): dynamic LDS bytes per workgroup, only to cap waves per SIMD
     static int occ_lds = -1;
     if (occ_lds < 0) { const char *e = getenv("RMDF_OCC_LDS"); occ_lds = e ? atoi(e) : 0; }
     const bool merge = p.merge_stragglers != 0;
-    if (scene == 2)      { if (merge) hipLaunchKernelGGL((k_render<2, true>), grid, block, occ_lds, stream, p); else hipLaunchKernelGGL((k_render<2, false>), grid, block, occ_lds, stream, p); }
-    else if (scene == 0) { if (merge) hipLaunchKernelGGL((k_render<0, true>), grid, block, occ_lds, stream, p); else hipLaunchKernelGGL((k_render<0, false>), grid, block, occ_lds, stream, p); }
-    else if (scene == 1) { if (merge) hipLaunchKernelGGL((k_render<1, true>), grid, block, occ_lds, stream, p); else hipLaunchKernelGGL((k_render<1, false>), grid, block, occ_lds, stream, p); }
-    else if (scene == 3) { if (merge) hipLaunchKernelGGL((k_render<3, true>), grid, block, occ_lds, stream, p); else hipLaunchKernelGGL((k_render<3, false>), grid, block, occ_lds, stream, p); }
-    else return hipErrorInvalidValue;
+#define RMDF_LAUNCH(SC, W)                                                                                   \
+    do {                                                                                                     \
+        if (merge) hipLaunchKernelGGL((k_render<SC, true, W>), grid, dim3(W * 64), occ_lds, stream, p);      \
+        else       hipLaunchKernelGGL((k_render<SC, false, W>), grid, dim3(W * 64), occ_lds, stream, p);     \
+    } while (0)
+    if (scene == 2)      { if (wpb == 8) RMDF_LAUNCH(2, 8); else RMDF_LAUNCH(2, 4); }
+    else if (scene == 0) RMDF_LAUNCH(0, 4);
+    else if (scene == 1) RMDF_LAUNCH(1, 4);
+    else if (scene == 3) RMDF_LAUNCH(3, 4);
+#undef RMDF_LAUNCH
     return hipGetLastError();
 }
 
