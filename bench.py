@@ -112,7 +112,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    rmdf_amd.build()
+    # one rank builds (a no-op when librmdf.so is current), the others wait: N ranks must not run make at once
+    if local_rank == 0:
+        rmdf_amd.build()
+    if world > 1:
+        dist.barrier()
     w, h, ms, scene = a.width, a.height, a.max_steps, a.scene
     sr = rmdf_amd.ShaderRenderer(local_rank, flags=int(os.environ.get("RMDF_FLAGS", "0")))
     sr.load_env_hdr(rmdf_amd.DEFAULT_ENV_HDR)

@@ -16,9 +16,21 @@ SCENE_CORNELL, SCENE_DETEST, SCENE_MB_POWER8, SCENE_MB_GENERAL = 0, 1, 2, 3
 
 
 def build(force=False):
+    """gcc the oracle (serialised with a file lock: test workers may race)."""
+    import fcntl
     src = [os.path.join(_HERE, f) for f in ("rmdf_oracle.c", "rmdf_oracle.h", "Makefile")]
-    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
-        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+
+    def stale():
+        return not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src)
+    if not (force or stale()):
+        return _LIB
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or stale():
+                subprocess.check_call(["make"] + (["-B"] if force else []) + ["-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return _LIB
 
 

@@ -81,12 +81,23 @@ def tile_rect(tile_idx, w, h):
 
 
 def build(force=False, verbose=False):
-    """Compile librmdf.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    """Compile librmdf.so for gfx950 with hipcc (cross-compiles without a GPU).  Serialised with a file lock:
+    several ranks of one node may call this at the same time."""
+    import fcntl
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "rmdf.h")]
-    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
-    if force or stale:
-        out = None if verbose else subprocess.DEVNULL
-        subprocess.check_call(["make", "-C", CSRC] + (["-B"] if force else []), stdout=out)
+
+    def stale():
+        return (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if not (force or stale()):
+        return LIB_PATH
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or stale():
+                out = None if verbose else subprocess.DEVNULL
+                subprocess.check_call(["make", "-C", CSRC] + (["-B"] if force else []), stdout=out)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
