@@ -31,6 +31,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# frames in flight live on separate HIP streams; give the runtime enough hardware queues for them (read at HIP init)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_TLANEOPS = 78.6       # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (157.3 TFLOPS only if every op were an FMA)
 
@@ -46,16 +49,27 @@ def load_oracle_env(orc):
                                     rd("uffizi_512_cache_pow_8.0.hdr"))
 
 
-def gather_shards(shard, rank, world, dist, out=None):
+def load_oracle_faces(orc):
+    """Oracle-built float32 cube faces of the same files (input shared by both sides in --check)."""
+    import rmdf_amd
+    d = os.path.join(rmdf_amd.DATA_DIR, "latlong_envmaps")
+    rd = lambda n: orc.hdr_decode(open(os.path.join(d, n), "rb").read())
+    return {"refl": orc.latlong_to_cube(rd("uffizi_512.hdr")), "cos1": orc.latlong_to_cube(rd("uffizi_512_cache_pow_1.0.hdr")),
+            "cos8": orc.latlong_to_cube(rd("uffizi_512_cache_pow_8.0.hdr"))}
+
+
+def gather_shards(shard, rank, world, dist, out=None, out_list=None):
     """The single exchange step of the path: gather every rank's packed tile shard on rank 0.
-    shard: (slots, th, tw) int32 tensor.  Returns (world, slots, th, tw) on rank 0, None elsewhere."""
+    shard: (slots, th, tw) int32 tensor.  Returns (world, slots, th, tw) on rank 0, None elsewhere.
+    out_list = list(out.unbind(0)), precomputed by callers that gather every frame."""
     import torch
     if world == 1:
         return shard.unsqueeze(0)
     if rank == 0:
         if out is None:
             out = torch.empty((world,) + tuple(shard.shape), dtype=shard.dtype, device=shard.device)
-        dist.gather(shard, list(out.unbind(0)), dst=0)
+            out_list = None
+        dist.gather(shard, out_list if out_list is not None else list(out.unbind(0)), dst=0)
         return out
     dist.gather(shard, None, dst=0)
     return None
@@ -89,6 +103,9 @@ def main():
     ap.add_argument("--scene", type=int, default=2, help="FragmentShader enum (2 = FSMBPower8Shader)")
     ap.add_argument("--supersample", type=int, default=0, help="mip levels of super-sampling: rays = (w<<L) x (h<<L), "
                     "resolved on the GPU before the gather (BASELINE config 4: --width 3840 --height 2160 --supersample 1)")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("RMDF_BENCH_STREAMS", "0")),
+                    help="frames kept in flight (one HIP stream + buffer set each); 1 = one frame at a time; "
+                         "0 = default: 2 on one GPU, min(8, 2 + N) on N GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also compare the frame with the oracle (slow)")
     a = ap.parse_args()
@@ -119,64 +136,85 @@ def main():
         dist.barrier()
     w, h, ms, scene = a.width, a.height, a.max_steps, a.scene
     sr = rmdf_amd.ShaderRenderer(local_rank, flags=int(os.environ.get("RMDF_FLAGS", "0")))
-    sr.load_env_hdr(rmdf_amd.DEFAULT_ENV_HDR)
+    if a.check:
+        # strict comparison: both sides get the oracle-built float32 cube faces (the device's own latlong -> cube uses the
+        # device libm where the oracle uses glibc: a few texels differ by one f16 ulp, see tests/test_gpu_parity.py)
+        from oracle import orc as _orc
+        _env = load_oracle_faces(_orc)
+        for slot, k in ((rmdf_amd.ENV_REFLECTION, "refl"), (rmdf_amd.ENV_COS_1, "cos1"), (rmdf_amd.ENV_COS_8, "cos8")):
+            sr.set_env_cube(slot, _env[k])
+    else:
+        sr.load_env_hdr(rmdf_amd.DEFAULT_ENV_HDR)
     dev_name, cus = sr.device_info()
-    # a dedicated (non-null) HIP stream: kernels, RCCL calls and the timing events all go on it
-    stream = torch.cuda.Stream(dev)
+    # Frames are independent, so S of them are kept in flight: frame i goes to HIP stream i % S (dedicated, non-null
+    # streams; kernels, the RCCL call and the timing events of a frame all go on its stream) and owns buffer set
+    # i % S.  On one GPU this overlaps the thin tail of a frame -- the launch cannot end before its longest ray has
+    # finished a ~0.45 ms serial chain -- with the bulk of the next; on N GPUs it also overlaps the gather of frame i
+    # with the render of frame i+1.  --streams 1 = strictly one frame at a time.
+    S = a.streams if a.streams > 0 else (2 if world == 1 else min(8, 2 + world))
+    streams = [torch.cuda.Stream(dev) for _ in range(S)]
+    stream = streams[0]
     torch.cuda.set_stream(stream)
     sptr = stream.cuda_stream
-    assert sptr != 0
+    assert all(st.cuda_stream != 0 for st in streams)
 
     L = a.supersample
     rw, rh = w << L, h << L                                   # ray grid
-    frame = torch.empty((h, w), dtype=torch.int32, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    frames = [torch.empty((h, w), **i32) for _ in range(S)]
     if world == 1:
-        big = torch.empty((rh, rw), dtype=torch.int32, device=dev) if L else frame
-        tmp = torch.empty((rh // 2, rw // 2), dtype=torch.int32, device=dev) if L > 1 else None
+        bigs = [torch.empty((rh, rw), **i32) for _ in range(S)] if L else frames
+        tmps = [torch.empty((rh // 2, rw // 2), **i32) if L > 1 else None for _ in range(S)]
     else:
         slots = rmdf_amd.shard_slots(world)
-        shard = torch.zeros((slots, h // 8, w // 8), dtype=torch.int32, device=dev)
-        big = torch.zeros((slots, rh // 8, rw // 8), dtype=torch.int32, device=dev) if L else shard
-        tmp = torch.empty((slots, rh // 16, rw // 16), dtype=torch.int32, device=dev) if L > 1 else None
-        gathered = torch.empty((world, slots, h // 8, w // 8), dtype=torch.int32, device=dev) if rank == 0 else None
+        shards = [torch.zeros((slots, h // 8, w // 8), **i32) for _ in range(S)]
+        bigs = [torch.zeros((slots, rh // 8, rw // 8), **i32) for _ in range(S)] if L else shards
+        tmps = [torch.empty((slots, rh // 16, rw // 16), **i32) if L > 1 else None for _ in range(S)]
+        gathereds = [torch.empty((world, slots, h // 8, w // 8), **i32) if rank == 0 else None for _ in range(S)]
+        gather_lists = [list(g.unbind(0)) if g is not None else None for g in gathereds]
+    frame = frames[0]
 
-    def resolve(src, sw, sh, dst):
+    def resolve(src, sw, sh, dst, tmp, sp):
         """`L` box-filter levels from src (sw x sh) into dst, ping-ponging through tmp"""
         cur, cw, ch = src, sw, sh
         for lvl in range(L):
             out = dst if lvl == L - 1 else (tmp if cur is not tmp else src)
-            sr.resolve_box2_device(cur.data_ptr(), cw, ch, out.data_ptr(), stream=sptr)
+            sr.resolve_box2_device(cur.data_ptr(), cw, ch, out.data_ptr(), stream=sp)
             cur, cw, ch = out, cw // 2, ch // 2
 
-    def render_only():
+    def render_only(k=0):
+        sp = streams[k].cuda_stream
         if world == 1:
-            sr.render_rect_device(scene, rw, rh, a.time, ms, (0, 0, rw, rh), d_rgba8=big.data_ptr(), stream=sptr)
+            sr.render_rect_device(scene, rw, rh, a.time, ms, (0, 0, rw, rh), d_rgba8=bigs[k].data_ptr(), stream=sp)
         else:
-            sr.render_shard_device(scene, rw, rh, a.time, ms, rank, world, big.data_ptr(), stream=sptr)
+            sr.render_shard_device(scene, rw, rh, a.time, ms, rank, world, bigs[k].data_ptr(), stream=sp)
 
-    def step():
-        render_only()
-        if world == 1:
-            if L:
-                resolve(big, rw, rh, frame)
-        else:
-            if L:
-                resolve(big, rw // 8, slots * (rh // 8), shard)
-            g = gather_shards(shard, rank, world, dist, out=gathered)
-            if rank == 0:
-                sr.assemble_shards_device(w, h, world, g.data_ptr(), frame.data_ptr(), stream=sptr)
+    def step(i=0):
+        k = i % S
+        sp = streams[k].cuda_stream
+        with torch.cuda.stream(streams[k]):                   # the RCCL call orders itself against the current stream
+            render_only(k)
+            if world == 1:
+                if L:
+                    resolve(bigs[k], rw, rh, frames[k], tmps[k], sp)
+            else:
+                if L:
+                    resolve(bigs[k], rw // 8, slots * (rh // 8), shards[k], tmps[k], sp)
+                g = gather_shards(shards[k], rank, world, dist, out=gathereds[k], out_list=gather_lists[k])
+                if rank == 0:
+                    sr.assemble_shards_device(w, h, world, g.data_ptr(), frames[k].data_ptr(), stream=sp)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
-        step()
+    for i in range(a.warmup):
+        step(i)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    for i in range(a.steps):
+        step(i)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0, dist, dev)
     ms_per_step = dt / a.steps * 1e3
@@ -232,8 +270,10 @@ def main():
                                    "full frame -> RGBA8 resident in HBM" % (scene, w, h, (" x %d rays/px, box-resolved on the GPU" % (4 ** L)) if L else "", ms, a.time),
                        "supersample_levels": L, "mrays_per_s": round(value * 4 ** L, 2),
                        "scene": scene, "width": w, "height": h, "max_steps": ms,
-                       "parallelism": "1 GPU, one launch per frame" if world == 1 else
-                                      "64 tiles interleaved over %d GPUs + one RCCL gather" % world,
+                       "parallelism": ("1 GPU, one launch per frame" if world == 1 else
+                                       "64 tiles interleaved over %d GPUs + one RCCL gather per frame" % world) +
+                                      ", %d frame(s) in flight" % S,
+                       "frames_in_flight": S,
                        "device": dev_name, "compute_units": cus},
             "roofline": {"bound": "hbm", "kernel": "k_render<2>", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
@@ -260,8 +300,8 @@ def main():
                                       "sample": "1 full frame %dx%d of the same workload, CPU oracle (C port of fragment.shd), "
                                                 "row segments over all host cores as ConcurrentSegments does" % (w, h)}
             if a.check:
-                got = frame.cpu().numpy().view(np.uint32)
-                result["check_rgba8_equal"] = bool(np.array_equal(got, ref["rgba8"]))
+                result["check_rgba8_equal"] = all(bool(np.array_equal(f.cpu().numpy().view(np.uint32), ref["rgba8"]))
+                                                  for f in frames)
         print(json.dumps(result), flush=True)
 
     if world > 1:

@@ -158,10 +158,14 @@ int rmdf_render_rect_device(rmdf_ctx *ctx, int scene, int w, int h, double time,
                             int x0, int y0, int x1, int y1,
                             void *d_rgba8, void *d_rgba_f32, void *d_steps, void *d_iters, void *stream);
 
-/* Multi-GPU sharding of the reference's 64 tiles: rank r of n renders the tiles
- * with idx mod n == r (interleaved), packed back to back in ascending idx order
- * into d_packed_rgba8 (tile = (w/8)*(h/8) uint32, rows bottom-up).  Requires
- * w mod 8 == 0 and h mod 8 == 0. */
+/* Multi-GPU sharding of the reference's 64 tiles (ShaderRendering.hs:49-52,183-193 renders them one per frame;
+ * here they are the units dealt to the GPUs).  rmdf_shard_tiles: the tile indices rank `rank` of `nranks`
+ * renders, in slot order; returns their number (<= ceil(64/nranks)) or a negative error code.  Host-only
+ * arithmetic, no device needed.  The deal is balanced for scenes centred in the frame: tiles sorted by ring around
+ * the frame centre and dealt to the ranks boustrophedon, so every rank gets tiles of every ring.
+ * rmdf_render_shard_device renders those tiles packed back to back in slot order into d_packed_rgba8
+ * (tile = (w/8)*(h/8) uint32, rows bottom-up).  Requires w mod 8 == 0 and h mod 8 == 0. */
+int rmdf_shard_tiles(int rank, int nranks, int tiles[64]);
 int rmdf_render_shard_device(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps,
                              int rank, int nranks, void *d_packed_rgba8, void *stream);
 /* Rank 0 after the gather: d_gathered holds the nranks shards back to back (rank

@@ -45,7 +45,7 @@ ABI_SYMBOLS = (
     "rmdf_is_tile_idx_first_tile", "rmdf_is_tile_idx_last_tile", "rmdf_render_tile", "rmdf_render_tile_ex",
     "rmdf_render_rect_device", "rmdf_render_shard_device", "rmdf_assemble_shards_device", "rmdf_synchronize",
     "rmdf_device_info", "rmdf_debug_march_stats", "rmdf_resolve_box2_device", "rmdf_render_supersampled",
-    "rmdf_selftest_exact_math",
+    "rmdf_selftest_exact_math", "rmdf_shard_tiles",
 )
 
 
@@ -131,6 +131,7 @@ def load_library():
     L.rmdf_render_tile_ex.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp]
     L.rmdf_render_rect_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int] + [C.c_int] * 4 + [vp] * 5
     L.rmdf_render_shard_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.rmdf_shard_tiles.argtypes = [C.c_int, C.c_int, ip]
     L.rmdf_assemble_shards_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.rmdf_synchronize.argtypes = [vp, vp]
     L.rmdf_device_info.argtypes = [vp, C.c_char_p, C.c_int, ip]
@@ -327,9 +328,32 @@ class FrameBuffer:
 
 # --- multi-GPU tile sharding: pure index arithmetic, testable without a GPU ------
 
+def _ring_order():
+    """The 64 tiles sorted by ring around the frame centre (innermost first, idx order inside a ring)."""
+    ring = lambda idx: max(abs(2 * (idx % 8) - 7), abs(2 * (idx // 8) - 7))
+    return sorted(range(N_TILES), key=lambda idx: (ring(idx), idx))
+
+
 def shard_tiles(rank, nranks):
-    """Tiles rank `rank` of `nranks` renders: idx = rank, rank+n, ... (interleaved for load balance)."""
-    return list(range(rank, N_TILES, nranks))
+    """Tiles rank `rank` of `nranks` renders, in slot order -- the same deal as rmdf_shard_tiles (rmdf.h): tiles sorted by
+    ring around the frame centre, dealt boustrophedon (0..n-1, n-1..0, ...), so every rank gets tiles of every ring (the
+    scenes are centred: cost falls off with the distance from the centre)."""
+    order = _ring_order()
+    out = []
+    for j, idx in enumerate(order):
+        rnd, pos = divmod(j, nranks)
+        if (nranks - 1 - pos if rnd & 1 else pos) == rank:
+            out.append(idx)
+    return out
+
+
+def shard_tiles_abi(rank, nranks):
+    """rmdf_shard_tiles through the library (host-only arithmetic, works without a GPU)."""
+    buf = (C.c_int * 64)()
+    n = load_library().rmdf_shard_tiles(rank, nranks, buf)
+    if n < 0:
+        raise RmdfError(n, "rmdf_shard_tiles")
+    return list(buf[:n])
 
 
 def shard_slots(nranks):

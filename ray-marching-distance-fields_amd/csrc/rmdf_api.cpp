@@ -24,6 +24,16 @@ struct CubeSlot {
     int    W = 0;
 };
 
+#define RMDF_MAX_ORDER_STREAMS 8
+struct OrderState {
+    hipStream_t stream = nullptr;
+    unsigned   *d_cost = nullptr, *d_order = nullptr;
+    int         cap = 0, n = 0;
+    int         key[10] = { -1, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    bool        used = false, valid = false;
+    unsigned    last_use = 0;
+};
+
 }  // namespace
 
 struct rmdf_ctx {
@@ -47,12 +57,10 @@ struct rmdf_ctx {
     unsigned    *d_gbuf_meta = nullptr;
     int         *d_work_counter = nullptr;
     int         *d_hit_list = nullptr;
-    // cost-ordered dispatch state of the nested-loop kernel (previous frame's per-strip costs)
-    unsigned    *d_block_cost = nullptr, *d_block_order = nullptr;
-    int          order_cap = 0, order_n = 0;
-    int          order_key[8] = { -1, 0, 0, 0, 0, 0, 0, 0 };
-    hipStream_t  order_stream = nullptr;
-    bool         order_valid = false;
+    // cost-ordered dispatch state of the nested-loop kernel (previous frame's per-strip costs), one per stream
+    // that renders: frames in flight on different streams (pipelined rendering) must not share the tables
+    OrderState   orders[RMDF_MAX_ORDER_STREAMS];
+    unsigned     order_tick = 0;
     unsigned long long *d_dbg = nullptr;   // per-wave march diagnostics (rmdf_debug_march_stats)
     size_t       gbuf_cap = 0;
     int          flags = 0;            // rmdf_config.reserved[0]
@@ -234,26 +242,41 @@ int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t str
     // The table only permutes which workgroup renders which strip: the image does not depend on it.
     FrameParams q = p;
     const int nblk = render_grid_blocks(scene, p);
-    const bool want = (p.n_shard_tiles == 0) && nblk >= 1024 && !(ctx->flags & RMDF_FLAG_RASTER_ORDER);
+    const bool want = nblk >= 1024 && !(ctx->flags & RMDF_FLAG_RASTER_ORDER);
     if (want) {
-        if (nblk > ctx->order_cap) {
-            if (ctx->d_block_cost) (void)hipFree(ctx->d_block_cost);
-            if (ctx->d_block_order) (void)hipFree(ctx->d_block_order);
-            ctx->d_block_cost = ctx->d_block_order = nullptr; ctx->order_cap = 0; ctx->order_valid = false;
-            HIP_TRY(ctx, hipMalloc((void **)&ctx->d_block_cost, (size_t)nblk * 4));
-            HIP_TRY(ctx, hipMalloc((void **)&ctx->d_block_order, (size_t)nblk * 4));
-            ctx->order_cap = nblk;
+        // the table set of this stream (least recently used one is recycled when more than 8 streams render)
+        OrderState *os = nullptr;
+        for (auto &o : ctx->orders) if (o.used && o.stream == stream) { os = &o; break; }
+        if (!os) {
+            for (auto &o : ctx->orders) if (!o.used) { os = &o; break; }
+            if (!os) {
+                os = &ctx->orders[0];
+                for (auto &o : ctx->orders) if (o.last_use < os->last_use) os = &o;
+                // its last launches may still be running on the stream it served (which may no longer exist)
+                HIP_TRY(ctx, hipDeviceSynchronize());
+            }
+            os->used = true; os->stream = stream; os->valid = false;
         }
-        const int key[8] = { scene, p.w, p.h, p.x0, p.y0, p.x1, p.y1, p.max_steps };
-        const bool same = ctx->order_valid && ctx->order_stream == stream && ctx->order_n == nblk &&
-                          memcmp(key, ctx->order_key, sizeof key) == 0;
-        q.block_cost = ctx->d_block_cost;
-        q.block_order = same ? ctx->d_block_order : nullptr;
+        os->last_use = ++ctx->order_tick;
+        if (nblk > os->cap) {
+            if (os->cap) HIP_TRY(ctx, hipStreamSynchronize(stream));
+            if (os->d_cost) (void)hipFree(os->d_cost);
+            if (os->d_order) (void)hipFree(os->d_order);
+            os->d_cost = os->d_order = nullptr; os->cap = 0; os->valid = false;
+            HIP_TRY(ctx, hipMalloc((void **)&os->d_cost, (size_t)nblk * 4));
+            HIP_TRY(ctx, hipMalloc((void **)&os->d_order, (size_t)nblk * 4));
+            os->cap = nblk;
+        }
+        const int key[10] = { scene, p.w, p.h, p.x0, p.y0, p.x1, p.y1, p.max_steps,
+                              p.n_shard_tiles, p.shard_key };
+        const bool same = os->valid && os->n == nblk && memcmp(key, os->key, sizeof key) == 0;
+        q.block_cost = os->d_cost;
+        q.block_order = same ? os->d_order : nullptr;
         { static int ps = -1; if (ps < 0) { const char *e = getenv("RMDF_PRIO_STRIPS"); ps = e ? atoi(e) : 256; } q.prio_strips = ps; }
         HIP_TRY(ctx, launch_render(scene, q, stream));
-        HIP_TRY(ctx, launch_order_blocks(ctx->d_block_cost, nblk, ctx->d_block_order, stream));
-        memcpy(ctx->order_key, key, sizeof key);
-        ctx->order_n = nblk; ctx->order_stream = stream; ctx->order_valid = true;
+        HIP_TRY(ctx, launch_order_blocks(os->d_cost, nblk, os->d_order, stream));
+        memcpy(os->key, key, sizeof key);
+        os->n = nblk; os->valid = true;
     } else {
         HIP_TRY(ctx, launch_render(scene, q, stream));
     }
@@ -544,8 +567,11 @@ void rmdf_destroy(rmdf_ctx *ctx)
     if (ctx->d_hit_list) (void)hipFree(ctx->d_hit_list);
     if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
     if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
-    if (ctx->d_block_cost) (void)hipFree(ctx->d_block_cost);
-    if (ctx->d_block_order) (void)hipFree(ctx->d_block_order);
+    (void)hipDeviceSynchronize();              // caller streams may still be running launches that use the tables
+    for (auto &o : ctx->orders) {
+        if (o.d_cost) (void)hipFree(o.d_cost);
+        if (o.d_order) (void)hipFree(o.d_order);
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -719,10 +745,19 @@ int rmdf_render_shard_device(rmdf_ctx *ctx, int scene, int w, int h, double time
     FrameParams p;
     int rc = fill_params(ctx, scene, w, h, (float)time, max_steps, p);
     if (rc != RMDF_OK) return rc;
-    p.n_shard_tiles = (RMDF_N_TILES - rank + nranks - 1) / nranks;   // tiles idx = rank, rank+n, ...
-    p.shard_first = rank; p.shard_stride = nranks;
+    p.n_shard_tiles = shard_tiles_of_rank(rank, nranks, p.shard_tile);
+    p.shard_key = rank * 256 + nranks;
     p.rgba8 = (uint32_t *)d_packed_rgba8;
     return launch_scene(ctx, scene, p, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int rmdf_shard_tiles(int rank, int nranks, int tiles[64])
+{
+    if (nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks || !tiles) return RMDF_E_INVALID;
+    unsigned char t[64];
+    const int cnt = shard_tiles_of_rank(rank, nranks, t);
+    for (int i = 0; i < cnt; i++) tiles[i] = t[i];
+    return cnt;
 }
 
 int rmdf_assemble_shards_device(rmdf_ctx *ctx, int w, int h, int nranks, const void *d_gathered,
@@ -793,7 +828,7 @@ int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[5])
 int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_waves)
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
-    const size_t cap = 8192;
+    const size_t cap = 32768;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (enable && !ctx->d_dbg) {
         HIP_TRY(ctx, hipMalloc((void **)&ctx->d_dbg, cap * 16 * sizeof(unsigned long long)));

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "rmdf_device.hpp"
 
@@ -20,8 +21,10 @@ struct FrameParams {
     int   max_steps;          // fragment.shd:634
     // pixel rectangle to produce (single-rect mode, n_shard_tiles == 0)
     int   x0, y0, x1, y1;
-    // tile-shard mode: blockIdx.z = slot; tile idx = shard_first + slot*shard_stride
-    int   n_shard_tiles, shard_first, shard_stride;
+    // tile-shard mode: blockIdx.z = slot; tile idx = shard_tile[slot] (shard_tiles_of_rank below);
+    // shard_key identifies (rank, nranks) for the dispatch-order cache
+    int   n_shard_tiles, shard_key;
+    unsigned char shard_tile[64];
     // outputs: element (px,py) lives at out_base + (px-ox) + (py-oy)*pitch, where for
     // single-rect mode ox=oy=0,pitch=w and for shard mode the slot's packed tile
     CubeDev env_refl, env_cos1, env_cos8;
@@ -52,6 +55,27 @@ struct FrameParams {
     unsigned long long *dbg;  // optional per-wave counters of k_march_mb8 (8 x u64 per wave), may be null   // scheduling thresholds of k_march_mb8 (see rmdf_march.hip)
 };
 
+// Which of the reference's 64 tiles rank `rank` of `nranks` renders, in slot order; returns how many (<= ceil(64/n)).
+// The scenes sit in the middle of the frame (the camera looks at the origin), so cost falls off with the distance
+// from the centre: the tiles are sorted by ring (Chebyshev distance from the frame centre, innermost first; idx
+// order inside a ring) and dealt to the ranks boustrophedon (0..n-1, n-1..0, ...).  Every rank gets tiles of every
+// ring; a plain idx mod n would hand rank r whole tile COLUMNS for n = 8.
+inline int shard_tiles_of_rank(int rank, int nranks, unsigned char tiles[64])
+{
+    int order[64], n = 0;
+    for (int ring = 1; ring <= 7; ring += 2)
+        for (int idx = 0; idx < 64; idx++) {
+            const int ax = abs(2 * (idx % 8) - 7), ay = abs(2 * (idx / 8) - 7);
+            if ((ax > ay ? ax : ay) == ring) order[n++] = idx;
+        }
+    int cnt = 0;
+    for (int j = 0; j < 64; j++) {
+        const int round = j / nranks, pos = j % nranks;
+        if (((round & 1) ? nranks - 1 - pos : pos) == rank) tiles[cnt++] = (unsigned char)order[j];
+    }
+    return cnt;
+}
+
 // tile idx -> pixel rectangle (ShaderRendering.hs:183-193), host copy in rmdf_api.cpp
 void tile_rect_host(int tile_idx, int w, int h, int *x0, int *y0, int *x1, int *y1);
 
@@ -71,5 +95,6 @@ hipError_t launch_latlong_to_cube(const float *d_latlong, int w, int h, float *d
 hipError_t launch_resize_latlong(const float *d_src, int sw, int sh, int dstw, int dsth, float *d_out, hipStream_t stream);
 hipError_t launch_prefilter(const float *d_src, int w, int h, float power, float *d_out, hipStream_t stream);
 hipError_t launch_assemble_shards(const uint32_t *d_gathered, uint32_t *d_frame, int w, int h, int nranks, hipStream_t stream);
+
 
 }  // namespace rmdf

@@ -63,12 +63,23 @@ __device__ __forceinline__ float bsphere_r() { return SCENE == 2 ? 1.15f : (SCEN
 template <int SCENE, bool MERGE, int WPB>
 __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
 {
+    // Which strip this workgroup renders: raster order over (slot, row, column), or most expensive first
+    // (block_order, a permutation of the launch's linear workgroup ids -- it spans all tiles of a shard launch)
+    const unsigned strips_per_slot = gridDim.x * gridDim.y;
+    unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (p.block_order) {
+        // the first workgroups carry last frame's most expensive strips: the launch cannot end before their
+        // longest ray has finished its serial chain, so let their waves win the issue arbitration on the SIMD
+        if (lin < (unsigned)p.prio_strips) __builtin_amdgcn_s_setprio(3);
+        lin = p.block_order[lin];
+    }
+    const unsigned strip = lin % strips_per_slot;
     // rectangle of this launch / shard slot
     int rx0, ry0, rx1, ry1, pitch, ox, oy;
     size_t obase;
     if (p.n_shard_tiles > 0) {
-        int slot = blockIdx.z;
-        tile_rect(p.shard_first + slot * p.shard_stride, p.w, p.h, rx0, ry0, rx1, ry1);
+        const int slot = (int)(lin / strips_per_slot);
+        tile_rect((int)p.shard_tile[slot], p.w, p.h, rx0, ry0, rx1, ry1);
         pitch = rx1 - rx0; ox = rx0; oy = ry0;
         obase = (size_t)slot * (size_t)(p.w / 8) * (size_t)(p.h / 8);
     } else {
@@ -83,14 +94,6 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lx = (lane & 1) | (((lane >> 2) & 3) << 1);
     const int ly = ((lane >> 1) & 1) | (((lane >> 4) & 3) << 1);
-    // strip handled by this workgroup: raster order, or most expensive first (block_order)
-    unsigned strip = blockIdx.y * gridDim.x + blockIdx.x;
-    if (p.block_order) {
-        // the first workgroups carry last frame's most expensive strips: the launch cannot end before their
-        // longest ray has finished its serial chain, so let their waves win the issue arbitration on the SIMD
-        if (strip < (unsigned)p.prio_strips) __builtin_amdgcn_s_setprio(3);
-        strip = p.block_order[strip];
-    }
     const int bx = strip % gridDim.x, by = strip / gridDim.x;
     const int px = ex0 + bx * (WPB * 8) + wave * 8 + lx;
     const int py = ey0 + by * 8 + ly;
@@ -336,11 +339,11 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
         for (int o = 32; o > 0; o >>= 1) { const unsigned v = __shfl_xor(c, o, 64); c = v > c ? v : c; }
         if (lane == 0) atomicMax(&s_cost, c);
         __syncthreads();
-        if (threadIdx.x == 0) p.block_cost[(size_t)blockIdx.z * gridDim.x * gridDim.y + strip] = s_cost;
+        if (threadIdx.x == 0) p.block_cost[lin] = s_cost;
     }
     if (p.dbg && lane == 0) {
         const unsigned wid = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
-        if (wid < 8192u * 2u) { p.dbg[wid * 8 + 6] = dbg_t0; p.dbg[wid * 8 + 7] = __builtin_amdgcn_s_memrealtime(); p.dbg[wid * 8] = (unsigned long long)steps; }
+        if (wid < 32768u * 2u) { p.dbg[wid * 8 + 6] = dbg_t0; p.dbg[wid * 8 + 7] = __builtin_amdgcn_s_memrealtime(); p.dbg[wid * 8] = (unsigned long long)steps; }
     }
 }
 
@@ -586,10 +589,12 @@ hipError_t launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t 
     return hipGetLastError();
 }
 
-// After the gather: shard r holds tiles r, r+n, r+2n, ... in slots 0,1,2,...; every
-// rank's shard has ceil(64/n) slots.  One thread per frame pixel (coalesced writes).
+// After the gather: shard r holds the tiles shard_tiles_of_rank(r, n) in slots 0,1,2,...; every rank's shard has
+// ceil(64/n) slots.  where.v[tile idx] = rank << 8 | slot.  One thread per frame pixel (coalesced writes).
+struct ShardWhere { unsigned short v[64]; };
+
 __global__ void k_assemble_shards(const uint32_t *__restrict__ gathered, uint32_t *__restrict__ frame,
-                                  int w, int h, int nranks)
+                                  int w, int h, int nranks, const ShardWhere where)
 {
     const int tw = w / 8, th = h / 8;
     const int slots = (64 + nranks - 1) / nranks;
@@ -598,8 +603,8 @@ __global__ void k_assemble_shards(const uint32_t *__restrict__ gathered, uint32_
     for (; i < n; i += stride) {
         int px = (int)(i % w), py = (int)(i / w);
         int tx = px / tw, ty = py / th;
-        int idx = tx + ty * 8;
-        int rank = idx % nranks, slot = idx / nranks;
+        const int rs = where.v[tx + ty * 8];
+        const int rank = rs >> 8, slot = rs & 255;
         size_t src = ((size_t)rank * slots + slot) * (size_t)tw * th + (size_t)(px - tx * tw) + (size_t)(py - ty * th) * tw;
         frame[i] = gathered[src];
     }
@@ -607,10 +612,16 @@ __global__ void k_assemble_shards(const uint32_t *__restrict__ gathered, uint32_
 
 hipError_t launch_assemble_shards(const uint32_t *d_gathered, uint32_t *d_frame, int w, int h, int nranks, hipStream_t stream)
 {
+    ShardWhere where;
+    for (int r = 0; r < nranks; r++) {
+        unsigned char tiles[64];
+        const int cnt = shard_tiles_of_rank(r, nranks, tiles);
+        for (int s = 0; s < cnt; s++) where.v[tiles[s]] = (unsigned short)((r << 8) | s);
+    }
     size_t n = (size_t)w * h;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_assemble_shards, dim3(blocks), dim3(256), 0, stream, d_gathered, d_frame, w, h, nranks);
+    hipLaunchKernelGGL(k_assemble_shards, dim3(blocks), dim3(256), 0, stream, d_gathered, d_frame, w, h, nranks, where);
     return hipGetLastError();
 }
 

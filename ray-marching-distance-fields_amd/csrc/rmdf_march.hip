@@ -56,7 +56,7 @@ __device__ __forceinline__ bool item_to_pixel(const FrameParams &p, int item, in
     if (p.n_shard_tiles > 0) {
         const int slot = item / p.items_per_shard_tile;
         local = item - slot * p.items_per_shard_tile;
-        const int midx = (p.shard_first + slot * p.shard_stride) % 64;
+        const int midx = (int)p.shard_tile[slot];
         const int tx = midx % 8, ty = midx / 8;
         rx0 = (2 * tx * p.w + 7) / 16; rx1 = (2 * (tx + 1) * p.w + 7) / 16;
         ry0 = (2 * ty * p.h + 7) / 16; ry1 = (2 * (ty + 1) * p.h + 7) / 16;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void k_shade(const FrameParams p)
     size_t obase;
     if (p.n_shard_tiles > 0) {
         const int slot = blockIdx.z;
-        const int midx = (p.shard_first + slot * p.shard_stride) % 64;
+        const int midx = (int)p.shard_tile[slot];
         const int tx = midx % 8, ty = midx / 8;
         rx0 = (2 * tx * p.w + 7) / 16; rx1 = (2 * (tx + 1) * p.w + 7) / 16;
         ry0 = (2 * ty * p.h + 7) / 16; ry1 = (2 * (ty + 1) * p.h + 7) / 16;

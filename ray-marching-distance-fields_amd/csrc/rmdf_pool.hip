@@ -62,7 +62,7 @@ __device__ __forceinline__ bool pool_item_to_pixel(const FrameParams &p, int ite
     if (p.n_shard_tiles > 0) {
         const int slot = item / p.items_per_shard_tile;
         local = item - slot * p.items_per_shard_tile;
-        const int midx = (p.shard_first + slot * p.shard_stride) % 64;
+        const int midx = (int)p.shard_tile[slot];
         const int tx = midx % 8, ty = midx / 8;
         rx0 = (2 * tx * p.w + 7) / 16; rx1 = (2 * (tx + 1) * p.w + 7) / 16;
         ry0 = (2 * ty * p.h + 7) / 16; ry1 = (2 * (ty + 1) * p.h + 7) / 16;

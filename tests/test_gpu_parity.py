@@ -321,3 +321,44 @@ def test_straggler_pooling_is_invisible(rmdf, sr, env_faces):
             assert np.array_equal(a["rgba_f32"].view(np.uint32), b["rgba_f32"].view(np.uint32))
     finally:
         plain.close()
+
+
+def test_frames_in_flight_and_ordered_shards(sr, rmdf):
+    """Pipelined rendering (bench.py --streams S): frames on different HIP streams run concurrently, each stream with its
+    own cost/order tables, and shard launches are cost-ordered across all their tiles from the second frame on.  None of
+    that may change a bit: every frame of every stream == the synchronous single-launch frame."""
+    import torch
+    w, h, ms = 1920, 1080, 256
+    dev = torch.device("cuda", 0)
+    ref = sr.render(2, w, h, 0.0, max_steps=ms)["rgba8"]
+    streams = [torch.cuda.Stream(dev) for _ in range(3)]
+    bufs = [torch.zeros((h, w), dtype=torch.int32, device=dev) for _ in range(3)]
+    for rep in range(3):                 # rep 0: raster order on every stream; later: ordered, overlapping launches
+        for b in bufs:
+            b.zero_()
+        torch.cuda.synchronize()
+        for st, b in zip(streams, bufs):
+            sr.render_rect_device(2, w, h, 0.0, ms, (0, 0, w, h), d_rgba8=b.data_ptr(), stream=st.cuda_stream)
+        torch.cuda.synchronize()
+        for k, b in enumerate(bufs):
+            assert np.array_equal(b.cpu().numpy().view(np.uint32), ref), "rep %d stream %d" % (rep, k)
+    # shard launches: two ranks' shards alternate on two streams, three frames each (second and third are cost-ordered)
+    n = 2
+    slots = rmdf.shard_slots(n)
+    for rep in range(3):
+        gathered = torch.zeros((n, slots, h // 8, w // 8), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        for r in range(n):
+            sr.render_shard_device(2, w, h, 0.0, ms, r, n, gathered[r].data_ptr(), stream=streams[r].cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(rmdf.assemble_shards_host(gathered.cpu().numpy().view(np.uint32), w, h, n), ref), rep
+    # 8 ranks on ONE stream: the key (first tile, stride) changes every launch -> raster; then the same rank twice -> ordered
+    n = 8
+    slots = rmdf.shard_slots(n)
+    gathered = torch.zeros((n, slots, h // 8, w // 8), dtype=torch.int32, device=dev)
+    s = streams[0].cuda_stream
+    for r in range(n):
+        for _ in range(2):
+            sr.render_shard_device(2, w, h, 0.0, ms, r, n, gathered[r].data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    assert np.array_equal(rmdf.assemble_shards_host(gathered.cpu().numpy().view(np.uint32), w, h, n), ref)

@@ -1,26 +1,30 @@
 #!/usr/bin/env python3
-"""Wave timeline of the nested-loop kernel (first 16384 waves): measurement aid."""
+"""Wave timeline of the nested-loop kernel (all waves of the headline frame): measurement aid.
+usage: nested_timeline.py [flags]   (flags = rmdf_config.reserved[0], e.g. 4 = raster order, 16 = no pooling)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rmdf_amd
 w, h, ms = 1920, 1080, 256
-sr = rmdf_amd.ShaderRenderer(0, flags=rmdf_amd.FLAG_NESTED_LOOPS)
+flags = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+sr = rmdf_amd.ShaderRenderer(0, flags=flags)
 sr.load_env_hdr(rmdf_amd.DEFAULT_ENV_HDR)
 fb = np.empty(w * h, np.uint32)
 sr.draw_shader_tile(2, None, w, h, 0.0, fb, max_steps=ms)
+sr.draw_shader_tile(2, None, w, h, 0.0, fb, max_steps=ms)
 sr.debug_march_stats(True)
 sr.draw_shader_tile(2, None, w, h, 0.0, fb, max_steps=ms)
-st = sr.debug_march_stats(True, 8192).astype(np.float64).reshape(-1, 8)
+st = sr.debug_march_stats(True, 32768).astype(np.float64).reshape(-1, 8)
 st = st[st[:, 7] > 0]
 t0 = st[:, 6].min()
 b, e = (st[:, 6] - t0) / 100.0, (st[:, 7] - t0) / 100.0
 d = e - b
-print("waves recorded %d (first half of the frame) span %.1f us" % (len(st), e.max()))
-print("wave duration us: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f ; sum %.3e us" % (d.mean(), *np.percentile(d, [50, 90, 99]), d.max(), d.sum()))
+print("flags %d: waves recorded %d, span %.1f us" % (flags, len(st), e.max()))
+print("wave duration us: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f ; sum %.3e us (= %.1f us x 8192 wave slots)" %
+      (d.mean(), *np.percentile(d, [50, 90, 99]), d.max(), d.sum(), d.sum() / 8192))
 print("start time us: p50 %.1f p90 %.1f max %.1f" % (*np.percentile(b, [50, 90]), b.max()))
-for q in (100, 200, 300, 400, 500, 600, 700, 800):
-    print("  running at t=%d us: %d waves" % (q, ((b <= q) & (e > q)).sum()))
+for q in range(25, int(e.max()) + 25, 25):
+    print("  resident at t=%d us: %d waves" % (q, ((b <= q) & (e > q)).sum()))
 idx = np.argsort(d)[-5:]
 for i in idx:
     print("  long wave: start %.1f dur %.1f lane0 steps %d" % (b[i], d[i], st[i, 0]))
