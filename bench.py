@@ -146,6 +146,23 @@ def main():
     else:
         sr.load_env_hdr(rmdf_amd.DEFAULT_ENV_HDR)
     dev_name, cus = sr.device_info()
+    deal = "single GPU"
+    if world > 1:
+        # cost-aware deal of the 64 tiles: every rank probes the view at 256 x 144 on its own GPU (bit-reproducible
+        # kernels -> identical costs, no exchange) and deals longest-processing-time-first.  Outside the timed region
+        # the ranks compare their deals once; any disagreement falls back to the static deal on all of them.
+        sr.set_shard_costs(sr.probe_tile_costs(a.scene, a.width << a.supersample, a.height << a.supersample, a.time, a.max_steps))
+        mine = torch.tensor([t for r in range(world) for t in (sr.shard_tiles(r, world) + [-1] * 64)[:64]],
+                            dtype=torch.int32, device=dev)
+        ref0 = mine.clone()
+        dist.broadcast(ref0, src=0)
+        agree = torch.tensor([1 if bool((ref0 == mine).all()) else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if int(agree.item()) == 1:
+            deal = "cost-aware (probe frame, LPT)"
+        else:
+            sr.set_shard_costs(None)
+            deal = "static (ranks disagreed on the probed costs)"
     # Frames are independent, so S of them are kept in flight: frame i goes to HIP stream i % S (dedicated, non-null
     # streams; kernels, the RCCL call and the timing events of a frame all go on its stream) and owns buffer set
     # i % S.  On one GPU this overlaps the thin tail of a frame -- the launch cannot end before its longest ray has
@@ -249,7 +266,7 @@ def main():
         d2h_rate = mpix / ((time.perf_counter() - t1) / reps)
 
         env_bytes = 6 * 172 * 172 * 8 + 2 * 6 * 87 * 87 * 8               # padded RGB16F cube maps read once
-        px_this_launch = rw * rh if world == 1 else len(rmdf_amd.shard_tiles(rank, world)) * (rw // 8) * (rh // 8)
+        px_this_launch = rw * rh if world == 1 else len(sr.shard_tiles(rank, world)) * (rw // 8) * (rh // 8)
         algo_bytes = px_this_launch * 4 + env_bytes                        # RGBA8 store + env read
         achieved_gbs = algo_bytes / (kern_ms * 1e-3) / 1e9
         traffic = None
@@ -273,7 +290,7 @@ def main():
                        "parallelism": ("1 GPU, one launch per frame" if world == 1 else
                                        "64 tiles interleaved over %d GPUs + one RCCL gather per frame" % world) +
                                       ", %d frame(s) in flight" % S,
-                       "frames_in_flight": S,
+                       "frames_in_flight": S, "tile_deal": deal,
                        "device": dev_name, "compute_units": cus},
             "roofline": {"bound": "hbm", "kernel": "k_render<2>", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,

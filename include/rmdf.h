@@ -161,11 +161,21 @@ int rmdf_render_rect_device(rmdf_ctx *ctx, int scene, int w, int h, double time,
 /* Multi-GPU sharding of the reference's 64 tiles (ShaderRendering.hs:49-52,183-193 renders them one per frame;
  * here they are the units dealt to the GPUs).  rmdf_shard_tiles: the tile indices rank `rank` of `nranks`
  * renders, in slot order; returns their number (<= ceil(64/nranks)) or a negative error code.  Host-only
- * arithmetic, no device needed.  The deal is balanced for scenes centred in the frame: tiles sorted by ring around
- * the frame centre and dealt to the ranks boustrophedon, so every rank gets tiles of every ring.
+ * arithmetic, no device needed.  The deal is balanced for scenes centred in the frame: tiles sorted by distance from
+ * the frame centre and dealt to the ranks boustrophedon, so every rank gets near and far tiles.
  * rmdf_render_shard_device renders those tiles packed back to back in slot order into d_packed_rgba8
  * (tile = (w/8)*(h/8) uint32, rows bottom-up).  Requires w mod 8 == 0 and h mod 8 == 0. */
 int rmdf_shard_tiles(int rank, int nranks, int tiles[64]);
+/* Cost-aware deal.  rmdf_probe_tile_costs renders the view at 256 x ~144 and returns, per tile, the work its rays
+ * took (escape iterations + march steps + 1 per ray): the kernels are bit-reproducible, so every rank that probes
+ * the same (scene, w, h, time, max_steps) gets the same 64 numbers without any exchange.  rmdf_set_shard_costs
+ * (NULL = back to the static deal) makes this ctx deal the tiles longest-processing-time-first on those costs:
+ * tiles in descending cost order, each to the least loaded rank that still has a free slot.  It applies to
+ * rmdf_render_shard_device and rmdf_assemble_shards_device of this ctx; ALL ranks of a job must set the same costs.
+ * rmdf_get_shard_tiles: the deal in effect on this ctx (same contract as rmdf_shard_tiles). */
+int rmdf_probe_tile_costs(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps, float cost[64]);
+int rmdf_set_shard_costs(rmdf_ctx *ctx, const float cost[64]);
+int rmdf_get_shard_tiles(rmdf_ctx *ctx, int rank, int nranks, int tiles[64]);
 int rmdf_render_shard_device(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps,
                              int rank, int nranks, void *d_packed_rgba8, void *stream);
 /* Rank 0 after the gather: d_gathered holds the nranks shards back to back (rank

@@ -45,7 +45,8 @@ ABI_SYMBOLS = (
     "rmdf_is_tile_idx_first_tile", "rmdf_is_tile_idx_last_tile", "rmdf_render_tile", "rmdf_render_tile_ex",
     "rmdf_render_rect_device", "rmdf_render_shard_device", "rmdf_assemble_shards_device", "rmdf_synchronize",
     "rmdf_device_info", "rmdf_debug_march_stats", "rmdf_resolve_box2_device", "rmdf_render_supersampled",
-    "rmdf_selftest_exact_math", "rmdf_shard_tiles",
+    "rmdf_selftest_exact_math", "rmdf_shard_tiles", "rmdf_probe_tile_costs", "rmdf_set_shard_costs",
+    "rmdf_get_shard_tiles",
 )
 
 
@@ -132,6 +133,9 @@ def load_library():
     L.rmdf_render_rect_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int] + [C.c_int] * 4 + [vp] * 5
     L.rmdf_render_shard_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, vp, vp]
     L.rmdf_shard_tiles.argtypes = [C.c_int, C.c_int, ip]
+    L.rmdf_probe_tile_costs.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]
+    L.rmdf_set_shard_costs.argtypes = [vp, vp]
+    L.rmdf_get_shard_tiles.argtypes = [vp, C.c_int, C.c_int, ip]
     L.rmdf_assemble_shards_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.rmdf_synchronize.argtypes = [vp, vp]
     L.rmdf_device_info.argtypes = [vp, C.c_char_p, C.c_int, ip]
@@ -259,6 +263,27 @@ class ShaderRenderer:
         self._check(self._lib.rmdf_render_shard_device(self._ctx, int(shd_enum), w, h, float(time), max_steps,
                                                        rank, nranks, d_packed_rgba8, stream or None))
 
+    def probe_tile_costs(self, shd_enum, w, h, time, max_steps):
+        """Per-tile work of this view measured on a 256 x ~144 probe frame (64 float32; identical on every rank)."""
+        cost = np.zeros(64, np.float32)
+        self._check(self._lib.rmdf_probe_tile_costs(self._ctx, int(shd_enum), w, h, float(time), max_steps, cost.ctypes.data))
+        return cost
+
+    def set_shard_costs(self, cost):
+        """Deal the tiles to the ranks longest-processing-time-first on `cost` (None = static deal).  All ranks of a
+        job must set the same costs."""
+        if cost is not None:
+            cost = np.ascontiguousarray(cost, np.float32)
+            assert cost.size == 64
+        self._check(self._lib.rmdf_set_shard_costs(self._ctx, _ptr(cost)))
+
+    def shard_tiles(self, rank, nranks):
+        """The deal in effect on this renderer (static, or by the costs set with set_shard_costs)."""
+        buf = (C.c_int * 64)()
+        n = self._lib.rmdf_get_shard_tiles(self._ctx, rank, nranks, buf)
+        self._check(n if n < 0 else 0)
+        return list(buf[:n])
+
     def assemble_shards_device(self, w, h, nranks, d_gathered, d_frame_rgba8, stream=0):
         self._check(self._lib.rmdf_assemble_shards_device(self._ctx, w, h, nranks, d_gathered, d_frame_rgba8,
                                                           stream or None))
@@ -329,20 +354,36 @@ class FrameBuffer:
 # --- multi-GPU tile sharding: pure index arithmetic, testable without a GPU ------
 
 def _ring_order():
-    """The 64 tiles sorted by ring around the frame centre (innermost first, idx order inside a ring)."""
-    ring = lambda idx: max(abs(2 * (idx % 8) - 7), abs(2 * (idx // 8) - 7))
-    return sorted(range(N_TILES), key=lambda idx: (ring(idx), idx))
+    """The 64 tiles sorted by squared distance from the frame centre (nearest first, idx order among equals)."""
+    d2 = lambda idx: (2 * (idx % 8) - 7) ** 2 + (2 * (idx // 8) - 7) ** 2
+    return sorted(range(N_TILES), key=lambda idx: (d2(idx), idx))
 
 
 def shard_tiles(rank, nranks):
     """Tiles rank `rank` of `nranks` renders, in slot order -- the same deal as rmdf_shard_tiles (rmdf.h): tiles sorted by
-    ring around the frame centre, dealt boustrophedon (0..n-1, n-1..0, ...), so every rank gets tiles of every ring (the
+    distance from the frame centre, dealt boustrophedon (0..n-1, n-1..0, ...), so every rank gets near and far tiles (the
     scenes are centred: cost falls off with the distance from the centre)."""
     order = _ring_order()
     out = []
     for j, idx in enumerate(order):
         rnd, pos = divmod(j, nranks)
         if (nranks - 1 - pos if rnd & 1 else pos) == rank:
+            out.append(idx)
+    return out
+
+
+def shard_tiles_by_cost(rank, nranks, cost):
+    """The cost-aware deal of rmdf_set_shard_costs restated: tiles in descending cost order (idx order among equals),
+    each to the least loaded rank that still has a free slot (lowest rank among equals)."""
+    cost = [float(np.float32(c)) for c in cost]
+    order = sorted(range(N_TILES), key=lambda i: (-cost[i], i))
+    cap = shard_slots(nranks)
+    load, used, out = [0.0] * nranks, [0] * nranks, []
+    for idx in order:
+        best = min((r for r in range(nranks) if used[r] < cap), key=lambda r: (load[r], r))
+        load[best] += cost[idx]
+        used[best] += 1
+        if best == rank:
             out.append(idx)
     return out
 
@@ -361,13 +402,14 @@ def shard_slots(nranks):
     return (N_TILES + nranks - 1) // nranks
 
 
-def assemble_shards_host(gathered, w, h, nranks):
+def assemble_shards_host(gathered, w, h, nranks, tiles_of=None):
     """Reference (numpy) statement of rmdf_assemble_shards_device, for the gloo tests.
-    gathered: (nranks, slots, h/8, w/8) uint32."""
+    gathered: (nranks, slots, h/8, w/8) uint32; tiles_of(rank, nranks) = the deal (default: the static one)."""
     tw, th = w // 8, h // 8
     frame = np.zeros((h, w), np.uint32)
+    tiles_of = tiles_of or shard_tiles
     for r in range(nranks):
-        for slot, idx in enumerate(shard_tiles(r, nranks)):
+        for slot, idx in enumerate(tiles_of(r, nranks)):
             tx, ty = idx % 8, idx // 8
             frame[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw] = gathered[r, slot]
     return frame

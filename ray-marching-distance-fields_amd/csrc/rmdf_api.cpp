@@ -59,6 +59,10 @@ struct rmdf_ctx {
     int         *d_hit_list = nullptr;
     // cost-ordered dispatch state of the nested-loop kernel (previous frame's per-strip costs), one per stream
     // that renders: frames in flight on different streams (pipelined rendering) must not share the tables
+    // per-tile costs that steer the deal of tiles to ranks (rmdf_set_shard_costs); unset = static deal
+    float        shard_cost[64];
+    bool         shard_cost_set = false;
+    unsigned     shard_cost_gen = 0;
     OrderState   orders[RMDF_MAX_ORDER_STREAMS];
     unsigned     order_tick = 0;
     unsigned long long *d_dbg = nullptr;   // per-wave march diagnostics (rmdf_debug_march_stats)
@@ -745,8 +749,8 @@ int rmdf_render_shard_device(rmdf_ctx *ctx, int scene, int w, int h, double time
     FrameParams p;
     int rc = fill_params(ctx, scene, w, h, (float)time, max_steps, p);
     if (rc != RMDF_OK) return rc;
-    p.n_shard_tiles = shard_tiles_of_rank(rank, nranks, p.shard_tile);
-    p.shard_key = rank * 256 + nranks;
+    p.n_shard_tiles = shard_tiles_of_rank(rank, nranks, p.shard_tile, ctx->shard_cost_set ? ctx->shard_cost : nullptr);
+    p.shard_key = (int)(ctx->shard_cost_gen << 16) + rank * 256 + nranks;
     p.rgba8 = (uint32_t *)d_packed_rgba8;
     return launch_scene(ctx, scene, p, stream ? (hipStream_t)stream : ctx->stream);
 }
@@ -760,6 +764,70 @@ int rmdf_shard_tiles(int rank, int nranks, int tiles[64])
     return cnt;
 }
 
+int rmdf_set_shard_costs(rmdf_ctx *ctx, const float cost[64])
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (cost) {
+        for (int i = 0; i < 64; i++)
+            if (!(cost[i] >= 0.0f) || cost[i] > 3.0e38f) return fail(ctx, RMDF_E_INVALID, "rmdf_set_shard_costs: costs must be finite and >= 0");
+        memcpy(ctx->shard_cost, cost, sizeof ctx->shard_cost);
+    }
+    ctx->shard_cost_set = cost != nullptr;
+    ctx->shard_cost_gen++;
+    return RMDF_OK;
+}
+
+int rmdf_get_shard_tiles(rmdf_ctx *ctx, int rank, int nranks, int tiles[64])
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks || !tiles) return fail(ctx, RMDF_E_INVALID, "rmdf_get_shard_tiles: bad argument");
+    unsigned char t[64];
+    const int cnt = shard_tiles_of_rank(rank, nranks, t, ctx->shard_cost_set ? ctx->shard_cost : nullptr);
+    for (int i = 0; i < cnt; i++) tiles[i] = t[i];
+    return cnt;
+}
+
+int rmdf_probe_tile_costs(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps, float cost[64])
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!cost || w <= 0 || h <= 0) return fail(ctx, RMDF_E_INVALID, "rmdf_probe_tile_costs: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // the same view at 256 x 144 (aspect ratio of the real frame kept to within a pixel): 32 x 18 rays per tile
+    const int pw = 256;
+    int ph = (int)((long long)pw * h / w);
+    ph = (ph + 7) & ~7;
+    if (ph < 8) ph = 8;
+    if (ph > 4096) ph = 4096;
+    FrameParams p;
+    int rc = fill_params(ctx, scene, pw, ph, (float)time, max_steps, p);
+    if (rc != RMDF_OK) return rc;
+    // aspect of the real frame, so that the probe rays cover the real frame's field of view
+    p.aspect = (float)w / (float)h;
+    DevBuf steps, iters;
+    const size_t npx = (size_t)pw * ph;
+    HIP_TRY(ctx, hipMalloc(&steps.p, npx * 2));
+    HIP_TRY(ctx, hipMalloc(&iters.p, npx * 2));
+    p.x0 = 0; p.y0 = 0; p.x1 = pw; p.y1 = ph;
+    p.steps = (uint16_t *)steps.p; p.iters = (uint16_t *)iters.p;
+    FrameParams q = p;
+    q.block_cost = nullptr; q.block_order = nullptr;
+    HIP_TRY(ctx, launch_render(scene, q, ctx->stream));
+    std::vector<uint16_t> hs(npx), hi(npx);
+    HIP_TRY(ctx, hipMemcpyAsync(hs.data(), steps.p, npx * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(hi.data(), iters.p, npx * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // cost of a ray ~ escape iterations (march + normal + AO) + march steps, plus a constant per pixel
+    double acc[64] = { 0 };
+    const int tw = pw / 8, th = ph / 8;
+    for (int y = 0; y < ph; y++)
+        for (int x = 0; x < pw; x++) {
+            const size_t i = (size_t)y * pw + x;
+            acc[(x / tw) + 8 * (y / th)] += 1.0 + (double)hi[i] + (double)(hs[i] & 0x7fff);
+        }
+    for (int i = 0; i < 64; i++) cost[i] = (float)acc[i];
+    return RMDF_OK;
+}
+
 int rmdf_assemble_shards_device(rmdf_ctx *ctx, int w, int h, int nranks, const void *d_gathered,
                                 void *d_frame_rgba8, void *stream)
 {
@@ -767,6 +835,7 @@ int rmdf_assemble_shards_device(rmdf_ctx *ctx, int w, int h, int nranks, const v
     if (nranks < 1 || nranks > 64 || !d_gathered || !d_frame_rgba8 || w % 8 || h % 8 || w <= 0 || h <= 0)
         return fail(ctx, RMDF_E_INVALID, "rmdf_assemble_shards_device: bad argument");
     HIP_TRY(ctx, launch_assemble_shards((const uint32_t *)d_gathered, (uint32_t *)d_frame_rgba8, w, h, nranks,
+                                        ctx->shard_cost_set ? ctx->shard_cost : nullptr,
                                         stream ? (hipStream_t)stream : ctx->stream));
     return RMDF_OK;
 }

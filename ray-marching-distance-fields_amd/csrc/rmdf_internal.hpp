@@ -56,22 +56,46 @@ struct FrameParams {
 };
 
 // Which of the reference's 64 tiles rank `rank` of `nranks` renders, in slot order; returns how many (<= ceil(64/n)).
-// The scenes sit in the middle of the frame (the camera looks at the origin), so cost falls off with the distance
-// from the centre: the tiles are sorted by ring (Chebyshev distance from the frame centre, innermost first; idx
-// order inside a ring) and dealt to the ranks boustrophedon (0..n-1, n-1..0, ...).  Every rank gets tiles of every
-// ring; a plain idx mod n would hand rank r whole tile COLUMNS for n = 8.
-inline int shard_tiles_of_rank(int rank, int nranks, unsigned char tiles[64])
+// cost == nullptr: the static deal.  The scenes sit in the middle of the frame (the camera looks at the origin), so the
+// tiles are sorted by their squared distance from the frame centre (nearest first; idx order among equals) and dealt
+// to the ranks boustrophedon (0..n-1, n-1..0, ...); a plain idx mod n would hand rank r whole tile COLUMNS for n = 8.
+// cost != nullptr (64 per-tile costs, e.g. rmdf_probe_tile_costs): longest-processing-time-first -- tiles in
+// descending cost order (idx order among equals), each to the least loaded rank that still has a free slot (lowest
+// rank among equals).  Deterministic: ranks that hold the same costs compute the same deal without talking.
+inline int shard_tiles_of_rank(int rank, int nranks, unsigned char tiles[64], const float *cost = nullptr)
 {
     int order[64], n = 0;
-    for (int ring = 1; ring <= 7; ring += 2)
-        for (int idx = 0; idx < 64; idx++) {
-            const int ax = abs(2 * (idx % 8) - 7), ay = abs(2 * (idx / 8) - 7);
-            if ((ax > ay ? ax : ay) == ring) order[n++] = idx;
+    if (!cost) {
+        for (int d2 = 2; d2 <= 98; d2 += 2)
+            for (int idx = 0; idx < 64; idx++) {
+                const int ax = 2 * (idx % 8) - 7, ay = 2 * (idx / 8) - 7;
+                if (ax * ax + ay * ay == d2) order[n++] = idx;
+            }
+        int cnt = 0;
+        for (int j = 0; j < 64; j++) {
+            const int round = j / nranks, pos = j % nranks;
+            if (((round & 1) ? nranks - 1 - pos : pos) == rank) tiles[cnt++] = (unsigned char)order[j];
         }
-    int cnt = 0;
+        return cnt;
+    }
+    for (int i = 0; i < 64; i++) order[i] = i;
+    for (int i = 1; i < 64; i++) {                       // stable insertion sort, descending cost
+        const int t = order[i];
+        int j = i;
+        while (j > 0 && cost[order[j - 1]] < cost[t]) { order[j] = order[j - 1]; j--; }
+        order[j] = t;
+    }
+    const int cap = (64 + nranks - 1) / nranks;
+    double load[64];
+    int used[64], cnt = 0;
+    for (int r = 0; r < nranks; r++) { load[r] = 0.0; used[r] = 0; }
     for (int j = 0; j < 64; j++) {
-        const int round = j / nranks, pos = j % nranks;
-        if (((round & 1) ? nranks - 1 - pos : pos) == rank) tiles[cnt++] = (unsigned char)order[j];
+        int best = -1;
+        for (int r = 0; r < nranks; r++)
+            if (used[r] < cap && (best < 0 || load[r] < load[best])) best = r;
+        load[best] += (double)cost[order[j]];
+        used[best]++;
+        if (best == rank) tiles[cnt++] = (unsigned char)order[j];
     }
     return cnt;
 }
@@ -94,7 +118,8 @@ hipError_t launch_cube_upload(const float *d_faces_f32, int W, uint2 *d_padded, 
 hipError_t launch_latlong_to_cube(const float *d_latlong, int w, int h, float *d_faces_f32, hipStream_t stream);
 hipError_t launch_resize_latlong(const float *d_src, int sw, int sh, int dstw, int dsth, float *d_out, hipStream_t stream);
 hipError_t launch_prefilter(const float *d_src, int w, int h, float power, float *d_out, hipStream_t stream);
-hipError_t launch_assemble_shards(const uint32_t *d_gathered, uint32_t *d_frame, int w, int h, int nranks, hipStream_t stream);
+hipError_t launch_assemble_shards(const uint32_t *d_gathered, uint32_t *d_frame, int w, int h, int nranks, const float *tile_cost,
+                                  hipStream_t stream);
 
 
 }  // namespace rmdf

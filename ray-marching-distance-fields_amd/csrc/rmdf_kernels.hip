@@ -415,7 +415,7 @@ static void render_grid(const FrameParams &p, dim3 &grid, int wpb)
 {
     int rx0, ry0, rx1, ry1, nz = 1;
     if (p.n_shard_tiles > 0) {
-        rx0 = 0; ry0 = 0; rx1 = p.w / 8 + 2; ry1 = p.h / 8 + 2;
+        rx0 = 0; ry0 = 0; rx1 = p.w / 8 + ((p.w / 8) & 1); ry1 = p.h / 8 + ((p.h / 8) & 1);   // odd-sized tiles: one helper column / row, on one side only
         nz = p.n_shard_tiles;
     } else {
         rx0 = p.x0; ry0 = p.y0; rx1 = p.x1; ry1 = p.y1;
@@ -469,7 +469,7 @@ hipError_t launch_render(int scene, const FrameParams &p, hipStream_t stream)
     if (p.n_shard_tiles > 0) {
         // all tiles have the same size when 8 | w and 8 | h (required in shard mode)
         // a tile may start and end on odd coordinates: up to one helper column/row per side
-        rx0 = 0; ry0 = 0; rx1 = p.w / 8 + 2; ry1 = p.h / 8 + 2;
+        rx0 = 0; ry0 = 0; rx1 = p.w / 8 + ((p.w / 8) & 1); ry1 = p.h / 8 + ((p.h / 8) & 1);   // odd-sized tiles: one helper column / row, on one side only
         nz = p.n_shard_tiles;
     } else {
         rx0 = p.x0; ry0 = p.y0; rx1 = p.x1; ry1 = p.y1;
@@ -610,12 +610,13 @@ __global__ void k_assemble_shards(const uint32_t *__restrict__ gathered, uint32_
     }
 }
 
-hipError_t launch_assemble_shards(const uint32_t *d_gathered, uint32_t *d_frame, int w, int h, int nranks, hipStream_t stream)
+hipError_t launch_assemble_shards(const uint32_t *d_gathered, uint32_t *d_frame, int w, int h, int nranks, const float *tile_cost,
+                                  hipStream_t stream)
 {
     ShardWhere where;
     for (int r = 0; r < nranks; r++) {
         unsigned char tiles[64];
-        const int cnt = shard_tiles_of_rank(r, nranks, tiles);
+        const int cnt = shard_tiles_of_rank(r, nranks, tiles, tile_cost);
         for (int s = 0; s < cnt; s++) where.v[tiles[s]] = (unsigned short)((r << 8) | s);
     }
     size_t n = (size_t)w * h;

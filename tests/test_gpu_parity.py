@@ -362,3 +362,36 @@ def test_frames_in_flight_and_ordered_shards(sr, rmdf):
             sr.render_shard_device(2, w, h, 0.0, ms, r, n, gathered[r].data_ptr(), stream=s)
     torch.cuda.synchronize()
     assert np.array_equal(rmdf.assemble_shards_host(gathered.cpu().numpy().view(np.uint32), w, h, n), ref)
+
+
+def test_cost_aware_tile_deal(sr, rmdf):
+    """rmdf_probe_tile_costs / rmdf_set_shard_costs: the probe is reproducible, the LPT deal is a partition that matches
+    its Python restatement, it balances the probed cost better than the static deal, and frames rendered and assembled
+    under it are the single-launch frame bit for bit."""
+    import torch
+    w, h, ms = 512, 288, 256
+    dev = torch.device("cuda", 0)
+    ref = sr.render(2, w, h, 0.0, max_steps=ms)["rgba8"]
+    cost = sr.probe_tile_costs(2, w, h, 0.0, ms)
+    assert np.array_equal(cost, sr.probe_tile_costs(2, w, h, 0.0, ms)) and (cost > 0).all()
+    assert cost.reshape(8, 8)[3:5, 3:5].min() > 4 * cost.reshape(8, 8)[0, 0]          # the bulb is in the middle
+    try:
+        sr.set_shard_costs(cost)
+        for n in (2, 3, 8):
+            tiles = [sr.shard_tiles(r, n) for r in range(n)]
+            assert sorted(sum(tiles, [])) == list(range(64)) and max(map(len, tiles)) <= rmdf.shard_slots(n)
+            assert tiles == [rmdf.shard_tiles_by_cost(r, n, cost) for r in range(n)]
+            load = lambda deal: max(sum(cost[t] for t in ts) for ts in deal)
+            assert load(tiles) <= load([rmdf.shard_tiles(r, n) for r in range(n)])
+            slots = rmdf.shard_slots(n)
+            gathered = torch.zeros((n, slots, h // 8, w // 8), dtype=torch.int32, device=dev)
+            for r in range(n):
+                sr.render_shard_device(2, w, h, 0.0, ms, r, n, gathered[r].data_ptr())
+            frame = torch.zeros((h, w), dtype=torch.int32, device=dev)
+            sr.assemble_shards_device(w, h, n, gathered.data_ptr(), frame.data_ptr())
+            sr.synchronize()
+            assert np.array_equal(frame.cpu().numpy().view(np.uint32), ref), n
+            assert np.array_equal(rmdf.assemble_shards_host(gathered.cpu().numpy().view(np.uint32), w, h, n, tiles_of=sr.shard_tiles), ref)
+    finally:
+        sr.set_shard_costs(None)
+    assert sr.shard_tiles(1, 8) == rmdf.shard_tiles(1, 8)
