@@ -63,7 +63,7 @@ def gather_shards(shard, rank, world, dist, out=None, out_list=None):
     shard: (slots, th, tw) int32 tensor.  Returns (world, slots, th, tw) on rank 0, None elsewhere.
     out_list = list(out.unbind(0)), precomputed by callers that gather every frame."""
     import torch
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return shard.unsqueeze(0)
     if rank == 0:
         if out is None:
@@ -92,6 +92,11 @@ def flops_model(c):
 # ---- the benchmark ----------------------------------------------------------------------------------
 
 def main():
+    # stdout carries exactly ONE line, the JSON result: everything else that writes to fd 1 (RCCL's version banner,
+    # library chatter) is sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -125,14 +130,18 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # the N > 1 path (shard render, RCCL gather, assemble); RMDF_BENCH_FORCE_DIST=1 runs it with world size 1 so that a
+    # 1-GPU box can smoke-test it
+    sharded = world > 1 or os.environ.get("RMDF_BENCH_FORCE_DIST") == "1"
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # one rank builds (a no-op when librmdf.so is current), the others wait: N ranks must not run make at once
     if local_rank == 0:
         rmdf_amd.build()
-    if world > 1:
+    if sharded:
         dist.barrier()
     w, h, ms, scene = a.width, a.height, a.max_steps, a.scene
     sr = rmdf_amd.ShaderRenderer(local_rank, flags=int(os.environ.get("RMDF_FLAGS", "0")))
@@ -147,7 +156,7 @@ def main():
         sr.load_env_hdr(rmdf_amd.DEFAULT_ENV_HDR)
     dev_name, cus = sr.device_info()
     deal = "single GPU"
-    if world > 1:
+    if sharded:
         # cost-aware deal of the 64 tiles: every rank probes the view at 256 x 144 on its own GPU (bit-reproducible
         # kernels -> identical costs, no exchange) and deals longest-processing-time-first.  Outside the timed region
         # the ranks compare their deals once; any disagreement falls back to the static deal on all of them.
@@ -168,7 +177,7 @@ def main():
     # i % S.  On one GPU this overlaps the thin tail of a frame -- the launch cannot end before its longest ray has
     # finished a ~0.45 ms serial chain -- with the bulk of the next; on N GPUs it also overlaps the gather of frame i
     # with the render of frame i+1.  --streams 1 = strictly one frame at a time.
-    S = a.streams if a.streams > 0 else (2 if world == 1 else min(8, 2 + world))
+    S = a.streams if a.streams > 0 else (2 if not sharded else min(8, 2 + world))
     streams = [torch.cuda.Stream(dev) for _ in range(S)]
     stream = streams[0]
     torch.cuda.set_stream(stream)
@@ -179,7 +188,7 @@ def main():
     rw, rh = w << L, h << L                                   # ray grid
     i32 = dict(dtype=torch.int32, device=dev)
     frames = [torch.empty((h, w), **i32) for _ in range(S)]
-    if world == 1:
+    if not sharded:
         bigs = [torch.empty((rh, rw), **i32) for _ in range(S)] if L else frames
         tmps = [torch.empty((rh // 2, rw // 2), **i32) if L > 1 else None for _ in range(S)]
     else:
@@ -201,7 +210,7 @@ def main():
 
     def render_only(k=0):
         sp = streams[k].cuda_stream
-        if world == 1:
+        if not sharded:
             sr.render_rect_device(scene, rw, rh, a.time, ms, (0, 0, rw, rh), d_rgba8=bigs[k].data_ptr(), stream=sp)
         else:
             sr.render_shard_device(scene, rw, rh, a.time, ms, rank, world, bigs[k].data_ptr(), stream=sp)
@@ -211,7 +220,7 @@ def main():
         sp = streams[k].cuda_stream
         with torch.cuda.stream(streams[k]):                   # the RCCL call orders itself against the current stream
             render_only(k)
-            if world == 1:
+            if not sharded:
                 if L:
                     resolve(bigs[k], rw, rh, frames[k], tmps[k], sp)
             else:
@@ -222,7 +231,7 @@ def main():
                     sr.assemble_shards_device(w, h, world, g.data_ptr(), frames[k].data_ptr(), stream=sp)
 
     def barrier():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -266,12 +275,12 @@ def main():
         d2h_rate = mpix / ((time.perf_counter() - t1) / reps)
 
         env_bytes = 6 * 172 * 172 * 8 + 2 * 6 * 87 * 87 * 8               # padded RGB16F cube maps read once
-        px_this_launch = rw * rh if world == 1 else len(sr.shard_tiles(rank, world)) * (rw // 8) * (rh // 8)
+        px_this_launch = rw * rh if not sharded else len(sr.shard_tiles(rank, world)) * (rw // 8) * (rh // 8)
         algo_bytes = px_this_launch * 4 + env_bytes                        # RGBA8 store + env read
         achieved_gbs = algo_bytes / (kern_ms * 1e-3) / 1e9
         traffic = None
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tj) and world == 1 and L == 0:
+        if os.path.exists(tj) and not sharded and L == 0:
             try:
                 t = json.load(open(tj))
                 if t.get("workload") == [scene, w, h, ms]:
@@ -287,8 +296,8 @@ def main():
                                    "full frame -> RGBA8 resident in HBM" % (scene, w, h, (" x %d rays/px, box-resolved on the GPU" % (4 ** L)) if L else "", ms, a.time),
                        "supersample_levels": L, "mrays_per_s": round(value * 4 ** L, 2),
                        "scene": scene, "width": w, "height": h, "max_steps": ms,
-                       "parallelism": ("1 GPU, one launch per frame" if world == 1 else
-                                       "64 tiles interleaved over %d GPUs + one RCCL gather per frame" % world) +
+                       "parallelism": ("1 GPU, one launch per frame" if not sharded else
+                                       "64 tiles dealt to %d GPUs + one RCCL gather per frame" % world) +
                                       ", %d frame(s) in flight" % S,
                        "frames_in_flight": S, "tile_deal": deal,
                        "device": dev_name, "compute_units": cus},
@@ -308,7 +317,7 @@ def main():
             cpu_dt = time.perf_counter() - tc
             ctr = ref["counters"]
             F = flops_model(ctr)
-            if world == 1:
+            if not sharded:
                 result["valu_roofline"] = {"achieved": round(F / (kern_ms * 1e-3) / 1e12, 3), "peak": VALU_PEAK_TLANEOPS,
                                            "unit": "T lane-ops/s (as-written IEEE ops, no FMA contraction)",
                                            "frac": round(F / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS, 4),
@@ -319,9 +328,9 @@ def main():
             if a.check:
                 result["check_rgba8_equal"] = all(bool(np.array_equal(f.cpu().numpy().view(np.uint32), ref["rgba8"]))
                                                   for f in frames)
-        print(json.dumps(result), flush=True)
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
 
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
     sr.close()
