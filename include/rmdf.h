@@ -74,6 +74,7 @@ typedef struct rmdf_ctx rmdf_ctx;
 #define RMDF_FLAG_FLAT_MARCH   2   /* Mandelbulb: flattened march kernel + shade kernel (rmdf_march.hip)   */
 #define RMDF_FLAG_PIPELINE     8   /* all scenes: march-with-refill + normal/AO-on-hit-list + shade kernels (rmdf_pipeline.hip) */
 #define RMDF_FLAG_NO_MERGE     16   /* nested-loop kernel: do NOT pool the last rays of a workgroup's four packets in one wave */
+#define RMDF_FLAG_NO_PRUNE     32   /* Cornell box: evaluate all 32 triangles per distance estimate (no bound-based skipping) */
 #define RMDF_FLAG_RASTER_ORDER 4   /* nested-loop kernel: always dispatch strips in raster order (no cost feedback) */
 /* neither bit set = the library's default (currently the fastest measured: nested loops) */
 
@@ -204,6 +205,11 @@ int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[5]);
  * iteration passes, march-tail passes, shade-tail passes, refill rounds, sum of iterating lanes over iteration
  * passes, sum of waiting lanes over march tails, begin / end timestamps (100 MHz s_memrealtime ticks). */
 int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_waves);
+
+/* Screenshot: saveFrameBufferToPNG (FrameBuffer.hs:215-228) for a frame buffer in the boundary's layout (w*h
+ * little-endian Word32 = R,G,B,A bytes, row 0 = bottom): rows flipped to top-down, alpha forced to 0xFF, written
+ * as an 8-bit RGBA PNG.  Host-only (no ctx, no device); errors are reported through rmdf_last_error(NULL). */
+int rmdf_save_png(const char *path, const uint32_t *fb_rgba8, int w, int h);
 
 /* Block until everything queued on `stream` (NULL = ctx stream) has finished. */
 int rmdf_synchronize(rmdf_ctx *ctx, void *stream);

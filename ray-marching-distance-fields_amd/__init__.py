@@ -33,7 +33,7 @@ DEFAULT_ENV_HDR = os.path.join(DATA_DIR, "latlong_envmaps", "uffizi_512.hdr")
 
 TILES_X, TILES_Y, N_TILES = 8, 8, 64          # ShaderRendering.hs:49-52
 ENV_REFLECTION, ENV_COS_1, ENV_COS_8, ENV_COS_64, ENV_COS_512 = range(5)
-FLAG_NESTED_LOOPS, FLAG_FLAT_MARCH, FLAG_RASTER_ORDER, FLAG_PIPELINE, FLAG_NO_MERGE = 1, 2, 4, 8, 16   # rmdf.h RMDF_FLAG_*
+FLAG_NESTED_LOOPS, FLAG_FLAT_MARCH, FLAG_RASTER_ORDER, FLAG_PIPELINE, FLAG_NO_MERGE, FLAG_NO_PRUNE = 1, 2, 4, 8, 16, 32   # rmdf.h RMDF_FLAG_*
 
 _ERRORS = {-1: "RMDF_E_INVALID", -2: "RMDF_E_NO_DEVICE", -3: "RMDF_E_HIP", -4: "RMDF_E_IO",
            -5: "RMDF_E_NO_ENV", -6: "RMDF_E_UNSUPPORTED", -7: "RMDF_E_NOMEM"}
@@ -46,7 +46,7 @@ ABI_SYMBOLS = (
     "rmdf_render_rect_device", "rmdf_render_shard_device", "rmdf_assemble_shards_device", "rmdf_synchronize",
     "rmdf_device_info", "rmdf_debug_march_stats", "rmdf_resolve_box2_device", "rmdf_render_supersampled",
     "rmdf_selftest_exact_math", "rmdf_shard_tiles", "rmdf_probe_tile_costs", "rmdf_set_shard_costs",
-    "rmdf_get_shard_tiles",
+    "rmdf_get_shard_tiles", "rmdf_save_png",
 )
 
 
@@ -133,6 +133,7 @@ def load_library():
     L.rmdf_render_rect_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int] + [C.c_int] * 4 + [vp] * 5
     L.rmdf_render_shard_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, vp, vp]
     L.rmdf_shard_tiles.argtypes = [C.c_int, C.c_int, ip]
+    L.rmdf_save_png.argtypes = [C.c_char_p, vp, C.c_int, C.c_int]
     L.rmdf_probe_tile_costs.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]
     L.rmdf_set_shard_costs.argtypes = [vp, vp]
     L.rmdf_get_shard_tiles.argtypes = [vp, C.c_int, C.c_int, ip]
@@ -347,8 +348,11 @@ class FrameBuffer:
         return rgba
 
     def save_png(self, fn):
-        from PIL import Image
-        Image.fromarray(self.to_image_rows_top_down(), "RGBA").save(fn)
+        """saveFrameBufferToPNG fb fn, written by the library's own encoder (rmdf_save_png)."""
+        L = load_library()
+        rc = L.rmdf_save_png(os.fsencode(fn), self.vec.ctypes.data, self.w, self.h)
+        if rc != 0:
+            raise RmdfError(rc, (L.rmdf_last_error(None) or b"").decode())
 
 
 # --- multi-GPU tile sharding (SURVEY.md 8e): pure index arithmetic, testable without a GPU ------

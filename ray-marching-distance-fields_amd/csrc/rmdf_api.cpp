@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <zlib.h>
 
 #include <new>
 #include <string>
@@ -174,7 +175,27 @@ void cornell_table(const float tri[96 * 3], float tab[32 * CORNELL_STRIDE])
         const float len12 = hdot(e12, e12);
         t[22] = len12;
         t[23] = 1.0f / dot00; t[24] = 1.0f / dot11; t[25] = 1.0f / len12;
-        t[26] = t[27] = 0.0f;
+        // pruning bounds of de_cornell_box_table (double arithmetic, rounded once): unit normal, plane offset,
+        // bounding sphere about the centroid
+        {
+            const double a[3] = { e0.x, e0.y, e0.z }, b[3] = { e1.x, e1.y, e1.z };
+            double n[3] = { a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0] };
+            const double nl = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            for (int k = 0; k < 3; k++) n[k] /= nl;
+            t[26] = (float)n[0]; t[27] = (float)n[1]; t[28] = (float)n[2];
+            t[29] = (float)(n[0] * v0[0] + n[1] * v0[1] + n[2] * v0[2]);
+            double c[3], R = 0.0;
+            for (int k = 0; k < 3; k++) c[k] = ((double)v0[k] + v1[k] + v2[k]) / 3.0;
+            for (int k = 0; k < 3; k++) t[30 + k] = (float)c[k];
+            const float *vs[3] = { v0, v1, v2 };
+            for (int j = 0; j < 3; j++) {
+                double d2 = 0.0;
+                for (int k = 0; k < 3; k++) { const double d = (double)vs[j][k] - (double)t[30 + k]; d2 += d * d; }
+                if (sqrt(d2) > R) R = sqrt(d2);
+            }
+            t[33] = (float)(R * (1.0 + 1e-6));
+            t[34] = t[35] = 0.0f;
+        }
     }
 }
 
@@ -318,6 +339,7 @@ int fill_params(rmdf_ctx *ctx, int scene, int w, int h, float time, int max_step
     // power and costs a few % where the distance estimate is cheap (test scene) or uniform in cost (Cornell)
     if (scene != RMDF_FS_MB_POWER8 && !getenv("RMDF_MERGE")) p.merge_stragglers = 0;
     p.cornell_tab = ctx->d_cornell_tab;
+    p.cornell_prune = (ctx->flags & RMDF_FLAG_NO_PRUNE) ? 0 : 1;
     { static int skip = -1; if (skip < 0) { const char *e = getenv("RMDF_DBG_SKIP"); skip = e ? atoi(e) : 0; } p.dbg_skip = skip; }
     int rc = ensure_gbuf(ctx, w, h);
     if (rc != RMDF_OK) return rc;
@@ -911,6 +933,46 @@ int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_wav
         HIP_TRY(ctx, hipMemset(ctx->d_dbg, 0, cap * 16 * sizeof(unsigned long long)));
     }
     if (!enable && ctx->d_dbg) { (void)hipFree(ctx->d_dbg); ctx->d_dbg = nullptr; }
+    return RMDF_OK;
+}
+
+int rmdf_save_png(const char *path, const uint32_t *fb_rgba8, int w, int h)
+{
+    // saveFrameBufferToPNG (FrameBuffer.hs:215-228): rows flipped (the frame buffer's row 0 is the bottom row, PNG
+    // stores top-down) and alpha forced to 0xFF; 8-bit RGBA, no interlace, filter type 0 on every scanline
+    if (!path || !fb_rgba8 || w <= 0 || h <= 0 || w > 65535 || h > 65535) return fail(nullptr, RMDF_E_INVALID, "rmdf_save_png: bad argument");
+    const size_t stride = (size_t)w * 4 + 1;
+    std::vector<uint8_t> raw(stride * (size_t)h);
+    for (int y = 0; y < h; y++) {
+        uint8_t *row = &raw[stride * (size_t)y];
+        const uint8_t *src = (const uint8_t *)(fb_rgba8 + (size_t)(h - 1 - y) * w);
+        row[0] = 0;
+        memcpy(row + 1, src, (size_t)w * 4);
+        for (int x = 0; x < w; x++) row[1 + 4 * x + 3] = 0xFF;
+    }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return fail(nullptr, RMDF_E_IO, "rmdf_save_png: deflate failed");
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(nullptr, RMDF_E_IO, std::string("cannot write ") + path);
+    bool ok = true;
+    auto chunk = [&](const char type[4], const uint8_t *data, size_t n) {
+        uint8_t hd[8] = { (uint8_t)(n >> 24), (uint8_t)(n >> 16), (uint8_t)(n >> 8), (uint8_t)n,
+                          (uint8_t)type[0], (uint8_t)type[1], (uint8_t)type[2], (uint8_t)type[3] };
+        uLong crc = crc32(0L, hd + 4, 4);
+        if (n) crc = crc32(crc, data, (uInt)n);
+        const uint8_t tl[4] = { (uint8_t)(crc >> 24), (uint8_t)(crc >> 16), (uint8_t)(crc >> 8), (uint8_t)crc };
+        ok = ok && fwrite(hd, 1, 8, f) == 8 && (n == 0 || fwrite(data, 1, n, f) == n) && fwrite(tl, 1, 4, f) == 4;
+    };
+    static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
+    ok = fwrite(sig, 1, 8, f) == 8;
+    const uint8_t ihdr[13] = { (uint8_t)(w >> 24), (uint8_t)(w >> 16), (uint8_t)(w >> 8), (uint8_t)w,
+                               (uint8_t)(h >> 24), (uint8_t)(h >> 16), (uint8_t)(h >> 8), (uint8_t)h, 8, 6, 0, 0, 0 };
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", z.data(), (size_t)zlen);
+    chunk("IEND", nullptr, 0);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { remove(path); return fail(nullptr, RMDF_E_IO, std::string("short write to ") + path); }
     return RMDF_OK;
 }
 

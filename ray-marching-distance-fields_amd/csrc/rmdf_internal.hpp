@@ -30,6 +30,7 @@ struct FrameParams {
     CubeDev env_refl, env_cos1, env_cos8;
     const float *cornell;     // 96 vertices
     const float *cornell_tab; // 32 x CORNELL_STRIDE per-triangle constants (rmdf_device.hpp: de_cornell_box_table)
+    int   cornell_prune;      // skip triangles that provably cannot undercut the running minimum (bit-identical result)
     uint32_t *rgba8;
     float4   *rgba_f32;
     uint16_t *steps;

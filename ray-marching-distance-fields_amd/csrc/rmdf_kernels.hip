@@ -41,7 +41,7 @@ __device__ __forceinline__ float distance_estimator(v3 pos, const FrameParams &p
     if (SCENE == 2)      return de_mandelbulb8(pos, iters);
     else if (SCENE == 3) return de_mandelbulb_general(pos, p.power, iters);
     else if (SCENE == 1) return de_test_scene(pos);
-    else                 return de_cornell_box_table(pos, p.cornell_tab);
+    else                 return de_cornell_box_table(pos, p.cornell_tab, p.cornell_prune);
 }
 
 template <int SCENE>
@@ -875,7 +875,8 @@ hipError_t launch_resize_latlong(const float *d_src, int sw, int sh, int dstw, i
 // x inner); the 8 partial sums are added in row order, so the result differs from a single serial sum only by the
 // re-association at 7 points (tolerance parity).  The source row and per-row cos/sin are wave-uniform
 // (scalar loads); cos|phiL - phi_x| is staged once per workgroup in LDS, transposed so lanes read consecutive
-// words.  LOG2P >= 0: power = 2^LOG2P <= 8 by repeated squaring (the reference's 1 and 8); -1: powf (64, 512, any other).
+// words.  LOG2P >= 0: power = 2^LOG2P <= 8 by repeated squaring
+// (float for the reference's 1 and 8, double for its 64 and 512); -1: powf (any other power).
 // ------------------------------------------------------------------------------------
 template <int LOG2P>
 __global__ __launch_bounds__(512) void k_prefilter(const float *__restrict__ src, int w, int h, float power,
@@ -901,10 +902,18 @@ __global__ __launch_bounds__(512) void k_prefilter(const float *__restrict__ src
             const float cos_angle = lc * pc + ls * ps * lut[x * 64 + lane];
             if (cos_angle > 0.0f) {
                 float cp;
-                if (LOG2P >= 0) {
+                if (LOG2P >= 0 && LOG2P <= 3) {
                     cp = cos_angle;
 #pragma unroll
                     for (int k = 0; k < LOG2P; k++) cp = cp * cp;
+                } else if (LOG2P > 3) {
+                    // 64, 512: float squaring would double the rounding error LOG2P times; in double the chain is
+                    // exact to ~2^LOG2P * 1e-16, i.e. the float result is the correctly rounded power (FP64 vector
+                    // multiplies issue at the FP32 rate on gfx950), for a fifth of powf's instructions
+                    double cd = (double)cos_angle;
+#pragma unroll
+                    for (int k = 0; k < LOG2P; k++) cd = cd * cd;
+                    cp = (float)cd;
                 } else {
                     cp = powf(cos_angle, power);
                 }
@@ -934,8 +943,10 @@ hipError_t launch_prefilter(const float *d_src, int w, int h, float power, float
     const size_t lds = (size_t)w * 64 * sizeof(float) + 8 * 64 * 4 * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     int log2p = -1;
-    // repeated squaring doubles the relative rounding error per step: fine up to 2^3 (<= 5e-7), not for 64 / 512
+    // repeated squaring: in float up to 2^3 (the error doubles per step: <= 5e-7), in double for 64 and 512
     for (int k = 0; k <= 3; k++) if (power == (float)(1 << k)) log2p = k;
+    if (power == 64.0f) log2p = 6;
+    if (power == 512.0f) log2p = 9;
     const void *fn = log2p == 0 ? (const void *)k_prefilter<0> : log2p == 3 ? (const void *)k_prefilter<3> :
                      log2p == 6 ? (const void *)k_prefilter<6> : log2p == 9 ? (const void *)k_prefilter<9> : (const void *)k_prefilter<-1>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -395,3 +395,23 @@ def test_cost_aware_tile_deal(sr, rmdf):
     finally:
         sr.set_shard_costs(None)
     assert sr.shard_tiles(1, 8) == rmdf.shard_tiles(1, 8)
+
+
+def test_cornell_pruning_is_invisible(rmdf, sr, orc, env_oracle, env_faces):
+    """The Cornell distance estimate skips triangles whose lower bounds (plane distance, bounding sphere) exceed the
+    running minimum by a safety margin (rmdf_device.hpp: de_cornell_box_table).  min() is exact and order-independent,
+    so the result must be the same bits as evaluating all 32 triangles (RMDF_FLAG_NO_PRUNE) -- checked on whole frames
+    (march positions, the 1e-5 finite-difference normals, the four AO taps) at several camera positions, and against
+    the oracle."""
+    plain = rmdf.ShaderRenderer(0, flags=rmdf.FLAG_NO_PRUNE)
+    try:
+        for slot, k in ((rmdf.ENV_REFLECTION, "refl"), (rmdf.ENV_COS_1, "cos1"), (rmdf.ENV_COS_8, "cos8")):
+            plain.set_env_cube(slot, env_faces[k])
+        for (w, h, t, ms) in ((1280, 720, 0.0, 128), (640, 360, 1.3, 128), (640, 360, 4.0, 128), (250, 130, 9.7, 64), (33, 17, 2.0, 128)):
+            a, b = sr.render(0, w, h, t, max_steps=ms), plain.render(0, w, h, t, max_steps=ms)
+            for k in ("rgba8", "steps", "iters"):
+                assert np.array_equal(a[k], b[k]), (k, w, h, t)
+            assert np.array_equal(a["rgba_f32"].view(np.uint32), b["rgba_f32"].view(np.uint32)), (w, h, t)
+        assert_frame_parity(sr.render(0, 250, 130, 9.7, max_steps=64), orc.render(0, 250, 130, 9.7, 64, env_oracle), "cornell t=9.7")
+    finally:
+        plain.close()

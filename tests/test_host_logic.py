@@ -77,6 +77,25 @@ def test_framebuffer_slot(rmdf):
     assert img[0, 0, 1] == 8 and img[2, 0, 1] == 0                # row 0 of the buffer is the bottom row
 
 
+def test_screenshot_png(rmdf, tmp_path):
+    """rmdf_save_png == saveFrameBufferToPNG (FrameBuffer.hs:215-228): decoded with an independent PNG reader, the
+    file holds the frame buffer flipped top-down with alpha 0xFF.  Host-only code: runs without a GPU."""
+    from PIL import Image
+    rmdf.build()
+    rng = np.random.RandomState(3)
+    for (w, h) in ((4, 3), (257, 131), (1, 1)):
+        fb = rmdf.FrameBuffer(w, h)
+        fb.vec[:] = rng.randint(0, 2 ** 32, w * h, dtype=np.uint64).astype(np.uint32)
+        fn = str(tmp_path / ("shot_%dx%d.png" % (w, h)))
+        fb.save_png(fn)
+        im = Image.open(fn)
+        assert im.mode == "RGBA" and im.size == (w, h)
+        assert np.array_equal(np.asarray(im), fb.to_image_rows_top_down())
+    with pytest.raises(rmdf.RmdfError) as e:
+        rmdf.FrameBuffer(2, 2).save_png("/nonexistent_dir/x.png")
+    assert e.value.code == -4
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

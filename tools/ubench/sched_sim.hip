@@ -1,0 +1,182 @@
+// sched_sim.hip -- how much VALU work could another lane schedule of the power-8 march save?
+// Measurement tool.  A kernel marches every ray of the headline frame (1920x1080, in_time 0, 256 steps) with the
+// product's arithmetic (rmdf_device.hpp) and records the escape-iteration count k of every distance estimate
+// (trace[step][pixel], uint8).  The host then replays lane schedules over that trace with the cost model
+//     wave-step = A * max_k(active lanes) + B          (A = instructions of one iteration pass, B = per-estimate tail)
+// and prints the wave-instruction totals of the march part:
+//   nested      : 8x8 packet per wave, runs until its last ray ends (k_render<.., MERGE=false>)
+//   wg-pool T   : + the <= T last rays of each of the 4 packets of a 32x8 strip move to one host wave (MERGE=true)
+//   global T    : a wave with <= T rays left hands them to a global pool; pooled rays are marched 64 at a time in
+//                 hand-over order, re-pooled at <= T again (what a cross-workgroup queue could reach at best)
+//   ideal       : every lane busy in every pass (sum of lane work / 64)
+// Build: make -C tools/ubench sched_sim ; run on an MI355X.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <vector>
+#include "rmdf_device.hpp"
+using namespace rmdf;
+
+#define W 1920
+#define H 1080
+#define MS 256
+
+struct Cam { float c[12]; float fov_xs; };
+
+__global__ void k_trace(Cam cam, unsigned char *trace, unsigned short *nsteps)
+{
+    const int px = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y;
+    if (px >= W) return;
+    const float ndcx = ((float)px + 0.5f) / (float)W * 2.0f - 1.0f;
+    const float ndcy = ((float)py + 0.5f) / (float)H * 2.0f - 1.0f;
+    const float aspect = (float)W / (float)H;
+    const v3 d = normalize3(mk3(ndcx * cam.fov_xs, ndcy * cam.fov_xs / aspect, -1.0f));
+    const float *c = cam.c;
+    const v3 dir = mk3(c[0] * d.x + c[3] * d.y + c[6] * d.z, c[1] * d.x + c[4] * d.y + c[7] * d.z, c[2] * d.x + c[5] * d.y + c[8] * d.z);
+    const v3 origin = mk3(c[9], c[10], c[11]);
+    float tmin, tmax;
+    int n = 0;
+    if (ray_sphere(origin, dir, 1.15f, tmin, tmax)) {
+        float t = gmax(0.0f, tmin);
+        for (int s = 0; s < MS; s++) {
+            unsigned it = 0;
+            const float dist = de_mandelbulb8(mk3(origin.x + t * dir.x, origin.y + t * dir.y, origin.z + t * dir.z), it);
+            trace[(size_t)s * W * H + (size_t)py * W + px] = (unsigned char)it;
+            n = s + 1;
+            t += dist;
+            if (t > tmax) break;
+            if (dist < 0.001f) break;
+        }
+    }
+    nsteps[(size_t)py * W + px] = (unsigned short)n;     // distance estimates taken (= march passes of this ray)
+}
+
+static void host_camera(float cam[12], float *fov_xs)
+{
+    // fragment.shd:892-897, 829-838 at in_time = 0 (same operation order as rmdf_api.cpp: host_camera)
+    float cx = sinf(0.0f), cy = cosf(0.0f), cz = cosf(0.0f);
+    float s = 1.0f / sqrtf((cx * cx + cy * cy) + cz * cz);
+    cx = cx * s * 2.414213562373095f; cy = cy * s * 2.414213562373095f; cz = cz * s * 2.414213562373095f;
+    float zl = 1.0f / sqrtf((cx * cx + cy * cy) + cz * cz);
+    float zx = cx * zl, zy = cy * zl, zz = cz * zl;
+    float xx = 1.0f * zz - 0.0f * zy, xy = 0.0f * zx - 0.0f * zz, xz = 0.0f * zy - 1.0f * zx;
+    float xl = 1.0f / sqrtf((xx * xx + xy * xy) + xz * xz);
+    xx *= xl; xy *= xl; xz *= xl;
+    float yx = zy * xz - zz * xy, yy = zz * xx - zx * xz, yz = zx * xy - zy * xx;
+    float v[12] = { xx, xy, xz, yx, yy, yz, zx, zy, zz, cx, cy, cz };
+    for (int i = 0; i < 12; i++) cam[i] = v[i];
+    *fov_xs = tanf(((45.0f * 1.5f) * 0.017453292519943295f) / 2.0f);
+}
+
+struct Ray { int pix; int step; };                 // a ray in flight: its pixel and the index of its next estimate
+
+static const unsigned char *g_trace;
+static const unsigned short *g_n;
+static inline int kof(int pix, int step) { return g_trace[(size_t)step * W * H + pix]; }
+
+// march `rays` (<= 64) in one wave until at most T of them are left (T = 0: to the end); returns the cost, leaves the
+// survivors in `rays`
+static double run_wave(std::vector<Ray> &rays, int T, double A, double B, double *lane_work)
+{
+    double cost = 0.0;
+    for (;;) {
+        int act = 0, mk = 0;
+        for (auto &r : rays) if (r.step < g_n[r.pix]) { act++; int k = kof(r.pix, r.step); if (k > mk) mk = k; *lane_work += A * k + B; }
+        if (act == 0) break;
+        cost += A * mk + B;
+        for (auto &r : rays) if (r.step < g_n[r.pix]) r.step++;
+        int left = 0;
+        for (auto &r : rays) if (r.step < g_n[r.pix]) left++;
+        if (left <= T) break;
+    }
+    std::vector<Ray> s;
+    for (auto &r : rays) if (r.step < g_n[r.pix]) s.push_back(r);
+    rays.swap(s);
+    return cost;
+}
+
+int main()
+{
+    Cam cam;
+    host_camera(cam.c, &cam.fov_xs);
+    const size_t npx = (size_t)W * H;
+    unsigned char *d_trace; unsigned short *d_n;
+    if (hipMalloc((void **)&d_trace, npx * MS) != hipSuccess || hipMalloc((void **)&d_n, npx * 2) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    hipMemset(d_trace, 0, npx * MS);
+    hipLaunchKernelGGL(k_trace, dim3((W + 63) / 64, H), dim3(64), 0, 0, cam, d_trace, d_n);
+    std::vector<unsigned char> trace(npx * MS);
+    std::vector<unsigned short> n(npx);
+    if (hipMemcpy(trace.data(), d_trace, npx * MS, hipMemcpyDeviceToHost) != hipSuccess) { printf("copy failed\n"); return 1; }
+    hipMemcpy(n.data(), d_n, npx * 2, hipMemcpyDeviceToHost);
+    g_trace = trace.data(); g_n = n.data();
+    double evals = 0, iters = 0; int maxn = 0;
+    for (size_t i = 0; i < npx; i++) { evals += n[i]; if (n[i] > maxn) maxn = n[i]; for (int s = 0; s < n[i]; s++) iters += kof((int)i, s); }
+    printf("rays with estimates: march estimates %.4e  escape iterations %.4e  mean k %.2f  longest ray %d estimates\n", evals, iters, iters / evals, maxn);
+
+    const double A = 117.0, B = 110.0;
+    auto packet = [&](int bx, int by, std::vector<Ray> &rays) {
+        rays.clear();
+        for (int ly = 0; ly < 8; ly++) for (int lx = 0; lx < 8; lx++) {
+            const int x = bx * 8 + lx, y = by * 8 + ly;
+            if (x < W && y < H && n[(size_t)y * W + x] > 0) rays.push_back(Ray{ y * W + x, 0 });
+        }
+    };
+    const int PX = (W + 7) / 8, PY = (H + 7) / 8;
+    double lane_work = 0.0, dummy = 0.0;
+    // nested
+    double c_nested = 0.0;
+    { std::vector<Ray> r; for (int by = 0; by < PY; by++) for (int bx = 0; bx < PX; bx++) { packet(bx, by, r); c_nested += run_wave(r, 0, A, B, &lane_work); } }
+    const double ideal = lane_work / 64.0;
+    printf("cost model: wave-step = %.0f * max k + %.0f wave instructions\n", A, B);
+    printf("%-28s %10.1f M wave-instr  (x%.3f of nested)\n", "ideal (all lanes busy)", ideal / 1e6, ideal / c_nested);
+    printf("%-28s %10.1f M wave-instr  lane utilisation %.3f\n", "nested 8x8 packets", c_nested / 1e6, ideal / c_nested);
+    for (int T : { 16, 24, 32, 40 }) {
+        // workgroup pooling: the four packets of a 32x8 strip; survivors of each (<= T) go to one host wave, which
+        // takes them 64 at a time in hand-over order and runs them to the end
+        double c = 0.0;
+        std::vector<Ray> r, pool;
+        for (int by = 0; by < PY; by++) for (int sx = 0; sx < (PX + 3) / 4; sx++) {
+            pool.clear();
+            for (int q = 0; q < 4; q++) { const int bx = sx * 4 + q; if (bx >= PX) break; packet(bx, by, r); c += run_wave(r, T, A, B, &dummy); pool.insert(pool.end(), r.begin(), r.end()); }
+            // host wave: refill idle lanes from the pool at step boundaries
+            std::vector<Ray> host;
+            size_t next = 0;
+            for (;;) {
+                while (host.size() < 64 && next < pool.size()) host.push_back(pool[next++]);
+                if (host.empty()) break;
+                int mk = 0;
+                for (auto &x : host) { int k = kof(x.pix, x.step); if (k > mk) mk = k; }
+                c += A * mk + B;
+                std::vector<Ray> s;
+                for (auto &x : host) { x.step++; if (x.step < g_n[x.pix]) s.push_back(x); }
+                host.swap(s);
+            }
+        }
+        printf("wg-pool T=%-2d %26.1f M wave-instr  (x%.3f of nested)  lane utilisation %.3f\n", T, c / 1e6, c / c_nested, ideal / c);
+    }
+    for (int T : { 16, 24, 32, 40, 48 }) {
+        // global pool: generations; a generation's waves are formed of 64 consecutive pooled rays (hand-over order keeps
+        // neighbours together), marched until <= T are left, survivors re-pooled; the last generation runs to the end
+        double c = 0.0;
+        std::vector<Ray> r, pool, nextpool;
+        for (int by = 0; by < PY; by++) for (int bx = 0; bx < PX; bx++) { packet(bx, by, r); c += run_wave(r, T, A, B, &dummy); pool.insert(pool.end(), r.begin(), r.end()); }
+        int gen = 0;
+        const size_t first_pool = pool.size();
+        while (!pool.empty()) {
+            nextpool.clear();
+            const bool last = pool.size() <= 64 * 256 || gen >= 12;       // fewer rays than a quarter of the wave slots: just finish
+            for (size_t i = 0; i < pool.size(); i += 64) {
+                std::vector<Ray> w(pool.begin() + i, pool.begin() + std::min(pool.size(), i + 64));
+                c += run_wave(w, last ? 0 : T, A, B, &dummy);
+                nextpool.insert(nextpool.end(), w.begin(), w.end());
+            }
+            pool.swap(nextpool);
+            gen++;
+        }
+        printf("global T=%-2d %27.1f M wave-instr  (x%.3f of nested)  lane utilisation %.3f  pooled rays %zu, %d generations\n",
+               T, c / 1e6, c / c_nested, ideal / c, first_pool, gen);
+    }
+    return 0;
+}
