@@ -75,6 +75,18 @@ def gather_shards(shard, rank, world, dist, out=None, out_list=None):
     return None
 
 
+def ranks_agree_on_deal(deal, dist, device):
+    """deal = [tiles of rank 0, tiles of rank 1, ...] as THIS rank computed it.  True iff every rank holds rank 0's deal
+    (one broadcast + one all-reduce, outside the timed region)."""
+    import torch
+    mine = torch.tensor([t for tiles in deal for t in (list(tiles) + [-1] * 64)[:64]], dtype=torch.int32, device=device)
+    ref0 = mine.clone()
+    dist.broadcast(ref0, src=0)
+    agree = torch.tensor([1 if bool((ref0 == mine).all()) else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+    return int(agree.item()) == 1
+
+
 def max_over_ranks(seconds, dist, device):
     import torch
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -161,13 +173,8 @@ def main():
         # kernels -> identical costs, no exchange) and deals longest-processing-time-first.  Outside the timed region
         # the ranks compare their deals once; any disagreement falls back to the static deal on all of them.
         sr.set_shard_costs(sr.probe_tile_costs(a.scene, a.width << a.supersample, a.height << a.supersample, a.time, a.max_steps))
-        mine = torch.tensor([t for r in range(world) for t in (sr.shard_tiles(r, world) + [-1] * 64)[:64]],
-                            dtype=torch.int32, device=dev)
-        ref0 = mine.clone()
-        dist.broadcast(ref0, src=0)
-        agree = torch.tensor([1 if bool((ref0 == mine).all()) else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
-        if int(agree.item()) == 1:
+        agree = ranks_agree_on_deal([sr.shard_tiles(r, world) for r in range(world)], dist, dev)
+        if agree:
             deal = "cost-aware (probe frame, LPT)"
         else:
             sr.set_shard_costs(None)

@@ -415,3 +415,33 @@ def test_cornell_pruning_is_invisible(rmdf, sr, orc, env_oracle, env_faces):
         assert_frame_parity(sr.render(0, 250, 130, 9.7, max_steps=64), orc.render(0, 250, 130, 9.7, 64, env_oracle), "cornell t=9.7")
     finally:
         plain.close()
+
+
+def test_config4_full_size_sharded_supersample(sr, rmdf, orc, env_oracle):
+    """BASELINE config 4 at full size: 3840x2160 output, 2x2 rays per pixel (7680x4320 rays), tiles dealt to 8 ranks
+    (cost-aware), each shard box-resolved before the exchange, assembled -> equals the single-launch supersampled frame
+    bit for bit; two bands of it equal the oracle's render + resolve of the same rows."""
+    import torch
+    W, H, ms, n = 3840, 2160, 256, 8
+    dev = torch.device("cuda", 0)
+    ref = sr.render_supersampled(2, W, H, 1, 0.0, max_steps=ms)
+    assert (ref >> 24 == 0xFF).all()
+    try:
+        sr.set_shard_costs(sr.probe_tile_costs(2, 2 * W, 2 * H, 0.0, ms))
+        slots = rmdf.shard_slots(n)
+        gathered = torch.zeros((n, slots, H // 8, W // 8), dtype=torch.int32, device=dev)
+        big = torch.zeros((slots, 2 * H // 8, 2 * W // 8), dtype=torch.int32, device=dev)
+        for r in range(n):
+            sr.render_shard_device(2, 2 * W, 2 * H, 0.0, ms, r, n, big.data_ptr())
+            sr.resolve_box2_device(big.data_ptr(), 2 * W // 8, slots * 2 * H // 8, gathered[r].data_ptr())
+        frame = torch.zeros((H, W), dtype=torch.int32, device=dev)
+        sr.assemble_shards_device(W, H, n, gathered.data_ptr(), frame.data_ptr())
+        sr.synchronize()
+        assert np.array_equal(frame.cpu().numpy().view(np.uint32), ref)
+    finally:
+        sr.set_shard_costs(None)
+    for y0 in (1078, 1400):                                  # output rows [y0, y0+4) = ray rows [2*y0, 2*y0+8)
+        hi = orc.render(2, 2 * W, 2 * H, 0.0, ms, env_oracle, rect=(0, 2 * y0, 2 * W, 2 * y0 + 8), want_f32=False)["rgba8"]
+        want = orc.resolve_box2(hi[2 * y0:2 * y0 + 8])
+        d = np.abs(ref[y0:y0 + 4].view(np.uint8).astype(int) - want.view(np.uint8).astype(int))
+        assert d.max() <= 1 and (d > 0).mean() <= 1e-3, (y0, d.max(), (d > 0).mean())

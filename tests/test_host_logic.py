@@ -132,6 +132,26 @@ def _gloo_worker(rank, world, port, q):
             env = bench.load_oracle_env(orc)
             full = orc.render(orc.SCENE_MB_POWER8, w, h, 0.0, 64, env, nthreads=2)["rgba8"]
             q.put(bool(np.array_equal(frame, full)))
+        # cost-aware deal (rmdf_set_shard_costs): every rank derives the same costs on its own (here: oracle step +
+        # iteration counts of a tiny probe frame), deals LPT, the ranks confirm they agree, and the frame assembles
+        probe = orc.render(orc.SCENE_MB_POWER8, 32, 16, 0.0, 64, bench.load_oracle_env(orc), nthreads=2)
+        cost = (1.0 + probe["iters"].astype(np.float64) + (probe["steps"] & 0x7FFF)).reshape(8, 2, 8, 4).sum(axis=(1, 3)).ravel().astype(np.float32)
+        deal = [rmdf_amd.shard_tiles_by_cost(r, world, cost) for r in range(world)]
+        ok_deal = bench.ranks_agree_on_deal(deal, dist, torch.device("cpu"))
+        bad = [list(d) for d in deal]
+        if rank == 1:
+            bad[0][0], bad[1][0] = bad[1][0], bad[0][0]
+        ok_bad = bench.ranks_agree_on_deal(bad, dist, torch.device("cpu"))
+        tiles_of = lambda r_, n_: deal[r_]
+        env2 = bench.load_oracle_env(orc)
+        out2 = np.zeros((rmdf_amd.shard_slots(world), h // 8, w // 8), np.uint32)
+        for slot, idx in enumerate(deal[rank]):
+            x0, y0, x1, y1 = rmdf_amd.tile_rect(idx, w, h)
+            out2[slot] = orc.render(orc.SCENE_MB_POWER8, w, h, 0.0, 64, env2, rect=(x0, y0, x1, y1), nthreads=2)["rgba8"][y0:y1, x0:x1]
+        g2 = bench.gather_shards(torch.from_numpy(out2.view(np.int32)), rank, world, dist)
+        if rank == 0:
+            frame2 = rmdf_amd.assemble_shards_host(g2.numpy().view(np.uint32), w, h, world, tiles_of=tiles_of)
+            q.put(bool(ok_deal and not ok_bad and np.array_equal(frame2, full) and sorted(sum(deal, [])) == list(range(64))))
         t = bench.max_over_ranks(float(rank + 1), dist, torch.device("cpu"))
         if rank == 1:
             q.put(t == float(world))
@@ -140,8 +160,9 @@ def _gloo_worker(rank, world, port, q):
 
 
 def test_two_rank_gather_reassembles_the_frame():
-    """world_size 2 over gloo: each rank produces its interleaved tile shard, ONE gather at frame end, rank 0
-    scatters tiles to frame positions -> identical to a single-process full-frame render."""
+    """world_size 2 over gloo: each rank produces its tile shard (static deal, then cost-aware deal confirmed by the
+    agreement protocol), ONE gather at frame end, rank 0 scatters tiles to frame positions -> identical to a
+    single-process full-frame render."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -152,5 +173,5 @@ def test_two_rank_gather_reassembles_the_frame():
     for p in procs:
         p.join(180)
         assert p.exitcode == 0
-    results = [q.get(timeout=10), q.get(timeout=10)]
-    assert results == [True, True]
+    results = [q.get(timeout=10) for _ in range(3)]     # static-deal frame, cost-aware-deal frame (+ agreement protocol), timing reduce
+    assert results == [True, True, True]

