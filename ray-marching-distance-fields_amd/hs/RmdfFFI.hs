@@ -14,6 +14,7 @@
 module RmdfFFI ( HipRenderer
                , withHipRenderer
                , drawHipTile
+               , saveHipFrameBufferToPNG
                , rmdfLastError
                ) where
 
@@ -45,6 +46,9 @@ foreign import ccall safe "rmdf_load_env_hdr"
     c_rmdf_load_env_hdr :: Ptr RmdfCtx -> CString -> IO CInt
 foreign import ccall safe "rmdf_render_tile"
     c_rmdf_render_tile :: Ptr RmdfCtx -> CInt -> CInt -> CInt -> CInt -> CDouble -> CInt -> Ptr Word32 -> IO CInt
+
+foreign import ccall safe "rmdf_save_png"
+    c_rmdf_save_png :: CString -> Ptr Word32 -> CInt -> CInt -> IO CInt
 
 rmdfLastError :: Ptr RmdfCtx -> IO String
 rmdfLastError ctx = c_rmdf_last_error ctx >>= peekCString
@@ -85,3 +89,13 @@ drawHipTile (HipRenderer ctx) shdEnum tileIdx w h time fbVec =
                                  p
         if rc == 0 then return $ Right ()
                    else Left <$> rmdfLastError ctx
+
+-- | saveFrameBufferToPNG (FrameBuffer.hs:215-228) for a host that has the frame-buffer vector but no GL
+--   texture to read back: rows flipped to top-down, alpha forced to 0xFF.  The viewer itself does not
+--   need it -- its own screenshot path sees the texture fillFrameBuffer uploaded.
+saveHipFrameBufferToPNG :: FilePath -> Int -> Int -> VSM.IOVector Word32 -> IO (Either String ())
+saveHipFrameBufferToPNG fn w h fbVec =
+    VSM.unsafeWith fbVec $ \p -> withCString fn $ \cfn -> do
+        rc <- c_rmdf_save_png cfn p (fromIntegral w) (fromIntegral h)
+        if rc == 0 then return $ Right ()
+                   else Left <$> rmdfLastError nullPtr

@@ -9,6 +9,7 @@
 //   global T    : a wave with <= T rays left hands them to a global pool; pooled rays are marched 64 at a time in
 //                 hand-over order, re-pooled at <= T again (what a cross-workgroup queue could reach at best)
 //   ideal       : every lane busy in every pass (sum of lane work / 64)
+//   flat T      : lanes iterate independently; escaped lanes wait for a tail pass run when >= T wait (no packets' pooling)
 // Build: make -C tools/ubench sched_sim ; run on an MI355X.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -177,6 +178,36 @@ int main()
         }
         printf("global T=%-2d %27.1f M wave-instr  (x%.3f of nested)  lane utilisation %.3f  pooled rays %zu, %d generations\n",
                T, c / 1e6, c / c_nested, ideal / c, first_pool, gen);
+    }
+    // flat state machine: every lane iterates on its own; a lane whose estimate has escaped waits for a tail pass
+    // (log, division, next position: B instructions), which the wave runs when >= T lanes wait or nobody iterates.
+    // Packets as in `nested` (no pooling): isolates the effect of decoupling the lanes' estimates from each other.
+    for (int T : { 1, 8, 16, 24, 32, 48 }) {
+        double c = 0.0;
+        std::vector<Ray> r;
+        for (int by = 0; by < PY; by++) for (int bx = 0; bx < PX; bx++) {
+            packet(bx, by, r);
+            const int nr = (int)r.size();
+            if (!nr) continue;
+            std::vector<int> left(nr);                 // iterations left in the current estimate; -1 = waiting for the tail; -2 = done
+            for (int i = 0; i < nr; i++) left[i] = kof(r[i].pix, 0);
+            for (;;) {
+                int iterating = 0, waiting = 0;
+                for (int i = 0; i < nr; i++) { if (left[i] > 0) iterating++; else if (left[i] == -1 || left[i] == 0) waiting++; }
+                if (!iterating && !waiting) break;
+                if (waiting >= T || !iterating) {
+                    c += B;
+                    for (int i = 0; i < nr; i++) if (left[i] == -1 || left[i] == 0) {
+                        r[i].step++;
+                        left[i] = r[i].step < g_n[r[i].pix] ? kof(r[i].pix, r[i].step) : -2;
+                    }
+                } else {
+                    c += A;
+                    for (int i = 0; i < nr; i++) if (left[i] > 0) { left[i]--; if (left[i] == 0) left[i] = -1; }
+                }
+            }
+        }
+        printf("flat, tail when >= %-2d wait %10.1f M wave-instr  (x%.3f of nested)  lane utilisation %.3f\n", T, c / 1e6, c / c_nested, ideal / c);
     }
     return 0;
 }
