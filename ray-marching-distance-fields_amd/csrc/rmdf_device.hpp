@@ -504,11 +504,18 @@ __device__ __forceinline__ float seg_dist_sq_table(v3 a, v3 ab, float len, float
 // margin four orders of magnitude above the float32 rounding of the bounds and of the reference's formulas (1e-7).
 // The test is 13 instructions against ~130 for the distance; a wave skips a triangle when all its lanes do (rays of
 // an 8x8 packet are close together): of 32 triangles ~5 survive on average.
-__device__ __forceinline__ float de_cornell_box_table(v3 pos, const float *__restrict__ tab, int prune)
+//
+// Order.  The sooner the running minimum is tight, the more gets skipped, and min() does not care about the order: the
+// triangle that was nearest in this lane's previous estimate (`hint`, taken from the wave's first active lane so that the
+// table reads stay scalar) is evaluated first, then the rest in table order.
+__device__ __forceinline__ float de_cornell_box_table(v3 pos, const float *__restrict__ tab, int prune, int &hint)
 {
     float dist2 = 998001.0f;                                   // 999^2
     float dmax = 1000.0f;
-    for (int i = 0; i < 32; i++) {
+    const int g = prune ? (__builtin_amdgcn_readfirstlane(hint) & 31) : 0;
+    for (int j = 0; j < 33; j++) {
+        const int i = (j == 0) ? g : j - 1;
+        if (j > 0 && i == g) continue;
         const float *t = tab + i * CORNELL_STRIDE;
         if (prune) {
             const float pd = fabsf(((t[26] * pos.x + t[27] * pos.y) + t[28] * pos.z) - t[29]);
@@ -540,6 +547,7 @@ __device__ __forceinline__ float de_cornell_box_table(v3 pos, const float *__res
         if (x < dist2) {
             dist2 = x;
             dmax = __builtin_amdgcn_sqrtf(x) * 1.001f + 1e-5f;
+            hint = i;
         }
     }
     return sqrt_rn(dist2);

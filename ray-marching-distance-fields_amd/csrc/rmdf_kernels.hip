@@ -36,12 +36,13 @@ __device__ __forceinline__ v3 shfl_xor3(v3 a, int mask)
 }
 
 template <int SCENE>
-__device__ __forceinline__ float distance_estimator(v3 pos, const FrameParams &p, unsigned &iters)
+// hint: Cornell only -- the triangle that was nearest in this lane's previous estimate (evaluation order, not a result)
+__device__ __forceinline__ float distance_estimator(v3 pos, const FrameParams &p, unsigned &iters, int &hint)
 {
     if (SCENE == 2)      return de_mandelbulb8(pos, iters);
     else if (SCENE == 3) return de_mandelbulb_general(pos, p.power, iters);
     else if (SCENE == 1) return de_test_scene(pos);
-    else                 return de_cornell_box_table(pos, p.cornell_tab, p.cornell_prune);
+    else                 return de_cornell_box_table(pos, p.cornell_tab, p.cornell_prune, hint);
 }
 
 template <int SCENE>
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
     bool hit = false;
     int steps = 0;
     unsigned iters = 0;
+    int tri_hint = 0;               // Cornell: evaluation-order hint of the distance estimate (never a result)
     float t = 0.0f;
     float tmin, tmax;
     if (!MERGE) {
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
             t = gmax(0.0f, tmin);
             for (steps = 0; steps < p.max_steps; steps++) {
                 v3 pos = mk3(origin.x + t * dir.x, origin.y + t * dir.y, origin.z + t * dir.z);
-                float dist = distance_estimator<SCENE>(pos, p, iters);
+                float dist = distance_estimator<SCENE>(pos, p, iters, tri_hint);
                 t += dist;
                 if (t > tmax) break;
                 if (dist < 0.001f) { hit = true; break; }
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
             // one march step (fragment.shd:661-672) for the rays in flight
             if (act) {
                 const v3 pos = mk3(origin.x + tt * dx, origin.y + tt * dy, origin.z + tt * dz);
-                const float dist = distance_estimator<SCENE>(pos, p, it);
+                const float dist = distance_estimator<SCENE>(pos, p, it, tri_hint);
                 tt += dist;
                 const bool out = tt > tmx;
                 const bool h2 = !out && (dist < 0.001f);
@@ -251,17 +253,17 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
         v3 isec = mk3(origin.x + dir.x * t, origin.y + dir.y * t, origin.z + dir.z * t);
         v3 np = mk3(isec.x - dir.x * 0.00001f, isec.y - dir.y * 0.00001f, isec.z - dir.z * 0.00001f);
         const float eps = 0.00001f;
-        float d0 = distance_estimator<SCENE>(np, p, iters);
-        float dx = distance_estimator<SCENE>(mk3(np.x - eps, np.y - 0.0f, np.z - 0.0f), p, iters);
-        float dy = distance_estimator<SCENE>(mk3(np.x - 0.0f, np.y - eps, np.z - 0.0f), p, iters);
-        float dz = distance_estimator<SCENE>(mk3(np.x - 0.0f, np.y - 0.0f, np.z - eps), p, iters);
+        float d0 = distance_estimator<SCENE>(np, p, iters, tri_hint);
+        float dx = distance_estimator<SCENE>(mk3(np.x - eps, np.y - 0.0f, np.z - 0.0f), p, iters, tri_hint);
+        float dy = distance_estimator<SCENE>(mk3(np.x - 0.0f, np.y - eps, np.z - 0.0f), p, iters, tri_hint);
+        float dz = distance_estimator<SCENE>(mk3(np.x - 0.0f, np.y - 0.0f, np.z - eps), p, iters, tri_hint);
         n = normalize3(mk3(d0 - dx, d0 - dy, d0 - dz));
         // distance_ao (fragment.shd:542-591)
         float occl = 0.0f;
         if (SCENE != 0) {
             const float w0 = 0.5f, e0 = 0.016f, w1 = 0.25f, e1 = 0.081f;
-            occl += w0 * gclamp(1.0f - distance_estimator<SCENE>(mk3(isec.x + n.x * e0, isec.y + n.y * e0, isec.z + n.z * e0), p, iters) / e0, 0.0f, 1.0f);
-            occl += w1 * gclamp(1.0f - distance_estimator<SCENE>(mk3(isec.x + n.x * e1, isec.y + n.y * e1, isec.z + n.z * e1), p, iters) / e1, 0.0f, 1.0f);
+            occl += w0 * gclamp(1.0f - distance_estimator<SCENE>(mk3(isec.x + n.x * e0, isec.y + n.y * e0, isec.z + n.z * e0), p, iters, tri_hint) / e0, 0.0f, 1.0f);
+            occl += w1 * gclamp(1.0f - distance_estimator<SCENE>(mk3(isec.x + n.x * e1, isec.y + n.y * e1, isec.z + n.z * e1), p, iters, tri_hint) / e1, 0.0f, 1.0f);
             occl = 1.0f - occl;
             occl -= 0.29f;
             occl *= 3.5f;
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
             const float wt[4] = { 0.1f, 0.2f, 0.125f, 0.0625f }, dl[4] = { 0.1f, 0.2f, 0.4f, 0.5f };
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                occl += wt[k] * gclamp(1.0f - distance_estimator<SCENE>(mk3(isec.x + n.x * dl[k], isec.y + n.y * dl[k], isec.z + n.z * dl[k]), p, iters) / dl[k], 0.0f, 1.0f);
+                occl += wt[k] * gclamp(1.0f - distance_estimator<SCENE>(mk3(isec.x + n.x * dl[k], isec.y + n.y * dl[k], isec.z + n.z * dl[k]), p, iters, tri_hint) / dl[k], 0.0f, 1.0f);
             ao = 1.0f - occl;
         }
         fresnel = fresnel_conductor(dot3(mk3(-dir.x, -dir.y, -dir.z), n), 0.4f, 0.8f);

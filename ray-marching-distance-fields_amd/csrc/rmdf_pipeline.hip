@@ -31,7 +31,7 @@ __device__ __forceinline__ float pl_de(v3 pos, const FrameParams &p, unsigned &i
     if (SCENE == 2)      return de_mandelbulb8(pos, iters);
     else if (SCENE == 3) return de_mandelbulb_general(pos, p.power, iters);
     else if (SCENE == 1) return de_test_scene(pos);
-    else                 return de_cornell_box_table(pos, p.cornell_tab, p.cornell_prune);
+    else                 { int hint = 0; return de_cornell_box_table(pos, p.cornell_tab, p.cornell_prune, hint); }   // no order hint in this schedule
 }
 
 template <int SCENE>
