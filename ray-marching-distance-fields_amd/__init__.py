@@ -110,10 +110,11 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("RMDF_LIB", LIB_PATH)          # measurement knob: an alternative build of the same sources
+    if not os.path.exists(path):
         raise RmdfError(-2, "librmdf.so is not built (run __graft_entry__.build() or `make -C %s`); "
                             "there is no CPU fallback" % CSRC)
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, ip = C.c_void_p, C.POINTER(C.c_int)
     L.rmdf_create.argtypes = [C.POINTER(vp), vp]
     L.rmdf_destroy.argtypes = [vp]
