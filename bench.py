@@ -248,6 +248,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
+    host_enqueue_ms = (time.perf_counter() - t0) / a.steps * 1e3      # host time to issue one step (this rank)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0, dist, dev)
     ms_per_step = dt / a.steps * 1e3
@@ -313,7 +314,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": round(kern_ms, 4),
                          "kernel_ms_min": round(kern_ms_min, 4),
                          "note": "VALU-bound path (SURVEY 8d): HBM fraction is a sanity figure, see valu_roofline"},
-            "d2h_inclusive_mpixels_s": round(d2h_rate, 2),
+            "d2h_inclusive_mpixels_s": round(d2h_rate, 2), "host_enqueue_ms_per_step_rank0": round(host_enqueue_ms, 4),
         }
         if (not a.no_cpu_baseline or a.check) and L == 0:
             from oracle import orc
@@ -332,6 +333,22 @@ def main():
             result["cpu_baseline"] = {"value": round(mpix / cpu_dt, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
                                       "sample": "1 full frame %dx%d of the same workload, CPU oracle (C port of fragment.shd), "
                                                 "row segments over all host cores as ConcurrentSegments does" % (w, h)}
+            # the reference's own CPU paths (BASELINE.json north_star: "timed on the same box's host cores ... as the
+            # reported, non-target baseline"), as their C restatements with the reference's threading model
+            # (SURVEY.md 8d): Fractal2D.juliaAnimated over all cores in row segments; cosineConvolveHDREnvMap with one
+            # thread per power (ShaderRendering.hs:142) -- one power timed on one thread -- and split over all cores
+            d = os.path.join(rmdf_amd.DATA_DIR, "latlong_envmaps")
+            small = orc.resize_hdr(orc.hdr_decode(open(os.path.join(d, "uffizi_512.hdr"), "rb").read()), 256)
+            tj0 = time.perf_counter(); orc.julia_animated(512, 512, 0, 0.0); tj = time.perf_counter() - tj0
+            tc0 = time.perf_counter(); orc.cosine_convolve(small, 8.0, nthreads=1); tc1 = time.perf_counter() - tc0
+            tc0 = time.perf_counter(); orc.cosine_convolve(small, 8.0, nthreads=0); tca = time.perf_counter() - tc0
+            tg0 = time.perf_counter(); sr.prefilter_env(small, 8.0); tg = time.perf_counter() - tg0
+            result["cpu_reference_paths"] = {
+                "cores": cores, "kind": "port",
+                "julia_animated_512x512_ms": round(tj * 1e3, 2), "julia_animated_mpixels_s": round(0.262144 / tj, 1),
+                "cosine_convolve_256x128_power8_one_thread_s": round(tc1, 3),
+                "cosine_convolve_256x128_power8_all_cores_s": round(tca, 3),
+                "gpu_prefilter_256x128_power8_ms_host_in_out": round(tg * 1e3, 3)}
             if a.check:
                 result["check_rgba8_equal"] = all(bool(np.array_equal(f.cpu().numpy().view(np.uint32), ref["rgba8"]))
                                                   for f in frames)

@@ -101,22 +101,13 @@ __device__ __forceinline__ v3 reflect3(v3 i, v3 n)
     return mk3(i.x - k * n.x, i.y - k * n.y, i.z - k * n.z);
 }
 
-// log(x), fixed operation order; < 1 ulp
-__device__ __forceinline__ float log_pinned(float x)
+// log(x), fixed operation order; < 1 ulp.  log_core: x positive and normal, k0 = exponent offset.
+__device__ __forceinline__ float log_core(float x, int32_t k0)
 {
     const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
     const float Lg1 = 0.66666662693f, Lg2 = 0.40000972152f, Lg3 = 0.28498786688f, Lg4 = 0.24279078841f;
     int32_t ix = __float_as_int(x);
-    int32_t k = 0;
-    if (ix < 0x00800000) {
-        if ((ix & 0x7fffffff) == 0) return -__builtin_inff();
-        if (ix < 0) return __builtin_nanf("");
-        k = -25;
-        x = x * 33554432.0f;
-        ix = __float_as_int(x);
-    }
-    if (ix >= 0x7f800000) return x + x;
-    k += (ix >> 23) - 127;
+    int32_t k = k0 + ((ix >> 23) - 127);
     ix &= 0x007fffff;
     int32_t i = (ix + 0x4afb20) & 0x800000;
     x = __int_as_float(ix | (i ^ 0x3f800000));
@@ -131,6 +122,23 @@ __device__ __forceinline__ float log_pinned(float x)
     float R = t2 + t1;
     float hfsq = (0.5f * f) * f;
     return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+// zero, negative, subnormal, inf, NaN
+__device__ __noinline__ float log_special(float x)
+{
+    int32_t ix = __float_as_int(x);
+    if ((ix & 0x7fffffff) == 0) return -__builtin_inff();
+    if (ix < 0) return __builtin_nanf("");
+    if (ix >= 0x7f800000) return x + x;
+    return log_core(x * 33554432.0f, -25);    // subnormal: scale by 2^25
+}
+// The core runs unconditionally; lanes outside the positive normal range are recomputed on a wave-uniform branch.
+__device__ __forceinline__ float log_pinned(float x)
+{
+    const bool special = (__float_as_uint(x) - 0x00800000u) >= (0x7f800000u - 0x00800000u);
+    float r = log_core(x, 0);
+    if (__builtin_expect(__ballot(special) != 0ull, 0)) { if (special) r = log_special(x); }
+    return r;
 }
 
 // exp(x), fixed operation order; x < -87 -> 0, x > 88.5 -> inf
