@@ -30,6 +30,21 @@ m, r = time_render(0, 1280, 720, 128)
 out["C2 CornellBox 1280x720/128"] = {"ms": round(m, 4), "Mpixels/s": round(r, 1)}
 m, r = time_render(2, 1920, 1080, 256)
 out["C3 Mandelbulb 1920x1080/256"] = {"ms": round(m, 4), "Mpixels/s": round(r, 1)}
+# the reference's tiled dispatch: 64 drawShaderTile calls per frame, each returning the whole accumulated frame to a host buffer
+fbv = np.empty(1920 * 1080, np.uint32)
+for idx in range(64):
+    sr.draw_shader_tile(2, idx, 1920, 1080, 0.0, fbv, max_steps=256)
+t0 = time.perf_counter()
+for idx in range(64):
+    sr.draw_shader_tile(2, idx, 1920, 1080, 0.0, fbv, max_steps=256)
+tt = time.perf_counter() - t0
+out["C3 tiled: 64 drawShaderTile calls (each copies the whole frame to the host, as fillFrameBuffer's orphaned PBO requires)"] = {
+    "ms per frame of 64 tiles": round(tt * 1e3, 2), "ms per call": round(tt / 64 * 1e3, 3), "Mpixels/s": round(1920 * 1080 / 1e6 / tt, 1)}
+t0 = time.perf_counter()
+for _ in range(20):
+    sr.draw_shader_tile(2, None, 1920, 1080, 0.0, fbv, max_steps=256)
+tt = (time.perf_counter() - t0) / 20
+out["C3 untiled through the host-buffer boundary (drawShaderTile Nothing)"] = {"ms": round(tt * 1e3, 3), "Mpixels/s": round(1920 * 1080 / 1e6 / tt, 1)}
 m, r = time_render(2, 7680, 4320, 256, n=5)
 out["C4 Mandelbulb 7680x4320 rays (4 rays/px of 3840x2160), 1 GPU, no resolve"] = {"ms": round(m, 3), "Mrays/s": round(r, 1)}
 # C5: env prefilter: synthetic 2048x1024 latlong -> resize 256 -> 4 powers (host buffers in/out, PCIe included)
