@@ -159,7 +159,7 @@ void cornell_triangles(float out[96 * 3])
 
 // per-triangle constants of de_cornell_box_table: the operation order of de_triangle / line_seg_min_dist_sq
 // (fragment.shd:312-372), evaluated once here instead of once per lane and distance estimate
-void cornell_table(const float tri[96 * 3], float tab[32 * CORNELL_STRIDE])
+void cornell_table(const float tri[96 * 3], float tab[CORNELL_TAB_FLOATS])
 {
     for (int i = 0; i < 32; i++) {
         const float *v0 = tri + i * 9, *v1 = v0 + 3, *v2 = v0 + 6;
@@ -197,6 +197,9 @@ void cornell_table(const float tri[96 * 3], float tab[32 * CORNELL_STRIDE])
             t[34] = t[35] = 0.0f;
         }
     }
+    // compact copy of the pruning bounds behind the rows (read four triangles at a time)
+    for (int i = 0; i < 32; i++)
+        for (int k = 0; k < 8; k++) tab[32 * CORNELL_STRIDE + i * 8 + k] = tab[i * CORNELL_STRIDE + 26 + k];
 }
 
 int ensure_frame(rmdf_ctx *ctx, int w, int h)
@@ -560,7 +563,7 @@ int rmdf_create(rmdf_ctx **out, const rmdf_config *cfg)
     snprintf(ctx->dev_name, sizeof ctx->dev_name, "%s (%s)", prop.name, prop.gcnArchName);
     float tri[96 * 3];
     cornell_triangles(tri);
-    float tab[32 * CORNELL_STRIDE];
+    float tab[CORNELL_TAB_FLOATS];
     cornell_table(tri, tab);
     if ((e = hipSetDevice(dev)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||

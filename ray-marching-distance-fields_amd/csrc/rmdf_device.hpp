@@ -484,7 +484,9 @@ __device__ __forceinline__ float de_cornell_box(v3 pos, const float *__restrict_
 //     quotient for these 96 divisors (checked for every numerator bit pattern by rmdf_selftest_exact_math); numerators
 //     outside 2^-60..2^60 (zeros included) take the compiler's division;
 //   * min over sqrt(x_i) = sqrt(min over x_i): correctly rounded sqrt is monotone, and 999 = sqrt(998001) exactly.
+// Behind the 32 rows: a compact copy of the pruning bounds, 32 x 8 floats (t[26..33] of every row).
 #define CORNELL_STRIDE 36
+#define CORNELL_TAB_FLOATS (32 * CORNELL_STRIDE + 32 * 8)
 __device__ __forceinline__ float div_by_table(float x, float len, float rlen)
 {
     const float q0 = x * rlen;
@@ -516,53 +518,76 @@ __device__ __forceinline__ float seg_dist_sq_table(v3 a, v3 ab, float len, float
 // Order.  The sooner the running minimum is tight, the more gets skipped, and min() does not care about the order: the
 // triangle that was nearest in this lane's previous estimate (`hint`, taken from the wave's first active lane so that the
 // table reads stay scalar) is evaluated first, then the rest in table order.
+typedef const float __attribute__((address_space(4))) cfloat;     // constant address space: wave-uniform reads become s_loads
+
+// squared distance to triangle row t (de_triangle, fragment.shd:348-372, constants from the table)
+__device__ __forceinline__ float cornell_tri_dist2(v3 pos, cfloat *t)
+{
+    const v3 v0 = mk3(t[0], t[1], t[2]), v1 = mk3(t[3], t[4], t[5]), v2 = mk3(t[6], t[7], t[8]);
+    const v3 e0 = mk3(t[9], t[10], t[11]), e1 = mk3(t[12], t[13], t[14]);
+    const float dot00 = t[15], dot01 = t[16], dot11 = t[17], inv_denom = t[18];
+    const v3 e12 = mk3(t[19], t[20], t[21]);
+    const float len12 = t[22], r00 = t[23], r11 = t[24], r12 = t[25];
+    const v3 e2 = sub3(pos, v0);
+    const float dot02 = dot3(e0, e2), dot12 = dot3(e1, e2);
+    const float u = (dot11 * dot02 - dot01 * dot12) * inv_denom;
+    const float v = (dot00 * dot12 - dot01 * dot02) * inv_denom;
+    if ((u >= 0.0f) && (v >= 0.0f) && (u + v < 1.0f)) {
+        const float k = 1.0f - (u + v);
+        const v3 pp = mk3(v2.x * u + v1.x * v + v0.x * k, v2.y * u + v1.y * v + v0.y * k, v2.z * u + v1.z * v + v0.z * k);
+        const v3 d = sub3(pos, pp);
+        return dot3(d, d);
+    }
+    const float s01 = seg_dist_sq_table(v0, e1, dot11, r11, e2, pos);                 // segment v0 v1: ab = e1
+    const float s02 = seg_dist_sq_table(v0, e0, dot00, r00, e2, pos);                 // segment v0 v2: ab = e0
+    const float s12 = seg_dist_sq_table(v1, e12, len12, r12, sub3(pos, v1), pos);     // segment v1 v2
+    return gmin(s01, gmin(s02, s12));
+}
+
 __device__ __forceinline__ float de_cornell_box_table(v3 pos, const float *__restrict__ tab, int prune, int &hint)
 {
     float dist2 = 998001.0f;                                   // 999^2
-    float dmax = 1000.0f;
-    const int g = prune ? (__builtin_amdgcn_readfirstlane(hint) & 31) : 0;
     // The table is read-only for the whole launch and every index below is wave-uniform: address it through the
     // constant address space so that the rows come in by scalar loads (s_load into SGPRs, used as instruction
     // operands).  Through a plain global pointer the compiler issues vector loads -- 9 global_load_dwordx4 and 27
     // VGPRs per triangle, with the memory latency exposed in front of every distance (measured: 0.23 G VALU
     // instructions/s/SIMD, waves waiting 68 % of the time).
-    typedef const float __attribute__((address_space(4))) cfloat;
     cfloat *ctab = (cfloat *)tab;
-    for (int j = 0; j < 33; j++) {
-        const int i = (j == 0) ? g : j - 1;
-        if (j > 0 && i == g) continue;
-        cfloat *t = ctab + i * CORNELL_STRIDE;
-        if (prune) {
-            const float pd = fabsf(((t[26] * pos.x + t[27] * pos.y) + t[28] * pos.z) - t[29]);
-            const v3 dc = mk3(pos.x - t[30], pos.y - t[31], pos.z - t[32]);
-            const float rs = t[33] + dmax;
+    if (!prune) {
+        for (int i = 0; i < 32; i++) {
+            const float x = cornell_tri_dist2(pos, ctab + i * CORNELL_STRIDE);
+            dist2 = (x < dist2) ? x : dist2;
+        }
+        return sqrt_rn(dist2);
+    }
+    // the triangle that was nearest last time first, unconditionally
+    const int g = __builtin_amdgcn_readfirstlane(hint) & 31;
+    dist2 = cornell_tri_dist2(pos, ctab + g * CORNELL_STRIDE);
+    float dmax = __builtin_amdgcn_sqrtf(dist2) * 1.001f + 1e-5f;
+    hint = g;
+    // then the rest in table order, four at a time: the bounds of four triangles (32 floats of the compact bounds table
+    // behind the rows) arrive with two wide scalar loads, so the tests do not each wait for their own load
+    cfloat *btab = ctab + 32 * CORNELL_STRIDE;
+#pragma unroll 1
+    for (int c = 0; c < 8; c++) {
+        cfloat *b = btab + c * 32;
+        float bb[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) bb[k] = b[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = c * 4 + k;
+            if (i == g) continue;
+            const float pd = fabsf(((bb[8 * k] * pos.x + bb[8 * k + 1] * pos.y) + bb[8 * k + 2] * pos.z) - bb[8 * k + 3]);
+            const v3 dc = mk3(pos.x - bb[8 * k + 4], pos.y - bb[8 * k + 5], pos.z - bb[8 * k + 6]);
+            const float rs = bb[8 * k + 7] + dmax;
             if ((pd > dmax) || (dot3(dc, dc) > rs * rs)) continue;
-        }
-        const v3 v0 = mk3(t[0], t[1], t[2]), v1 = mk3(t[3], t[4], t[5]), v2 = mk3(t[6], t[7], t[8]);
-        const v3 e0 = mk3(t[9], t[10], t[11]), e1 = mk3(t[12], t[13], t[14]);
-        const float dot00 = t[15], dot01 = t[16], dot11 = t[17], inv_denom = t[18];
-        const v3 e12 = mk3(t[19], t[20], t[21]);
-        const float len12 = t[22], r00 = t[23], r11 = t[24], r12 = t[25];
-        const v3 e2 = sub3(pos, v0);
-        const float dot02 = dot3(e0, e2), dot12 = dot3(e1, e2);
-        const float u = (dot11 * dot02 - dot01 * dot12) * inv_denom;
-        const float v = (dot00 * dot12 - dot01 * dot02) * inv_denom;
-        float x;
-        if ((u >= 0.0f) && (v >= 0.0f) && (u + v < 1.0f)) {
-            const float k = 1.0f - (u + v);
-            const v3 pp = mk3(v2.x * u + v1.x * v + v0.x * k, v2.y * u + v1.y * v + v0.y * k, v2.z * u + v1.z * v + v0.z * k);
-            const v3 d = sub3(pos, pp);
-            x = dot3(d, d);
-        } else {
-            const float s01 = seg_dist_sq_table(v0, e1, dot11, r11, e2, pos);                 // segment v0 v1: ab = e1
-            const float s02 = seg_dist_sq_table(v0, e0, dot00, r00, e2, pos);                 // segment v0 v2: ab = e0
-            const float s12 = seg_dist_sq_table(v1, e12, len12, r12, sub3(pos, v1), pos);     // segment v1 v2
-            x = gmin(s01, gmin(s02, s12));
-        }
-        if (x < dist2) {
-            dist2 = x;
-            dmax = __builtin_amdgcn_sqrtf(x) * 1.001f + 1e-5f;
-            hint = i;
+            const float x = cornell_tri_dist2(pos, ctab + i * CORNELL_STRIDE);
+            if (x < dist2) {
+                dist2 = x;
+                dmax = __builtin_amdgcn_sqrtf(x) * 1.001f + 1e-5f;
+                hint = i;
+            }
         }
     }
     return sqrt_rn(dist2);
