@@ -26,7 +26,7 @@ using namespace rmdf;
 
 struct Cam { float c[12]; float fov_xs; };
 
-__global__ void k_trace(Cam cam, unsigned char *trace, unsigned short *nsteps)
+__global__ void k_trace(Cam cam, unsigned char *trace, unsigned short *nsteps, unsigned char *k_normal)
 {
     const int px = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y;
     if (px >= W) return;
@@ -39,6 +39,7 @@ __global__ void k_trace(Cam cam, unsigned char *trace, unsigned short *nsteps)
     const v3 origin = mk3(c[9], c[10], c[11]);
     float tmin, tmax;
     int n = 0;
+    unsigned char kn = 0;
     if (ray_sphere(origin, dir, 1.15f, tmin, tmax)) {
         float t = gmax(0.0f, tmin);
         for (int s = 0; s < MS; s++) {
@@ -48,9 +49,17 @@ __global__ void k_trace(Cam cam, unsigned char *trace, unsigned short *nsteps)
             n = s + 1;
             t += dist;
             if (t > tmax) break;
-            if (dist < 0.001f) break;
+            if (dist < 0.001f) {
+                // hit: k of the distance estimate at the finite-difference base point (the normal's four estimates share it)
+                unsigned it2 = 0;
+                const v3 isec = mk3(origin.x + dir.x * t, origin.y + dir.y * t, origin.z + dir.z * t);
+                (void)de_mandelbulb8(mk3(isec.x - dir.x * 0.00001f, isec.y - dir.y * 0.00001f, isec.z - dir.z * 0.00001f), it2);
+                kn = (unsigned char)(it2 + 1);                  // +1: 0 means "no hit"
+                break;
+            }
         }
     }
+    k_normal[(size_t)py * W + px] = kn;
     nsteps[(size_t)py * W + px] = (unsigned short)n;     // distance estimates taken (= march passes of this ray)
 }
 
@@ -103,14 +112,17 @@ int main()
     Cam cam;
     host_camera(cam.c, &cam.fov_xs);
     const size_t npx = (size_t)W * H;
-    unsigned char *d_trace; unsigned short *d_n;
-    if (hipMalloc((void **)&d_trace, npx * MS) != hipSuccess || hipMalloc((void **)&d_n, npx * 2) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    unsigned char *d_trace, *d_kn; unsigned short *d_n;
+    if (hipMalloc((void **)&d_trace, npx * MS) != hipSuccess || hipMalloc((void **)&d_n, npx * 2) != hipSuccess ||
+        hipMalloc((void **)&d_kn, npx) != hipSuccess) { printf("alloc failed\n"); return 1; }
     hipMemset(d_trace, 0, npx * MS);
-    hipLaunchKernelGGL(k_trace, dim3((W + 63) / 64, H), dim3(64), 0, 0, cam, d_trace, d_n);
+    hipLaunchKernelGGL(k_trace, dim3((W + 63) / 64, H), dim3(64), 0, 0, cam, d_trace, d_n, d_kn);
     std::vector<unsigned char> trace(npx * MS);
     std::vector<unsigned short> n(npx);
     if (hipMemcpy(trace.data(), d_trace, npx * MS, hipMemcpyDeviceToHost) != hipSuccess) { printf("copy failed\n"); return 1; }
     hipMemcpy(n.data(), d_n, npx * 2, hipMemcpyDeviceToHost);
+    std::vector<unsigned char> kn(npx);
+    hipMemcpy(kn.data(), d_kn, npx, hipMemcpyDeviceToHost);
     g_trace = trace.data(); g_n = n.data();
     double evals = 0, iters = 0; int maxn = 0;
     for (size_t i = 0; i < npx; i++) { evals += n[i]; if (n[i] > maxn) maxn = n[i]; for (int s = 0; s < n[i]; s++) iters += kof((int)i, s); }
@@ -208,6 +220,81 @@ int main()
             }
         }
         printf("flat, tail when >= %-2d wait %10.1f M wave-instr  (x%.3f of nested)  lane utilisation %.3f\n", T, c / 1e6, c / c_nested, ideal / c);
+    }
+    // Event-driven replay of the four waves of a workgroup running concurrently (each wave's clock advances by the cost
+    // of its wave-steps; the wave with the smallest clock moves next), for two pooling policies at threshold T = 32:
+    //   host     : what k_render<.., MERGE> does -- the first wave down to <= T rays becomes the host and keeps marching;
+    //              every other wave that gets down to <= T hands its rays to the host's mailbox and leaves; the host adopts
+    //              mail into idle lanes at step boundaries
+    //   exchange : a wave down to <= T rays adopts posted mail if there is any (as far as idle lanes allow), otherwise it
+    //              posts its own rays and leaves; a wave that runs out of rays adopts posted mail too; rays may wait in a
+    //              mailbox until the next wave comes by (the last wave standing takes everything)
+    for (int policy = 0; policy < 2; policy++) {
+        const int T = 32;
+        double c = 0.0, wait_cost = 0.0;
+        for (int by = 0; by < PY; by++) for (int sx = 0; sx < (PX + 3) / 4; sx++) {
+            std::vector<Ray> wv[4], mail;            // rays in flight per wave; posted rays
+            double clk[4] = { 0, 0, 0, 0 };
+            bool alive[4] = { false, false, false, false };
+            int host = -1, nalive = 0;
+            for (int q = 0; q < 4; q++) { const int bx = sx * 4 + q; if (bx >= PX) break; packet(bx, by, wv[q]); alive[q] = !wv[q].empty(); nalive += alive[q]; }
+            while (nalive > 0) {
+                int w = -1;
+                for (int q = 0; q < 4; q++) if (alive[q] && (w < 0 || clk[q] < clk[w])) w = q;
+                std::vector<Ray> &r = wv[w];
+                // step boundary decisions
+                if (policy == 0) {
+                    if ((int)r.size() <= T && host < 0) host = w;
+                    if (w == host) { while (r.size() < 64 && !mail.empty()) { r.push_back(mail.back()); mail.pop_back(); } }
+                    else if ((int)r.size() <= T && host >= 0) { mail.insert(mail.end(), r.begin(), r.end()); r.clear(); }
+                    if (r.empty()) {
+                        if (w == host && nalive > 1) { // host idles until mail arrives: jump its clock to the next wave's
+                            double nxt = 1e300; for (int q = 0; q < 4; q++) if (alive[q] && q != w && clk[q] < nxt) nxt = clk[q];
+                            clk[w] = nxt + 1e-9; continue;
+                        }
+                        alive[w] = false; nalive--; continue;
+                    }
+                } else {
+                    if ((int)r.size() <= T) {
+                        if (!mail.empty() || nalive == 1) { while (r.size() < 64 && !mail.empty()) { r.push_back(mail.back()); mail.pop_back(); } }
+                        else if (nalive > 1) { mail.insert(mail.end(), r.begin(), r.end()); r.clear(); }
+                    }
+                    if (r.empty()) { alive[w] = false; nalive--; if (nalive == 0 && !mail.empty()) { alive[w] = true; nalive = 1; r.swap(mail); } continue; }
+                }
+                // one wave-step
+                int mk = 0;
+                for (auto &x : r) { const int k = kof(x.pix, x.step); if (k > mk) mk = k; }
+                const double cost = A * mk + B;
+                c += cost; clk[w] += cost;
+                std::vector<Ray> nr;
+                for (auto &x : r) { x.step++; if (x.step < g_n[x.pix]) nr.push_back(x); }
+                r.swap(nr);
+            }
+            (void)wait_cost;
+        }
+        printf("event-driven wg-pool T=32, %-8s %10.1f M wave-instr  (x%.3f of nested)  lane utilisation %.3f\n",
+               policy == 0 ? "host" : "exchange", c / 1e6, c / c_nested, ideal / c);
+    }
+    // normal estimates: the four estimates of a hit pixel share k; a wave pays max k over its hit lanes.  What would
+    // regrouping the hit pixels of a workgroup (32x8 strip, 4 waves) by k save?
+    {
+        double now = 0, sorted = 0, lanes = 0;
+        for (int by = 0; by < PY; by++) for (int sx = 0; sx < (PX + 3) / 4; sx++) {
+            std::vector<int> ks;
+            for (int q = 0; q < 4; q++) {
+                const int bx = sx * 4 + q; if (bx >= PX) break;
+                int mk = 0;
+                for (int ly = 0; ly < 8; ly++) for (int lx = 0; lx < 8; lx++) {
+                    const int x = bx * 8 + lx, y = by * 8 + ly;
+                    if (x < W && y < H && kn[(size_t)y * W + x]) { const int k = kn[(size_t)y * W + x] - 1; ks.push_back(k); if (k > mk) mk = k; lanes += k; }
+                }
+                now += mk;
+            }
+            std::sort(ks.begin(), ks.end(), [](int a, int b) { return a > b; });
+            for (size_t i = 0; i < ks.size(); i += 64) sorted += ks[i];
+        }
+        printf("normal estimates (per estimate): wave passes now %.3e, hit pixels of a workgroup regrouped by k %.3e (x%.3f); lane utilisation %.3f -> %.3f\n",
+               now, sorted, sorted / now, lanes / 64 / now, lanes / 64 / sorted);
     }
     return 0;
 }
