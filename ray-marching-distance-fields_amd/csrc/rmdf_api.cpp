@@ -64,6 +64,12 @@ struct rmdf_ctx {
     float        shard_cost[64];
     bool         shard_cost_set = false;
     unsigned     shard_cost_gen = 0;
+    // the deal of the last (nranks, cost generation) asked for: per-frame calls must not redo the sort
+    int          deal_nranks = 0;
+    unsigned     deal_gen = ~0u;
+    unsigned char deal_tiles[64][64];
+    int          deal_count[64];
+    ShardWhere   deal_where;
     OrderState   orders[RMDF_MAX_ORDER_STREAMS];
     unsigned     order_tick = 0;
     unsigned long long *d_dbg = nullptr;   // per-wave march diagnostics (rmdf_debug_march_stats)
@@ -309,6 +315,17 @@ int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t str
         HIP_TRY(ctx, launch_render(scene, q, stream));
     }
     return RMDF_OK;
+}
+
+// the deal in effect for `nranks` ranks, computed once per (nranks, set of costs)
+void ensure_deal(rmdf_ctx *ctx, int nranks)
+{
+    if (ctx->deal_nranks == nranks && ctx->deal_gen == ctx->shard_cost_gen) return;
+    for (int r = 0; r < nranks; r++) {
+        ctx->deal_count[r] = shard_tiles_of_rank(r, nranks, ctx->deal_tiles[r], ctx->shard_cost_set ? ctx->shard_cost : nullptr);
+        for (int s = 0; s < ctx->deal_count[r]; s++) ctx->deal_where.v[ctx->deal_tiles[r][s]] = (unsigned short)((r << 8) | s);
+    }
+    ctx->deal_nranks = nranks; ctx->deal_gen = ctx->shard_cost_gen;
 }
 
 int fill_params(rmdf_ctx *ctx, int scene, int w, int h, float time, int max_steps, FrameParams &p)
@@ -774,7 +791,9 @@ int rmdf_render_shard_device(rmdf_ctx *ctx, int scene, int w, int h, double time
     FrameParams p;
     int rc = fill_params(ctx, scene, w, h, (float)time, max_steps, p);
     if (rc != RMDF_OK) return rc;
-    p.n_shard_tiles = shard_tiles_of_rank(rank, nranks, p.shard_tile, ctx->shard_cost_set ? ctx->shard_cost : nullptr);
+    ensure_deal(ctx, nranks);
+    p.n_shard_tiles = ctx->deal_count[rank];
+    memcpy(p.shard_tile, ctx->deal_tiles[rank], sizeof p.shard_tile);
     p.shard_key = (int)(ctx->shard_cost_gen << 16) + rank * 256 + nranks;
     p.rgba8 = (uint32_t *)d_packed_rgba8;
     return launch_scene(ctx, scene, p, stream ? (hipStream_t)stream : ctx->stream);
@@ -806,10 +825,9 @@ int rmdf_get_shard_tiles(rmdf_ctx *ctx, int rank, int nranks, int tiles[64])
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
     if (nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks || !tiles) return fail(ctx, RMDF_E_INVALID, "rmdf_get_shard_tiles: bad argument");
-    unsigned char t[64];
-    const int cnt = shard_tiles_of_rank(rank, nranks, t, ctx->shard_cost_set ? ctx->shard_cost : nullptr);
-    for (int i = 0; i < cnt; i++) tiles[i] = t[i];
-    return cnt;
+    ensure_deal(ctx, nranks);
+    for (int i = 0; i < ctx->deal_count[rank]; i++) tiles[i] = ctx->deal_tiles[rank][i];
+    return ctx->deal_count[rank];
 }
 
 int rmdf_probe_tile_costs(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps, float cost[64])
@@ -859,8 +877,8 @@ int rmdf_assemble_shards_device(rmdf_ctx *ctx, int w, int h, int nranks, const v
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
     if (nranks < 1 || nranks > 64 || !d_gathered || !d_frame_rgba8 || w % 8 || h % 8 || w <= 0 || h <= 0)
         return fail(ctx, RMDF_E_INVALID, "rmdf_assemble_shards_device: bad argument");
-    HIP_TRY(ctx, launch_assemble_shards((const uint32_t *)d_gathered, (uint32_t *)d_frame_rgba8, w, h, nranks,
-                                        ctx->shard_cost_set ? ctx->shard_cost : nullptr,
+    ensure_deal(ctx, nranks);
+    HIP_TRY(ctx, launch_assemble_shards((const uint32_t *)d_gathered, (uint32_t *)d_frame_rgba8, w, h, nranks, ctx->deal_where,
                                         stream ? (hipStream_t)stream : ctx->stream));
     return RMDF_OK;
 }

@@ -119,7 +119,9 @@ hipError_t launch_cube_upload(const float *d_faces_f32, int W, uint2 *d_padded, 
 hipError_t launch_latlong_to_cube(const float *d_latlong, int w, int h, float *d_faces_f32, hipStream_t stream);
 hipError_t launch_resize_latlong(const float *d_src, int sw, int sh, int dstw, int dsth, float *d_out, hipStream_t stream);
 hipError_t launch_prefilter(const float *d_src, int w, int h, float power, float *d_out, hipStream_t stream);
-hipError_t launch_assemble_shards(const uint32_t *d_gathered, uint32_t *d_frame, int w, int h, int nranks, const float *tile_cost,
+// where[tile idx] = rank << 8 | slot under the deal in effect (built by the caller, cached per ctx)
+struct ShardWhere { unsigned short v[64]; };
+hipError_t launch_assemble_shards(const uint32_t *d_gathered, uint32_t *d_frame, int w, int h, int nranks, const ShardWhere &where,
                                   hipStream_t stream);
 
 

@@ -593,8 +593,6 @@ hipError_t launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t 
 
 // After the gather: shard r holds the tiles shard_tiles_of_rank(r, n) in slots 0,1,2,...; every rank's shard has
 // ceil(64/n) slots.  where.v[tile idx] = rank << 8 | slot.  One thread per frame pixel (coalesced writes).
-struct ShardWhere { unsigned short v[64]; };
-
 __global__ void k_assemble_shards(const uint32_t *__restrict__ gathered, uint32_t *__restrict__ frame,
                                   int w, int h, int nranks, const ShardWhere where)
 {
@@ -612,14 +610,29 @@ __global__ void k_assemble_shards(const uint32_t *__restrict__ gathered, uint32_
     }
 }
 
-hipError_t launch_assemble_shards(const uint32_t *d_gathered, uint32_t *d_frame, int w, int h, int nranks, const float *tile_cost,
+// same, four pixels per thread (16-byte loads and stores, one tile lookup per thread): tiles whose width is a multiple of 4.
+// HBM-bound: 8 B per pixel (4 read + 4 written).
+__global__ void k_assemble_shards_x4(const uint4 *__restrict__ gathered, uint4 *__restrict__ frame,
+                                     int w, int h, int nranks, const ShardWhere where)
+{
+    const int tw4 = w / 32, th = h / 8, w4 = w / 4;            // tile width and frame width in uint4 units
+    const int slots = (64 + nranks - 1) / nranks;
+    const int x4 = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y;
+    if (x4 >= w4) return;
+    const int tx = x4 / tw4, ty = py / th;
+    const int rs = where.v[tx + ty * 8];
+    const int rank = rs >> 8, slot = rs & 255;
+    const size_t src = ((size_t)rank * slots + slot) * (size_t)tw4 * th + (size_t)(x4 - tx * tw4) + (size_t)(py - ty * th) * tw4;
+    frame[(size_t)py * w4 + x4] = gathered[src];
+}
+
+hipError_t launch_assemble_shards(const uint32_t *d_gathered, uint32_t *d_frame, int w, int h, int nranks, const ShardWhere &where,
                                   hipStream_t stream)
 {
-    ShardWhere where;
-    for (int r = 0; r < nranks; r++) {
-        unsigned char tiles[64];
-        const int cnt = shard_tiles_of_rank(r, nranks, tiles, tile_cost);
-        for (int s = 0; s < cnt; s++) where.v[tiles[s]] = (unsigned short)((r << 8) | s);
+    if (w % 32 == 0 && ((uintptr_t)d_gathered % 16) == 0 && ((uintptr_t)d_frame % 16) == 0) {
+        hipLaunchKernelGGL(k_assemble_shards_x4, dim3((w / 4 + 255) / 256, h), dim3(256), 0, stream,
+                           (const uint4 *)d_gathered, (uint4 *)d_frame, w, h, nranks, where);
+        return hipGetLastError();
     }
     size_t n = (size_t)w * h;
     int blocks = (int)((n + 255) / 256);
