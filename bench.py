@@ -316,7 +316,7 @@ def main():
                          "note": "VALU-bound path (SURVEY 8d): HBM fraction is a sanity figure, see valu_roofline"},
             "d2h_inclusive_mpixels_s": round(d2h_rate, 2), "host_enqueue_ms_per_step_rank0": round(host_enqueue_ms, 4),
         }
-        if (not a.no_cpu_baseline or a.check) and L == 0:
+        if ((not a.no_cpu_baseline and world == 1) or a.check) and L == 0:      # CPU baselines: rank 0 at N = 1 only
             from oracle import orc
             env = load_oracle_env(orc)
             cores = orc.num_processors()
