@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("RMDF_BENCH_STREAMS", "0")),
                     help="frames kept in flight (one HIP stream + buffer set each); 1 = one frame at a time; "
                          "0 = default: 2 on one GPU, min(8, 2 + N) on N GPUs")
+    ap.add_argument("--animate", type=float, default=0.0, help="advance in_time by this many seconds per frame (the viewer's "
+                    "animation: the cost-ordered dispatch then works from the previous frame's costs of a slightly different view)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also compare the frame with the oracle (slow)")
     a = ap.parse_args()
@@ -215,18 +217,18 @@ def main():
             sr.resolve_box2_device(cur.data_ptr(), cw, ch, out.data_ptr(), stream=sp)
             cur, cw, ch = out, cw // 2, ch // 2
 
-    def render_only(k=0):
+    def render_only(k=0, t=a.time):
         sp = streams[k].cuda_stream
         if not sharded:
-            sr.render_rect_device(scene, rw, rh, a.time, ms, (0, 0, rw, rh), d_rgba8=bigs[k].data_ptr(), stream=sp)
+            sr.render_rect_device(scene, rw, rh, t, ms, (0, 0, rw, rh), d_rgba8=bigs[k].data_ptr(), stream=sp)
         else:
-            sr.render_shard_device(scene, rw, rh, a.time, ms, rank, world, bigs[k].data_ptr(), stream=sp)
+            sr.render_shard_device(scene, rw, rh, t, ms, rank, world, bigs[k].data_ptr(), stream=sp)
 
     def step(i=0):
         k = i % S
         sp = streams[k].cuda_stream
         with torch.cuda.stream(streams[k]):                   # the RCCL call orders itself against the current stream
-            render_only(k)
+            render_only(k, a.time + a.animate * i)
             if not sharded:
                 if L:
                     resolve(bigs[k], rw, rh, frames[k], tmps[k], sp)
@@ -307,7 +309,7 @@ def main():
                        "parallelism": ("1 GPU, one launch per frame" if not sharded else
                                        "64 tiles dealt to %d GPUs + one RCCL gather per frame" % world) +
                                       ", %d frame(s) in flight" % S,
-                       "frames_in_flight": S, "tile_deal": deal,
+                       "frames_in_flight": S, "tile_deal": deal, "animate_dt": a.animate,
                        "device": dev_name, "compute_units": cus},
             "roofline": {"bound": "hbm", "kernel": "k_render<2>", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
