@@ -141,14 +141,11 @@ __device__ __forceinline__ float log_pinned(float x)
     return r;
 }
 
-// exp(x), fixed operation order; x < -87 -> 0, x > 88.5 -> inf
-__device__ __forceinline__ float exp_pinned(float x)
+// exp(x), fixed operation order; x < -87 -> 0, x > 88.5 -> inf.  exp_core: -87 <= x <= 88.5.
+__device__ __forceinline__ float exp_core(float x)
 {
     const float ln2_hi = 6.9314575195e-01f, ln2_lo = 1.4286067653e-06f, invln2 = 1.4426950216e+00f;
     const float P1 = 1.6666625440e-1f, P2 = -2.7667332906e-3f;
-    if (x != x) return x;
-    if (x > 88.5f) return __builtin_inff();
-    if (x < -87.0f) return 0.0f;
     float kf = x * invln2 + ((x < 0.0f) ? -0.5f : 0.5f);
     int32_t k = (int32_t)kf;
     float t = (float)k;
@@ -163,12 +160,23 @@ __device__ __forceinline__ float exp_pinned(float x)
     y = y * __int_as_float((k2 + 127) << 23);
     return y;
 }
+// Straight-line core for every lane; NaN / overflow / underflow lanes are patched on a wave-uniform branch.
+__device__ __forceinline__ float exp_pinned(float x)
+{
+    const bool special = !((x >= -87.0f) && (x <= 88.5f));
+    float y = exp_core(special ? 0.0f : x);
+    if (__builtin_expect(__ballot(special) != 0ull, 0)) {
+        if (special) y = (x != x) ? x : ((x > 88.5f) ? __builtin_inff() : 0.0f);
+    }
+    return y;
+}
 
 // pow(x,y) = exp(y*log(x)); x <= 0 or NaN -> 0 (GLSL leaves it undefined)
 __device__ __forceinline__ float pow_pinned(float x, float y)
 {
-    if (!(x > 0.0f)) return 0.0f;
-    return exp_pinned(y * log_pinned(x));
+    const bool bad = !(x > 0.0f);
+    const float r = exp_pinned(y * log_pinned(bad ? 1.0f : x));
+    return bad ? 0.0f : r;
 }
 
 // ---- distance estimators ---------------------------------------------------------
@@ -240,21 +248,21 @@ __device__ __forceinline__ float kcos_pinned(float x)
     const float r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
     return 1.0f - (0.5f * z - z * r);
 }
-// sin and cos of the same argument share the reduction (the shader always needs both)
+// sin and cos of the same argument share the reduction (the shader always needs both).  Branch-free: the quadrant
+// logic is two selects and two sign flips, inf / NaN are overridden at the end.
 __device__ __forceinline__ void sincos_pinned(float x, float &s, float &c)
 {
-    if (!(fabsf(x) <= 3.4e38f)) { s = x - x; c = x - x; return; }
+    const bool bad = !(fabsf(x) <= 3.4e38f);
     float r; int q;
-    rem_pio2_pinned(x, r, q);
+    rem_pio2_pinned(bad ? 0.0f : x, r, q);
     const float ks = ksin_pinned(r), kc = kcos_pinned(r);
-    switch (q & 3) {
-    case 0:  s = ks;  c = kc;  break;
-    case 1:  s = kc;  c = -ks; break;
-    case 2:  s = -ks; c = -kc; break;
-    default: s = -kc; c = ks;  break;
-    }
+    const bool swap = (q & 1) != 0;
+    const float s0 = swap ? kc : ks, c0 = swap ? ks : kc;
+    s = (q & 2) ? -s0 : s0;                 // q mod 4 = 0: ( ks,  kc)  1: ( kc, -ks)  2: (-ks, -kc)  3: (-kc,  ks)
+    c = ((q + 1) & 2) ? -c0 : c0;
+    if (bad) { s = x - x; c = x - x; }
 }
-__device__ __forceinline__ float acos_pinned(float x)
+__device__ __noinline__ float acos_full(float x)
 {
     const float pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f, pi = 3.1415925026e+00f;
     const float pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f,
@@ -290,7 +298,36 @@ __device__ __forceinline__ float acos_pinned(float x)
         return 2.0f * (df + w);
     }
 }
-__device__ __forceinline__ float atan_pinned(float x)
+// Branch-free main path for 2^-26 < |x| < 1 (one p/q, one sqrt, one division for the upper-range correction, results
+// selected); |x| >= 1, tiny |x| and NaN go through acos_full on a wave-uniform branch.  Lanes of one wave span the whole
+// [-1, 1] in the general-power Mandelbulb, so the three-way branch of acos_full used to run all its arms.
+__device__ __forceinline__ float acos_pinned(float x)
+{
+    const float pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f, pi = 3.1415925026e+00f;
+    const float pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f,
+                pS4 = 7.9153501429e-04f, pS5 = 3.4793309169e-05f;
+    const float qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f, qS3 = -6.8828397989e-01f, qS4 = 7.7038154006e-02f;
+    const float ax = fabsf(x);
+    const bool special = !((ax < 1.0f) && (ax > 1.4901161e-8f));
+    const bool small = ax < 0.5f;
+    // (1 + x) * 0.5 for x < 0 and (1 - x) * 0.5 for x > 0 are the same operation on |x|
+    const float z = small ? x * x : (1.0f - ax) * 0.5f;
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float r = p / q;
+    const float s = sqrt_rn(z);
+    const float r_small = pio2_hi - (x - (pio2_lo - x * r));
+    const float wn = r * s - pio2_lo;
+    const float r_neg = pi - 2.0f * (s + wn);
+    const float df = __uint_as_float(__float_as_uint(s) & 0xfffff000u);
+    const float c = (z - df * df) / (s + df);
+    const float wp = r * s + c;
+    const float r_pos = 2.0f * (df + wp);
+    float res = small ? r_small : ((x < 0.0f) ? r_neg : r_pos);
+    if (__builtin_expect(__ballot(special) != 0ull, 0)) { if (special) res = acos_full(x); }
+    return res;
+}
+__device__ __noinline__ float atan_full(float x)
 {
     const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
                 aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
@@ -322,8 +359,39 @@ __device__ __forceinline__ float atan_pinned(float x)
     const float zz = hi - ((t * (s1 + s2) - lo) - t);
     return neg ? -zz : zz;
 }
-// GLSL atan(y, x)
-__device__ __forceinline__ float atan2_pinned(float y, float x)
+// Branch-free main path for 2^-12 <= |x| < 2^26: the argument reduction picks numerator and denominator by selects
+// and divides once (the four reduced ranges of atan_full each carried their own division); everything else (tiny, huge,
+// NaN) goes through atan_full on a wave-uniform branch.
+__device__ __forceinline__ float atan_pinned(float x)
+{
+    const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
+                aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
+                aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+    const float ax = fabsf(x);
+    const bool special = !((ax >= 2.44140625e-4f) && (ax < 67108864.0f));
+    const bool neg = (__float_as_uint(x) >> 31) != 0u;
+    const bool small = ax < 0.4375f;
+    const bool r1 = ax < 0.6875f, r2 = ax < 1.1875f, r3 = ax < 2.4375f;
+    // ranges: [0.4375, 0.6875) (2ax - 1)/(2 + ax); [0.6875, 1.1875) (ax - 1)/(ax + 1); [1.1875, 2.4375) (ax - 1.5)/(1 + 1.5 ax);
+    // above: -1/ax.  small: t = x, no division (the quotient below is computed and dropped)
+    const float num = r1 ? (2.0f * ax - 1.0f) : (r2 ? (ax - 1.0f) : (r3 ? (ax - 1.5f) : -1.0f));
+    const float den = r1 ? (2.0f + ax) : (r2 ? (ax + 1.0f) : (r3 ? (1.0f + 1.5f * ax) : ax));
+    const float hi = r1 ? 4.6364760399e-01f : (r2 ? 7.8539812565e-01f : (r3 ? 9.8279368877e-01f : 1.5707962513e+00f));
+    const float lo = r1 ? 5.0121582440e-09f : (r2 ? 3.7748947079e-08f : (r3 ? 3.4473217170e-08f : 7.5497894159e-08f));
+    const float quo = num / den;
+    const float t = small ? x : quo;
+    const float z = t * t;
+    const float w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    const float r_small = t - t * (s1 + s2);
+    const float zz = hi - ((t * (s1 + s2) - lo) - t);
+    float res = small ? r_small : (neg ? -zz : zz);
+    if (__builtin_expect(__ballot(special) != 0ull, 0)) { if (special) res = atan_full(x); }
+    return res;
+}
+// GLSL atan(y, x), every special case
+__device__ __noinline__ float atan2_full(float y, float x)
 {
     const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f, pio2 = 1.5707963705e+00f;
     const float inf = __builtin_inff();
@@ -339,6 +407,19 @@ __device__ __forceinline__ float atan2_pinned(float y, float x)
     if (ay == inf) return (m & 1) ? -pio2 : pio2;
     const float z = atan_pinned(ay / ax);
     return (m == 0) ? z : (m == 1) ? -z : (m == 2) ? pi - (z - pi_lo) : (z - pi_lo) - pi;
+}
+
+// GLSL atan(y, x): finite non-zero operands take the straight-line path; zeros, infinities and NaN go through atan2_full
+__device__ __forceinline__ float atan2_pinned(float y, float x)
+{
+    const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const float ax = fabsf(x), ay = fabsf(y);
+    const bool special = !((ax > 0.0f) && (ax < __builtin_inff()) && (ay > 0.0f) && (ay < __builtin_inff()));
+    const int m = (int)((__float_as_uint(y) >> 31) | ((__float_as_uint(x) >> 30) & 2u));
+    const float z = atan_pinned(special ? 1.0f : ay / ax);
+    float res = (m == 0) ? z : (m == 1) ? -z : (m == 2) ? pi - (z - pi_lo) : (z - pi_lo) - pi;
+    if (__builtin_expect(__ballot(special) != 0ull, 0)) { if (special) res = atan2_full(y, x); }
+    return res;
 }
 
 // fragment.shd:42-72
