@@ -289,12 +289,14 @@ def main():
         algo_bytes = px_this_launch * 4 + env_bytes                        # RGBA8 store + env read
         achieved_gbs = algo_bytes / (kern_ms * 1e-3) / 1e9
         traffic = None
+        valu_instr = None           # SQ_INSTS_VALU per launch, from the committed PMC pass (profiles/pmc_traffic.json)
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tj) and not sharded and L == 0:
             try:
                 t = json.load(open(tj))
                 if t.get("workload") == [scene, w, h, ms]:
                     traffic = t.get("hbm_bytes_per_launch")
+                    valu_instr = (t.get("valu") or {}).get("SQ_INSTS_VALU_per_launch")
             except Exception:
                 traffic = None
         result = {
@@ -332,6 +334,14 @@ def main():
                                            "unit": "T lane-ops/s (as-written IEEE ops, no FMA contraction)",
                                            "frac": round(F / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS, 4),
                                            "flop_per_frame": F, "counters": ctr}
+                if valu_instr:
+                    # what actually bounds the kernel: VALU instruction issue.  Peak = the rate a stream of simple VALU
+                    # instructions sustains on this chip (tools/ubench/valu_rates: 0.93 G wave-instructions/s/SIMD)
+                    simds = cus * 4
+                    rate = valu_instr / simds / (kern_ms * 1e-3) / 1e9
+                    result["valu_roofline"]["issue"] = {"valu_instructions_per_launch_pmc": valu_instr, "simds": simds,
+                                                        "achieved": round(rate, 3), "peak": 0.93, "frac": round(rate / 0.93, 3),
+                                                        "unit": "G wave-instructions/s/SIMD"}
             result["cpu_baseline"] = {"value": round(mpix / cpu_dt, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
                                       "sample": "1 full frame %dx%d of the same workload, CPU oracle (C port of fragment.shd), "
                                                 "row segments over all host cores as ConcurrentSegments does" % (w, h)}
