@@ -65,6 +65,18 @@ def gather_shards(shard, rank, world, dist, out=None, out_list=None):
     import torch
     if not (dist.is_available() and dist.is_initialized()):
         return shard.unsqueeze(0)
+    if shard.is_cuda and dist.get_backend() == "gloo":
+        # test aid (RMDF_BENCH_SHARE_GPU): gloo gathers host tensors; stage through the host, synchronously
+        host = shard.cpu()
+        if rank == 0:
+            parts = [torch.empty_like(host) for _ in range(world)]
+            dist.gather(host, parts, dst=0)
+            if out is None:
+                out = torch.empty((world,) + tuple(shard.shape), dtype=shard.dtype, device=shard.device)
+            out.copy_(torch.stack(parts))
+            return out
+        dist.gather(host, None, dst=0)
+        return None
     if rank == 0:
         if out is None:
             out = torch.empty((world,) + tuple(shard.shape), dtype=shard.dtype, device=shard.device)
@@ -142,15 +154,25 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    # RMDF_BENCH_SHARE_GPU=1 (test aid for a 1-GPU box): every rank uses cuda:0 and the exchange goes over gloo through
+    # host staging -- RCCL cannot put two ranks on one device.  It exercises the multi-rank logic (probe determinism across
+    # processes, deal agreement, per-rank shards, assembly), not the transport; the numbers it prints mean nothing.
+    share_gpu = os.environ.get("RMDF_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if share_gpu else dev          # where the small control-plane tensors live
     # the N > 1 path (shard render, RCCL gather, assemble); RMDF_BENCH_FORCE_DIST=1 runs it with world size 1 so that a
     # 1-GPU box can smoke-test it
     sharded = world > 1 or os.environ.get("RMDF_BENCH_FORCE_DIST") == "1"
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # one rank builds (a no-op when librmdf.so is current), the others wait: N ranks must not run make at once
     if local_rank == 0:
@@ -175,7 +197,7 @@ def main():
         # kernels -> identical costs, no exchange) and deals longest-processing-time-first.  Outside the timed region
         # the ranks compare their deals once; any disagreement falls back to the static deal on all of them.
         sr.set_shard_costs(sr.probe_tile_costs(a.scene, a.width << a.supersample, a.height << a.supersample, a.time, a.max_steps))
-        agree = ranks_agree_on_deal([sr.shard_tiles(r, world) for r in range(world)], dist, dev)
+        agree = ranks_agree_on_deal([sr.shard_tiles(r, world) for r in range(world)], dist, cdev)
         if agree:
             deal = "cost-aware (probe frame, LPT)"
         else:
@@ -252,7 +274,7 @@ def main():
         step(i)
     host_enqueue_ms = (time.perf_counter() - t0) / a.steps * 1e3      # host time to issue one step (this rank)
     barrier()
-    dt = max_over_ranks(time.perf_counter() - t0, dist, dev)
+    dt = max_over_ranks(time.perf_counter() - t0, dist, cdev)
     ms_per_step = dt / a.steps * 1e3
     mpix = w * h / 1e6
     value = mpix / (dt / a.steps)
@@ -309,7 +331,8 @@ def main():
                        "supersample_levels": L, "mrays_per_s": round(value * 4 ** L, 2),
                        "scene": scene, "width": w, "height": h, "max_steps": ms,
                        "parallelism": ("1 GPU, one launch per frame" if not sharded else
-                                       "64 tiles dealt to %d GPUs + one RCCL gather per frame" % world) +
+                                       "64 tiles dealt to %d %s + one %s gather per frame" %
+                                       (world, "ranks sharing one GPU (test aid)" if share_gpu else "GPUs", "gloo (host-staged)" if share_gpu else "RCCL")) +
                                       ", %d frame(s) in flight" % S,
                        "frames_in_flight": S, "tile_deal": deal, "animate_dt": a.animate,
                        "device": dev_name, "compute_units": cus},

@@ -445,3 +445,25 @@ def test_config4_full_size_sharded_supersample(sr, rmdf, orc, env_oracle):
         want = orc.resolve_box2(hi[2 * y0:2 * y0 + 8])
         d = np.abs(ref[y0:y0 + 4].view(np.uint8).astype(int) - want.view(np.uint8).astype(int))
         assert d.max() <= 1 and (d > 0).mean() <= 1e-3, (y0, d.max(), (d > 0).mean())
+
+
+def test_multirank_bench_logic_on_one_gpu():
+    """bench.py's N > 1 path with three real processes that share cuda:0 (RMDF_BENCH_SHARE_GPU=1: gloo transport through
+    host staging, because RCCL cannot put several ranks on one device): every rank probes the tile costs by itself, the
+    ranks agree on the deal, render their shards with frames in flight, rank 0 gathers and assembles -- and every
+    assembled frame equals the oracle's 1920x1080 frame bit for bit (--check)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, RMDF_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+           "--master-port", "29633", os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "9", "--warmup", "3", "--check"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                        # exactly one JSON line on stdout, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["check_rgba8_equal"] is True
+    assert d["config"]["tile_deal"].startswith("cost-aware") and d["config"]["frames_in_flight"] == 5
+    assert d["scaling"] == "strong" and d["metric"].startswith("Mpixels/s")
