@@ -305,6 +305,17 @@ def main():
             else:
                 sr.render_supersampled(scene, w, h, L, a.time, max_steps=ms)
         d2h_rate = mpix / ((time.perf_counter() - t1) / reps)
+        d2h_registered = None
+        if L == 0:
+            # the same hand-over into a buffer the caller registered once (rmdf_register_host_buffer): the render kernel
+            # writes it over PCIe while it renders
+            sr.register_host_buffer(host)
+            sr.draw_shader_tile(scene, None, w, h, a.time, host, max_steps=ms)
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                sr.draw_shader_tile(scene, None, w, h, a.time, host, max_steps=ms)
+            d2h_registered = mpix / ((time.perf_counter() - t1) / reps)
+            sr.unregister_host_buffer(host)
 
         env_bytes = 6 * 172 * 172 * 8 + 2 * 6 * 87 * 87 * 8               # padded RGB16F cube maps read once
         px_this_launch = rw * rh if not sharded else len(sr.shard_tiles(rank, world)) * (rw // 8) * (rh // 8)
@@ -341,7 +352,8 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": round(kern_ms, 4),
                          "kernel_ms_min": round(kern_ms_min, 4),
                          "note": "VALU-bound path (SURVEY 8d): HBM fraction is a sanity figure, see valu_roofline"},
-            "d2h_inclusive_mpixels_s": round(d2h_rate, 2), "host_enqueue_ms_per_step_rank0": round(host_enqueue_ms, 4),
+            "d2h_inclusive_mpixels_s": round(d2h_rate, 2),
+            "d2h_inclusive_registered_buffer_mpixels_s": None if d2h_registered is None else round(d2h_registered, 2), "host_enqueue_ms_per_step_rank0": round(host_enqueue_ms, 4),
         }
         if ((not a.no_cpu_baseline and world == 1) or a.check) and L == 0:      # CPU baselines: rank 0 at N = 1 only
             from oracle import orc

@@ -30,6 +30,7 @@
 #ifndef RMDF_H
 #define RMDF_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -205,6 +206,16 @@ int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[5]);
  * iteration passes, march-tail passes, shade-tail passes, refill rounds, sum of iterating lanes over iteration
  * passes, sum of waiting lanes over march tails, begin / end timestamps (100 MHz s_memrealtime ticks). */
 int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_waves);
+
+/* Optional: pin a host buffer the caller reuses from frame to frame (page-locks it and maps it into the GPU's address
+ * space).  A whole-frame rmdf_render_tile (tile_idx = -1) whose out_rgba8 lies inside a registered range is then
+ * written by the render kernel itself, row by row while it renders, instead of being copied after the launch: the PCIe
+ * transfer hides behind the frame.  Everything else about the call is unchanged (it still blocks until the buffer is
+ * complete; the library's accumulating frame is updated too).  The buffer must stay valid until it is unregistered or
+ * the ctx is destroyed.  A viewer whose frame-buffer pointer changes every frame (an orphaned PBO, FrameBuffer.hs:129)
+ * simply does not register. */
+int rmdf_register_host_buffer(rmdf_ctx *ctx, void *ptr, size_t bytes);
+int rmdf_unregister_host_buffer(rmdf_ctx *ctx, void *ptr);
 
 /* Screenshot: saveFrameBufferToPNG (FrameBuffer.hs:215-228) for a frame buffer in the boundary's layout (w*h
  * little-endian Word32 = R,G,B,A bytes, row 0 = bottom): rows flipped to top-down, alpha forced to 0xFF, written

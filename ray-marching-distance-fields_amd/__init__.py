@@ -46,7 +46,7 @@ ABI_SYMBOLS = (
     "rmdf_render_rect_device", "rmdf_render_shard_device", "rmdf_assemble_shards_device", "rmdf_synchronize",
     "rmdf_device_info", "rmdf_debug_march_stats", "rmdf_resolve_box2_device", "rmdf_render_supersampled",
     "rmdf_selftest_exact_math", "rmdf_shard_tiles", "rmdf_probe_tile_costs", "rmdf_set_shard_costs",
-    "rmdf_get_shard_tiles", "rmdf_save_png",
+    "rmdf_get_shard_tiles", "rmdf_save_png", "rmdf_register_host_buffer", "rmdf_unregister_host_buffer",
 )
 
 
@@ -135,6 +135,8 @@ def load_library():
     L.rmdf_render_shard_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, vp, vp]
     L.rmdf_shard_tiles.argtypes = [C.c_int, C.c_int, ip]
     L.rmdf_save_png.argtypes = [C.c_char_p, vp, C.c_int, C.c_int]
+    L.rmdf_register_host_buffer.argtypes = [vp, vp, C.c_size_t]
+    L.rmdf_unregister_host_buffer.argtypes = [vp, vp]
     L.rmdf_probe_tile_costs.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]
     L.rmdf_set_shard_costs.argtypes = [vp, vp]
     L.rmdf_get_shard_tiles.argtypes = [vp, C.c_int, C.c_int, ip]
@@ -233,6 +235,14 @@ class ShaderRenderer:
         out = np.empty_like(rgb)
         self._check(self._lib.rmdf_prefilter_env(self._ctx, rgb.ctypes.data, w, h, float(power), out.ctypes.data))
         return out
+
+    def register_host_buffer(self, arr):
+        """Pin + GPU-map a numpy frame buffer that is reused from frame to frame: whole-frame draw_shader_tile calls into
+        it are then written by the render kernel directly (the PCIe copy hides behind the frame)."""
+        self._check(self._lib.rmdf_register_host_buffer(self._ctx, arr.ctypes.data, arr.nbytes))
+
+    def unregister_host_buffer(self, arr):
+        self._check(self._lib.rmdf_unregister_host_buffer(self._ctx, arr.ctypes.data))
 
     # -- rendering ----------------------------------------------------------------------------
     def draw_shader_tile(self, shd_enum, tile_idx, w, h, time, fb_vec, max_steps=128):

@@ -60,6 +60,9 @@ struct rmdf_ctx {
     int         *d_hit_list = nullptr;
     // cost-ordered dispatch state of the nested-loop kernel (previous frame's per-strip costs), one per stream
     // that renders: frames in flight on different streams (pipelined rendering) must not share the tables
+    // host buffers registered for direct GPU writes (rmdf_register_host_buffer)
+    struct HostReg { char *host; size_t bytes; char *dev; };
+    std::vector<HostReg> host_regs;
     // per-tile costs that steer the deal of tiles to ranks (rmdf_set_shard_costs); unset = static deal
     float        shard_cost[64];
     bool         shard_cost_set = false;
@@ -529,10 +532,22 @@ int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double t
     if (whole) { p.x0 = 0; p.y0 = 0; p.x1 = ctx->w; p.y1 = ctx->h; }
     else tile_rect_host(tile_idx, ctx->w, ctx->h, &p.x0, &p.y0, &p.x1, &p.y1);
     p.rgba8 = ctx->d_rgba8; p.rgba_f32 = ctx->d_rgba_f32; p.steps = ctx->d_steps; p.iters = ctx->d_iters;
+    const size_t npx = (size_t)ctx->w * ctx->h;
+    // Whole-frame call into a registered host buffer: the render kernel stores the RGBA8 rows into it directly (next to
+    // the library's own accumulating frame), so the PCIe transfer overlaps the render instead of following it.  Only the
+    // default nested-loop kernel knows the mirror pointer.
+    bool direct = false;
+    if (whole && out_rgba8 && !(ctx->flags & (RMDF_FLAG_PIPELINE | RMDF_FLAG_FLAT_MARCH))) {
+        for (auto &r : ctx->host_regs)
+            if ((char *)out_rgba8 >= r.host && (char *)out_rgba8 + npx * 4 <= r.host + r.bytes) {
+                p.rgba8_mirror = (uint32_t *)(r.dev + ((char *)out_rgba8 - r.host));
+                direct = true;
+                break;
+            }
+    }
     rc = launch_scene(ctx, scene, p, ctx->stream);
     if (rc != RMDF_OK) return rc;
-    const size_t npx = (size_t)ctx->w * ctx->h;
-    if (out_rgba8) HIP_TRY(ctx, hipMemcpyAsync(out_rgba8, ctx->d_rgba8, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_rgba8 && !direct) HIP_TRY(ctx, hipMemcpyAsync(out_rgba8, ctx->d_rgba8, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (out_rgba_f32) HIP_TRY(ctx, hipMemcpyAsync(out_rgba_f32, ctx->d_rgba_f32, npx * 16, hipMemcpyDeviceToHost, ctx->stream));
     if (out_steps) HIP_TRY(ctx, hipMemcpyAsync(out_steps, ctx->d_steps, npx * 2, hipMemcpyDeviceToHost, ctx->stream));
     if (out_iters) HIP_TRY(ctx, hipMemcpyAsync(out_iters, ctx->d_iters, npx * 2, hipMemcpyDeviceToHost, ctx->stream));
@@ -614,6 +629,7 @@ void rmdf_destroy(rmdf_ctx *ctx)
     if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
     if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
     (void)hipDeviceSynchronize();              // caller streams may still be running launches that use the tables
+    for (auto &r : ctx->host_regs) (void)hipHostUnregister(r.host);
     for (auto &o : ctx->orders) {
         if (o.d_cost) (void)hipFree(o.d_cost);
         if (o.d_order) (void)hipFree(o.d_order);
@@ -995,6 +1011,37 @@ int rmdf_save_png(const char *path, const uint32_t *fb_rgba8, int w, int h)
     ok = (fclose(f) == 0) && ok;
     if (!ok) { remove(path); return fail(nullptr, RMDF_E_IO, std::string("short write to ") + path); }
     return RMDF_OK;
+}
+
+int rmdf_register_host_buffer(rmdf_ctx *ctx, void *ptr, size_t bytes)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!ptr || bytes == 0) return fail(ctx, RMDF_E_INVALID, "rmdf_register_host_buffer: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (auto &r : ctx->host_regs) if (r.host == (char *)ptr && r.bytes == bytes) return RMDF_OK;
+    HIP_TRY(ctx, hipHostRegister(ptr, bytes, hipHostRegisterMapped));
+    void *dev = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&dev, ptr, 0);
+    if (e != hipSuccess) {
+        (void)hipHostUnregister(ptr);
+        return fail(ctx, RMDF_E_HIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));
+    }
+    ctx->host_regs.push_back(rmdf_ctx::HostReg{ (char *)ptr, bytes, (char *)dev });
+    return RMDF_OK;
+}
+
+int rmdf_unregister_host_buffer(rmdf_ctx *ctx, void *ptr)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    for (size_t i = 0; i < ctx->host_regs.size(); i++)
+        if (ctx->host_regs[i].host == (char *)ptr) {
+            HIP_TRY(ctx, hipSetDevice(ctx->device));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipHostUnregister(ptr));
+            ctx->host_regs.erase(ctx->host_regs.begin() + (long)i);
+            return RMDF_OK;
+        }
+    return fail(ctx, RMDF_E_INVALID, "rmdf_unregister_host_buffer: not registered");
 }
 
 int rmdf_synchronize(rmdf_ctx *ctx, void *stream)

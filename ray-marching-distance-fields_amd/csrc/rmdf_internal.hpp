@@ -32,6 +32,8 @@ struct FrameParams {
     const float *cornell_tab; // 32 x CORNELL_STRIDE per-triangle constants (rmdf_device.hpp: de_cornell_box_table)
     int   cornell_prune;      // skip triangles that provably cannot undercut the running minimum (bit-identical result)
     uint32_t *rgba8;
+    uint32_t *rgba8_mirror;   // optional second destination of the RGBA8 frame: a registered (GPU-mapped) host buffer, written
+                              // by the render kernel itself so that the copy over PCIe hides behind the frame (k_render only)
     float4   *rgba_f32;
     uint16_t *steps;
     uint16_t *iters;

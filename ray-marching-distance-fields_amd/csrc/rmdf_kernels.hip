@@ -325,6 +325,7 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
         if (qx >= rx0 && qx < rx1 && qy >= ry0 && qy < ry1) {
             const size_t idx = obase + (size_t)(qx - ox) + (size_t)(qy - oy) * (size_t)pitch;
             if (p.rgba8) p.rgba8[idx] = s_rgba8[oy_][ox_];
+            if (p.rgba8_mirror) p.rgba8_mirror[idx] = s_rgba8[oy_][ox_];
             if (p.rgba_f32) p.rgba_f32[idx] = s_f32[oy_][ox_];
             const uint32_t m = s_meta[oy_][ox_];
             if (p.steps) p.steps[idx] = (uint16_t)(m & 0xffffu);

@@ -467,3 +467,33 @@ def test_multirank_bench_logic_on_one_gpu():
     assert d["n_gpus"] == 3 and d["check_rgba8_equal"] is True
     assert d["config"]["tile_deal"].startswith("cost-aware") and d["config"]["frames_in_flight"] == 5
     assert d["scaling"] == "strong" and d["metric"].startswith("Mpixels/s")
+
+
+def test_registered_host_buffer(sr, rmdf):
+    """rmdf_register_host_buffer: whole-frame calls into a registered buffer are written by the render kernel directly;
+    same pixels as the copying path, the accumulating frame stays in step (a later tiled call returns it), buffers that are
+    not registered (or only partly inside a registration) take the copy."""
+    w, h, ms = 640, 360, 256
+    ref = sr.render(2, w, h, 0.0, max_steps=ms)["rgba8"]
+    big = np.zeros(w * h + 4096, np.uint32)
+    sr.register_host_buffer(big)
+    try:
+        sr.register_host_buffer(big)                                   # idempotent
+        inside = big[1024:1024 + w * h]
+        sr.draw_shader_tile(2, None, w, h, 0.0, inside, max_steps=ms)
+        assert np.array_equal(inside.reshape(h, w), ref)
+        assert (big[:1024] == 0).all() and (big[1024 + w * h:] == 0).all()
+        # the library's own frame was updated by the same launch: tile 5 of a new frame returns the t = 0 frame elsewhere
+        other = sr.render(2, w, h, 2.5, max_steps=ms)["rgba8"]
+        sr.draw_shader_tile(2, None, w, h, 0.0, inside, max_steps=ms)
+        plain = np.zeros(w * h, np.uint32)
+        sr.draw_shader_tile(2, 5, w, h, 2.5, plain, max_steps=ms)      # tiled call: latches on tile 0 only -> still t = 0
+        assert np.array_equal(plain.reshape(h, w), ref)
+        assert not np.array_equal(other, ref)
+    finally:
+        sr.unregister_host_buffer(big)
+    with pytest.raises(rmdf.RmdfError):
+        sr.unregister_host_buffer(big)
+    again = np.zeros(w * h, np.uint32)
+    sr.draw_shader_tile(2, None, w, h, 0.0, again, max_steps=ms)
+    assert np.array_equal(again.reshape(h, w), ref)
