@@ -456,9 +456,14 @@ def test_multirank_bench_logic_on_one_gpu():
     import subprocess
     import sys
     from conftest import ROOT
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
     env = dict(os.environ, RMDF_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
-           "--master-port", "29633", os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "9", "--warmup", "3", "--check"]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "9", "--warmup", "3", "--check"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
