@@ -275,6 +275,55 @@ int main()
         printf("event-driven wg-pool T=32, %-8s %10.1f M wave-instr  (x%.3f of nested)  lane utilisation %.3f\n",
                policy == 0 ? "host" : "exchange", c / 1e6, c / c_nested, ideal / c);
     }
+    // nested packets + deferring straggler estimates: when an estimate has run >= K0 passes and only <= L0 lanes are still
+    // iterating while other lanes of the wave wait for their tail, the stragglers are parked (their w, dr, i stay in their
+    // registers) and the others go on marching; parked estimates are resumed together once >= R0 are parked or nothing else
+    // is left.  Costs: pass A + 2 (per-lane iteration counters), tail B.  No pooling across packets here.
+    for (int cfg = 0; cfg < 6; cfg++) {
+        const int K0s[6] = { 6, 8, 8, 10, 12, 8 }, L0s[6] = { 8, 8, 16, 8, 8, 4 }, R0s[6] = { 16, 16, 24, 16, 16, 8 };
+        const int K0 = K0s[cfg], L0 = L0s[cfg], R0 = R0s[cfg];
+        double c = 0.0;
+        std::vector<Ray> r;
+        for (int by = 0; by < PY; by++) for (int bx = 0; bx < PX; bx++) {
+            packet(bx, by, r);
+            const int nr = (int)r.size();
+            if (!nr) continue;
+            std::vector<int> rem(nr, 0);        // remaining iterations of the lane's parked estimate (0 = not parked)
+            std::vector<int> done_it(nr, 0);
+            for (;;) {
+                // lanes that can start an estimate now
+                int nstart = 0, nparked = 0;
+                for (int i = 0; i < nr; i++) { if (rem[i] > 0) nparked++; else if (r[i].step < g_n[r[i].pix]) nstart++; }
+                if (!nstart && !nparked) break;
+                if (nparked >= R0 || !nstart) {
+                    // resume the parked estimates together, to the end
+                    int mk = 0;
+                    for (int i = 0; i < nr; i++) if (rem[i] > mk) mk = rem[i];
+                    c += (A + 2) * mk + B;
+                    for (int i = 0; i < nr; i++) if (rem[i] > 0) { rem[i] = 0; r[i].step++; }
+                    continue;
+                }
+                // one wave-step of the startable lanes, parking stragglers
+                std::vector<int> ks(nr, 0);
+                for (int i = 0; i < nr; i++) if (rem[i] == 0 && r[i].step < g_n[r[i].pix]) ks[i] = kof(r[i].pix, r[i].step);
+                int pass = 0;
+                for (;;) {
+                    int running = 0;
+                    for (int i = 0; i < nr; i++) if (ks[i] > pass) running++;
+                    if (!running) break;
+                    if (pass >= K0 && running <= L0 && running < nstart) {
+                        for (int i = 0; i < nr; i++) if (ks[i] > pass) { rem[i] = ks[i] - pass; ks[i] = -1; }   // parked
+                        break;
+                    }
+                    pass++;
+                }
+                c += (A + 2) * pass + B;
+                for (int i = 0; i < nr; i++) if (ks[i] > 0) r[i].step++;      // estimate finished -> tail -> next step
+            }
+        }
+        printf("nested + parked stragglers (K0=%d L0=%d R0=%d) %10.1f M wave-instr  (x%.3f of nested)  lane utilisation %.3f\n",
+               K0, L0, R0, c / 1e6, c / c_nested, ideal / c);
+    }
     // normal estimates: the four estimates of a hit pixel share k; a wave pays max k over its hit lanes.  What would
     // regrouping the hit pixels of a workgroup (32x8 strip, 4 waves) by k save?
     {
