@@ -275,6 +275,48 @@ int main()
         printf("event-driven wg-pool T=32, %-8s %10.1f M wave-instr  (x%.3f of nested)  lane utilisation %.3f\n",
                policy == 0 ? "host" : "exchange", c / 1e6, c / c_nested, ideal / c);
     }
+    // Event-driven host pooling with larger workgroups and several hosts: NW waves per workgroup (NW/4 strips of 32x8 side
+    // by side), up to NH of them may become hosts (first come), all hosts adopt from one shared mailbox pool.
+    for (int cfg = 0; cfg < 6; cfg++) {
+        const int NWs[6] = { 4, 8, 8, 16, 16, 8 }, NHs[6] = { 1, 1, 2, 2, 4, 2 }, Ts[6] = { 32, 32, 32, 32, 32, 40 };
+        const int NW = NWs[cfg], NH = NHs[cfg], T = Ts[cfg];
+        double c = 0.0;
+        const int SXN = (PX + NW - 1) / NW;
+        for (int by = 0; by < PY; by++) for (int sx = 0; sx < SXN; sx++) {
+            std::vector<std::vector<Ray>> wv(NW);
+            std::vector<Ray> mail;
+            std::vector<double> clk(NW, 0.0);
+            std::vector<char> alive(NW, 0), is_host(NW, 0);
+            int nalive = 0, nhost = 0;
+            for (int q = 0; q < NW; q++) { const int bx = sx * NW + q; if (bx >= PX) break; packet(bx, by, wv[q]); alive[q] = !wv[q].empty(); nalive += alive[q]; }
+            while (nalive > 0) {
+                int w = -1;
+                for (int q = 0; q < NW; q++) if (alive[q] && (w < 0 || clk[q] < clk[w])) w = q;
+                std::vector<Ray> &r = wv[w];
+                if ((int)r.size() <= T && !is_host[w] && nhost < NH) { is_host[w] = 1; nhost++; }
+                if (is_host[w]) { while (r.size() < 64 && !mail.empty()) { r.push_back(mail.back()); mail.pop_back(); } }
+                else if ((int)r.size() <= T && nhost > 0) { mail.insert(mail.end(), r.begin(), r.end()); r.clear(); }
+                if (r.empty()) {
+                    int others = 0; for (int q = 0; q < NW; q++) if (alive[q] && q != w && !is_host[q]) others++;
+                    if (is_host[w] && (others > 0 || !mail.empty())) {
+                        if (!mail.empty()) continue;
+                        double nxt = 1e300; for (int q = 0; q < NW; q++) if (alive[q] && q != w && !is_host[q] && clk[q] < nxt) nxt = clk[q];
+                        clk[w] = nxt + 1e-9; continue;
+                    }
+                    alive[w] = 0; nalive--; continue;
+                }
+                int mk = 0;
+                for (auto &x : r) { const int k = kof(x.pix, x.step); if (k > mk) mk = k; }
+                const double cost = A * mk + B;
+                c += cost; clk[w] += cost;
+                std::vector<Ray> nr;
+                for (auto &x : r) { x.step++; if (x.step < g_n[x.pix]) nr.push_back(x); }
+                r.swap(nr);
+            }
+        }
+        printf("event-driven pooling, %2d waves per workgroup, %d host(s), T=%d %10.1f M wave-instr  (x%.3f of nested)  lane utilisation %.3f\n",
+               NW, NH, T, c / 1e6, c / c_nested, ideal / c);
+    }
     // nested packets + deferring straggler estimates: when an estimate has run >= K0 passes and only <= L0 lanes are still
     // iterating while other lanes of the wave wait for their tail, the stragglers are parked (their w, dr, i stay in their
     // registers) and the others go on marching; parked estimates are resumed together once >= R0 are parked or nothing else
