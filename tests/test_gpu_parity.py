@@ -502,3 +502,16 @@ def test_registered_host_buffer(sr, rmdf):
     again = np.zeros(w * h, np.uint32)
     sr.draw_shader_tile(2, None, w, h, 0.0, again, max_steps=ms)
     assert np.array_equal(again.reshape(h, w), ref)
+
+
+def test_random_views_vs_oracle(sr, orc, env_oracle):
+    """Seeded random sweep: scene, frame size (odd sizes included), camera time and step limit drawn at random -- every
+    plane against the oracle (steps / hit / iteration counts bit-exact, colour <= 1e-4)."""
+    rng = np.random.RandomState(20261002)
+    for case in range(16):
+        scene = int(rng.randint(0, 4))
+        w, h = int(rng.randint(17, 200)), int(rng.randint(9, 120))
+        t = float(np.float32(rng.uniform(0.0, 40.0)))
+        ms = int(rng.choice([16, 64, 128, 256]))
+        got = sr.render(scene, w, h, t, max_steps=ms)
+        assert_frame_parity(got, orc.render(scene, w, h, t, ms, env_oracle), "case %d: scene %d %dx%d t=%.3f ms=%d" % (case, scene, w, h, t, ms))
