@@ -63,10 +63,10 @@ __global__ void k_trace(Cam cam, unsigned char *trace, unsigned short *nsteps, u
     nsteps[(size_t)py * W + px] = (unsigned short)n;     // distance estimates taken (= march passes of this ray)
 }
 
-static void host_camera(float cam[12], float *fov_xs)
+static void host_camera(float cam[12], float *fov_xs, float time = 0.0f)
 {
     // fragment.shd:892-897, 829-838 at in_time = 0 (same operation order as rmdf_api.cpp: host_camera)
-    float cx = sinf(0.0f), cy = cosf(0.0f), cz = cosf(0.0f);
+    float cx = sinf(time / 3.0f), cy = cosf(time / 4.0f), cz = cosf(time / 3.0f);
     float s = 1.0f / sqrtf((cx * cx + cy * cy) + cz * cz);
     cx = cx * s * 2.414213562373095f; cy = cy * s * 2.414213562373095f; cz = cz * s * 2.414213562373095f;
     float zl = 1.0f / sqrtf((cx * cx + cy * cy) + cz * cz);
@@ -124,6 +124,17 @@ int main()
     std::vector<unsigned char> kn(npx);
     hipMemcpy(kn.data(), d_kn, npx, hipMemcpyDeviceToHost);
     g_trace = trace.data(); g_n = n.data();
+    // step counts of the same scene a moment earlier (what a viewer's previous frame would have measured)
+    std::vector<unsigned short> n_prev60(npx), n_prev10(npx);
+    {
+        Cam cam2;
+        host_camera(cam2.c, &cam2.fov_xs, -1.0f / 60.0f);
+        hipLaunchKernelGGL(k_trace, dim3((W + 63) / 64, H), dim3(64), 0, 0, cam2, d_trace, d_n, d_kn);
+        hipMemcpy(n_prev60.data(), d_n, npx * 2, hipMemcpyDeviceToHost);
+        host_camera(cam2.c, &cam2.fov_xs, -0.1f);
+        hipLaunchKernelGGL(k_trace, dim3((W + 63) / 64, H), dim3(64), 0, 0, cam2, d_trace, d_n, d_kn);
+        hipMemcpy(n_prev10.data(), d_n, npx * 2, hipMemcpyDeviceToHost);
+    }
     double evals = 0, iters = 0; int maxn = 0;
     for (size_t i = 0; i < npx; i++) { evals += n[i]; if (n[i] > maxn) maxn = n[i]; for (int s = 0; s < n[i]; s++) iters += kof((int)i, s); }
     printf("rays with estimates: march estimates %.4e  escape iterations %.4e  mean k %.2f  longest ray %d estimates\n", evals, iters, iters / evals, maxn);
@@ -316,6 +327,120 @@ int main()
         }
         printf("event-driven pooling, %2d waves per workgroup, %d host(s), T=%d %10.1f M wave-instr  (x%.3f of nested)  lane utilisation %.3f\n",
                NW, NH, T, c / 1e6, c / c_nested, ideal / c);
+    }
+    // Packets formed from the previous frame's step counts: the 64 quads (2x2 pixels, kept together for the texture
+    // derivatives) of a 32x8 strip are sorted by their longest ray and dealt 16 to a wave, so a wave's rays have similar
+    // lengths a priori.  Upper bound: sorted by THIS frame's step counts.  Then nested, and with event-driven host pooling.
+    for (int pooled = 0; pooled < 2; pooled++) {
+        const int T = 32;
+        double c = 0.0;
+        for (int by = 0; by < PY; by++) for (int sx = 0; sx < (PX + 3) / 4; sx++) {
+            struct Quad { int key; int pix[4]; };
+            std::vector<Quad> quads;
+            for (int qy = 0; qy < 4; qy++) for (int qx = 0; qx < 16; qx++) {
+                Quad q; q.key = 0;
+                for (int k = 0; k < 4; k++) {
+                    const int x = sx * 32 + qx * 2 + (k & 1), y = by * 8 + qy * 2 + (k >> 1);
+                    q.pix[k] = (x < W && y < H) ? y * W + x : -1;
+                    if (q.pix[k] >= 0 && g_n[q.pix[k]] > q.key) q.key = g_n[q.pix[k]];
+                }
+                quads.push_back(q);
+            }
+            std::stable_sort(quads.begin(), quads.end(), [](const Quad &a, const Quad &b) { return a.key > b.key; });
+            std::vector<Ray> wv[4], mail;
+            for (int j = 0; j < 64; j++) for (int k = 0; k < 4; k++) { const int p = quads[j].pix[k]; if (p >= 0 && g_n[p] > 0) wv[j / 16].push_back(Ray{ p, 0 }); }
+            if (!pooled) { for (int q = 0; q < 4; q++) c += run_wave(wv[q], 0, A, B, &dummy); continue; }
+            double clk[4] = { 0, 0, 0, 0 };
+            bool alive[4]; int host = -1, nalive = 0;
+            for (int q = 0; q < 4; q++) { alive[q] = !wv[q].empty(); nalive += alive[q]; }
+            while (nalive > 0) {
+                int w = -1;
+                for (int q = 0; q < 4; q++) if (alive[q] && (w < 0 || clk[q] < clk[w])) w = q;
+                std::vector<Ray> &r = wv[w];
+                if ((int)r.size() <= T && host < 0) host = w;
+                if (w == host) { while (r.size() < 64 && !mail.empty()) { r.push_back(mail.back()); mail.pop_back(); } }
+                else if ((int)r.size() <= T && host >= 0) { mail.insert(mail.end(), r.begin(), r.end()); r.clear(); }
+                if (r.empty()) {
+                    if (w == host && nalive > 1) { double nxt = 1e300; for (int q = 0; q < 4; q++) if (alive[q] && q != w && clk[q] < nxt) nxt = clk[q]; clk[w] = nxt + 1e-9; continue; }
+                    alive[w] = false; nalive--; continue;
+                }
+                int mk = 0;
+                for (auto &x : r) { const int k = kof(x.pix, x.step); if (k > mk) mk = k; }
+                const double cost = A * mk + B;
+                c += cost; clk[w] += cost;
+                std::vector<Ray> nr;
+                for (auto &x : r) { x.step++; if (x.step < g_n[x.pix]) nr.push_back(x); }
+                r.swap(nr);
+            }
+        }
+        printf("waves formed from quads sorted by ray length within a strip%s %10.1f M wave-instr  (x%.3f of nested)  lane utilisation %.3f\n",
+               pooled ? " + host pooling" : "               ", c / 1e6, c / c_nested, ideal / c);
+    }
+    // the same with larger sorting domains: DWxDH packets (8x8 pixels each) per domain, quads sorted by ray length over the
+    // whole domain and dealt 16 to a wave; no run-time pooling
+    for (int cfg = 0; cfg < 6; cfg++) {
+        const int DWs[6] = { 4, 8, 8, 16, 30, 240 }, DHs[6] = { 1, 1, 2, 4, 9, 135 };
+        const int DW = DWs[cfg], DH = DHs[cfg];
+        double c = 0.0;
+        for (int dy = 0; dy < (PY + DH - 1) / DH; dy++) for (int dx = 0; dx < (PX + DW - 1) / DW; dx++) {
+            struct Quad { int key; int pix[4]; };
+            std::vector<Quad> quads;
+            for (int qy = 0; qy < DH * 4; qy++) for (int qx = 0; qx < DW * 4; qx++) {
+                Quad q; q.key = 0; bool any = false;
+                for (int k = 0; k < 4; k++) {
+                    const int x = dx * DW * 8 + qx * 2 + (k & 1), y = dy * DH * 8 + qy * 2 + (k >> 1);
+                    q.pix[k] = (x < W && y < H) ? y * W + x : -1;
+                    if (q.pix[k] >= 0) { any = true; if (g_n[q.pix[k]] > q.key) q.key = g_n[q.pix[k]]; }
+                }
+                if (any) quads.push_back(q);
+            }
+            std::stable_sort(quads.begin(), quads.end(), [](const Quad &a, const Quad &b) { return a.key > b.key; });
+            for (size_t j = 0; j < quads.size(); j += 16) {
+                std::vector<Ray> wv;
+                for (size_t jj = j; jj < std::min(quads.size(), j + 16); jj++)
+                    for (int k = 0; k < 4; k++) { const int p = quads[jj].pix[k]; if (p >= 0 && g_n[p] > 0) wv.push_back(Ray{ p, 0 }); }
+                c += run_wave(wv, 0, A, B, &dummy);
+            }
+        }
+        printf("quads sorted by ray length over %3dx%-3d packets (%5d waves per domain) %10.1f M wave-instr  (x%.3f of nested)  lane utilisation %.3f\n",
+               DW, DH, DW * DH, c / 1e6, c / c_nested, ideal / c);
+    }
+    // key variants on the 16x4 domain: total escape iterations of the quad's longest ray; step count in coarse bins; the step
+    // counts of the frame 1/60 s and 0.1 s earlier (animated camera)
+    for (int variant = 0; variant < 4; variant++) {
+        const int DW = 16, DH = 4;
+        double c = 0.0;
+        for (int dy = 0; dy < (PY + DH - 1) / DH; dy++) for (int dx = 0; dx < (PX + DW - 1) / DW; dx++) {
+            struct Quad { int key; int pix[4]; };
+            std::vector<Quad> quads;
+            for (int qy = 0; qy < DH * 4; qy++) for (int qx = 0; qx < DW * 4; qx++) {
+                Quad q; q.key = 0; bool any = false;
+                for (int k = 0; k < 4; k++) {
+                    const int x = dx * DW * 8 + qx * 2 + (k & 1), y = dy * DH * 8 + qy * 2 + (k >> 1);
+                    q.pix[k] = (x < W && y < H) ? y * W + x : -1;
+                    if (q.pix[k] >= 0) {
+                        any = true;
+                        int key = 0;
+                        if (variant == 0) { for (int st = 0; st < g_n[q.pix[k]]; st++) key += kof(q.pix[k], st); }
+                        else if (variant == 1) key = (g_n[q.pix[k]] + 7) / 8;
+                        else if (variant == 2) key = n_prev60[q.pix[k]];
+                        else key = n_prev10[q.pix[k]];
+                        if (key > q.key) q.key = key;
+                    }
+                }
+                if (any) quads.push_back(q);
+            }
+            std::stable_sort(quads.begin(), quads.end(), [](const Quad &a, const Quad &b) { return a.key > b.key; });
+            for (size_t j = 0; j < quads.size(); j += 16) {
+                std::vector<Ray> wv;
+                for (size_t jj = j; jj < std::min(quads.size(), j + 16); jj++)
+                    for (int k = 0; k < 4; k++) { const int p = quads[jj].pix[k]; if (p >= 0 && g_n[p] > 0) wv.push_back(Ray{ p, 0 }); }
+                c += run_wave(wv, 0, A, B, &dummy);
+            }
+        }
+        printf("quads sorted over 16x4 packets by %-42s %10.1f M wave-instr  (x%.3f of nested)  lane utilisation %.3f\n",
+               variant == 0 ? "total escape iterations of the longest ray" : variant == 1 ? "step count in bins of 8" :
+               variant == 2 ? "step counts of the frame 1/60 s earlier" : "step counts of the frame 0.1 s earlier", c / 1e6, c / c_nested, ideal / c);
     }
     // nested packets + deferring straggler estimates: when an estimate has run >= K0 passes and only <= L0 lanes are still
     // iterating while other lanes of the wave wait for their tail, the stragglers are parked (their w, dr, i stay in their
