@@ -308,16 +308,17 @@ def test_exact_math_exhaustive(sr, orc):
 
 
 def test_straggler_pooling_is_invisible(rmdf, sr, env_faces):
-    """The default power-8 kernel pools the last rays of a workgroup's four packets in one wave; a
-    renderer with RMDF_FLAG_NO_MERGE must produce the same bits; forcing the pooling on for the other scenes too."""
+    """The default kernels of both Mandelbulbs and of the test scene pool the last rays of a workgroup's four packets in one
+    wave; a renderer with RMDF_FLAG_NO_MERGE must produce the same bits."""
     plain = rmdf.ShaderRenderer(0, flags=rmdf.FLAG_NO_MERGE)
     try:
         for slot, k in ((rmdf.ENV_REFLECTION, "refl"), (rmdf.ENV_COS_1, "cos1"), (rmdf.ENV_COS_8, "cos8")):
             plain.set_env_cube(slot, env_faces[k])
-        for (w, h, t, ms) in ((480, 270, 0.0, 256), (250, 130, 2.5, 64), (33, 17, 1.0, 256), (1280, 720, 7.0, 256)):
-            a, b = sr.render(2, w, h, t, max_steps=ms), plain.render(2, w, h, t, max_steps=ms)
+        for (scene, w, h, t, ms) in ((2, 480, 270, 0.0, 256), (2, 250, 130, 2.5, 64), (2, 33, 17, 1.0, 256), (2, 1280, 720, 7.0, 256),
+                                     (1, 640, 360, 1.0, 128), (1, 250, 130, 5.0, 64), (3, 640, 360, 3.0, 128), (3, 33, 17, 0.0, 128)):
+            a, b = sr.render(scene, w, h, t, max_steps=ms), plain.render(scene, w, h, t, max_steps=ms)
             for k in ("rgba8", "steps", "iters"):
-                assert np.array_equal(a[k], b[k]), (k, w, h)
+                assert np.array_equal(a[k], b[k]), (k, scene, w, h)
             assert np.array_equal(a["rgba_f32"].view(np.uint32), b["rgba_f32"].view(np.uint32))
     finally:
         plain.close()
