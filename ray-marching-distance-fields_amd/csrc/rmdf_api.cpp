@@ -357,10 +357,13 @@ int fill_params(rmdf_ctx *ctx, int scene, int w, int h, float time, int max_step
     p.env_cos1 = CubeDev{ ctx->env[RMDF_ENV_COS_1].d_texels, ctx->env[RMDF_ENV_COS_1].W };
     p.env_cos8 = CubeDev{ ctx->env[RMDF_ENV_COS_8].d_texels, ctx->env[RMDF_ENV_COS_8].W };
     p.cornell = ctx->d_cornell;
-    { static int mg = -1; if (mg < 0) { const char *e = getenv("RMDF_MERGE"); mg = e ? atoi(e) : 32; } p.merge_stragglers = (ctx->flags & RMDF_FLAG_NO_MERGE) ? 0 : mg; }
+    // measurement knobs are read once per process
+    static int mg = -1, mg_forced = 0;
+    if (mg < 0) { const char *e = getenv("RMDF_MERGE"); mg_forced = e != nullptr; mg = e ? atoi(e) : 32; }
+    p.merge_stragglers = (ctx->flags & RMDF_FLAG_NO_MERGE) ? 0 : mg;
     // measured (current build): pooling pays for both Mandelbulbs (+5 %, +8 %) and the test scene (+8 %); it costs 6 % for
     // the Cornell box, whose distance estimate has the same cost for every ray
-    if (scene == RMDF_FS_DE_CORNELL_BOX && !getenv("RMDF_MERGE")) p.merge_stragglers = 0;
+    if (scene == RMDF_FS_DE_CORNELL_BOX && !mg_forced) p.merge_stragglers = 0;
     p.cornell_tab = ctx->d_cornell_tab;
     p.cornell_prune = (ctx->flags & RMDF_FLAG_NO_PRUNE) ? 0 : 1;
     { static int skip = -1; if (skip < 0) { const char *e = getenv("RMDF_DBG_SKIP"); skip = e ? atoi(e) : 0; } p.dbg_skip = skip; }
