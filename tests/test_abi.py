@@ -80,3 +80,40 @@ def test_product_never_touches_the_oracle(rmdf):
                 assert "liboracle" not in text and "rmdf_oracle" not in text and "from oracle" not in text, f
     deps = os.popen("ldd %s" % rmdf.LIB_PATH).read()
     assert "oracle" not in deps and "amdhip64" in deps
+
+
+def _build_c_host(tmp_path):
+    import subprocess
+    import rmdf_amd
+    rmdf_amd.build()
+    exe = str(tmp_path / "c_host")
+    libdir = os.path.dirname(rmdf_amd.LIB_PATH)
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-std=c99", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_host.c"), "-o", exe, "-L", libdir, "-lrmdf", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_c_host_compiles_against_the_header(tmp_path):
+    """include/rmdf.h is plain C (C99, -Wall -Werror) and librmdf.so links into a C program: the example host that does what
+    App.draw does (64 drawShaderTile calls into a Word32 buffer, then the screenshot) builds without a GPU."""
+    exe = _build_c_host(tmp_path)
+    assert os.path.exists(exe)
+
+
+@pytest.mark.gpu
+def test_c_host_runs(tmp_path):
+    """The C host on the GPU: 64 tiled calls accumulate the untiled frame (it checks that itself) and the PNG it writes
+    decodes to the frame the Python mirror renders."""
+    import subprocess
+    import numpy as np
+    from PIL import Image
+    import rmdf_amd
+    exe = _build_c_host(tmp_path)
+    png = str(tmp_path / "c_host.png")
+    out = subprocess.run([exe, rmdf_amd.DEFAULT_ENV_HDR, png, "2", "320", "184"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "64 tiles == untiled: yes" in out.stdout
+    with rmdf_amd.with_shader_renderer() as sr:
+        fb = rmdf_amd.FrameBuffer(320, 184)
+        sr.draw_shader_tile(2, None, 320, 184, 1.5, fb.vec, max_steps=256)
+    assert np.array_equal(np.asarray(Image.open(png)), fb.to_image_rows_top_down())
