@@ -25,7 +25,7 @@ struct CubeSlot {
     int    W = 0;
 };
 
-#define RMDF_MAX_ORDER_STREAMS 8
+#define RMDF_MAX_ORDER_STREAMS 32
 struct OrderState {
     hipStream_t stream = nullptr;
     unsigned   *d_cost = nullptr, *d_order = nullptr;

@@ -471,7 +471,7 @@ def test_multirank_bench_logic_on_one_gpu():
     assert len(lines) == 1, r.stdout                        # exactly one JSON line on stdout, from rank 0
     d = json.loads(lines[0])
     assert d["n_gpus"] == 3 and d["check_rgba8_equal"] is True
-    assert d["config"]["tile_deal"].startswith("cost-aware") and d["config"]["frames_in_flight"] == 5
+    assert d["config"]["tile_deal"].startswith("cost-aware") and d["config"]["frames_in_flight"] == 8
     assert d["scaling"] == "strong" and d["metric"].startswith("Mpixels/s")
 
 

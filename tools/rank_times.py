@@ -1,5 +1,5 @@
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, "/root/repo")
 import torch, rmdf_amd
 dev = torch.device("cuda", 0)

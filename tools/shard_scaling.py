@@ -3,7 +3,7 @@
 frames in flight.  Shows what bounds the N-GPU strong-scaling run: the longest ray's serial chain (one frame at a time)
 vs the shard's share of the work (frames in flight).  Measurement aid."""
 import os, sys, time, json
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import rmdf_amd

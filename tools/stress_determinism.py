@@ -2,7 +2,7 @@
 """Race hunt for the ray pooling / frames-in-flight machinery: many frames on several streams, every one compared on the
 device with the first (scene 2 and 0, two sizes).  Prints the number of differing frames (must be 0)."""
 import os, sys
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, rmdf_amd
 dev = torch.device("cuda", 0)
