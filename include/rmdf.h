@@ -46,7 +46,7 @@ typedef struct rmdf_ctx rmdf_ctx;
 #define RMDF_E_HIP          -3   /* a HIP runtime call failed                      */
 #define RMDF_E_IO           -4   /* file missing / unreadable / malformed          */
 #define RMDF_E_NO_ENV       -5   /* a cube map the scene samples has not been set  */
-#define RMDF_E_UNSUPPORTED  -6   /* scene not built yet                            */
+#define RMDF_E_UNSUPPORTED  -6   /* reserved                                       */
 #define RMDF_E_NOMEM        -7
 
 /* `data FragmentShader = FSDECornellBoxShader | FSDETestShader | FSMBPower8Shader |
@@ -155,7 +155,10 @@ int rmdf_render_tile_ex(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, do
 
 /* Render the pixel rectangle [x0,x1) x [y0,y1) of a w x h frame into caller-owned
  * DEVICE buffers laid out as full frames (any may be NULL).  `stream` is a
- * hipStream_t (NULL = the ctx stream); the call is asynchronous on it. */
+ * hipStream_t (NULL = the ctx stream); the call is asynchronous on it.  Calls on different streams may overlap (frames in
+ * flight): the library keeps its dispatch-order tables per stream (up to 32).  For more than about four concurrent streams
+ * set GPU_MAX_HW_QUEUES (e.g. 16) in the environment before the HIP runtime initialises, or streams share hardware queues
+ * and serialise. */
 int rmdf_render_rect_device(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps,
                             int x0, int y0, int x1, int y1,
                             void *d_rgba8, void *d_rgba_f32, void *d_steps, void *d_iters, void *stream);
