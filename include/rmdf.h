@@ -203,6 +203,10 @@ int rmdf_render_supersampled(rmdf_ctx *ctx, int scene, int w, int h, int levels,
  * mismatches[0..3] = sqrt, reciprocal, log, 1/sqrt; mismatches[4] = the table-driven division of the Cornell
  * distance estimator against the compiler's for every numerator and each of its 96 divisors.  All must be 0. */
 int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[5]);
+/* Self-test of the straight-line device forms of the pinned GLSL built-ins (exp, acos, atan, sin, cos: all 2^32 inputs;
+ * atan(y,x) and pow(x,y): 2^32 operand pairs) against the branchy fdlibm-style forms they restate.
+ * mismatches[0..6] = exp, acos, atan, sin, cos, atan2, pow.  All must be 0. */
+int rmdf_selftest_pinned_math(rmdf_ctx *ctx, uint64_t mismatches[7]);
 
 /* Measurement aid: per-wave counters of the Mandelbulb march kernel.  enable != 0 switches collection on
  * (off: frees the buffer); out (may be NULL) receives 16 uint64 per wave for the launches since the last read:

@@ -47,6 +47,7 @@ ABI_SYMBOLS = (
     "rmdf_device_info", "rmdf_debug_march_stats", "rmdf_resolve_box2_device", "rmdf_render_supersampled",
     "rmdf_selftest_exact_math", "rmdf_shard_tiles", "rmdf_probe_tile_costs", "rmdf_set_shard_costs",
     "rmdf_get_shard_tiles", "rmdf_save_png", "rmdf_register_host_buffer", "rmdf_unregister_host_buffer",
+    "rmdf_selftest_pinned_math",
 )
 
 
@@ -145,6 +146,7 @@ def load_library():
     L.rmdf_device_info.argtypes = [vp, C.c_char_p, C.c_int, ip]
     L.rmdf_debug_march_stats.argtypes = [vp, C.c_int, vp, C.c_int]
     L.rmdf_selftest_exact_math.argtypes = [vp, vp]
+    L.rmdf_selftest_pinned_math.argtypes = [vp, vp]
     L.rmdf_resolve_box2_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     L.rmdf_render_supersampled.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]
     _lib = L
@@ -314,6 +316,12 @@ class ShaderRenderer:
         """Mismatch counts (sqrt, rcp, log, rsqrt) of the short exact sequences vs the compiler's, all 2^32 inputs."""
         out = np.zeros(5, np.uint64)
         self._check(self._lib.rmdf_selftest_exact_math(self._ctx, out.ctypes.data))
+        return out
+
+    def selftest_pinned_math(self):
+        """Mismatch counts (exp, acos, atan, sin, cos, atan2, pow) of the straight-line device forms vs the branchy ones."""
+        out = np.zeros(7, np.uint64)
+        self._check(self._lib.rmdf_selftest_pinned_math(self._ctx, out.ctypes.data))
         return out
 
     def debug_march_stats(self, enable=True, read_waves=0):

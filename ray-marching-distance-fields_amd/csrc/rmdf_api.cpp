@@ -956,6 +956,20 @@ int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[5])
     return RMDF_OK;
 }
 
+int rmdf_selftest_pinned_math(rmdf_ctx *ctx, uint64_t mismatches[7])
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!mismatches) return fail(ctx, RMDF_E_INVALID, "null output");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf d;
+    HIP_TRY(ctx, hipMalloc(&d.p, 8 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(d.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, launch_selftest_pinned_math((unsigned long long *)d.p, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(mismatches, d.p, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RMDF_OK;
+}
+
 int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_waves)
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");

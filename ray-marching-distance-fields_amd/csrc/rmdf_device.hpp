@@ -160,6 +160,14 @@ __device__ __forceinline__ float exp_core(float x)
     y = y * __int_as_float((k2 + 127) << 23);
     return y;
 }
+// the branchy form (reference of the device self-test)
+__device__ __noinline__ float exp_full(float x)
+{
+    if (x != x) return x;
+    if (x > 88.5f) return __builtin_inff();
+    if (x < -87.0f) return 0.0f;
+    return exp_core(x);
+}
 // Straight-line core for every lane; NaN / overflow / underflow lanes are patched on a wave-uniform branch.
 __device__ __forceinline__ float exp_pinned(float x)
 {
@@ -247,6 +255,20 @@ __device__ __forceinline__ float kcos_pinned(float x)
     const float z = x * x;
     const float r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
     return 1.0f - (0.5f * z - z * r);
+}
+// the branchy form (reference of the device self-test)
+__device__ __noinline__ void sincos_full(float x, float &s, float &c)
+{
+    if (!(fabsf(x) <= 3.4e38f)) { s = x - x; c = x - x; return; }
+    float r; int q;
+    rem_pio2_pinned(x, r, q);
+    const float ks = ksin_pinned(r), kc = kcos_pinned(r);
+    switch (q & 3) {
+    case 0:  s = ks;  c = kc;  break;
+    case 1:  s = kc;  c = -ks; break;
+    case 2:  s = -ks; c = -kc; break;
+    default: s = -kc; c = ks;  break;
+    }
 }
 // sin and cos of the same argument share the reduction (the shader always needs both).  Branch-free: the quadrant
 // logic is two selects and two sign flips, inf / NaN are overridden at the end.

@@ -116,6 +116,7 @@ hipError_t launch_render_pipeline(int scene, const FrameParams &p, hipStream_t s
 hipError_t launch_march_pool(const FrameParams &p, int blocks, hipStream_t stream);   // rmdf_pool.hip
 hipError_t launch_resolve_box2(const uint32_t *d_src, int sw, int sh, uint32_t *d_dst, hipStream_t stream);
 hipError_t launch_selftest_exact_math(unsigned long long *d_counts, const float *d_cornell_tab, hipStream_t stream);
+hipError_t launch_selftest_pinned_math(unsigned long long *d_counts, hipStream_t stream);
 hipError_t launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t stream);
 hipError_t launch_cube_upload(const float *d_faces_f32, int W, uint2 *d_padded, hipStream_t stream);
 hipError_t launch_latlong_to_cube(const float *d_latlong, int w, int h, float *d_faces_f32, hipStream_t stream);

@@ -566,6 +566,41 @@ __global__ void k_selftest_exact_math(unsigned long long *counts)
     atomicAdd(&counts[0], c0); atomicAdd(&counts[1], c1); atomicAdd(&counts[2], c2); atomicAdd(&counts[3], c3);
 }
 
+// Self-test of the straight-line pinned functions (rmdf_device.hpp) against their branchy fdlibm-style forms, over ALL 2^32
+// float bit patterns: exp, acos, atan, sin, cos; atan2 and pow over 2^32 pseudo-random operand pairs (every bit pattern of y
+// paired with a hashed x).  counts[0..6] = differing inputs (NaN == NaN).
+__global__ void k_selftest_pinned_math(unsigned long long *counts)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long c[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    auto differ = [](float a, float b) { return !((__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b)); };
+    for (uint64_t i = tid; i < (1ull << 32); i += stride) {
+        const float x = __uint_as_float((uint32_t)i);
+        c[0] += differ(exp_pinned(x), exp_full(x));
+        c[1] += differ(acos_pinned(x), acos_full(x));
+        c[2] += differ(atan_pinned(x), atan_full(x));
+        float s0, c0, s1, c1;
+        sincos_pinned(x, s0, c0);
+        sincos_full(x, s1, c1);
+        c[3] += differ(s0, s1);
+        c[4] += differ(c0, c1);
+        uint32_t h = (uint32_t)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        // every fourth pair uses a "shader-like" second operand (finite, moderate) so that the main path is exercised densely
+        const float y = (i & 3) ? __uint_as_float(h) : (float)((int)(h >> 8) - 8388608) * (1.0f / 1048576.0f);
+        c[5] += differ(atan2_pinned(x, y), atan2_full(x, y));
+        const float pw = 2.0f + (float)(h & 1023u) * (4.5f / 1023.0f);         // the animated power range 2 .. 6.5
+        const float pr = !(x > 0.0f) ? 0.0f : exp_full(pw * log_ref_division(x));
+        c[6] += differ(pow_pinned(x, pw), pr);
+    }
+    for (int k = 0; k < 7; k++) if (c[k]) atomicAdd(&counts[k], c[k]);
+}
+
+hipError_t launch_selftest_pinned_math(unsigned long long *d_counts, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_selftest_pinned_math, dim3(8192), dim3(256), 0, stream, d_counts);
+    return hipGetLastError();
+}
+
 hipError_t launch_selftest_exact_math(unsigned long long *d_counts, const float *d_cornell_tab, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_selftest_exact_math, dim3(8192), dim3(256), 0, stream, d_counts);

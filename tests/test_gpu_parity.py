@@ -516,3 +516,11 @@ def test_random_views_vs_oracle(sr, orc, env_oracle):
         ms = int(rng.choice([16, 64, 128, 256]))
         got = sr.render(scene, w, h, t, max_steps=ms)
         assert_frame_parity(got, orc.render(scene, w, h, t, ms, env_oracle), "case %d: scene %d %dx%d t=%.3f ms=%d" % (case, scene, w, h, t, ms))
+
+
+def test_pinned_math_exhaustive(sr):
+    """The device evaluates exp / acos / atan / sin / cos / atan2 / pow with straight-line cores and wave-uniform special-case
+    paths (rmdf_device.hpp).  They must return the bits of the branchy fdlibm-style forms they restate (the forms the oracle
+    is written in): checked on the device for all 2^32 inputs (two-operand functions: 2^32 pairs)."""
+    mism = sr.selftest_pinned_math()
+    assert mism.tolist() == [0] * 7, mism
