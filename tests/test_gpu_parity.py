@@ -524,3 +524,33 @@ def test_pinned_math_exhaustive(sr):
     is written in): checked on the device for all 2^32 inputs (two-operand functions: 2^32 pairs)."""
     mism = sr.selftest_pinned_math()
     assert mism.tolist() == [0] * 7, mism
+
+
+@pytest.mark.parametrize("scene", [0, 1, 2, 3])
+def test_degenerate_frame_sizes(sr, orc, env_oracle, scene):
+    """1x1, 2x2, single rows and columns: lone pixels have no quad neighbours inside the frame (helper invocations only)."""
+    for (w, h) in ((1, 1), (2, 2), (1, 37), (41, 1), (3, 2)):
+        assert_frame_parity(sr.render(scene, w, h, 0.7, max_steps=64), orc.render(scene, w, h, 0.7, 64, env_oracle), "s%d %dx%d" % (scene, w, h))
+
+
+def test_tiles_of_sizes_8_does_not_divide(sr, rmdf, orc, env_oracle):
+    """Tile mode on a frame whose size 8 does not divide (centre-inside rasterisation of the NDC tile rectangles,
+    ShaderRendering.hs:183-193): the 64 tiles partition the frame and accumulate the untiled frame, which equals the oracle's."""
+    w, h, ms = 250, 131, 64
+    full = sr.render(2, w, h, 0.3, max_steps=ms)
+    assert_frame_parity(full, orc.render(2, w, h, 0.3, ms, env_oracle))
+    fb = rmdf.FrameBuffer(w, h)
+    for idx in range(64):
+        sr.draw_shader_tile(2, idx, w, h, 0.3, fb.vec, max_steps=ms)
+    assert np.array_equal(fb.vec.reshape(h, w), full["rgba8"])
+
+
+def test_argument_limits(sr, rmdf):
+    for bad in (dict(w=32769, h=8), dict(w=8, h=0)):
+        with pytest.raises(rmdf.RmdfError) as e:
+            sr.render(2, bad["w"], bad["h"], 0.0)
+        assert e.value.code == -1
+    with pytest.raises(rmdf.RmdfError) as e:
+        sr.render(2, 16, 8, 0.0, max_steps=32768)                 # the step counter shares a 16-bit plane with the hit bit
+    assert e.value.code == -1
+    assert sr.render(2, 16, 8, 0.0, max_steps=32767)["rgba8"].shape == (8, 16)
