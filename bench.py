@@ -226,11 +226,13 @@ def main():
         tmps = [torch.empty((rh // 2, rw // 2), **i32) if L > 1 else None for _ in range(S)]
     else:
         slots = rmdf_amd.shard_slots(world)
-        shards = [torch.zeros((slots, h // 8, w // 8), **i32) for _ in range(S)]
+        gathereds = [torch.zeros((world, slots, h // 8, w // 8), **i32) if rank == 0 else None for _ in range(S)]
+        gather_lists = [list(g.unbind(0)) if g is not None else None for g in gathereds]
+        # rank 0 renders straight into its own slot of the gather buffer (the gather's copy of the root's part is then a
+        # copy onto itself)
+        shards = [gathereds[k][0] if rank == 0 else torch.zeros((slots, h // 8, w // 8), **i32) for k in range(S)]
         bigs = [torch.zeros((slots, rh // 8, rw // 8), **i32) for _ in range(S)] if L else shards
         tmps = [torch.empty((slots, rh // 16, rw // 16), **i32) if L > 1 else None for _ in range(S)]
-        gathereds = [torch.empty((world, slots, h // 8, w // 8), **i32) if rank == 0 else None for _ in range(S)]
-        gather_lists = [list(g.unbind(0)) if g is not None else None for g in gathereds]
     frame = frames[0]
 
     def resolve(src, sw, sh, dst, tmp, sp):
