@@ -199,11 +199,17 @@ def main():
         # kernels -> identical costs, no exchange) and deals longest-processing-time-first.  Outside the timed region
         # the ranks compare their deals once; any disagreement falls back to the static deal on all of them.
         sr.set_shard_costs(sr.probe_tile_costs(a.scene, a.width << a.supersample, a.height << a.supersample, a.time, a.max_steps))
+        # rank 0 also receives 63/64 of every frame and assembles it: about 10 us per frame next to 68 us of render at N = 8
+        # (measured on one GPU: the N > 1 path with world size 1 against the plain path), less in proportion at smaller N.
+        # The deal therefore starts rank 0 with that share of load.  RMDF_ROOT_HANDICAP overrides (a fraction of a rank's share).
+        handicap = float(os.environ.get("RMDF_ROOT_HANDICAP", min(0.25, 0.015 * world)))
+        sr.set_shard_root_handicap(handicap)
         agree = ranks_agree_on_deal([sr.shard_tiles(r, world) for r in range(world)], dist, cdev)
         if agree:
-            deal = "cost-aware (probe frame, LPT)"
+            deal = "cost-aware (probe frame, LPT, rank 0 handicap %.3f)" % handicap
         else:
             sr.set_shard_costs(None)
+            sr.set_shard_root_handicap(0.0)
             deal = "static (ranks disagreed on the probed costs)"
     # Frames are independent, so S of them are kept in flight: frame i goes to HIP stream i % S (dedicated, non-null
     # streams; kernels, the RCCL call and the timing events of a frame all go on its stream) and owns buffer set

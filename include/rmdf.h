@@ -181,6 +181,10 @@ int rmdf_shard_tiles(int rank, int nranks, int tiles[64]);
 int rmdf_probe_tile_costs(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps, float cost[64]);
 int rmdf_set_shard_costs(rmdf_ctx *ctx, const float cost[64]);
 int rmdf_get_shard_tiles(rmdf_ctx *ctx, int rank, int nranks, int tiles[64]);
+/* Rank 0 also receives the other ranks' shards and assembles the frame.  With a handicap the cost-aware deal starts rank 0 at
+ * fraction x (total cost / nranks) instead of 0, so it is dealt correspondingly less to render (0 = off, the default; only
+ * effective together with rmdf_set_shard_costs; ALL ranks must set the same value). */
+int rmdf_set_shard_root_handicap(rmdf_ctx *ctx, float fraction);
 int rmdf_render_shard_device(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps,
                              int rank, int nranks, void *d_packed_rgba8, void *stream);
 /* Rank 0 after the gather: d_gathered holds the nranks shards back to back (rank

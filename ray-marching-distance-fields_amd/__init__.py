@@ -47,7 +47,7 @@ ABI_SYMBOLS = (
     "rmdf_device_info", "rmdf_debug_march_stats", "rmdf_resolve_box2_device", "rmdf_render_supersampled",
     "rmdf_selftest_exact_math", "rmdf_shard_tiles", "rmdf_probe_tile_costs", "rmdf_set_shard_costs",
     "rmdf_get_shard_tiles", "rmdf_save_png", "rmdf_register_host_buffer", "rmdf_unregister_host_buffer",
-    "rmdf_selftest_pinned_math",
+    "rmdf_selftest_pinned_math", "rmdf_set_shard_root_handicap",
 )
 
 
@@ -141,6 +141,7 @@ def load_library():
     L.rmdf_probe_tile_costs.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]
     L.rmdf_set_shard_costs.argtypes = [vp, vp]
     L.rmdf_get_shard_tiles.argtypes = [vp, C.c_int, C.c_int, ip]
+    L.rmdf_set_shard_root_handicap.argtypes = [vp, C.c_float]
     L.rmdf_assemble_shards_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.rmdf_synchronize.argtypes = [vp, vp]
     L.rmdf_device_info.argtypes = [vp, C.c_char_p, C.c_int, ip]
@@ -291,6 +292,10 @@ class ShaderRenderer:
             assert cost.size == 64
         self._check(self._lib.rmdf_set_shard_costs(self._ctx, _ptr(cost)))
 
+    def set_shard_root_handicap(self, fraction):
+        """Start rank 0 of the cost-aware deal at fraction x (total cost / nranks): it also receives and assembles."""
+        self._check(self._lib.rmdf_set_shard_root_handicap(self._ctx, float(fraction)))
+
     def shard_tiles(self, rank, nranks):
         """The deal in effect on this renderer (static, or by the costs set with set_shard_costs)."""
         buf = (C.c_int * 64)()
@@ -395,13 +400,15 @@ def shard_tiles(rank, nranks):
     return out
 
 
-def shard_tiles_by_cost(rank, nranks, cost):
+def shard_tiles_by_cost(rank, nranks, cost, root_handicap=0.0):
     """The cost-aware deal of rmdf_set_shard_costs restated: tiles in descending cost order (idx order among equals),
-    each to the least loaded rank that still has a free slot (lowest rank among equals)."""
+    each to the least loaded rank that still has a free slot (lowest rank among equals); rank 0 starts at
+    root_handicap x (total cost / nranks) (rmdf_set_shard_root_handicap)."""
     cost = [float(np.float32(c)) for c in cost]
     order = sorted(range(N_TILES), key=lambda i: (-cost[i], i))
     cap = shard_slots(nranks)
     load, used, out = [0.0] * nranks, [0] * nranks, []
+    load[0] = float(np.float32(root_handicap)) * sum(cost) / nranks
     for idx in order:
         best = min((r for r in range(nranks) if used[r] < cap), key=lambda r: (load[r], r))
         load[best] += cost[idx]

@@ -67,6 +67,7 @@ struct rmdf_ctx {
     float        shard_cost[64];
     bool         shard_cost_set = false;
     unsigned     shard_cost_gen = 0;
+    float        shard_root_handicap = 0.0f;
     // the deal of the last (nranks, cost generation) asked for: per-frame calls must not redo the sort
     int          deal_nranks = 0;
     unsigned     deal_gen = ~0u;
@@ -325,7 +326,8 @@ void ensure_deal(rmdf_ctx *ctx, int nranks)
 {
     if (ctx->deal_nranks == nranks && ctx->deal_gen == ctx->shard_cost_gen) return;
     for (int r = 0; r < nranks; r++) {
-        ctx->deal_count[r] = shard_tiles_of_rank(r, nranks, ctx->deal_tiles[r], ctx->shard_cost_set ? ctx->shard_cost : nullptr);
+        ctx->deal_count[r] = shard_tiles_of_rank(r, nranks, ctx->deal_tiles[r], ctx->shard_cost_set ? ctx->shard_cost : nullptr,
+                                                 ctx->shard_root_handicap);
         for (int s = 0; s < ctx->deal_count[r]; s++) ctx->deal_where.v[ctx->deal_tiles[r][s]] = (unsigned short)((r << 8) | s);
     }
     ctx->deal_nranks = nranks; ctx->deal_gen = ctx->shard_cost_gen;
@@ -836,6 +838,15 @@ int rmdf_set_shard_costs(rmdf_ctx *ctx, const float cost[64])
         memcpy(ctx->shard_cost, cost, sizeof ctx->shard_cost);
     }
     ctx->shard_cost_set = cost != nullptr;
+    ctx->shard_cost_gen++;
+    return RMDF_OK;
+}
+
+int rmdf_set_shard_root_handicap(rmdf_ctx *ctx, float fraction)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!(fraction >= 0.0f) || fraction > 1.0f) return fail(ctx, RMDF_E_INVALID, "rmdf_set_shard_root_handicap: 0 <= fraction <= 1");
+    ctx->shard_root_handicap = fraction;
     ctx->shard_cost_gen++;
     return RMDF_OK;
 }

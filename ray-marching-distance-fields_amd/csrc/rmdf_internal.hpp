@@ -65,7 +65,8 @@ struct FrameParams {
 // cost != nullptr (64 per-tile costs, e.g. rmdf_probe_tile_costs): longest-processing-time-first -- tiles in
 // descending cost order (idx order among equals), each to the least loaded rank that still has a free slot (lowest
 // rank among equals).  Deterministic: ranks that hold the same costs compute the same deal without talking.
-inline int shard_tiles_of_rank(int rank, int nranks, unsigned char tiles[64], const float *cost = nullptr)
+// root_handicap: see rmdf_set_shard_root_handicap (rmdf.h).
+inline int shard_tiles_of_rank(int rank, int nranks, unsigned char tiles[64], const float *cost = nullptr, float root_handicap = 0.0f)
 {
     int order[64], n = 0;
     if (!cost) {
@@ -92,6 +93,8 @@ inline int shard_tiles_of_rank(int rank, int nranks, unsigned char tiles[64], co
     double load[64];
     int used[64], cnt = 0;
     for (int r = 0; r < nranks; r++) { load[r] = 0.0; used[r] = 0; }
+    // rank 0 also receives and assembles every frame: it starts the deal with that much load (a fraction of a rank's fair share)
+    { double total = 0.0; for (int i = 0; i < 64; i++) total += (double)cost[i]; load[0] = (double)root_handicap * total / nranks; }
     for (int j = 0; j < 64; j++) {
         int best = -1;
         for (int r = 0; r < nranks; r++)

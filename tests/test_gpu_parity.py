@@ -393,7 +393,15 @@ def test_cost_aware_tile_deal(sr, rmdf):
             sr.synchronize()
             assert np.array_equal(frame.cpu().numpy().view(np.uint32), ref), n
             assert np.array_equal(rmdf.assemble_shards_host(gathered.cpu().numpy().view(np.uint32), w, h, n, tiles_of=sr.shard_tiles), ref)
+        # rank 0 handicap (it also receives and assembles): the library's deal == its restatement, rank 0 gets less
+        sr.set_shard_root_handicap(0.12)
+        tiles = [sr.shard_tiles(r, 8) for r in range(8)]
+        assert tiles == [rmdf.shard_tiles_by_cost(r, 8, cost, 0.12) for r in range(8)]
+        assert sorted(sum(tiles, [])) == list(range(64))
+        loads = [sum(cost[t] for t in ts) for ts in tiles]
+        assert loads[0] < min(loads[1:])
     finally:
+        sr.set_shard_root_handicap(0.0)
         sr.set_shard_costs(None)
     assert sr.shard_tiles(1, 8) == rmdf.shard_tiles(1, 8)
 
@@ -471,7 +479,7 @@ def test_multirank_bench_logic_on_one_gpu():
     assert len(lines) == 1, r.stdout                        # exactly one JSON line on stdout, from rank 0
     d = json.loads(lines[0])
     assert d["n_gpus"] == 3 and d["check_rgba8_equal"] is True
-    assert d["config"]["tile_deal"].startswith("cost-aware") and d["config"]["frames_in_flight"] == 8
+    assert d["config"]["tile_deal"].startswith("cost-aware") and "handicap" in d["config"]["tile_deal"] and d["config"]["frames_in_flight"] == 8
     assert d["scaling"] == "strong" and d["metric"].startswith("Mpixels/s")
 
 
