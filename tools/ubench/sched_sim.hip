@@ -491,6 +491,31 @@ int main()
         printf("nested + parked stragglers (K0=%d L0=%d R0=%d) %10.1f M wave-instr  (x%.3f of nested)  lane utilisation %.3f\n",
                K0, L0, R0, c / 1e6, c / c_nested, ideal / c);
     }
+    // the serial chain of the frame's longest rays: instructions a wave issues until that ray is done, when the ray marches in
+    // a full 8x8 packet (max k of the packet's active lanes per step), in an 8x2 sub-packet, in its 2x2 quad, or alone
+    {
+        std::vector<int> top;
+        { std::vector<std::pair<int,int>> v; for (size_t i = 0; i < npx; i++) if (g_n[i] > 150) v.push_back({ -(int)g_n[i], (int)i });
+          std::sort(v.begin(), v.end()); for (size_t j = 0; j < v.size() && j < 12; j++) top.push_back(v[j].second); }
+        for (int pix : top) {
+            const int px = pix % W, py = pix / W;
+            double chain[4] = { 0, 0, 0, 0 };
+            const int bw[4] = { 8, 8, 2, 1 }, bh[4] = { 8, 2, 2, 1 };
+            for (int m = 0; m < 4; m++) {
+                const int x0 = px / bw[m] * bw[m], y0 = py / bh[m] * bh[m];
+                for (int st = 0; st < g_n[pix]; st++) {
+                    int mk = 0;
+                    for (int y = y0; y < y0 + bh[m] && y < H; y++) for (int x = x0; x < x0 + bw[m] && x < W; x++) {
+                        const int q = y * W + x;
+                        if (st < g_n[q]) { const int k = kof(q, st); if (k > mk) mk = k; }
+                    }
+                    chain[m] += A * mk + B;
+                }
+            }
+            printf("ray (%4d,%4d) %3d estimates: chain in 8x8 packet %7.0f instr, 8x2 %7.0f, quad %7.0f, alone %7.0f\n",
+                   px, py, (int)g_n[pix], chain[0], chain[1], chain[2], chain[3]);
+        }
+    }
     // normal estimates: the four estimates of a hit pixel share k; a wave pays max k over its hit lanes.  What would
     // regrouping the hit pixels of a workgroup (32x8 strip, 4 waves) by k save?
     {
