@@ -6,20 +6,29 @@
 Metric (BASELINE.json): Mpixels/s, Mandelbulb power-8, 1920x1080, 256 max march steps, uffizi_512.hdr
 environment, in_time = 0.  One "step" = one full frame of the hot path (ray generation, bounding-sphere
 clip, march loop, finite-difference normal, distance AO, prefiltered-env-map shading, gamma, RGBA8 pack)
-with the cube maps already resident in HBM; the frame stays in HBM (the PCIe-inclusive rate is reported
-separately as `d2h_inclusive_mpixels_s`, never as `value`).
+with the cube maps already resident in HBM -- built by the product's own env pipeline (rmdf_load_env_hdr: GPU resize,
+GPU lobe prefilter, RGBE cache files, GPU cube conversion) before the timed region; the frame stays in HBM (the
+PCIe-inclusive rate is reported separately as `d2h_inclusive_mpixels_s`, never as `value`).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the reference's 64 tiles are dealt to the ranks
-interleaved (tile idx mod N), each rank renders its shard, ONE gather over RCCL/xGMI brings the shards to
-rank 0, which scatters them to frame positions.  Per-GPU work shrinks as N grows: "scaling": "strong".
+Timing: after the W warm-up steps the run keeps stepping until at least 0.3 s have passed (clocks ramp up on a fresh box),
+then times `repeats` (3) blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both sides with the MAX over
+ranks taken; `ms_per_step` / `value` are those of the MEDIAN block, the others are listed in `ms_per_step_blocks`.
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (k_render): algorithmic HBM bytes per
-launch / its average duration measured with HIP events on the launch stream.  The path is FP32-VALU bound by
-construction, so `roofline.frac` is expected to be ~1 %; the VALU-side figure is reported next
-to it in `valu_roofline`.  `cpu_baseline` = the CPU oracle (a port of the reference's shader to C) on the host
-cores of this box, reported, never the target.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the reference's 64 tiles are dealt to the ranks by measured
+cost (a probe frame rendered on every rank, longest-processing-time-first, rank 0 handicapped by its measured receive +
+assemble time), each rank renders its shard, ONE gather over RCCL/xGMI -- issued by the library itself
+(rmdf_render_frame_sharded_device: grouped ncclRecv fan-in on rank 0; torch.distributed only carries the 128-byte
+unique id and the control-plane reductions) -- brings the shards to rank 0, which scatters them to frame positions.
+Per-GPU work shrinks as N grows: "scaling": "strong".
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (k_render) against the roof that binds it, FP32
+vector-ALU issue: as-written IEEE operations of the frame (counted by the instrumented oracle) / the
+kernel's average duration, measured with HIP events on the launch stream, against 78.6 T lane-ops/s.  `hbm_roofline` is the
+same kernel's algorithmic HBM bytes against 8 TB/s (the north star asks for it; ~0.3 % by construction).  `cpu_baseline` =
+the CPU oracle (a port of the reference's shader to C) on the host cores of this box, reported, never the target.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,37 +40,47 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# frames in flight live on separate HIP streams; give the runtime enough hardware queues for them (read at HIP init).
-# Measured with 8 frames in flight (one GPU standing in for a rank of 8): 0.109 ms per frame with 8 queues -- streams share
-# queues -- 0.069 ms with 12 or more.
+# frames in flight live on separate HIP streams and need more than the runtime's 4 hardware queues (read at HIP init).
+# rmdf_create sets this too, but torch initialises HIP first in this process.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_TLANEOPS = 78.6       # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (157.3 TFLOPS only if every op were an FMA)
+VALU_ISSUE_PEAK = 0.93          # G wave-instructions/s/SIMD a stream of simple VALU instructions sustains (tools/ubench/valu_rates)
+MIN_WARM_SECONDS = 0.3
+
+# as-written operation counters of the headline frame (scene 2, 1920x1080, in_time 0, 256 steps), counted by the
+# instrumented oracle (tests/golden/full_size_digests.json holds the same numbers; `--check` or the cpu_baseline leg
+# recount them live).  They depend on the geometry only, not on the environment map.
+HEADLINE_COUNTERS = {"de_evals": 39739969, "triplex_iters": 128870630, "march_steps": 32356849, "hit_pixels": 1230520,
+                     "sphere_pixels": 1534400, "pixels": 2073600}
 
 
 # ---- helpers shared with the CPU-tier tests --------------------------------------------------------
 
+_ORACLE_ENV = {}
+
+
+def oracle_env_latlongs(orc):
+    """The ORACLE's env pipeline on the shipped uffizi_512.hdr (checker side only): reflection map + lobe maps 1 and 8 after
+    resize, prefilter and the RGBE round trip.  Cached per process."""
+    if "lat" not in _ORACLE_ENV:
+        import rmdf_amd
+        _ORACLE_ENV["lat"] = orc.env_pipeline(open(rmdf_amd.DEFAULT_ENV_HDR, "rb").read(), powers=(1.0, 8.0))[0]
+    return _ORACLE_ENV["lat"]
+
+
 def load_oracle_env(orc):
-    """Oracle-built cube maps of the shipped uffizi_512 + cache files (checker side only)."""
-    import rmdf_amd
-    d = os.path.join(rmdf_amd.DATA_DIR, "latlong_envmaps")
-    rd = lambda n: orc.hdr_decode(open(os.path.join(d, n), "rb").read())
-    return orc.EnvSet.from_latlongs(rd("uffizi_512.hdr"), rd("uffizi_512_cache_pow_1.0.hdr"),
-                                    rd("uffizi_512_cache_pow_8.0.hdr"))
-
-
-def load_oracle_faces(orc):
-    """Oracle-built float32 cube faces of the same files (input shared by both sides in --check)."""
-    import rmdf_amd
-    d = os.path.join(rmdf_amd.DATA_DIR, "latlong_envmaps")
-    rd = lambda n: orc.hdr_decode(open(os.path.join(d, n), "rb").read())
-    return {"refl": orc.latlong_to_cube(rd("uffizi_512.hdr")), "cos1": orc.latlong_to_cube(rd("uffizi_512_cache_pow_1.0.hdr")),
-            "cos8": orc.latlong_to_cube(rd("uffizi_512_cache_pow_8.0.hdr"))}
+    """Oracle-built cube maps of the shipped uffizi_512 (checker side only)."""
+    if "env" not in _ORACLE_ENV:
+        lat = oracle_env_latlongs(orc)
+        _ORACLE_ENV["env"] = orc.EnvSet.from_latlongs(lat["refl"], lat["cos1"], lat["cos8"])
+    return _ORACLE_ENV["env"]
 
 
 def gather_shards(shard, rank, world, dist, out=None, out_list=None):
-    """The single exchange step of the path: gather every rank's packed tile shard on rank 0.
+    """The exchange step over torch.distributed (fallback of the library's own RCCL gather, and the gloo transport of the
+    CPU-tier tests): gather every rank's packed tile shard on rank 0.
     shard: (slots, th, tw) int32 tensor.  Returns (world, slots, th, tw) on rank 0, None elsewhere.
     out_list = list(out.unbind(0)), precomputed by callers that gather every frame."""
     import torch
@@ -115,6 +134,34 @@ def flops_model(c):
     return 79 * c["triplex_iters"] + 11 * c["de_evals"] + 9 * c["march_steps"] + 150 * c["hit_pixels"] + 30 * c["pixels"]
 
 
+def sha256_file(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def pmc_record(lib_path, workload):
+    """PMC figures of the dominant kernel from the committed counter passes (profiles/pmc_traffic.json, written by
+    tools/pmc_summary.py on the GPU box).  They are measurements of ONE build: used only when the file names this very
+    librmdf.so (sha256) and this workload, and labelled with where they come from."""
+    tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tj):
+        return None, "no profiles/pmc_traffic.json"
+    try:
+        t = json.load(open(tj))
+    except Exception as e:                                      # noqa: BLE001
+        return None, "unreadable profiles/pmc_traffic.json: %s" % e
+    if t.get("workload") != workload:
+        return None, "profiles/pmc_traffic.json is for workload %s" % t.get("workload")
+    have = sha256_file(lib_path)
+    if t.get("lib_sha256") != have:
+        return None, "profiles/pmc_traffic.json was collected with another build of librmdf.so (%s..., this is %s...)" % (
+            str(t.get("lib_sha256"))[:12], have[:12])
+    return t, "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this build, librmdf.so sha256 %s...)" % have[:12]
+
+
 # ---- the benchmark ----------------------------------------------------------------------------------
 
 def main():
@@ -127,6 +174,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=3, help="timed blocks of --steps steps; the median block is reported")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--max-steps", type=int, default=256)
@@ -140,6 +188,7 @@ def main():
     ap.add_argument("--animate", type=float, default=0.0, help="advance in_time by this many seconds per frame (the viewer's "
                     "animation: the cost-ordered dispatch then works from the previous frame's costs of a slightly different view)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (Cornell config 2, env prefilter config 5)")
     ap.add_argument("--check", action="store_true", help="also compare the frame with the oracle (slow)")
     a = ap.parse_args()
 
@@ -182,37 +231,22 @@ def main():
     if sharded:
         dist.barrier()
     w, h, ms, scene = a.width, a.height, a.max_steps, a.scene
+    lib_path = os.environ.get("RMDF_LIB", rmdf_amd.LIB_PATH)
     sr = rmdf_amd.ShaderRenderer(local_rank, flags=int(os.environ.get("RMDF_FLAGS", "0")))
-    if a.check:
-        # strict comparison: both sides get the oracle-built float32 cube faces (the device's own latlong -> cube uses the
-        # device libm where the oracle uses glibc: a few texels differ by one f16 ulp, see tests/test_gpu_parity.py)
-        from oracle import orc as _orc
-        _env = load_oracle_faces(_orc)
-        for slot, k in ((rmdf_amd.ENV_REFLECTION, "refl"), (rmdf_amd.ENV_COS_1, "cos1"), (rmdf_amd.ENV_COS_8, "cos8")):
-            sr.set_env_cube(slot, _env[k])
-    else:
+    # the product's own env pipeline (cache files are built on the GPU at first load; local rank 0 first, so that the
+    # other ranks find complete files)
+    t_env0 = time.perf_counter()
+    if local_rank == 0 or share_gpu:
         sr.load_env_hdr(rmdf_amd.DEFAULT_ENV_HDR)
-    dev_name, cus = sr.device_info()
-    deal = "single GPU"
     if sharded:
-        # cost-aware deal of the 64 tiles: every rank probes the view at 256 x 144 on its own GPU (bit-reproducible
-        # kernels -> identical costs, no exchange) and deals longest-processing-time-first.  Outside the timed region
-        # the ranks compare their deals once; any disagreement falls back to the static deal on all of them.
-        sr.set_shard_costs(sr.probe_tile_costs(a.scene, a.width << a.supersample, a.height << a.supersample, a.time, a.max_steps))
-        # rank 0 also receives 63/64 of every frame and assembles it: about 10 us per frame next to 68 us of render at N = 8
-        # (measured on one GPU: the N > 1 path with world size 1 against the plain path), less in proportion at smaller N.
-        # The deal therefore starts rank 0 with that share of load.  RMDF_ROOT_HANDICAP overrides (a fraction of a rank's share).
-        handicap = float(os.environ.get("RMDF_ROOT_HANDICAP", min(0.25, 0.015 * world)))
-        sr.set_shard_root_handicap(handicap)
-        agree = ranks_agree_on_deal([sr.shard_tiles(r, world) for r in range(world)], dist, cdev)
-        if agree:
-            deal = "cost-aware (probe frame, LPT, rank 0 handicap %.3f)" % handicap
-        else:
-            sr.set_shard_costs(None)
-            sr.set_shard_root_handicap(0.0)
-            deal = "static (ranks disagreed on the probed costs)"
+        dist.barrier()
+    if not (local_rank == 0 or share_gpu):
+        sr.load_env_hdr(rmdf_amd.DEFAULT_ENV_HDR)
+    env_load_s = time.perf_counter() - t_env0
+    dev_name, cus = sr.device_info()
+
     # Frames are independent, so S of them are kept in flight: frame i goes to HIP stream i % S (dedicated, non-null
-    # streams; kernels, the RCCL call and the timing events of a frame all go on its stream) and owns buffer set
+    # streams; kernels, the RCCL calls and the timing events of a frame all go on its stream) and owns buffer set
     # i % S.  On one GPU this overlaps the thin tail of a frame -- the launch cannot end before its longest ray has
     # finished a ~0.45 ms serial chain -- with the bulk of the next; on N GPUs it also overlaps the gather of frame i
     # with the render of frame i+1.  --streams 1 = strictly one frame at a time.
@@ -220,13 +254,14 @@ def main():
     streams = [torch.cuda.Stream(dev) for _ in range(S)]
     stream = streams[0]
     torch.cuda.set_stream(stream)
-    sptr = stream.cuda_stream
     assert all(st.cuda_stream != 0 for st in streams)
 
     L = a.supersample
     rw, rh = w << L, h << L                                   # ray grid
     i32 = dict(dtype=torch.int32, device=dev)
     frames = [torch.empty((h, w), **i32) for _ in range(S)]
+    exchange = "none (single GPU)"
+    rccl_ranks = 0
     if not sharded:
         bigs = [torch.empty((rh, rw), **i32) for _ in range(S)] if L else frames
         tmps = [torch.empty((rh // 2, rw // 2), **i32) if L > 1 else None for _ in range(S)]
@@ -239,6 +274,30 @@ def main():
         shards = [gathereds[k][0] if rank == 0 else torch.zeros((slots, h // 8, w // 8), **i32) for k in range(S)]
         bigs = [torch.zeros((slots, rh // 8, rw // 8), **i32) for _ in range(S)] if L else shards
         tmps = [torch.empty((slots, rh // 16, rw // 16), **i32) if L > 1 else None for _ in range(S)]
+        # The exchange behind the C ABI: rank 0 draws an RCCL unique id, torch.distributed ships the 128 bytes, every rank
+        # joins the library's communicator.  Any failure (all ranks decide together) falls back to dist.gather.
+        use_abi_comm = not share_gpu and os.environ.get("RMDF_BENCH_TORCH_GATHER") != "1"
+        if use_abi_comm:
+            ok = 1
+            try:
+                uid = torch.zeros(rmdf_amd.COMM_ID_BYTES, dtype=torch.uint8, device=cdev)
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(rmdf_amd.comm_get_unique_id()), dtype=torch.uint8))
+                dist.broadcast(uid, src=0)
+                sr.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+            except Exception as e:                              # noqa: BLE001
+                print("rank %d: rmdf_comm_init failed (%s); falling back to torch.distributed gather" % (rank, e), file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            use_abi_comm = int(flag.item()) == 1
+            if not use_abi_comm and ok:
+                sr.comm_destroy()
+        if use_abi_comm:
+            rccl_ranks = sr.comm_info()[1]
+            exchange = "librmdf: rmdf_render_frame_sharded_device (grouped ncclSend/ncclRecv fan-in to rank 0), RCCL communicator of %d ranks" % rccl_ranks
+        else:
+            exchange = "torch.distributed gather (%s)" % ("gloo, host-staged: test aid" if share_gpu else "nccl = RCCL")
     frame = frames[0]
 
     def resolve(src, sw, sh, dst, tmp, sp):
@@ -256,48 +315,114 @@ def main():
         else:
             sr.render_shard_device(scene, rw, rh, t, ms, rank, world, bigs[k].data_ptr(), stream=sp)
 
+    def exchange_only(k=0):
+        sp = streams[k].cuda_stream
+        if use_abi_comm:
+            sr.gather_shards_device(w, h, shards[k].data_ptr(), gathereds[k].data_ptr() if rank == 0 else 0, stream=sp)
+            g = gathereds[k]
+        else:
+            with torch.cuda.stream(streams[k]):                # the RCCL call orders itself against the current stream
+                g = gather_shards(shards[k], rank, world, dist, out=gathereds[k], out_list=gather_lists[k])
+        if rank == 0:
+            sr.assemble_shards_device(w, h, world, g.data_ptr(), frames[k].data_ptr(), stream=sp)
+
     def step(i=0):
         k = i % S
         sp = streams[k].cuda_stream
-        with torch.cuda.stream(streams[k]):                   # the RCCL call orders itself against the current stream
-            render_only(k, a.time + a.animate * i)
-            if not sharded:
-                if L:
-                    resolve(bigs[k], rw, rh, frames[k], tmps[k], sp)
-            else:
-                if L:
-                    resolve(bigs[k], rw // 8, slots * (rh // 8), shards[k], tmps[k], sp)
-                g = gather_shards(shards[k], rank, world, dist, out=gathereds[k], out_list=gather_lists[k])
-                if rank == 0:
-                    sr.assemble_shards_device(w, h, world, g.data_ptr(), frames[k].data_ptr(), stream=sp)
+        t = a.time + a.animate * i
+        if not sharded:
+            render_only(k, t)
+            if L:
+                resolve(bigs[k], rw, rh, frames[k], tmps[k], sp)
+        elif use_abi_comm and not L:
+            sr.render_frame_sharded_device(scene, w, h, t, ms, shards[k].data_ptr(), gathereds[k].data_ptr() if rank == 0 else 0,
+                                           frames[k].data_ptr() if rank == 0 else 0, stream=sp)
+        else:
+            render_only(k, t)
+            if L:
+                resolve(bigs[k], rw // 8, slots * (rh // 8), shards[k], tmps[k], sp)
+            exchange_only(k)
 
     def barrier():
         if sharded:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def event_ms(fn, reps):
+        """average GPU time of fn() on stream 0 (HIP events on the stream the work is launched on)"""
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for e0, e1 in evs:
+            e0.record(stream)
+            fn()
+            e1.record(stream)
+        torch.cuda.synchronize(dev)
+        ts = [e0.elapsed_time(e1) for e0, e1 in evs]
+        return float(np.mean(ts)), float(np.min(ts))
+
+    deal = "single GPU"
+    if sharded:
+        # cost-aware deal of the 64 tiles: every rank probes the view at 256 x 144 on its own GPU (bit-reproducible
+        # kernels -> identical costs, no exchange) and deals longest-processing-time-first.  Outside the timed region
+        # the ranks compare their deals once; any disagreement falls back to the static deal on all of them.
+        sr.set_shard_costs(sr.probe_tile_costs(a.scene, a.width << a.supersample, a.height << a.supersample, a.time, a.max_steps))
+        # Rank 0 also receives (world-1)/world of every frame and assembles it.  Measured here, before the timed region:
+        # the exchange + assembly alone on rank 0's stream (all ranks send at once, so the root sees transfer + launch cost,
+        # not waiting) against the mean render time of a rank's shard; the deal starts rank 0 with that share of load.
+        # RMDF_ROOT_HANDICAP overrides (a fraction of a rank's fair share).
+        for _ in range(3):
+            render_only(0)
+            exchange_only(0)
+        barrier()
+        t_render = event_ms(lambda: render_only(0), 10)[0]
+        barrier()
+        t_exch = event_ms(lambda: exchange_only(0), 10)[0]
+        barrier()
+        tt = torch.tensor([t_render, t_exch if rank == 0 else 0.0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        mean_render, root_exchange = float(tt[0].item()) / world, float(tt[1].item())
+        measured = min(0.5, root_exchange / max(mean_render, 1e-6))
+        handicap = float(os.environ.get("RMDF_ROOT_HANDICAP", measured))
+        sr.set_shard_root_handicap(handicap)
+        agree = ranks_agree_on_deal([sr.shard_tiles(r, world) for r in range(world)], dist, cdev)
+        if agree:
+            deal = "cost-aware (probe frame, LPT, rank 0 handicap %.3f = measured exchange+assemble %.4f ms / mean shard render %.4f ms%s)" % (
+                handicap, root_exchange, mean_render, ", overridden by RMDF_ROOT_HANDICAP" if "RMDF_ROOT_HANDICAP" in os.environ else "")
+        else:
+            sr.set_shard_costs(None)
+            sr.set_shard_root_handicap(0.0)
+            deal = "static (ranks disagreed on the probed costs)"
+
+    # warm-up: W steps, then keep stepping until MIN_WARM_SECONDS have passed (all ranks decide together)
     for i in range(a.warmup):
         step(i)
     barrier()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i)
-    host_enqueue_ms = (time.perf_counter() - t0) / a.steps * 1e3      # host time to issue one step (this rank)
-    barrier()
-    dt = max_over_ranks(time.perf_counter() - t0, dist, cdev)
+    t_w0 = time.perf_counter()
+    extra_warm = 0
+    while True:
+        for i in range(max(a.warmup, 10)):
+            step(i)
+        extra_warm += max(a.warmup, 10)
+        barrier()
+        if max_over_ranks(time.perf_counter() - t_w0, dist, cdev) >= MIN_WARM_SECONDS or extra_warm >= 100000:
+            break
+    blocks, host_enqueue = [], []
+    for _ in range(max(1, a.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(i)
+        host_enqueue.append((time.perf_counter() - t0) / a.steps * 1e3)      # host time to issue one step (this rank)
+        barrier()
+        blocks.append(max_over_ranks(time.perf_counter() - t0, dist, cdev))
+    order = sorted(range(len(blocks)), key=lambda i: blocks[i])
+    med = order[len(order) // 2]
+    dt = blocks[med]
     ms_per_step = dt / a.steps * 1e3
     mpix = w * h / 1e6
     value = mpix / (dt / a.steps)
 
     # dominant kernel alone: HIP events on the launch stream around each launch (this rank's share)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(a.steps, 100))]
-    for e0, e1 in evs:
-        e0.record(stream)
-        render_only()
-        e1.record(stream)
-    torch.cuda.synchronize(dev)
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
-    kern_ms_min = float(np.min([e0.elapsed_time(e1) for e0, e1 in evs]))
+    kern_ms, kern_ms_min = event_ms(lambda: render_only(0), min(max(a.steps, 20), 100))
 
     result = None
     if rank == 0:
@@ -331,40 +456,44 @@ def main():
         px_this_launch = rw * rh if not sharded else len(sr.shard_tiles(rank, world)) * (rw // 8) * (rh // 8)
         algo_bytes = px_this_launch * 4 + env_bytes                        # RGBA8 store + env read
         achieved_gbs = algo_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        valu_instr = None           # SQ_INSTS_VALU per launch, from the committed PMC pass (profiles/pmc_traffic.json)
-        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tj) and not sharded and L == 0:
-            try:
-                t = json.load(open(tj))
-                if t.get("workload") == [scene, w, h, ms]:
-                    traffic = t.get("hbm_bytes_per_launch")
-                    valu_instr = (t.get("valu") or {}).get("SQ_INSTS_VALU_per_launch")
-            except Exception:
-                traffic = None
+        headline = [scene, w, h, ms] == [2, 1920, 1080, 256] and a.time == 0.0 and L == 0
+        pmc, pmc_src = (None, "not collected for this workload")
+        if not sharded and L == 0:
+            pmc, pmc_src = pmc_record(lib_path, [scene, w, h, ms])
+        kname = "k_render<%d, %s, OUT_RGBA8>" % (scene, "true" if scene != 0 and not (int(os.environ.get("RMDF_FLAGS", "0")) & 16) else "false")
         result = {
             "metric": "Mpixels/s, Mandelbulb power-8 1920x1080 @256 steps; 1/2/4/8 GPU",
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "FragmentShader %d (2 = FSMBPower8Shader) %dx%d%s, max_steps %d, in_time %.1f, uffizi_512.hdr env, "
-                                   "full frame -> RGBA8 resident in HBM" % (scene, w, h, (" x %d rays/px, box-resolved on the GPU" % (4 ** L)) if L else "", ms, a.time),
+            "config": {"workload": "FragmentShader %d (2 = FSMBPower8Shader) %dx%d%s, max_steps %d, in_time %.1f, uffizi_512.hdr env "
+                                   "(cube maps built by the product's own env pipeline), full frame -> RGBA8 resident in HBM" %
+                                   (scene, w, h, (" x %d rays/px, box-resolved on the GPU" % (4 ** L)) if L else "", ms, a.time),
                        "supersample_levels": L, "mrays_per_s": round(value * 4 ** L, 2),
                        "scene": scene, "width": w, "height": h, "max_steps": ms,
                        "parallelism": ("1 GPU, one launch per frame" if not sharded else
-                                       "64 tiles dealt to %d %s + one %s gather per frame" %
-                                       (world, "ranks sharing one GPU (test aid)" if share_gpu else "GPUs", "gloo (host-staged)" if share_gpu else "RCCL")) +
+                                       "64 tiles dealt to %d %s + one gather per frame" %
+                                       (world, "ranks sharing one GPU (test aid)" if share_gpu else "GPUs")) +
                                       ", %d frame(s) in flight" % S,
+                       "exchange": exchange, "rccl_ranks": rccl_ranks,
                        "frames_in_flight": S, "tile_deal": deal, "animate_dt": a.animate,
                        "device": dev_name, "compute_units": cus},
-            "roofline": {"bound": "hbm", "kernel": "k_render<2>", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": round(kern_ms, 4),
-                         "kernel_ms_min": round(kern_ms_min, 4),
-                         "note": "VALU-bound path (SURVEY 8d): HBM fraction is a sanity figure, see valu_roofline"},
+            "repeats": len(blocks), "ms_per_step_blocks": [round(b / a.steps * 1e3, 4) for b in blocks],
+            "ms_per_step_min": round(min(blocks) / a.steps * 1e3, 4),
+            "timing_note": "value / ms_per_step = the median of `repeats` blocks of exactly `steps` steps, each bracketed by "
+                           "barrier + synchronize; %d + %d untimed warm-up steps (>= %.1f s) ran before the first block" % (a.warmup, extra_warm, MIN_WARM_SECONDS),
+            "hbm_roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 6),
+                             "algorithmic_bytes_per_launch": algo_bytes,
+                             "traffic": None if not pmc else pmc.get("hbm_bytes_per_launch"), "traffic_source": pmc_src,
+                             "note": "asked for by the north star; the path is VALU-bound (SURVEY 8d), so this is a sanity figure"},
             "d2h_inclusive_mpixels_s": round(d2h_rate, 2),
-            "d2h_inclusive_registered_buffer_mpixels_s": None if d2h_registered is None else round(d2h_registered, 2), "host_enqueue_ms_per_step_rank0": round(host_enqueue_ms, 4),
+            "d2h_inclusive_registered_buffer_mpixels_s": None if d2h_registered is None else round(d2h_registered, 2),
+            "host_enqueue_ms_per_step_rank0": round(float(np.median(host_enqueue)), 4),
+            "env_pipeline_load_s": round(env_load_s, 3),
         }
+        ctr, ctr_src = (dict(HEADLINE_COUNTERS), "instrumented oracle, committed (tests/golden/full_size_digests.json)") if headline else (None, None)
+        ref = None
         if ((not a.no_cpu_baseline and world == 1) or a.check) and L == 0:      # CPU baselines: rank 0 at N = 1 only
             from oracle import orc
             env = load_oracle_env(orc)
@@ -372,40 +501,51 @@ def main():
             tc = time.perf_counter()
             ref = orc.render(scene, w, h, a.time, ms, env, nthreads=cores, want_f32=False)
             cpu_dt = time.perf_counter() - tc
-            ctr = ref["counters"]
-            F = flops_model(ctr)
-            if not sharded:
-                result["valu_roofline"] = {"achieved": round(F / (kern_ms * 1e-3) / 1e12, 3), "peak": VALU_PEAK_TLANEOPS,
-                                           "unit": "T lane-ops/s (as-written IEEE ops, no FMA contraction)",
-                                           "frac": round(F / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS, 4),
-                                           "flop_per_frame": F, "counters": ctr}
-                if valu_instr:
-                    # what actually bounds the kernel: VALU instruction issue.  Peak = the rate a stream of simple VALU
-                    # instructions sustains on this chip (tools/ubench/valu_rates: 0.93 G wave-instructions/s/SIMD)
-                    simds = cus * 4
-                    rate = valu_instr / simds / (kern_ms * 1e-3) / 1e9
-                    result["valu_roofline"]["issue"] = {"valu_instructions_per_launch_pmc": valu_instr, "simds": simds,
-                                                        "achieved": round(rate, 3), "peak": 0.93, "frac": round(rate / 0.93, 3),
-                                                        "unit": "G wave-instructions/s/SIMD"}
+            ctr, ctr_src = ref["counters"], "instrumented oracle, counted in this run"
             result["cpu_baseline"] = {"value": round(mpix / cpu_dt, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
                                       "sample": "1 full frame %dx%d of the same workload, CPU oracle (C port of fragment.shd), "
                                                 "row segments over all host cores as ConcurrentSegments does" % (w, h)}
+        if ctr is not None and not sharded and L == 0:
+            F = flops_model(ctr)
+            ach = F / (kern_ms * 1e-3) / 1e12
+            result["roofline"] = {"bound": "valu", "kernel": kname, "achieved": round(ach, 3), "peak": VALU_PEAK_TLANEOPS,
+                                  "unit": "T lane-ops/s", "frac": round(ach / VALU_PEAK_TLANEOPS, 4),
+                                  "traffic": None if not pmc else pmc.get("hbm_bytes_per_launch"), "traffic_source": pmc_src,
+                                  "kernel_ms_avg": round(kern_ms, 4), "kernel_ms_min": round(kern_ms_min, 4),
+                                  "ops_per_launch": F, "op_counters": ctr, "op_counters_source": ctr_src,
+                                  "note": "binding roof = FP32 vector-ALU issue (SURVEY 8d): as-written IEEE operations (sqrt, 1/sqrt, "
+                                          "log, pow, / each 1; no FMA contraction by the parity contract) per second against 256 CU x "
+                                          "4 SIMD x 32 lanes x 2.4 GHz; HBM side in hbm_roofline"}
+            valu_instr = None if not pmc else (pmc.get("valu") or {}).get("SQ_INSTS_VALU_per_launch")
+            if valu_instr:
+                simds = cus * 4
+                rate = valu_instr / simds / (kern_ms * 1e-3) / 1e9
+                result["roofline"]["issue"] = {"valu_instructions_per_launch": valu_instr, "source": pmc_src, "simds": simds,
+                                               "achieved": round(rate, 3), "peak": VALU_ISSUE_PEAK, "frac": round(rate / VALU_ISSUE_PEAK, 3),
+                                               "unit": "G wave-instructions/s/SIMD",
+                                               "lane_utilisation": (pmc.get("valu") or {}).get("lane_utilisation")}
+        else:
+            result["roofline"] = {"bound": "valu", "kernel": kname, "achieved": None, "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
+                                  "frac": None, "traffic": None, "kernel_ms_avg": round(kern_ms, 4), "kernel_ms_min": round(kern_ms_min, 4),
+                                  "note": "operation counters are only known for the headline workload on one GPU (or after the "
+                                          "cpu_baseline leg counted them)"}
+        if not a.no_secondary and world == 1 and not sharded and L == 0:
+            result["secondary"] = secondary_workloads(sr, torch, dev, stream, cus)
+        if ref is not None:
+            from oracle import orc
             # the reference's own CPU paths (BASELINE.json north_star: "timed on the same box's host cores ... as the
             # reported, non-target baseline"), as their C restatements with the reference's threading model
             # (SURVEY.md 8d): Fractal2D.juliaAnimated over all cores in row segments; cosineConvolveHDREnvMap with one
             # thread per power (ShaderRendering.hs:142) -- one power timed on one thread -- and split over all cores
-            d = os.path.join(rmdf_amd.DATA_DIR, "latlong_envmaps")
-            small = orc.resize_hdr(orc.hdr_decode(open(os.path.join(d, "uffizi_512.hdr"), "rb").read()), 256)
+            small = orc.resize_hdr(oracle_env_latlongs(orc)["refl"], 256)
             tj0 = time.perf_counter(); orc.julia_animated(512, 512, 0, 0.0); tj = time.perf_counter() - tj0
-            tc0 = time.perf_counter(); orc.cosine_convolve(small, 8.0, nthreads=1); tc1 = time.perf_counter() - tc0
-            tc0 = time.perf_counter(); orc.cosine_convolve(small, 8.0, nthreads=0); tca = time.perf_counter() - tc0
-            tg0 = time.perf_counter(); sr.prefilter_env(small, 8.0); tg = time.perf_counter() - tg0
+            tc0 = time.perf_counter(); orc.cosine_convolve(small, 8.0, nthreads=1, pow_mode=0); tc1 = time.perf_counter() - tc0
+            tc0 = time.perf_counter(); orc.cosine_convolve(small, 8.0, nthreads=0, pow_mode=0); tca = time.perf_counter() - tc0
             result["cpu_reference_paths"] = {
-                "cores": cores, "kind": "port",
+                "cores": orc.num_processors(), "kind": "port",
                 "julia_animated_512x512_ms": round(tj * 1e3, 2), "julia_animated_mpixels_s": round(0.262144 / tj, 1),
                 "cosine_convolve_256x128_power8_one_thread_s": round(tc1, 3),
-                "cosine_convolve_256x128_power8_all_cores_s": round(tca, 3),
-                "gpu_prefilter_256x128_power8_ms_host_in_out": round(tg * 1e3, 3)}
+                "cosine_convolve_256x128_power8_all_cores_s": round(tca, 3)}
             if a.check:
                 result["check_rgba8_equal"] = all(bool(np.array_equal(f.cpu().numpy().view(np.uint32), ref["rgba8"]))
                                                   for f in frames)
@@ -416,6 +556,48 @@ def main():
         dist.destroy_process_group()
     sr.close()
     return result
+
+
+def secondary_workloads(sr, torch, dev, stream, cus):
+    """The other single-GPU configurations of BASELINE.json, timed with HIP events after the headline run (device-resident,
+    one frame at a time): config 2 (Cornell box 1280x720 @128) and config 5 (lobe prefilter 256x128, the four powers)."""
+    out = {}
+    fb = torch.empty((720, 1280), dtype=torch.int32, device=dev)
+    sp = stream.cuda_stream
+
+    def ev(fn, reps):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for e0, e1 in evs:
+            e0.record(stream)
+            fn()
+            e1.record(stream)
+        torch.cuda.synchronize(dev)
+        return float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
+    cornell = lambda: sr.render_rect_device(0, 1280, 720, 0.0, 128, (0, 0, 1280, 720), d_rgba8=fb.data_ptr(), stream=sp)
+    for _ in range(20):
+        cornell()
+    t = ev(cornell, 50)
+    out["config2_cornell_1280x720_m128"] = {"kernel_ms_avg": round(t, 4), "mpixels_s": round(0.9216 / (t * 1e-3), 1)}
+    # config 5: the prefilter kernel, 256x128, each reference power alone, then the four concurrently through the host entry
+    rng = np.random.RandomState(3)
+    src = rng.uniform(0.0, 4.0, (128, 256, 3)).astype(np.float32)
+    d_src = torch.from_numpy(src).to(dev)
+    d_out = torch.empty_like(d_src)
+    pair_terms = (256 * 128) ** 2
+    per = {}
+    for p in (1.0, 8.0, 64.0, 512.0):
+        f = lambda p=p: sr.prefilter_env_device(d_src.data_ptr(), 256, 128, p, d_out.data_ptr(), stream=sp)
+        f(); f()
+        t = ev(f, 5)
+        per["power_%d" % int(p)] = {"kernel_ms": round(t, 3), "g_pair_terms_s": round(pair_terms / (t * 1e-3) / 1e9, 1)}
+    t0 = time.perf_counter()
+    sr.prefilter_env_powers(src, (1.0, 8.0, 64.0, 512.0))
+    four = time.perf_counter() - t0
+    out["config5_lobe_prefilter_256x128"] = {"per_power": per, "four_powers_concurrent_host_in_out_ms": round(four * 1e3, 3),
+                                             "pair_terms_per_power": pair_terms,
+                                             "note": "one lane per destination texel, source summed serially in the reference's order "
+                                                     "(bit-exact); 512 waves = half the SIMDs at this size"}
+    return out
 
 
 if __name__ == "__main__":

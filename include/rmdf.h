@@ -46,8 +46,9 @@ typedef struct rmdf_ctx rmdf_ctx;
 #define RMDF_E_HIP          -3   /* a HIP runtime call failed                      */
 #define RMDF_E_IO           -4   /* file missing / unreadable / malformed          */
 #define RMDF_E_NO_ENV       -5   /* a cube map the scene samples has not been set  */
-#define RMDF_E_UNSUPPORTED  -6   /* reserved                                       */
+#define RMDF_E_UNSUPPORTED  -6   /* not available in this build / on this stream   */
 #define RMDF_E_NOMEM        -7
+#define RMDF_E_COMM         -8   /* an RCCL call failed / no communicator          */
 
 /* `data FragmentShader = FSDECornellBoxShader | FSDETestShader | FSMBPower8Shader |
  * FSMBGeneralShader deriving Enum` (ShaderRendering.hs:46-47) */
@@ -70,14 +71,12 @@ typedef struct rmdf_ctx rmdf_ctx;
 #define RMDF_TILES_Y 8
 #define RMDF_N_TILES 64
 
-/* rmdf_config.reserved[0] flags */
-#define RMDF_FLAG_NESTED_LOOPS 1   /* Mandelbulb: single nested-loop kernel (k_render<2>)                  */
-#define RMDF_FLAG_FLAT_MARCH   2   /* Mandelbulb: flattened march kernel + shade kernel (rmdf_march.hip)   */
-#define RMDF_FLAG_PIPELINE     8   /* all scenes: march-with-refill + normal/AO-on-hit-list + shade kernels (rmdf_pipeline.hip) */
-#define RMDF_FLAG_NO_MERGE     16   /* nested-loop kernel: do NOT pool the last rays of a workgroup's four packets in one wave */
+/* rmdf_config.reserved[0] flags: each switches ONE optimisation of the render kernel off, so that tests can show it does
+ * not change a bit of the output.  (Bits 1, 2 and 8 select alternative schedules that only librmdf_xcheck.so contains, see
+ * include/rmdf_xcheck.h; librmdf.so rejects them with RMDF_E_UNSUPPORTED.) */
+#define RMDF_FLAG_RASTER_ORDER 4    /* always dispatch strips in raster order (no cost feedback from the previous frame)    */
+#define RMDF_FLAG_NO_MERGE     16   /* do NOT pool the last rays of a workgroup's four packets in one wave                  */
 #define RMDF_FLAG_NO_PRUNE     32   /* Cornell box: evaluate all 32 triangles per distance estimate (no bound-based skipping) */
-#define RMDF_FLAG_RASTER_ORDER 4   /* nested-loop kernel: always dispatch strips in raster order (no cost feedback) */
-/* neither bit set = the library's default (currently the fastest measured: nested loops) */
 
 typedef struct {
     int device;      /* HIP device ordinal                                              */
@@ -88,11 +87,18 @@ typedef struct {
 
 /* Opens the resource bracket: picks the device, creates the stream, uploads the
  * Cornell-box vertex table (mkCornellBoxVerticesTex, CornellBox.hs:21-46).
- * cfg may be NULL (device 0). */
+ * cfg may be NULL (device 0).
+ * Hardware queues: frames in flight on more than four HIP streams need GPU_MAX_HW_QUEUES > 4 (the runtime's default; with it,
+ * streams share queues and serialise).  The variable is read when the HIP runtime initialises: rmdf_create sets it to 16 unless
+ * the host already set a value, which takes effect only if rmdf_create is the process's first HIP call -- a host that uses HIP
+ * before creating the renderer must export GPU_MAX_HW_QUEUES itself.
+ * rmdf_create_ex also copies the failure message into err (for hosts whose threads are not bound to one OS thread). */
 int rmdf_create(rmdf_ctx **out, const rmdf_config *cfg);
+int rmdf_create_ex(rmdf_ctx **out, const rmdf_config *cfg, char *err, size_t err_len);
 /* Closes the bracket; frees every device object (ResourceT release, :63-99). */
 void rmdf_destroy(rmdf_ctx *ctx);
-/* Message of the last failure on ctx (ctx == NULL: of the last failed rmdf_create). */
+/* Message of the last failure on ctx.  ctx == NULL: of the last failed call that takes no ctx (rmdf_create, rmdf_save_png, ...)
+ * in this PROCESS, whichever thread it failed on; the returned pointer is a per-thread copy. */
 const char *rmdf_last_error(const rmdf_ctx *ctx);
 
 /* ---- environment maps (ShaderRendering.hs:65-91, HDREnvMap.hs) --------------------- */
@@ -100,8 +106,10 @@ const char *rmdf_last_error(const rmdf_ctx *ctx);
 /* The whole env pipeline of withShaderRenderer for one latlong .hdr file
  * (ShaderRendering.hs:67-91): load reflMapFn, build any missing
  * `<name>_cache_pow_<p>.hdr` (p = 1.0, 8.0, 64.0, 512.0) with the device
- * prefilter (buildPreConvolvedHDREnvMapCache, :131-149), reload the caches,
- * convert all five maps to cube maps on the device. */
+ * prefilter (buildPreConvolvedHDREnvMapCache, :131-149: resize to 256 texels, the missing powers concurrently, written as
+ * Radiance RGBE), reload the caches, convert all five maps to cube maps on the device.  Cache files are written under a
+ * private name and renamed into place (several ranks may build them at once); if the directory cannot be written the
+ * file images are used from memory. */
 int rmdf_load_env_hdr(rmdf_ctx *ctx, const char *latlong_hdr_path);
 
 /* latLongHDREnvMapToCubeMap (HDREnvMap.hs:118-163) for one slot: rgb = w*h*3
@@ -120,8 +128,16 @@ int rmdf_get_env_cube_padded(rmdf_ctx *ctx, int slot, uint16_t *out, int *face_w
  * floats (may be NULL to query *dsth). */
 int rmdf_resize_latlong(rmdf_ctx *ctx, const float *rgb, int w, int h, int dstw, float *out, int *dsth);
 
-/* cosineConvolveHDREnvMap (HDREnvMap.hs:217-254) on the device: out = w*h*3 floats. */
+/* cosineConvolveHDREnvMap (HDREnvMap.hs:217-254) on the device: out = w*h*3 floats.  Every destination texel is summed in the
+ * reference's order (source rows outer, columns inner); sin / cos come from host-built tables (the libm the reference calls);
+ * cos^power for the reference's powers 1, 8, 64, 512 = 2^k is k squarings in binary64 rounded once (DESIGN.md "spec pins"),
+ * other powers use the device powf.  2 <= w <= 8192, 2 <= h <= 4096.
+ * rmdf_prefilter_env_powers: `npowers` powers of one map, concurrently like the reference's mapConcurrently
+ * (ShaderRendering.hs:142); out = npowers * w*h*3 floats.
+ * rmdf_prefilter_env_device: one power, device-resident source and destination, asynchronous on `stream`. */
 int rmdf_prefilter_env(rmdf_ctx *ctx, const float *rgb, int w, int h, float power, float *out);
+int rmdf_prefilter_env_powers(rmdf_ctx *ctx, const float *rgb, int w, int h, const float *powers, int npowers, float *out);
+int rmdf_prefilter_env_device(rmdf_ctx *ctx, const void *d_rgb, int w, int h, float power, void *d_out, void *stream);
 
 /* ---- rendering: drawShaderTile (ShaderRendering.hs:151-196) ------------------------ */
 
@@ -142,7 +158,8 @@ int rmdf_is_tile_idx_last_tile(int idx);
 int rmdf_render_tile(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double time, int max_steps,
                      uint32_t *out_rgba8);
 
-/* Same, with the extra planes parity tests need (any pointer may be NULL):
+/* Same, with the extra planes parity tests need (any pointer may be NULL; the library allocates and accumulates these
+ * planes only from the first call that asks for one, and in tile mode they hold the tiles rendered through this entry):
  *   out_rgba_f32  w*h*4 floats, the shader's frag_color before RGBA8 conversion
  *   out_steps     w*h uint16: bits 0..14 ray_march loop counter at exit
  *                 (fragment.shd:659-673), bit 15 = hit
@@ -202,6 +219,27 @@ int rmdf_resolve_box2_device(rmdf_ctx *ctx, const void *d_src_rgba8, int sw, int
 int rmdf_render_supersampled(rmdf_ctx *ctx, int scene, int w, int h, int levels, double time, int max_steps,
                              uint32_t *out_rgba8);
 
+/* ---- multi-GPU exchange: one process per GPU, RCCL over xGMI ------------------------------------------------
+ * The reference renders its 64 tiles one per frame (ShaderRendering.hs:49-52,183-193); here they are dealt to the GPUs of a
+ * node and ONE gather per frame brings the packed shards to rank 0.  librccl.so.1 is dlopen()ed by the first rmdf_comm_* call
+ * (a single-GPU host does not need it).
+ *   rank 0:      rmdf_comm_get_unique_id(id); ship the RMDF_COMM_ID_BYTES bytes to the other ranks by any channel
+ *   every rank:  rmdf_comm_init(ctx, id, rank, nranks)            -- collective (ncclCommInitRank on the ctx's device)
+ *   per frame:   rmdf_render_frame_sharded_device(...)            -- = rmdf_render_shard_device + rmdf_gather_shards_device
+ *                                                                    + (rank 0) rmdf_assemble_shards_device, all on `stream`
+ * rmdf_gather_shards_device: every rank's packed shard (ceil(64/nranks) tile slots of (w/8)*(h/8) uint32) lands in
+ * d_gathered[rank] on rank 0 (grouped ncclRecv fan-in; the other ranks ncclSend).  Rank 0 may pass d_shard == d_gathered (it
+ * rendered straight into its own slot).  d_gathered is ignored on the other ranks. */
+#define RMDF_COMM_ID_BYTES 128
+int rmdf_comm_get_unique_id(void *id);
+int rmdf_comm_init(rmdf_ctx *ctx, const void *id, int rank, int nranks);
+int rmdf_comm_destroy(rmdf_ctx *ctx);
+/* *nranks = 0 when the ctx has no communicator */
+int rmdf_comm_info(rmdf_ctx *ctx, int *rank, int *nranks);
+int rmdf_gather_shards_device(rmdf_ctx *ctx, int w, int h, const void *d_shard, void *d_gathered, void *stream);
+int rmdf_render_frame_sharded_device(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps,
+                                     void *d_shard, void *d_gathered, void *d_frame_rgba8, void *stream);
+
 /* Self-test of the kernels' short correctly-rounded sequences (sqrt, reciprocal, 1/sqrt, and the known-range
  * division inside log) against the compiler's IEEE expansions for ALL 2^32 float inputs on the device.
  * mismatches[0..3] = sqrt, reciprocal, log, 1/sqrt; mismatches[4] = the table-driven division of the Cornell
@@ -211,12 +249,6 @@ int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[5]);
  * atan(y,x) and pow(x,y): 2^32 operand pairs) against the branchy fdlibm-style forms they restate.
  * mismatches[0..6] = exp, acos, atan, sin, cos, atan2, pow.  All must be 0. */
 int rmdf_selftest_pinned_math(rmdf_ctx *ctx, uint64_t mismatches[7]);
-
-/* Measurement aid: per-wave counters of the Mandelbulb march kernel.  enable != 0 switches collection on
- * (off: frees the buffer); out (may be NULL) receives 16 uint64 per wave for the launches since the last read:
- * iteration passes, march-tail passes, shade-tail passes, refill rounds, sum of iterating lanes over iteration
- * passes, sum of waiting lanes over march tails, begin / end timestamps (100 MHz s_memrealtime ticks). */
-int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_waves);
 
 /* Optional: pin a host buffer the caller reuses from frame to frame (page-locks it and maps it into the GPU's address
  * space).  A whole-frame rmdf_render_tile (tile_idx = -1) whose out_rgba8 lies inside a registered range is then

@@ -1,0 +1,34 @@
+/*
+ * rmdf_xcheck.h -- additions of librmdf_xcheck.so, the cross-check / measurement build of the renderer.
+ *
+ * librmdf_xcheck.so is built from the same sources as librmdf.so (make -C .../csrc xcheck) plus three alternative
+ * schedules of the same per-ray arithmetic (csrc/xcheck/): they are slower than the product kernel and exist
+ * so that independently scheduled implementations can be compared bit for bit in the tests, and for A/B measurements.
+ * Nothing here is part of the drop-in boundary; the product library rejects these flag bits.
+ * The alternative schedules keep ONE scratch set (G-buffer, hit list, work counters) per ctx: calls must use the ctx stream
+ * (stream = NULL) -- another stream returns RMDF_E_UNSUPPORTED -- so frames in flight are not available with them.
+ */
+#ifndef RMDF_XCHECK_H
+#define RMDF_XCHECK_H
+
+#include "rmdf.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* rmdf_config.reserved[0] */
+#define RMDF_FLAG_NESTED_LOOPS 1   /* no-op (the default render kernel)                                                      */
+#define RMDF_FLAG_FLAT_MARCH   2   /* Mandelbulb power 8: flattened march kernel + shade kernel (xcheck/rmdf_march.hip, rmdf_pool.hip) */
+#define RMDF_FLAG_PIPELINE     8   /* all scenes: march-with-refill + normal/AO-on-hit-list + shade kernels (xcheck/rmdf_pipeline.hip) */
+
+/* Measurement aid: per-wave counters of the Mandelbulb march kernels.  enable != 0 switches collection on
+ * (off: frees the buffer); out (may be NULL) receives 16 uint64 per wave for the launches since the last read:
+ * iteration passes, march-tail passes, shade-tail passes, refill rounds, sum of iterating lanes over iteration
+ * passes, sum of waiting lanes over march tails, begin / end timestamps (100 MHz s_memrealtime ticks). */
+int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_waves);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMDF_XCHECK_H */

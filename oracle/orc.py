@@ -86,7 +86,7 @@ def lib():
         L.orc_latlong_to_cube.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.orc_cube_pad_f16.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_resize_hdr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        L.orc_cosine_convolve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int]
+        L.orc_cosine_convolve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int]
         L.orc_pixel_at_bilinear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, fp]
         L.orc_cube_pixel_to_dir.argtypes = [C.c_int] * 4 + [fp]
         L.orc_cube_sample.argtypes = [C.POINTER(Cube), fp, C.c_int, fp]
@@ -225,12 +225,27 @@ def resize_hdr(src, dstw):
     return out
 
 
-def cosine_convolve(src, power, nthreads=0):
+def cosine_convolve(src, power, nthreads=0, pow_mode=1):
+    """pow_mode 1 (default): cos^p by the pinned binary64 squaring chain for the reference's powers 1/8/64/512;
+    pow_mode 0: libm powf, the reference's literal call (not correctly rounded, libm-build dependent)."""
     src = np.ascontiguousarray(src, np.float32)
     h, w, _ = src.shape
     out = np.empty_like(src)
-    lib().orc_cosine_convolve(src.ctypes.data, w, h, float(power), out.ctypes.data, nthreads)
+    lib().orc_cosine_convolve(src.ctypes.data, w, h, float(power), out.ctypes.data, nthreads, int(pow_mode))
     return out
+
+
+def env_pipeline(hdr_bytes, powers=(1.0, 8.0), nthreads=0, pow_mode=1):
+    """The env part of withShaderRenderer (ShaderRendering.hs:65-91) in the oracle, cache miss: decode the reflection map,
+    resizeHDRImage to 256, cosineConvolveHDREnvMap per power, Radiance RGBE write + reload.  Returns
+    (latlongs, cache_files): latlongs = {"refl": ..., "cos1": ..., "cos8": ..., ...}, cache_files = {power: file bytes}."""
+    refl = hdr_decode(hdr_bytes)
+    small = resize_hdr(refl, 256)
+    lat, files = {"refl": refl}, {}
+    for p in powers:
+        files[float(p)] = hdr_encode(cosine_convolve(small, p, nthreads=nthreads, pow_mode=pow_mode))
+        lat["cos%d" % int(p)] = hdr_decode(files[float(p)])
+    return lat, files
 
 
 def pixel_at_bilinear(img, u, v):

@@ -1447,10 +1447,31 @@ int orc_resize_hdr(const float *src, int sw, int sh, int dstw, float *out)
     return dsth;
 }
 
-typedef struct { const float *src; int w, h; float power; float *out; int lo, hi; } conv_job;
+typedef struct { const float *src; int w, h; float power; float *out; int lo, hi; int pow_mode; } conv_job;
 
-/* cosineConvolveHDREnvMap, HDREnvMap.hs:217-254; libm cosf/sinf/powf stand in
- * for GHC's Float cos/sin/(**) which call the same libm */
+/* cos^p of cosineConvolveHDREnvMap (`cosAngle ** power`, HDREnvMap.hs:246).
+ * pow_mode 0: the literal call -- GHC's (**) :: Float is libm powf, whose result is NOT correctly rounded
+ *             (glibc 2.35: differs from the correctly rounded power in ~0.1 % of arguments) and depends on
+ *             the libm build, so the reference's own cache files are only defined up to that.
+ * pow_mode 1: SPEC PIN for the reference's four powers 1, 8, 64, 512 = 2^k: k squarings in
+ *             binary64 rounded once to binary32 (relative error <= 2^k * 2^-53 before the rounding).  Other
+ *             powers have no pin and use powf.  tests/test_oracle_kat.py bounds the distance between the modes. */
+static inline float conv_pow(float c, float power, int pow_mode)
+{
+    if (pow_mode == 1) {
+        int k = -1;
+        if (power == 1.0f) k = 0; else if (power == 8.0f) k = 3; else if (power == 64.0f) k = 6; else if (power == 512.0f) k = 9;
+        if (k >= 0) {
+            double d = (double)c;
+            for (int i = 0; i < k; i++) d = d * d;
+            return (float)d;
+        }
+    }
+    return powf(c, power);
+}
+
+/* cosineConvolveHDREnvMap, HDREnvMap.hs:217-254; libm cosf/sinf stand in for GHC's Float cos/sin, which call
+ * the same libm */
 static void *conv_worker(void *arg)
 {
     conv_job *j = (conv_job *)arg;
@@ -1475,7 +1496,7 @@ static void *conv_worker(void *arg)
                 for (int x = 0; x < w; x++) {
                     float cos_angle = lc * pc + ls * ps * lut[x];
                     if (cos_angle > 0.0f) {
-                        float fac = ps * powf(cos_angle, j->power);
+                        float fac = ps * conv_pow(cos_angle, j->power, j->pow_mode);
                         ar = ar + row[x * 3] * fac; ag = ag + row[x * 3 + 1] * fac; ab = ab + row[x * 3 + 2] * fac;
                         n = n + 1.0f;
                     }
@@ -1490,10 +1511,10 @@ static void *conv_worker(void *arg)
 
 static void conv_set_range(void *job, int lo, int hi) { ((conv_job *)job)->lo = lo; ((conv_job *)job)->hi = hi; }
 
-void orc_cosine_convolve(const float *src, int w, int h, float power, float *out, int nthreads)
+void orc_cosine_convolve(const float *src, int w, int h, float power, float *out, int nthreads, int pow_mode)
 {
     conv_job *jobs = (conv_job *)calloc(256, sizeof(conv_job));
-    jobs[0].src = src; jobs[0].w = w; jobs[0].h = h; jobs[0].power = power; jobs[0].out = out;
+    jobs[0].src = src; jobs[0].w = w; jobs[0].h = h; jobs[0].power = power; jobs[0].out = out; jobs[0].pow_mode = pow_mode;
     run_segments(nthreads, 0, h, conv_worker, jobs, sizeof(conv_job), conv_set_range);
     free(jobs);
 }

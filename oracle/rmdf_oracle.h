@@ -126,7 +126,9 @@ float    orc_f16_to_f32(uint16_t hbits);
 void orc_cube_pad_f16(const float *faces_f32, int cw, uint16_t *padded);
 /* resizeHDRImage: returns dst height; out may be NULL to query */
 int  orc_resize_hdr(const float *src, int sw, int sh, int dstw, float *out);
-void orc_cosine_convolve(const float *src, int w, int h, float power, float *out, int nthreads);
+/* pow_mode: 0 = cos^p through libm powf (the reference's literal `**`), 1 = the spec pin for powers 1/8/64/512
+ * (binary64 squaring chain rounded once); see conv_pow in rmdf_oracle.c */
+void orc_cosine_convolve(const float *src, int w, int h, float power, float *out, int nthreads, int pow_mode);
 
 /* ---- geometry (CornellBox.hs) ------------------------------------------------ */
 void orc_cornell_vertices(float out[96 * 3]);

@@ -27,16 +27,19 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librmdf.so")
+XCHECK_LIB_PATH = os.path.join(_HERE, "librmdf_xcheck.so")     # cross-check build: product sources + alternative schedules
 CSRC = os.path.join(_HERE, "csrc")
 DATA_DIR = os.path.join(_HERE, "data")
 DEFAULT_ENV_HDR = os.path.join(DATA_DIR, "latlong_envmaps", "uffizi_512.hdr")
 
 TILES_X, TILES_Y, N_TILES = 8, 8, 64          # ShaderRendering.hs:49-52
 ENV_REFLECTION, ENV_COS_1, ENV_COS_8, ENV_COS_64, ENV_COS_512 = range(5)
-FLAG_NESTED_LOOPS, FLAG_FLAT_MARCH, FLAG_RASTER_ORDER, FLAG_PIPELINE, FLAG_NO_MERGE, FLAG_NO_PRUNE = 1, 2, 4, 8, 16, 32   # rmdf.h RMDF_FLAG_*
+FLAG_RASTER_ORDER, FLAG_NO_MERGE, FLAG_NO_PRUNE = 4, 16, 32          # rmdf.h RMDF_FLAG_*
+FLAG_NESTED_LOOPS, FLAG_FLAT_MARCH, FLAG_PIPELINE = 1, 2, 8         # rmdf_xcheck.h: librmdf_xcheck.so only
+COMM_ID_BYTES = 128
 
 _ERRORS = {-1: "RMDF_E_INVALID", -2: "RMDF_E_NO_DEVICE", -3: "RMDF_E_HIP", -4: "RMDF_E_IO",
-           -5: "RMDF_E_NO_ENV", -6: "RMDF_E_UNSUPPORTED", -7: "RMDF_E_NOMEM"}
+           -5: "RMDF_E_NO_ENV", -6: "RMDF_E_UNSUPPORTED", -7: "RMDF_E_NOMEM", -8: "RMDF_E_COMM"}
 
 # every symbol include/rmdf.h declares
 ABI_SYMBOLS = (
@@ -44,11 +47,14 @@ ABI_SYMBOLS = (
     "rmdf_set_env_cube", "rmdf_get_env_cube_padded", "rmdf_resize_latlong", "rmdf_prefilter_env",
     "rmdf_is_tile_idx_first_tile", "rmdf_is_tile_idx_last_tile", "rmdf_render_tile", "rmdf_render_tile_ex",
     "rmdf_render_rect_device", "rmdf_render_shard_device", "rmdf_assemble_shards_device", "rmdf_synchronize",
-    "rmdf_device_info", "rmdf_debug_march_stats", "rmdf_resolve_box2_device", "rmdf_render_supersampled",
+    "rmdf_device_info", "rmdf_resolve_box2_device", "rmdf_render_supersampled",
     "rmdf_selftest_exact_math", "rmdf_shard_tiles", "rmdf_probe_tile_costs", "rmdf_set_shard_costs",
     "rmdf_get_shard_tiles", "rmdf_save_png", "rmdf_register_host_buffer", "rmdf_unregister_host_buffer",
-    "rmdf_selftest_pinned_math", "rmdf_set_shard_root_handicap",
+    "rmdf_selftest_pinned_math", "rmdf_set_shard_root_handicap", "rmdf_create_ex", "rmdf_prefilter_env_powers",
+    "rmdf_prefilter_env_device", "rmdf_comm_get_unique_id", "rmdf_comm_init", "rmdf_comm_destroy", "rmdf_comm_info",
+    "rmdf_gather_shards_device", "rmdf_render_frame_sharded_device",
 )
+XCHECK_SYMBOLS = ("rmdf_debug_march_stats",)      # include/rmdf_xcheck.h
 
 
 class RmdfError(RuntimeError):
@@ -86,10 +92,12 @@ def build(force=False, verbose=False):
     """Compile librmdf.so for gfx950 with hipcc (cross-compiles without a GPU).  Serialised with a file lock:
     several ranks of one node may call this at the same time."""
     import fcntl
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "rmdf.h")]
+    srcs = [os.path.join(r, f) for r, _, fs in os.walk(CSRC) for f in fs]
+    srcs += [os.path.join(_HERE, "..", "include", h) for h in ("rmdf.h", "rmdf_xcheck.h")]
 
     def stale():
-        return (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+        return any((not os.path.exists(lib)) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs)
+                   for lib in (LIB_PATH, XCHECK_LIB_PATH))
     if not (force or stale()):
         return LIB_PATH
     with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
@@ -103,21 +111,22 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def load_library():
-    """dlopen librmdf.so and declare the prototypes.  Raises if the HIP library is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = os.environ.get("RMDF_LIB", LIB_PATH)          # measurement knob: an alternative build of the same sources
+def load_library(xcheck=False):
+    """dlopen librmdf.so (xcheck=True: librmdf_xcheck.so) and declare the prototypes.  Raises if the HIP library is missing."""
+    if xcheck in _libs:
+        return _libs[xcheck]
+    # RMDF_LIB: measurement knob, an alternative build of the product sources (tools/abtest)
+    path = XCHECK_LIB_PATH if xcheck else os.environ.get("RMDF_LIB", LIB_PATH)
     if not os.path.exists(path):
-        raise RmdfError(-2, "librmdf.so is not built (run __graft_entry__.build() or `make -C %s`); "
-                            "there is no CPU fallback" % CSRC)
+        raise RmdfError(-2, "%s is not built (run __graft_entry__.build() or `make -C %s`); "
+                            "there is no CPU fallback" % (os.path.basename(path), CSRC))
     L = C.CDLL(path)
     vp, ip = C.c_void_p, C.POINTER(C.c_int)
     L.rmdf_create.argtypes = [C.POINTER(vp), vp]
+    L.rmdf_create_ex.argtypes = [C.POINTER(vp), vp, C.c_char_p, C.c_size_t]
     L.rmdf_destroy.argtypes = [vp]
     L.rmdf_destroy.restype = None
     L.rmdf_last_error.argtypes = [vp]
@@ -128,6 +137,14 @@ def load_library():
     L.rmdf_get_env_cube_padded.argtypes = [vp, C.c_int, vp, ip]
     L.rmdf_resize_latlong.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, ip]
     L.rmdf_prefilter_env.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, vp]
+    L.rmdf_prefilter_env_powers.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp]
+    L.rmdf_prefilter_env_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp]
+    L.rmdf_comm_get_unique_id.argtypes = [vp]
+    L.rmdf_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.rmdf_comm_destroy.argtypes = [vp]
+    L.rmdf_comm_info.argtypes = [vp, ip, ip]
+    L.rmdf_gather_shards_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+    L.rmdf_render_frame_sharded_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp]
     L.rmdf_is_tile_idx_first_tile.argtypes = [C.c_int]
     L.rmdf_is_tile_idx_last_tile.argtypes = [C.c_int]
     L.rmdf_render_tile.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]
@@ -145,12 +162,13 @@ def load_library():
     L.rmdf_assemble_shards_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.rmdf_synchronize.argtypes = [vp, vp]
     L.rmdf_device_info.argtypes = [vp, C.c_char_p, C.c_int, ip]
-    L.rmdf_debug_march_stats.argtypes = [vp, C.c_int, vp, C.c_int]
+    if xcheck:
+        L.rmdf_debug_march_stats.argtypes = [vp, C.c_int, vp, C.c_int]
     L.rmdf_selftest_exact_math.argtypes = [vp, vp]
     L.rmdf_selftest_pinned_math.argtypes = [vp, vp]
     L.rmdf_resolve_box2_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     L.rmdf_render_supersampled.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]
-    _lib = L
+    _libs[xcheck] = L
     return L
 
 
@@ -166,14 +184,17 @@ class ShaderRenderer:
     """The `ShaderRenderer` record (ShaderRendering.hs:36-44): owns the device-side env cube maps,
     the Cornell geometry table and the accumulating frame."""
 
-    def __init__(self, device=0, flags=0):
-        self._lib = load_library()
+    def __init__(self, device=0, flags=0, xcheck=False):
+        """xcheck=True (implied by FLAG_FLAT_MARCH / FLAG_PIPELINE): run on librmdf_xcheck.so, the cross-check build."""
+        self.xcheck = bool(xcheck or (flags & (FLAG_FLAT_MARCH | FLAG_PIPELINE)))
+        self._lib = load_library(self.xcheck)
         self._ctx = C.c_void_p()
         cfg = _Config(device=device)
         cfg.reserved[0] = flags
-        rc = self._lib.rmdf_create(C.byref(self._ctx), C.byref(cfg))
+        err = C.create_string_buffer(1024)
+        rc = self._lib.rmdf_create_ex(C.byref(self._ctx), C.byref(cfg), err, 1024)
         if rc != 0:
-            raise RmdfError(rc, (self._lib.rmdf_last_error(None) or b"").decode())
+            raise RmdfError(rc, err.value.decode())
 
     # -- lifetime --------------------------------------------------------------------------
     def close(self):
@@ -238,6 +259,41 @@ class ShaderRenderer:
         out = np.empty_like(rgb)
         self._check(self._lib.rmdf_prefilter_env(self._ctx, rgb.ctypes.data, w, h, float(power), out.ctypes.data))
         return out
+
+    def prefilter_env_powers(self, rgb, powers):
+        """Several lobe powers of one map, concurrently (the reference's mapConcurrently): (len(powers), h, w, 3)."""
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        h, w, _ = rgb.shape
+        pw = np.ascontiguousarray(powers, np.float32)
+        out = np.empty((pw.size, h, w, 3), np.float32)
+        self._check(self._lib.rmdf_prefilter_env_powers(self._ctx, rgb.ctypes.data, w, h, pw.ctypes.data, pw.size, out.ctypes.data))
+        return out
+
+    def prefilter_env_device(self, d_rgb, w, h, power, d_out, stream=0):
+        self._check(self._lib.rmdf_prefilter_env_device(self._ctx, d_rgb, w, h, float(power), d_out, stream or None))
+
+    # -- multi-GPU exchange (RCCL behind the C ABI) ----------------------------------------------
+    def comm_init(self, unique_id, rank, nranks):
+        """Collective: join the job's RCCL communicator.  unique_id = the 128 bytes rank 0 got from comm_get_unique_id()."""
+        assert len(unique_id) == COMM_ID_BYTES
+        buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self._check(self._lib.rmdf_comm_init(self._ctx, buf, rank, nranks))
+
+    def comm_destroy(self):
+        self._check(self._lib.rmdf_comm_destroy(self._ctx))
+
+    def comm_info(self):
+        r, n = C.c_int(), C.c_int()
+        self._check(self._lib.rmdf_comm_info(self._ctx, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
+    def gather_shards_device(self, w, h, d_shard, d_gathered=0, stream=0):
+        self._check(self._lib.rmdf_gather_shards_device(self._ctx, w, h, d_shard, d_gathered or None, stream or None))
+
+    def render_frame_sharded_device(self, shd_enum, w, h, time, max_steps, d_shard, d_gathered=0, d_frame=0, stream=0):
+        """One frame of the multi-GPU path on `stream`: this rank's shard, the RCCL gather, rank 0's assembly."""
+        self._check(self._lib.rmdf_render_frame_sharded_device(self._ctx, int(shd_enum), w, h, float(time), max_steps, d_shard,
+                                                               d_gathered or None, d_frame or None, stream or None))
 
     def register_host_buffer(self, arr):
         """Pin + GPU-map a numpy frame buffer that is reused from frame to frame: whole-frame draw_shader_tile calls into
@@ -330,7 +386,9 @@ class ShaderRenderer:
         return out
 
     def debug_march_stats(self, enable=True, read_waves=0):
-        """Per-wave counters of the march kernel (see rmdf.h); returns (n, 8) uint64 or None."""
+        """Per-wave counters of the march kernels (rmdf_xcheck.h, xcheck renderers only); returns (n, 16) uint64 or None."""
+        if not self.xcheck:
+            raise RmdfError(-6, "debug_march_stats needs ShaderRenderer(..., xcheck=True)")
         out = np.zeros((read_waves, 16), np.uint64) if read_waves else None
         self._check(self._lib.rmdf_debug_march_stats(self._ctx, int(enable), _ptr(out), read_waves))
         return out
@@ -351,6 +409,16 @@ def with_shader_renderer(refl_map_fn=DEFAULT_ENV_HDR, device=0):
         yield sr
     finally:
         sr.close()
+
+
+def comm_get_unique_id():
+    """Rank 0: the RCCL unique id (128 bytes) the other ranks need for ShaderRenderer.comm_init (ship it by any channel)."""
+    L = load_library()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = L.rmdf_comm_get_unique_id(buf)
+    if rc != 0:
+        raise RmdfError(rc, (L.rmdf_last_error(None) or b"").decode())
+    return buf.raw
 
 
 class FrameBuffer:

@@ -1,24 +1,38 @@
 // rmdf_api.cpp -- the C ABI of librmdf.so (include/rmdf.h): host-side counterpart of
 // ShaderRendering.hs (withShaderRenderer / drawShaderTile) for the HIP renderer.
 // No CPU rendering path exists here: every pixel comes from the gfx950 kernels.
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <exception>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
+#include <rccl/rccl.h>          // types and prototypes only: the library is dlopen()ed by rmdf_comm_init
+
 #include "../../include/rmdf.h"
+#ifdef RMDF_XCHECK
+#include "../../include/rmdf_xcheck.h"
+#endif
 #include "rmdf_internal.hpp"
 
 using namespace rmdf;
 
 namespace {
 
-thread_local std::string g_create_error;
+// message of the last failed call that had no ctx (rmdf_create, rmdf_save_png, ...).  Process-wide and mutex-guarded, not
+// thread-local: a host whose runtime migrates its green threads between OS threads (GHC without a bound thread) may ask for
+// the message on another OS thread than the one the call failed on.  rmdf_last_error(NULL) hands out a per-thread copy.
+std::mutex  g_error_mutex;
+std::string g_global_error;
 
 struct CubeSlot {
     uint2 *d_texels = nullptr;
@@ -35,31 +49,32 @@ struct OrderState {
     unsigned    last_use = 0;
 };
 
+// host-built tables of the env-map kernels (rmdf_env.hip), cached per size
+struct UvTable  { int cw = 0; float2 *d_uv = nullptr; };
+struct LobeTable { int w = 0, h = 0; float *d_lutT = nullptr; float2 *d_tcs = nullptr; };
+
 }  // namespace
 
 struct rmdf_ctx {
     int          device = 0;
     hipStream_t  stream = nullptr;
+    hipStream_t  pstream[4] = { nullptr, nullptr, nullptr, nullptr };   // the four lobe powers run concurrently (ShaderRendering.hs:142)
+    hipEvent_t   ev_fork = nullptr, ev_join[4] = { nullptr, nullptr, nullptr, nullptr };
     float       *d_cornell = nullptr;
     float       *d_cornell_tab = nullptr;
     CubeSlot     env[RMDF_ENV_SLOTS];
+    std::vector<UvTable>   uv_tables;
+    std::vector<LobeTable> lobe_tables;
     // frame latched on the first tile (ShaderRendering.hs:162-176)
     int          w = 0, h = 0, max_steps = 128;
     float        time = 0.0f;
     bool         latched = false;
-    // accumulating frame (device)
+    // accumulating frame (device); the float / steps / iteration planes exist only once a caller asked for them
     uint32_t    *d_rgba8 = nullptr;
     float4      *d_rgba_f32 = nullptr;
     uint16_t    *d_steps = nullptr;
     uint16_t    *d_iters = nullptr;
-    size_t       cap_px = 0;
-    // G-buffer + work counter of the two-kernel Mandelbulb path
-    float4      *d_gbuf_nao = nullptr;
-    unsigned    *d_gbuf_meta = nullptr;
-    int         *d_work_counter = nullptr;
-    int         *d_hit_list = nullptr;
-    // cost-ordered dispatch state of the nested-loop kernel (previous frame's per-strip costs), one per stream
-    // that renders: frames in flight on different streams (pipelined rendering) must not share the tables
+    size_t       cap_px = 0, cap_planes_px = 0;
     // host buffers registered for direct GPU writes (rmdf_register_host_buffer)
     struct HostReg { char *host; size_t bytes; char *dev; };
     std::vector<HostReg> host_regs;
@@ -74,10 +89,22 @@ struct rmdf_ctx {
     unsigned char deal_tiles[64][64];
     int          deal_count[64];
     ShardWhere   deal_where;
+    // cost-ordered dispatch state of the render kernel (previous frame's per-strip costs), one per stream that renders:
+    // frames in flight on different streams (pipelined rendering) must not share the tables
     OrderState   orders[RMDF_MAX_ORDER_STREAMS];
     unsigned     order_tick = 0;
-    unsigned long long *d_dbg = nullptr;   // per-wave march diagnostics (rmdf_debug_march_stats)
+#ifdef RMDF_XCHECK
+    // G-buffer + work counter of the alternative schedules (one set: they support the ctx stream only)
+    float4      *d_gbuf_nao = nullptr;
+    unsigned    *d_gbuf_meta = nullptr;
+    int         *d_work_counter = nullptr;
+    int         *d_hit_list = nullptr;
     size_t       gbuf_cap = 0;
+    unsigned long long *d_dbg = nullptr;   // per-wave march diagnostics (rmdf_debug_march_stats)
+#endif
+    // the job's RCCL communicator (rmdf_comm_init): one rank per GPU, this ctx is rank comm_rank of comm_nranks
+    ncclComm_t   comm = nullptr;
+    int          comm_rank = 0, comm_nranks = 1;
     int          flags = 0;            // rmdf_config.reserved[0]
     std::string  err;
     char         dev_name[256] = { 0 };
@@ -88,7 +115,9 @@ namespace {
 
 int fail(rmdf_ctx *ctx, int code, const std::string &msg)
 {
-    if (ctx) ctx->err = msg; else g_create_error = msg;
+    if (ctx) { ctx->err = msg; return code; }
+    std::lock_guard<std::mutex> lock(g_error_mutex);
+    g_global_error = msg;
     return code;
 }
 
@@ -98,6 +127,15 @@ int fail(rmdf_ctx *ctx, int code, const std::string &msg)
         if (e_ != hipSuccess)                                                                     \
             return fail(ctx, RMDF_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
     } while (0)
+
+// Nothing may unwind through the C ABI into a foreign host (the Haskell viewer): every entry point that can allocate wraps
+// its body in these.
+#define RMDF_GUARD_BEGIN try {
+#define RMDF_GUARD_END(ctx)                                                                                   \
+    } catch (const std::bad_alloc &) { return fail(ctx, RMDF_E_NOMEM, "out of host memory");                  \
+    } catch (const std::exception &e_) { return fail(ctx, RMDF_E_INVALID, std::string("exception: ") + e_.what()); \
+    } catch (...) { return fail(ctx, RMDF_E_INVALID, "unknown exception"); }
+
 
 // one IEEE rounding per operation on the host too (this file is built with -ffp-contract=off)
 struct hv3 { float x, y, z; };
@@ -212,35 +250,45 @@ void cornell_table(const float tri[96 * 3], float tab[CORNELL_TAB_FLOATS])
         for (int k = 0; k < 8; k++) tab[32 * CORNELL_STRIDE + i * 8 + k] = tab[i * CORNELL_STRIDE + 26 + k];
 }
 
-int ensure_frame(rmdf_ctx *ctx, int w, int h)
+int ensure_frame(rmdf_ctx *ctx, int w, int h, bool planes)
 {
-    size_t npx = (size_t)w * (size_t)h;
-    if (npx <= ctx->cap_px && ctx->d_rgba8) return RMDF_OK;
-    if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
-    if (ctx->d_rgba_f32) (void)hipFree(ctx->d_rgba_f32);
-    if (ctx->d_steps) (void)hipFree(ctx->d_steps);
-    if (ctx->d_iters) (void)hipFree(ctx->d_iters);
-    ctx->d_rgba8 = nullptr; ctx->d_rgba_f32 = nullptr; ctx->d_steps = nullptr; ctx->d_iters = nullptr;
-    ctx->cap_px = 0;
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_rgba8, npx * 4));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_rgba_f32, npx * 16));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_steps, npx * 2));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_iters, npx * 2));
-    ctx->cap_px = npx;
+    const size_t npx = (size_t)w * (size_t)h;
+    if (!(npx <= ctx->cap_px && ctx->d_rgba8)) {
+        if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
+        ctx->d_rgba8 = nullptr; ctx->cap_px = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_rgba8, npx * 4));
+        ctx->cap_px = npx;
+    }
+    if (planes && !(npx <= ctx->cap_planes_px && ctx->d_rgba_f32)) {
+        if (ctx->d_rgba_f32) (void)hipFree(ctx->d_rgba_f32);
+        if (ctx->d_steps) (void)hipFree(ctx->d_steps);
+        if (ctx->d_iters) (void)hipFree(ctx->d_iters);
+        ctx->d_rgba_f32 = nullptr; ctx->d_steps = nullptr; ctx->d_iters = nullptr; ctx->cap_planes_px = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_rgba_f32, npx * 16));
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_steps, npx * 2));
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_iters, npx * 2));
+        ctx->cap_planes_px = npx;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_rgba_f32, 0, npx * 16, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_steps, 0, npx * 2, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_iters, 0, npx * 2, ctx->stream));
+    }
     return RMDF_OK;
 }
 
 // resizeFrameBuffer clears the new texture to opaque black (FrameBuffer.hs:109-111)
 int clear_frame(rmdf_ctx *ctx, int w, int h)
 {
-    size_t npx = (size_t)w * (size_t)h;
+    const size_t npx = (size_t)w * (size_t)h;
     HIP_TRY(ctx, launch_fill_u32(ctx->d_rgba8, 0xff000000u, npx, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_rgba_f32, 0, npx * 16, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_steps, 0, npx * 2, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_iters, 0, npx * 2, ctx->stream));
+    if (ctx->d_rgba_f32 && npx <= ctx->cap_planes_px) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_rgba_f32, 0, npx * 16, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_steps, 0, npx * 2, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_iters, 0, npx * 2, ctx->stream));
+    }
     return RMDF_OK;
 }
 
+#ifdef RMDF_XCHECK
 int ensure_gbuf(rmdf_ctx *ctx, int w, int h)
 {
     const size_t gw = (size_t)((w + 1) & ~1), gh = (size_t)((h + 1) & ~1);
@@ -257,32 +305,40 @@ int ensure_gbuf(rmdf_ctx *ctx, int w, int h)
     ctx->gbuf_cap = need;
     return RMDF_OK;
 }
+#endif
 
-// scene dispatch: the Mandelbulb has two schedules of the same per-ray arithmetic; the default is the
-// fastest measured one, the other stays selectable for A/B measurements and tests
 int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t stream)
 {
+#ifdef RMDF_XCHECK
+    // librmdf_xcheck.so: the alternative schedules of the same per-ray arithmetic (cross-check tests, A/B measurements).
+    // They share ONE G-buffer / work counter / hit list per ctx, so they run on the ctx stream only.
     if (scene == RMDF_FS_MB_POWER8 && ctx->d_dbg && getenv("RMDF_NESTED_STATS")) {
         HIP_TRY(ctx, launch_march_stats(p, stream));
         return RMDF_OK;
     }
-    if (ctx->flags & RMDF_FLAG_PIPELINE) {
-        HIP_TRY(ctx, launch_render_pipeline(scene, p, stream, ctx->cus));
+    if ((ctx->flags & RMDF_FLAG_PIPELINE) || (scene == RMDF_FS_MB_POWER8 && (ctx->flags & RMDF_FLAG_FLAT_MARCH))) {
+        if (stream != ctx->stream)
+            return fail(ctx, RMDF_E_UNSUPPORTED, "the alternative schedules keep one scratch set per ctx: use the ctx stream (stream = NULL)");
+        FrameParams q = p;
+        int rc = ensure_gbuf(ctx, p.w, p.h);
+        if (rc != RMDF_OK) return rc;
+        q.gbuf_nao = ctx->d_gbuf_nao; q.gbuf_meta = ctx->d_gbuf_meta; q.gw = (p.w + 1) & ~1;
+        q.work_counter = ctx->d_work_counter; q.hit_count = ctx->d_work_counter + 1; q.hit_list = ctx->d_hit_list;
+        q.tile_order = nullptr;
+        if (ctx->flags & RMDF_FLAG_PIPELINE) HIP_TRY(ctx, launch_render_pipeline(scene, q, stream, ctx->cus));
+        else                                 HIP_TRY(ctx, launch_render_mb8(q, stream, ctx->cus));
         return RMDF_OK;
     }
-    if (scene == RMDF_FS_MB_POWER8 && (ctx->flags & RMDF_FLAG_FLAT_MARCH)) {
-        HIP_TRY(ctx, launch_render_mb8(p, stream, ctx->cus));
-        return RMDF_OK;
-    }
-    // Nested-loop kernel.  Its run time is set by the strips that hold the longest rays (a 226-step ray is a
-    // ~0.4 ms serial chain), so large launches dispatch the strips that were most expensive in the previous
-    // frame of the same configuration first (temporal coherence; `time` is deliberately not part of the key).
-    // The table only permutes which workgroup renders which strip: the image does not depend on it.
+#endif
+    // The run time of a launch is set by the strips that hold the longest rays (a 226-step ray is a ~0.4 ms serial
+    // chain), so large launches dispatch the strips that were most expensive in the previous frame of the same
+    // configuration first (temporal coherence; `time` is deliberately not part of the key).  The table only permutes
+    // which workgroup renders which strip: the image does not depend on it.
     FrameParams q = p;
-    const int nblk = render_grid_blocks(scene, p);
+    const int nblk = render_grid_blocks(p);
     const bool want = nblk >= 1024 && !(ctx->flags & RMDF_FLAG_RASTER_ORDER);
     if (want) {
-        // the table set of this stream (least recently used one is recycled when more than 8 streams render)
+        // the table set of this stream (the least recently used one is recycled when more than RMDF_MAX_ORDER_STREAMS render)
         OrderState *os = nullptr;
         for (auto &o : ctx->orders) if (o.used && o.stream == stream) { os = &o; break; }
         if (!os) {
@@ -310,7 +366,6 @@ int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t str
         const bool same = os->valid && os->n == nblk && memcmp(key, os->key, sizeof key) == 0;
         q.block_cost = os->d_cost;
         q.block_order = same ? os->d_order : nullptr;
-        { static int ps = -1; if (ps < 0) { const char *e = getenv("RMDF_PRIO_STRIPS"); ps = e ? atoi(e) : 256; } q.prio_strips = ps; }
         HIP_TRY(ctx, launch_render(scene, q, stream));
         HIP_TRY(ctx, launch_order_blocks(os->d_cost, nblk, os->d_order, stream));
         memcpy(os->key, key, sizeof key);
@@ -320,6 +375,7 @@ int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t str
     }
     return RMDF_OK;
 }
+
 
 // the deal in effect for `nranks` ranks, computed once per (nranks, set of costs)
 void ensure_deal(rmdf_ctx *ctx, int nranks)
@@ -332,6 +388,7 @@ void ensure_deal(rmdf_ctx *ctx, int nranks)
     }
     ctx->deal_nranks = nranks; ctx->deal_gen = ctx->shard_cost_gen;
 }
+
 
 int fill_params(rmdf_ctx *ctx, int scene, int w, int h, float time, int max_steps, FrameParams &p)
 {
@@ -359,24 +416,14 @@ int fill_params(rmdf_ctx *ctx, int scene, int w, int h, float time, int max_step
     p.env_cos1 = CubeDev{ ctx->env[RMDF_ENV_COS_1].d_texels, ctx->env[RMDF_ENV_COS_1].W };
     p.env_cos8 = CubeDev{ ctx->env[RMDF_ENV_COS_8].d_texels, ctx->env[RMDF_ENV_COS_8].W };
     p.cornell = ctx->d_cornell;
-    // measurement knobs are read once per process
-    static int mg = -1, mg_forced = 0;
-    if (mg < 0) { const char *e = getenv("RMDF_MERGE"); mg_forced = e != nullptr; mg = e ? atoi(e) : 32; }
-    p.merge_stragglers = (ctx->flags & RMDF_FLAG_NO_MERGE) ? 0 : mg;
-    // measured (current build): pooling pays for both Mandelbulbs (+5 %, +8 %) and the test scene (+8 %); it costs 6 % for
-    // the Cornell box, whose distance estimate has the same cost for every ray
-    if (scene == RMDF_FS_DE_CORNELL_BOX && !mg_forced) p.merge_stragglers = 0;
+    // pooling the last rays of a workgroup pays for both Mandelbulbs (+5 %, +8 %) and the test scene (+8 %);
+    // it costs 6 % for the Cornell box, whose distance estimate has the same cost for every ray
+    p.merge_stragglers = ((ctx->flags & RMDF_FLAG_NO_MERGE) || scene == RMDF_FS_DE_CORNELL_BOX) ? 0 : 32;
     p.cornell_tab = ctx->d_cornell_tab;
     p.cornell_prune = (ctx->flags & RMDF_FLAG_NO_PRUNE) ? 0 : 1;
-    { static int skip = -1; if (skip < 0) { const char *e = getenv("RMDF_DBG_SKIP"); skip = e ? atoi(e) : 0; } p.dbg_skip = skip; }
-    int rc = ensure_gbuf(ctx, w, h);
-    if (rc != RMDF_OK) return rc;
-    p.gbuf_nao = ctx->d_gbuf_nao; p.gbuf_meta = ctx->d_gbuf_meta; p.gw = (w + 1) & ~1;
-    p.work_counter = ctx->d_work_counter;
-    p.hit_count = ctx->d_work_counter + 1;
-    p.hit_list = ctx->d_hit_list;
-    p.tile_order = nullptr;
+#ifdef RMDF_XCHECK
     p.dbg = ctx->d_dbg;
+#endif
     return RMDF_OK;
 }
 
@@ -401,6 +448,7 @@ bool file_exists(const std::string &p)
     fclose(f);
     return true;
 }
+
 
 // Radiance RGBE <-> float as JuicyPixels does it (third-party arithmetic behind
 // JP.readImage / JP.saveRadianceImage, HDREnvMap.hs:33, ShaderRendering.hs:147)
@@ -427,10 +475,11 @@ void float_to_rgbe(const float *rgb, uint8_t *p)
     p[3] = (uint8_t)(e + 128);
 }
 
+
 // loadHDRImage (HDREnvMap.hs:31-52): flat or new-style-RLE Radiance files
-bool decode_hdr(const std::vector<uint8_t> &file, int &w, int &h, std::vector<float> &rgb, std::string &why)
+bool decode_hdr(const uint8_t *file, size_t len, int &w, int &h, std::vector<float> &rgb, std::string &why)
 {
-    size_t pos = 0, len = file.size();
+    size_t pos = 0;
     bool blank = false;
     while (pos < len) {                        // header lines up to the empty line
         size_t eol = pos;
@@ -446,6 +495,8 @@ bool decode_hdr(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
     if (eol >= len || eol - pos > 100) { why = "no resolution line"; return false; }
     std::string line((const char *)&file[pos], eol - pos);
     if (sscanf(line.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) { why = "unsupported resolution line '" + line + "'"; return false; }
+    // the size comes from the file: bound it before it sizes an allocation (and by what the file can hold: >= 1 byte per 128 texels even fully run-length coded)
+    if (w > 65536 || h > 32768 || (size_t)w * (size_t)h / 128 > len) { why = "implausible image size in resolution line '" + line + "'"; return false; }
     pos = eol + 1;
     rgb.resize((size_t)w * h * 3);
     std::vector<uint8_t> scan((size_t)w * 4);
@@ -479,16 +530,27 @@ bool decode_hdr(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
     return true;
 }
 
-bool write_hdr(const std::string &path, const std::vector<float> &rgb, int w, int h)
+// JP.saveRadianceImage (ShaderRendering.hs:147) as a flat Radiance file image in memory
+void encode_hdr(const std::vector<float> &rgb, int w, int h, std::vector<uint8_t> &file)
 {
-    FILE *f = fopen(path.c_str(), "wb");
+    char hdr[96];
+    const int n = snprintf(hdr, sizeof hdr, "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n", h, w);
+    file.resize((size_t)n + (size_t)w * h * 4);
+    memcpy(file.data(), hdr, (size_t)n);
+    for (size_t i = 0; i < (size_t)w * h; i++) float_to_rgbe(&rgb[i * 3], &file[(size_t)n + i * 4]);
+}
+
+// Several ranks of one node may build the same cache at once (bench.py, any multi-process host): write under a private
+// name and rename() into place, so a reader sees either no file or a complete one.
+bool write_file_atomic(const std::string &path, const std::vector<uint8_t> &data)
+{
+    const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return false;
-    fprintf(f, "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n", h, w);
-    std::vector<uint8_t> px((size_t)w * h * 4);
-    for (size_t i = 0; i < (size_t)w * h; i++) float_to_rgbe(&rgb[i * 3], &px[i * 4]);
-    bool ok = fwrite(px.data(), 1, px.size(), f) == px.size();
+    bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
     ok = (fclose(f) == 0) && ok;
-    if (!ok) remove(path.c_str());            // removeFile on failure, ShaderRendering.hs:146-148
+    if (ok) ok = rename(tmp.c_str(), path.c_str()) == 0;
+    if (!ok) remove(tmp.c_str());              // removeFile on failure, ShaderRendering.hs:146-148
     return ok;
 }
 
@@ -496,6 +558,155 @@ struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
 };
+
+// Run fn(lo, hi) over [0, n) in row segments on the host cores, as forSegmentsConcurrently does for the reference's
+// cube-map resampler (HDREnvMap.hs:139).
+template <typename F>
+void host_segments(int n, F fn)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > 64) nt = 64;
+    if ((int)nt > n) nt = (unsigned)(n > 0 ? n : 1);
+    if (nt == 1 || n < 64) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) {
+        const int lo = (int)((long long)n * t / nt), hi = (int)((long long)n * (t + 1) / nt);
+        th.emplace_back([=] { fn(lo, hi); });
+    }
+    for (auto &t : th) t.join();
+}
+
+const float kPi = 3.14159265358979323846f;       // `pi :: Float`
+
+// GHC's class-default RealFloat atan2 (Float has no specialised one), atan = libm atanf
+float hs_atan2f(float y, float x)
+{
+    if (x > 0.0f) return atanf(y / x);
+    if (x == 0.0f && y > 0.0f) return kPi / 2.0f;
+    if (x < 0.0f && y > 0.0f) return kPi + atanf(y / x);
+    if ((x <= 0.0f && y < 0.0f) || (x < 0.0f && y == 0.0f && signbit(y)) || (x == 0.0f && signbit(x) && y == 0.0f && signbit(y)))
+        return -hs_atan2f(-y, x);
+    if (y == 0.0f && (x < 0.0f || (x == 0.0f && signbit(x)))) return kPi;
+    if (x == 0.0f && y == 0.0f) return y;
+    return x + y;
+}
+
+// Environment (u, v) of every texel of the six cw x cw faces: cubeMapPixelToDir (HDREnvMap.hs:76-87, Linear.normalize's
+// near-unit short cut), worldToLocal (CoordTransf.hs:46-50), cartesianToSpherical (35-44), sphericalToEnvironmentUV
+// (60-70).  A function of the face size alone, so it is evaluated once per size on the host -- with glibc's acosf / atanf,
+// the very functions GHC's Float acos / atan call in the reference -- and k_latlong_to_cube only gathers.
+void cube_uv_table_host(int cw, std::vector<float> &uv)
+{
+    uv.resize((size_t)6 * cw * cw * 2);
+    host_segments(6 * cw, [&](int lo, int hi) {
+        for (int r = lo; r < hi; r++) {
+            const int face = r / cw, y = r % cw;
+            for (int x = 0; x < cw; x++) {
+                const float vw = ((float)x + 0.5f) / (float)cw * 2.0f - 1.0f;
+                const float vh = ((float)y + 0.5f) / (float)cw * 2.0f - 1.0f;
+                hv3 d;
+                switch (face) {
+                case 0:  d = hv3{ 1.0f, -vh, -vw }; break;
+                case 1:  d = hv3{ -1.0f, -vh, vw }; break;
+                case 2:  d = hv3{ vw, 1.0f, vh }; break;
+                case 3:  d = hv3{ vw, -1.0f, -vh }; break;
+                case 4:  d = hv3{ vw, -vh, 1.0f }; break;
+                default: d = hv3{ -vw, -vh, -1.0f }; break;
+                }
+                // Linear.normalize: unchanged if the squared length is within 1e-6 of 0 or 1
+                const float l = d.x * d.x + d.y * d.y + d.z * d.z;
+                if (!(fabsf(l) <= 1e-6f || fabsf(1.0f - l) <= 1e-6f)) {
+                    const float s = sqrtf(l);
+                    d = hv3{ d.x / s, d.y / s, d.z / s };
+                }
+                const hv3 loc{ (d.x * 1.0f + d.y * 0.0f) + d.z * 0.0f,
+                               (d.x * 0.0f + d.y * 0.0f) + d.z * -1.0f,
+                               (d.x * 0.0f + d.y * 1.0f) + d.z * 0.0f };
+                float cz = loc.z;
+                if (cz > 1.0f) cz = 1.0f;
+                if (cz < -1.0f) cz = -1.0f;
+                const float theta = acosf(cz);
+                const float p2 = hs_atan2f(loc.y, loc.x);
+                const float p1 = (p2 < 0.0f) ? p2 + 2.0f * kPi : p2;
+                const float phi = (p1 == 2.0f * kPi) ? 0.0f : p1;
+                const float q1 = phi + kPi / 2.0f;
+                const float q2 = (q1 > 2.0f * kPi) ? q1 - 2.0f * kPi : q1;
+                const float q3 = 2.0f * kPi - q2;
+                float *o = &uv[((size_t)r * cw + x) * 2];
+                o[0] = q3 / (kPi * 2.0f);
+                o[1] = theta / kPi;
+            }
+        }
+    });
+}
+
+int get_uv_table(rmdf_ctx *ctx, int cw, const float2 **d_uv)
+{
+    for (auto &t : ctx->uv_tables) if (t.cw == cw) { *d_uv = t.d_uv; return RMDF_OK; }
+    std::vector<float> uv;
+    cube_uv_table_host(cw, uv);
+    UvTable t;
+    t.cw = cw;
+    HIP_TRY(ctx, hipMalloc((void **)&t.d_uv, uv.size() * sizeof(float)));
+    hipError_t e = hipMemcpy(t.d_uv, uv.data(), uv.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(t.d_uv); return fail(ctx, RMDF_E_HIP, std::string("uv table upload: ") + hipGetErrorString(e)); }
+    if (ctx->uv_tables.size() >= 8) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->uv_tables[0].d_uv); ctx->uv_tables.erase(ctx->uv_tables.begin()); }
+    ctx->uv_tables.push_back(t);
+    *d_uv = t.d_uv;
+    return RMDF_OK;
+}
+
+// Cosine tables of cosineConvolveHDREnvMap (HDREnvMap.hs:222-239) for a w x h map, host glibc cosf / sinf:
+//   lutT[(blk*w + x)*64 + lane] = cos |pxToPhi(blk*64+lane) - pxToPhi(x)|   (absPhiDiffCosLookup, per destination column)
+//   tcs[2y], tcs[2y+1]          = cos, sin of pxToTheta(y)
+void lobe_tables_host(int w, int h, std::vector<float> &lutT, std::vector<float> &tcs)
+{
+    const int nblk = (w + 63) / 64;
+    lutT.resize((size_t)nblk * w * 64);
+    host_segments(nblk * w, [&](int lo, int hi) {
+        for (int r = lo; r < hi; r++) {
+            const int blk = r / w, x = r % w;
+            const float phi_x = (float)x / (float)(w - 1) * 2.0f * kPi;
+            for (int lane = 0; lane < 64; lane++) {
+                int dx = blk * 64 + lane;
+                if (dx > w - 1) dx = w - 1;
+                const float phi_l = (float)dx / (float)(w - 1) * 2.0f * kPi;
+                lutT[(size_t)r * 64 + lane] = cosf(fabsf(phi_l - phi_x));
+            }
+        }
+    });
+    tcs.resize((size_t)h * 2);
+    for (int y = 0; y < h; y++) {
+        const float th = (float)y / (float)(h - 1) * kPi;
+        tcs[2 * y] = cosf(th); tcs[2 * y + 1] = sinf(th);
+    }
+}
+
+int get_lobe_tables(rmdf_ctx *ctx, int w, int h, const float **d_lutT, const float2 **d_tcs)
+{
+    for (auto &t : ctx->lobe_tables) if (t.w == w && t.h == h) { *d_lutT = t.d_lutT; *d_tcs = t.d_tcs; return RMDF_OK; }
+    std::vector<float> lutT, tcs;
+    lobe_tables_host(w, h, lutT, tcs);
+    LobeTable t;
+    t.w = w; t.h = h;
+    HIP_TRY(ctx, hipMalloc((void **)&t.d_lutT, lutT.size() * sizeof(float)));
+    hipError_t e = hipMalloc((void **)&t.d_tcs, tcs.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(t.d_lutT, lutT.data(), lutT.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t.d_tcs, tcs.data(), tcs.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(t.d_lutT); if (t.d_tcs) (void)hipFree(t.d_tcs);
+        return fail(ctx, RMDF_E_HIP, std::string("lobe table upload: ") + hipGetErrorString(e));
+    }
+    if (ctx->lobe_tables.size() >= 4) {
+        (void)hipDeviceSynchronize();
+        (void)hipFree(ctx->lobe_tables[0].d_lutT); (void)hipFree(ctx->lobe_tables[0].d_tcs);
+        ctx->lobe_tables.erase(ctx->lobe_tables.begin());
+    }
+    ctx->lobe_tables.push_back(t);
+    *d_lutT = t.d_lutT; *d_tcs = t.d_tcs;
+    return RMDF_OK;
+}
 
 int set_env_from_device_faces(rmdf_ctx *ctx, int slot, const float *d_faces, int W)
 {
@@ -505,11 +716,73 @@ int set_env_from_device_faces(rmdf_ctx *ctx, int slot, const float *d_faces, int
     hipError_t e = launch_cube_upload(d_faces, W, d_padded, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { (void)hipFree(d_padded); return fail(ctx, RMDF_E_HIP, std::string("cube upload: ") + hipGetErrorString(e)); }
-    if (ctx->env[slot].d_texels) (void)hipFree(ctx->env[slot].d_texels);
+    if (ctx->env[slot].d_texels) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->env[slot].d_texels); }
     ctx->env[slot].d_texels = d_padded;
     ctx->env[slot].W = W;
     return RMDF_OK;
 }
+
+// the lobe prefilter of `n` powers of one device-resident map, concurrently on the ctx's four power streams
+int prefilter_powers_device(rmdf_ctx *ctx, const float *d_src, int w, int h, const float *powers, int n, float *const *d_out)
+{
+    const float *d_lutT = nullptr; const float2 *d_tcs = nullptr;
+    int rc = get_lobe_tables(ctx, w, h, &d_lutT, &d_tcs);
+    if (rc != RMDF_OK) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    const int ns = n < 4 ? n : 4;
+    for (int k = 0; k < ns; k++) HIP_TRY(ctx, hipStreamWaitEvent(ctx->pstream[k], ctx->ev_fork, 0));
+    for (int i = 0; i < n; i++)
+        HIP_TRY(ctx, launch_prefilter(d_src, w, h, powers[i], d_lutT, d_tcs, d_out[i], ctx->pstream[i % 4]));
+    for (int k = 0; k < ns; k++) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_join[k], ctx->pstream[k]));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[k], 0));
+    }
+    return RMDF_OK;
+}
+
+
+// ---- the exchange step: RCCL over xGMI, one process per GPU ----------------------------------------------------------------
+// librccl is opened on first use, by soname: a single-GPU host never needs it, and a process that already carries an RCCL
+// (PyTorch ships one with the same soname) gets that copy instead of a second one.
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId)   GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank)  CommInitRank = nullptr;
+    decltype(&ncclCommDestroy)   CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclSend)          Send = nullptr;
+    decltype(&ncclRecv)          Recv = nullptr;
+    decltype(&ncclGroupStart)    GroupStart = nullptr;
+    decltype(&ncclGroupEnd)      GroupEnd = nullptr;
+};
+RcclApi    g_rccl;
+std::mutex g_rccl_mutex;
+
+int load_rccl(rmdf_ctx *ctx)
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.handle) return RMDF_OK;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(ctx, RMDF_E_UNSUPPORTED, std::string("cannot load librccl.so.1: ") + dlerror());
+    RcclApi a;
+    a.handle = h;
+#define RMDF_SYM(field, name) a.field = (decltype(a.field))dlsym(h, name); if (!a.field) { dlclose(h); return fail(ctx, RMDF_E_UNSUPPORTED, std::string("librccl lacks ") + name); }
+    RMDF_SYM(GetUniqueId, "ncclGetUniqueId") RMDF_SYM(CommInitRank, "ncclCommInitRank") RMDF_SYM(CommDestroy, "ncclCommDestroy")
+    RMDF_SYM(GetErrorString, "ncclGetErrorString") RMDF_SYM(Send, "ncclSend") RMDF_SYM(Recv, "ncclRecv")
+    RMDF_SYM(GroupStart, "ncclGroupStart") RMDF_SYM(GroupEnd, "ncclGroupEnd")
+#undef RMDF_SYM
+    g_rccl = a;
+    return RMDF_OK;
+}
+
+#define RCCL_TRY(ctx, expr)                                                                               \
+    do {                                                                                                  \
+        ncclResult_t r_ = (expr);                                                                         \
+        if (r_ != ncclSuccess)                                                                            \
+            return fail(ctx, RMDF_E_COMM, std::string(#expr) + ": " + g_rccl.GetErrorString(r_));         \
+    } while (0)
 
 int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double time, int max_steps,
                   uint32_t *out_rgba8, float *out_rgba_f32, uint16_t *out_steps, uint16_t *out_iters)
@@ -518,6 +791,7 @@ int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double t
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const bool whole = tile_idx < 0;
     const bool first = whole || rmdf_is_tile_idx_first_tile(tile_idx);
+    const bool planes = out_rgba_f32 || out_steps || out_iters;
     // latch on the first tile (ShaderRendering.hs:162-176).  A size change in the middle
     // of a tiled frame re-latches (the reference would resize its FBO texture and clear it).
     if (first || !ctx->latched || w != ctx->w || h != ctx->h) {
@@ -525,7 +799,7 @@ int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double t
         int rc = fill_params(ctx, scene, w, h, (float)time, max_steps, probe);
         if (rc != RMDF_OK) return rc;
         const bool resized = (w != ctx->w || h != ctx->h || !ctx->d_rgba8);
-        rc = ensure_frame(ctx, w, h);
+        rc = ensure_frame(ctx, w, h, planes);
         if (rc != RMDF_OK) return rc;
         if (resized) { rc = clear_frame(ctx, w, h); if (rc != RMDF_OK) return rc; }
         ctx->w = w; ctx->h = h; ctx->time = (float)time; ctx->max_steps = max_steps <= 0 ? 128 : max_steps;
@@ -534,15 +808,21 @@ int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double t
     FrameParams p;
     int rc = fill_params(ctx, scene, ctx->w, ctx->h, ctx->time, ctx->max_steps, p);
     if (rc != RMDF_OK) return rc;
+    rc = ensure_frame(ctx, ctx->w, ctx->h, planes);     // the extra planes appear the first time a caller asks for them
+    if (rc != RMDF_OK) return rc;
     if (whole) { p.x0 = 0; p.y0 = 0; p.x1 = ctx->w; p.y1 = ctx->h; }
     else tile_rect_host(tile_idx, ctx->w, ctx->h, &p.x0, &p.y0, &p.x1, &p.y1);
-    p.rgba8 = ctx->d_rgba8; p.rgba_f32 = ctx->d_rgba_f32; p.steps = ctx->d_steps; p.iters = ctx->d_iters;
+    p.rgba8 = ctx->d_rgba8;
+    if (planes) { p.rgba_f32 = ctx->d_rgba_f32; p.steps = ctx->d_steps; p.iters = ctx->d_iters; }
     const size_t npx = (size_t)ctx->w * ctx->h;
     // Whole-frame call into a registered host buffer: the render kernel stores the RGBA8 rows into it directly (next to
-    // the library's own accumulating frame), so the PCIe transfer overlaps the render instead of following it.  Only the
-    // default nested-loop kernel knows the mirror pointer.
+    // the library's own accumulating frame), so the PCIe transfer overlaps the render instead of following it.
     bool direct = false;
-    if (whole && out_rgba8 && !(ctx->flags & (RMDF_FLAG_PIPELINE | RMDF_FLAG_FLAT_MARCH))) {
+    if (whole && out_rgba8 && !planes
+#ifdef RMDF_XCHECK
+        && !(ctx->flags & (RMDF_FLAG_PIPELINE | RMDF_FLAG_FLAT_MARCH))
+#endif
+    ) {
         for (auto &r : ctx->host_regs)
             if ((char *)out_rgba8 >= r.host && (char *)out_rgba8 + npx * 4 <= r.host + r.bytes) {
                 p.rgba8_mirror = (uint32_t *)(r.dev + ((char *)out_rgba8 - r.host));
@@ -562,10 +842,11 @@ int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double t
 
 }  // namespace
 
+
 namespace rmdf {
 void tile_rect_host(int tile_idx, int w, int h, int *x0, int *y0, int *x1, int *y1)
 {
-    // ShaderRendering.hs:183-193, centre-inside rasterisation (see rmdf_kernels.hip)
+    // ShaderRendering.hs:183-193, centre-inside rasterisation (see tile_rect in rmdf_render.hip)
     int midx = tile_idx % 64;
     int tx = midx % 8, ty = midx / 8;
     *x0 = (2 * tx * w + 7) / 16;
@@ -575,12 +856,26 @@ void tile_rect_host(int tile_idx, int w, int h, int *x0, int *y0, int *x1, int *
 }
 }  // namespace rmdf
 
+
 extern "C" {
+
+int rmdf_create_ex(rmdf_ctx **out, const rmdf_config *cfg, char *err, size_t err_len)
+{
+    const int rc = rmdf_create(out, cfg);
+    if (err && err_len > 0) snprintf(err, err_len, "%s", rc == RMDF_OK ? "" : rmdf_last_error(nullptr));
+    return rc;
+}
 
 int rmdf_create(rmdf_ctx **out, const rmdf_config *cfg)
 {
     if (!out) return fail(nullptr, RMDF_E_INVALID, "null out pointer");
     *out = nullptr;
+    RMDF_GUARD_BEGIN
+    // Frames in flight live on separate HIP streams (rmdf_render_rect_device / rmdf_render_shard_device): with the
+    // runtime's default of 4 hardware queues more than four streams share queues and serialise (measured: 8 frames in
+    // flight run at 0.11 ms per frame with 8 queues, 0.069 ms with 12 or more).  The variable is read when the HIP runtime
+    // initialises, so it only takes effect if this is the process's first HIP call; a value the host set itself is kept.
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -592,10 +887,15 @@ int rmdf_create(rmdf_ctx **out, const rmdf_config *cfg)
     if (e != hipSuccess) return fail(nullptr, RMDF_E_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, RMDF_E_NO_DEVICE, std::string("librmdf is built for gfx950 only, found ") + prop.gcnArchName);
+    const int flags = cfg ? cfg->reserved[0] : 0;
+#ifndef RMDF_XCHECK
+    if (flags & ~(RMDF_FLAG_RASTER_ORDER | RMDF_FLAG_NO_MERGE | RMDF_FLAG_NO_PRUNE))
+        return fail(nullptr, RMDF_E_UNSUPPORTED, "unknown flag bits (the alternative schedules live in librmdf_xcheck.so, include/rmdf_xcheck.h)");
+#endif
     rmdf_ctx *ctx = new (std::nothrow) rmdf_ctx();
     if (!ctx) return fail(nullptr, RMDF_E_NOMEM, "out of host memory");
     ctx->device = dev;
-    ctx->flags = cfg ? cfg->reserved[0] : 0;
+    ctx->flags = flags;
     ctx->cus = prop.multiProcessorCount;
     snprintf(ctx->dev_name, sizeof ctx->dev_name, "%s (%s)", prop.name, prop.gcnArchName);
     float tri[96 * 3];
@@ -607,45 +907,68 @@ int rmdf_create(rmdf_ctx **out, const rmdf_config *cfg)
         (e = hipMalloc((void **)&ctx->d_cornell, sizeof tri)) != hipSuccess ||
         (e = hipMemcpy(ctx->d_cornell, tri, sizeof tri, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMalloc((void **)&ctx->d_cornell_tab, sizeof tab)) != hipSuccess ||
-        (e = hipMemcpy(ctx->d_cornell_tab, tab, sizeof tab, hipMemcpyHostToDevice)) != hipSuccess) {
+        (e = hipMemcpy(ctx->d_cornell_tab, tab, sizeof tab, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) {
         std::string msg = std::string("device init: ") + hipGetErrorString(e);
         rmdf_destroy(ctx);
         return fail(nullptr, RMDF_E_HIP, msg);
     }
+    for (int k = 0; k < 4; k++)
+        if ((e = hipStreamCreateWithFlags(&ctx->pstream[k], hipStreamNonBlocking)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming)) != hipSuccess) {
+            std::string msg = std::string("device init: ") + hipGetErrorString(e);
+            rmdf_destroy(ctx);
+            return fail(nullptr, RMDF_E_HIP, msg);
+        }
     *out = ctx;
     return RMDF_OK;
+    RMDF_GUARD_END(nullptr)
 }
 
 void rmdf_destroy(rmdf_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipDeviceSynchronize();              // caller streams may still be running launches that use the ctx's tables
+    rmdf_comm_destroy(ctx);
     for (auto &s : ctx->env) if (s.d_texels) (void)hipFree(s.d_texels);
+    for (auto &t : ctx->uv_tables) (void)hipFree(t.d_uv);
+    for (auto &t : ctx->lobe_tables) { (void)hipFree(t.d_lutT); (void)hipFree(t.d_tcs); }
     if (ctx->d_cornell) (void)hipFree(ctx->d_cornell);
     if (ctx->d_cornell_tab) (void)hipFree(ctx->d_cornell_tab);
     if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
     if (ctx->d_rgba_f32) (void)hipFree(ctx->d_rgba_f32);
     if (ctx->d_steps) (void)hipFree(ctx->d_steps);
     if (ctx->d_iters) (void)hipFree(ctx->d_iters);
+#ifdef RMDF_XCHECK
     if (ctx->d_gbuf_nao) (void)hipFree(ctx->d_gbuf_nao);
     if (ctx->d_gbuf_meta) (void)hipFree(ctx->d_gbuf_meta);
     if (ctx->d_hit_list) (void)hipFree(ctx->d_hit_list);
     if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
     if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
-    (void)hipDeviceSynchronize();              // caller streams may still be running launches that use the tables
+#endif
     for (auto &r : ctx->host_regs) (void)hipHostUnregister(r.host);
     for (auto &o : ctx->orders) {
         if (o.d_cost) (void)hipFree(o.d_cost);
         if (o.d_order) (void)hipFree(o.d_order);
     }
+    for (int k = 0; k < 4; k++) {
+        if (ctx->pstream[k]) (void)hipStreamDestroy(ctx->pstream[k]);
+        if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 const char *rmdf_last_error(const rmdf_ctx *ctx)
 {
-    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+    if (ctx) return ctx->err.c_str();
+    // a per-thread copy of the process-wide message: the pointer stays valid while other threads fail and overwrite it
+    static thread_local char buf[1024];
+    std::lock_guard<std::mutex> lock(g_error_mutex);
+    snprintf(buf, sizeof buf, "%s", g_global_error.c_str());
+    return buf;
 }
 
 int rmdf_is_tile_idx_first_tile(int idx) { return idx % RMDF_N_TILES == 0; }
@@ -656,12 +979,14 @@ int rmdf_set_env_cube(rmdf_ctx *ctx, int slot, const float *faces_rgb, int face_
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
     if (slot < 0 || slot >= RMDF_ENV_SLOTS || !faces_rgb || face_w < 1 || face_w > 8192)
         return fail(ctx, RMDF_E_INVALID, "rmdf_set_env_cube: bad argument");
+    RMDF_GUARD_BEGIN
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf faces;
     size_t bytes = (size_t)6 * face_w * face_w * 3 * sizeof(float);
     HIP_TRY(ctx, hipMalloc(&faces.p, bytes));
     HIP_TRY(ctx, hipMemcpyAsync(faces.p, faces_rgb, bytes, hipMemcpyHostToDevice, ctx->stream));
     return set_env_from_device_faces(ctx, slot, (const float *)faces.p, face_w);
+    RMDF_GUARD_END(ctx)
 }
 
 int rmdf_set_env_latlong(rmdf_ctx *ctx, int slot, const float *rgb, int w, int h)
@@ -669,15 +994,20 @@ int rmdf_set_env_latlong(rmdf_ctx *ctx, int slot, const float *rgb, int w, int h
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
     if (slot < 0 || slot >= RMDF_ENV_SLOTS || !rgb || w < 6 || h < 2 || w > 65536 || h > 32768)
         return fail(ctx, RMDF_E_INVALID, "rmdf_set_env_latlong: bad argument");
+    RMDF_GUARD_BEGIN
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int cw = w / 3;
+    const float2 *d_uv = nullptr;
+    int rc = get_uv_table(ctx, cw, &d_uv);
+    if (rc != RMDF_OK) return rc;
     DevBuf ll, faces;
     size_t ll_bytes = (size_t)w * h * 3 * sizeof(float), f_bytes = (size_t)6 * cw * cw * 3 * sizeof(float);
     HIP_TRY(ctx, hipMalloc(&ll.p, ll_bytes));
     HIP_TRY(ctx, hipMalloc(&faces.p, f_bytes));
     HIP_TRY(ctx, hipMemcpyAsync(ll.p, rgb, ll_bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, launch_latlong_to_cube((const float *)ll.p, w, h, (float *)faces.p, ctx->stream));
+    HIP_TRY(ctx, launch_latlong_to_cube((const float *)ll.p, w, h, d_uv, (float *)faces.p, ctx->stream));
     return set_env_from_device_faces(ctx, slot, (const float *)faces.p, cw);
+    RMDF_GUARD_END(ctx)
 }
 
 int rmdf_get_env_cube_padded(rmdf_ctx *ctx, int slot, uint16_t *out, int *face_w)
@@ -702,6 +1032,7 @@ int rmdf_resize_latlong(rmdf_ctx *ctx, const float *rgb, int w, int h, int dstw,
     *dsth = dh;
     if (!out) return RMDF_OK;
     if (dh < 1) return fail(ctx, RMDF_E_INVALID, "destination height < 1");
+    RMDF_GUARD_BEGIN
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf src, dst;
     size_t sb = (size_t)w * h * 12, db = (size_t)dstw * dh * 12;
@@ -712,34 +1043,64 @@ int rmdf_resize_latlong(rmdf_ctx *ctx, const float *rgb, int w, int h, int dstw,
     HIP_TRY(ctx, hipMemcpyAsync(out, dst.p, db, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RMDF_OK;
+    RMDF_GUARD_END(ctx)
+}
+
+int rmdf_prefilter_env_powers(rmdf_ctx *ctx, const float *rgb, int w, int h, const float *powers, int npowers, float *out)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!rgb || !out || !powers || npowers < 1 || npowers > 16 || w < 2 || h < 2 || w > 8192 || h > 4096)
+        return fail(ctx, RMDF_E_INVALID, "rmdf_prefilter_env_powers: bad argument (2 <= w <= 8192, 2 <= h <= 4096, 1 <= npowers <= 16)");
+    RMDF_GUARD_BEGIN
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf src;
+    std::vector<DevBuf> dst((size_t)npowers);
+    std::vector<float *> d_out((size_t)npowers);
+    const size_t b = (size_t)w * h * 12;
+    HIP_TRY(ctx, hipMalloc(&src.p, b));
+    for (int i = 0; i < npowers; i++) { HIP_TRY(ctx, hipMalloc(&dst[i].p, b)); d_out[i] = (float *)dst[i].p; }
+    HIP_TRY(ctx, hipMemcpyAsync(src.p, rgb, b, hipMemcpyHostToDevice, ctx->stream));
+    int rc = prefilter_powers_device(ctx, (const float *)src.p, w, h, powers, npowers, d_out.data());
+    if (rc != RMDF_OK) { (void)hipDeviceSynchronize(); return rc; }
+    for (int i = 0; i < npowers; i++)
+        HIP_TRY(ctx, hipMemcpyAsync(out + (size_t)i * w * h * 3, d_out[i], b, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RMDF_OK;
+    RMDF_GUARD_END(ctx)
 }
 
 int rmdf_prefilter_env(rmdf_ctx *ctx, const float *rgb, int w, int h, float power, float *out)
 {
+    return rmdf_prefilter_env_powers(ctx, rgb, w, h, &power, 1, out);
+}
+
+int rmdf_prefilter_env_device(rmdf_ctx *ctx, const void *d_rgb, int w, int h, float power, void *d_out, void *stream)
+{
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
-    if (!rgb || !out || w < 2 || h < 2 || w > 600) return fail(ctx, RMDF_E_INVALID, "rmdf_prefilter_env: bad argument (2 <= w <= 600)");
+    if (!d_rgb || !d_out || w < 2 || h < 2 || w > 8192 || h > 4096) return fail(ctx, RMDF_E_INVALID, "rmdf_prefilter_env_device: bad argument");
+    RMDF_GUARD_BEGIN
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf src, dst;
-    size_t b = (size_t)w * h * 12;
-    HIP_TRY(ctx, hipMalloc(&src.p, b));
-    HIP_TRY(ctx, hipMalloc(&dst.p, b));
-    HIP_TRY(ctx, hipMemcpyAsync(src.p, rgb, b, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, launch_prefilter((const float *)src.p, w, h, power, (float *)dst.p, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(out, dst.p, b, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const float *d_lutT = nullptr; const float2 *d_tcs = nullptr;
+    int rc = get_lobe_tables(ctx, w, h, &d_lutT, &d_tcs);
+    if (rc != RMDF_OK) return rc;
+    HIP_TRY(ctx, launch_prefilter((const float *)d_rgb, w, h, power, d_lutT, d_tcs, (float *)d_out, stream ? (hipStream_t)stream : ctx->stream));
     return RMDF_OK;
+    RMDF_GUARD_END(ctx)
 }
 
 int rmdf_load_env_hdr(rmdf_ctx *ctx, const char *path)
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
     if (!path) return fail(ctx, RMDF_E_INVALID, "null path");
+    RMDF_GUARD_BEGIN
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::vector<uint8_t> file;
     if (!read_file(path, file)) return fail(ctx, RMDF_E_IO, std::string("cannot read ") + path);
     int w = 0, h = 0;
     std::vector<float> refl;
     std::string why;
-    if (!decode_hdr(file, w, h, refl, why)) return fail(ctx, RMDF_E_IO, std::string(path) + ": " + why);
+    if (!decode_hdr(file.data(), file.size(), w, h, refl, why)) return fail(ctx, RMDF_E_IO, std::string(path) + ": " + why);
+    if (w < 6 || h < 2) return fail(ctx, RMDF_E_IO, std::string(path) + ": image too small for an environment map");
     // powers / cache file names, ShaderRendering.hs:71-75 (`show pow` of a Float: "1.0")
     static const struct { int slot; const char *suffix; float power; } kPow[4] = {
         { RMDF_ENV_COS_1, "1.0", 1.0f }, { RMDF_ENV_COS_8, "8.0", 8.0f },
@@ -747,45 +1108,61 @@ int rmdf_load_env_hdr(rmdf_ctx *ctx, const char *path)
     std::string stem(path);
     size_t dot = stem.find_last_of('.'), slash = stem.find_last_of('/');
     if (dot != std::string::npos && (slash == std::string::npos || dot > slash)) stem = stem.substr(0, dot);
-    std::vector<float> resized;
-    int rw = 256, rh = 0;
-    for (const auto &pw : kPow) {
-        std::string fn = stem + "_cache_pow_" + pw.suffix + ".hdr";
-        if (!file_exists(fn)) {
-            // buildPreConvolvedHDREnvMapCache, ShaderRendering.hs:131-149
-            if (resized.empty()) {
-                int rc = rmdf_resize_latlong(ctx, refl.data(), w, h, rw, nullptr, &rh);
-                if (rc != RMDF_OK) return rc;
-                resized.resize((size_t)rw * rh * 3);
-                rc = rmdf_resize_latlong(ctx, refl.data(), w, h, rw, resized.data(), &rh);
-                if (rc != RMDF_OK) return rc;
-            }
-            std::vector<float> conv((size_t)rw * rh * 3);
-            int rc = rmdf_prefilter_env(ctx, resized.data(), rw, rh, pw.power, conv.data());
-            if (rc != RMDF_OK) return rc;
-            if (!write_hdr(fn, conv, rw, rh)) return fail(ctx, RMDF_E_IO, "cannot write cache file " + fn);
+    // buildPreConvolvedHDREnvMapCache (ShaderRendering.hs:131-149): the missing maps are convolved from the reflection map
+    // resized to 256 texels, all missing powers concurrently, each written as a Radiance file
+    std::vector<uint8_t> cache_img[4];
+    int missing[4], nmiss = 0;
+    float mpow[4];
+    for (int k = 0; k < 4; k++)
+        if (!file_exists(stem + "_cache_pow_" + kPow[k].suffix + ".hdr")) { mpow[nmiss] = kPow[k].power; missing[nmiss++] = k; }
+    if (nmiss > 0) {
+        const int rw = 256;
+        int rh = 0;
+        int rc = rmdf_resize_latlong(ctx, refl.data(), w, h, rw, nullptr, &rh);
+        if (rc != RMDF_OK) return rc;
+        if (rh < 2) return fail(ctx, RMDF_E_IO, std::string(path) + ": aspect ratio leaves no rows at 256 texels width");
+        std::vector<float> resized((size_t)rw * rh * 3), conv((size_t)nmiss * rw * rh * 3);
+        rc = rmdf_resize_latlong(ctx, refl.data(), w, h, rw, resized.data(), &rh);
+        if (rc != RMDF_OK) return rc;
+        rc = rmdf_prefilter_env_powers(ctx, resized.data(), rw, rh, mpow, nmiss, conv.data());
+        if (rc != RMDF_OK) return rc;
+        for (int m = 0; m < nmiss; m++) {
+            const int k = missing[m];
+            std::vector<float> one(conv.begin() + (size_t)m * rw * rh * 3, conv.begin() + (size_t)(m + 1) * rw * rh * 3);
+            encode_hdr(one, rw, rh, cache_img[k]);
+            // A directory that cannot be written (read-only install) is not an error here: the file image just built is
+            // used from memory -- the same bytes the reload would read -- and the cache is rebuilt next time.
+            (void)write_file_atomic(stem + "_cache_pow_" + kPow[k].suffix + ".hdr", cache_img[k]);
         }
-        std::vector<uint8_t> cf;
-        if (!read_file(fn.c_str(), cf)) return fail(ctx, RMDF_E_IO, "cannot read cache file " + fn);
+    }
+    for (int k = 0; k < 4; k++) {
+        const std::string fn = stem + "_cache_pow_" + kPow[k].suffix + ".hdr";
+        if (cache_img[k].empty() && !read_file(fn.c_str(), cache_img[k])) return fail(ctx, RMDF_E_IO, "cannot read cache file " + fn);
         int cw = 0, chh = 0;
         std::vector<float> cimg;
-        if (!decode_hdr(cf, cw, chh, cimg, why)) return fail(ctx, RMDF_E_IO, fn + ": " + why);
-        int rc = rmdf_set_env_latlong(ctx, pw.slot, cimg.data(), cw, chh);
+        if (!decode_hdr(cache_img[k].data(), cache_img[k].size(), cw, chh, cimg, why)) return fail(ctx, RMDF_E_IO, fn + ": " + why);
+        if (cw < 6 || chh < 2) return fail(ctx, RMDF_E_IO, fn + ": image too small for an environment map");
+        int rc = rmdf_set_env_latlong(ctx, kPow[k].slot, cimg.data(), cw, chh);
         if (rc != RMDF_OK) return rc;
     }
     return rmdf_set_env_latlong(ctx, RMDF_ENV_REFLECTION, refl.data(), w, h);
+    RMDF_GUARD_END(ctx)
 }
 
 int rmdf_render_tile(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double time, int max_steps,
                      uint32_t *out_rgba8)
 {
+    RMDF_GUARD_BEGIN
     return render_common(ctx, scene, tile_idx, w, h, time, max_steps, out_rgba8, nullptr, nullptr, nullptr);
+    RMDF_GUARD_END(ctx)
 }
 
 int rmdf_render_tile_ex(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double time, int max_steps,
                         uint32_t *out_rgba8, float *out_rgba_f32, uint16_t *out_steps, uint16_t *out_iters)
 {
+    RMDF_GUARD_BEGIN
     return render_common(ctx, scene, tile_idx, w, h, time, max_steps, out_rgba8, out_rgba_f32, out_steps, out_iters);
+    RMDF_GUARD_END(ctx)
 }
 
 int rmdf_render_rect_device(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps,
@@ -793,13 +1170,17 @@ int rmdf_render_rect_device(rmdf_ctx *ctx, int scene, int w, int h, double time,
                             void *d_rgba8, void *d_rgba_f32, void *d_steps, void *d_iters, void *stream)
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    RMDF_GUARD_BEGIN
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     FrameParams p;
     int rc = fill_params(ctx, scene, w, h, (float)time, max_steps, p);
     if (rc != RMDF_OK) return rc;
     if (x0 < 0 || y0 < 0 || x1 > w || y1 > h || x0 > x1 || y0 > y1) return fail(ctx, RMDF_E_INVALID, "bad rectangle");
+    if (!d_rgba8 && !d_rgba_f32 && !d_steps && !d_iters) return fail(ctx, RMDF_E_INVALID, "rmdf_render_rect_device: no output buffer");
     p.x0 = x0; p.y0 = y0; p.x1 = x1; p.y1 = y1;
     p.rgba8 = (uint32_t *)d_rgba8; p.rgba_f32 = (float4 *)d_rgba_f32; p.steps = (uint16_t *)d_steps; p.iters = (uint16_t *)d_iters;
     return launch_scene(ctx, scene, p, stream ? (hipStream_t)stream : ctx->stream);
+    RMDF_GUARD_END(ctx)
 }
 
 int rmdf_render_shard_device(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps,
@@ -809,6 +1190,8 @@ int rmdf_render_shard_device(rmdf_ctx *ctx, int scene, int w, int h, double time
     if (nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks || !d_packed_rgba8)
         return fail(ctx, RMDF_E_INVALID, "rmdf_render_shard_device: bad rank / nranks / buffer");
     if (w % 8 || h % 8) return fail(ctx, RMDF_E_INVALID, "tile sharding needs w and h divisible by 8");
+    RMDF_GUARD_BEGIN
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     FrameParams p;
     int rc = fill_params(ctx, scene, w, h, (float)time, max_steps, p);
     if (rc != RMDF_OK) return rc;
@@ -818,6 +1201,7 @@ int rmdf_render_shard_device(rmdf_ctx *ctx, int scene, int w, int h, double time
     p.shard_key = (int)(ctx->shard_cost_gen << 16) + rank * 256 + nranks;
     p.rgba8 = (uint32_t *)d_packed_rgba8;
     return launch_scene(ctx, scene, p, stream ? (hipStream_t)stream : ctx->stream);
+    RMDF_GUARD_END(ctx)
 }
 
 int rmdf_shard_tiles(int rank, int nranks, int tiles[64])
@@ -860,10 +1244,12 @@ int rmdf_get_shard_tiles(rmdf_ctx *ctx, int rank, int nranks, int tiles[64])
     return ctx->deal_count[rank];
 }
 
+
 int rmdf_probe_tile_costs(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps, float cost[64])
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
     if (!cost || w <= 0 || h <= 0) return fail(ctx, RMDF_E_INVALID, "rmdf_probe_tile_costs: bad argument");
+    RMDF_GUARD_BEGIN
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // the same view at 256 x 144 (aspect ratio of the real frame kept to within a pixel): 32 x 18 rays per tile
     const int pw = 256;
@@ -882,9 +1268,7 @@ int rmdf_probe_tile_costs(rmdf_ctx *ctx, int scene, int w, int h, double time, i
     HIP_TRY(ctx, hipMalloc(&iters.p, npx * 2));
     p.x0 = 0; p.y0 = 0; p.x1 = pw; p.y1 = ph;
     p.steps = (uint16_t *)steps.p; p.iters = (uint16_t *)iters.p;
-    FrameParams q = p;
-    q.block_cost = nullptr; q.block_order = nullptr;
-    HIP_TRY(ctx, launch_render(scene, q, ctx->stream));
+    HIP_TRY(ctx, launch_render(scene, p, ctx->stream));
     std::vector<uint16_t> hs(npx), hi(npx);
     HIP_TRY(ctx, hipMemcpyAsync(hs.data(), steps.p, npx * 2, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(hi.data(), iters.p, npx * 2, hipMemcpyDeviceToHost, ctx->stream));
@@ -899,6 +1283,7 @@ int rmdf_probe_tile_costs(rmdf_ctx *ctx, int scene, int w, int h, double time, i
         }
     for (int i = 0; i < 64; i++) cost[i] = (float)acc[i];
     return RMDF_OK;
+    RMDF_GUARD_END(ctx)
 }
 
 int rmdf_assemble_shards_device(rmdf_ctx *ctx, int w, int h, int nranks, const void *d_gathered,
@@ -907,10 +1292,109 @@ int rmdf_assemble_shards_device(rmdf_ctx *ctx, int w, int h, int nranks, const v
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
     if (nranks < 1 || nranks > 64 || !d_gathered || !d_frame_rgba8 || w % 8 || h % 8 || w <= 0 || h <= 0)
         return fail(ctx, RMDF_E_INVALID, "rmdf_assemble_shards_device: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     ensure_deal(ctx, nranks);
     HIP_TRY(ctx, launch_assemble_shards((const uint32_t *)d_gathered, (uint32_t *)d_frame_rgba8, w, h, nranks, ctx->deal_where,
                                         stream ? (hipStream_t)stream : ctx->stream));
     return RMDF_OK;
+}
+
+
+// ---- multi-GPU: the single exchange of the path behind the C ABI ------------------------------------------
+
+int rmdf_comm_get_unique_id(void *id)
+{
+    if (!id) return fail(nullptr, RMDF_E_INVALID, "rmdf_comm_get_unique_id: null id");
+    RMDF_GUARD_BEGIN
+    int rc = load_rccl(nullptr);
+    if (rc != RMDF_OK) return rc;
+    static_assert(sizeof(ncclUniqueId) == RMDF_COMM_ID_BYTES, "RMDF_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");
+    ncclUniqueId uid;
+    RCCL_TRY(nullptr, g_rccl.GetUniqueId(&uid));
+    memcpy(id, &uid, sizeof uid);
+    return RMDF_OK;
+    RMDF_GUARD_END(nullptr)
+}
+
+int rmdf_comm_init(rmdf_ctx *ctx, const void *id, int rank, int nranks)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!id || nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks) return fail(ctx, RMDF_E_INVALID, "rmdf_comm_init: bad id / rank / nranks (<= 64: one rank per tile at most)");
+    if (ctx->comm) return fail(ctx, RMDF_E_INVALID, "rmdf_comm_init: this ctx already has a communicator (rmdf_comm_destroy first)");
+    RMDF_GUARD_BEGIN
+    int rc = load_rccl(ctx);
+    if (rc != RMDF_OK) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    ncclComm_t comm = nullptr;
+    RCCL_TRY(ctx, g_rccl.CommInitRank(&comm, nranks, uid, rank));
+    ctx->comm = comm; ctx->comm_rank = rank; ctx->comm_nranks = nranks;
+    return RMDF_OK;
+    RMDF_GUARD_END(ctx)
+}
+
+int rmdf_comm_destroy(rmdf_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!ctx->comm) return RMDF_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    ncclComm_t c = ctx->comm;
+    ctx->comm = nullptr; ctx->comm_rank = 0; ctx->comm_nranks = 1;
+    RCCL_TRY(ctx, g_rccl.CommDestroy(c));
+    return RMDF_OK;
+}
+
+int rmdf_comm_info(rmdf_ctx *ctx, int *rank, int *nranks)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (rank) *rank = ctx->comm_rank;
+    if (nranks) *nranks = ctx->comm ? ctx->comm_nranks : 0;
+    return RMDF_OK;
+}
+
+int rmdf_gather_shards_device(rmdf_ctx *ctx, int w, int h, const void *d_shard, void *d_gathered, void *stream)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!ctx->comm) return fail(ctx, RMDF_E_COMM, "rmdf_gather_shards_device: no communicator (rmdf_comm_init)");
+    if (w <= 0 || h <= 0 || w % 8 || h % 8 || !d_shard) return fail(ctx, RMDF_E_INVALID, "rmdf_gather_shards_device: bad argument");
+    const int n = ctx->comm_nranks, rank = ctx->comm_rank;
+    if (rank == 0 && !d_gathered) return fail(ctx, RMDF_E_INVALID, "rmdf_gather_shards_device: rank 0 needs the gather buffer");
+    RMDF_GUARD_BEGIN
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    const size_t slots = (size_t)((64 + n - 1) / n);
+    const size_t bytes = slots * (size_t)(w / 8) * (size_t)(h / 8) * 4;          // every rank's shard has the same size
+    if (rank == 0) {
+        // fan-in: one receive per peer, grouped so that they progress together over the seven xGMI links of the root
+        if (n > 1) {
+            RCCL_TRY(ctx, g_rccl.GroupStart());
+            for (int r = 1; r < n; r++)
+                RCCL_TRY(ctx, g_rccl.Recv((char *)d_gathered + (size_t)r * bytes, bytes, ncclChar, r, ctx->comm, st));
+            RCCL_TRY(ctx, g_rccl.GroupEnd());
+        }
+        if ((const char *)d_shard != (const char *)d_gathered)     // the root may render straight into its own slot
+            HIP_TRY(ctx, hipMemcpyAsync(d_gathered, d_shard, bytes, hipMemcpyDeviceToDevice, st));
+    } else {
+        RCCL_TRY(ctx, g_rccl.Send(d_shard, bytes, ncclChar, 0, ctx->comm, st));
+    }
+    return RMDF_OK;
+    RMDF_GUARD_END(ctx)
+}
+
+int rmdf_render_frame_sharded_device(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps,
+                                     void *d_shard, void *d_gathered, void *d_frame_rgba8, void *stream)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!ctx->comm) return fail(ctx, RMDF_E_COMM, "rmdf_render_frame_sharded_device: no communicator (rmdf_comm_init)");
+    if (ctx->comm_rank == 0 && (!d_gathered || !d_frame_rgba8)) return fail(ctx, RMDF_E_INVALID, "rmdf_render_frame_sharded_device: rank 0 needs the gather buffer and the frame");
+    int rc = rmdf_render_shard_device(ctx, scene, w, h, time, max_steps, ctx->comm_rank, ctx->comm_nranks, d_shard, stream);
+    if (rc != RMDF_OK) return rc;
+    rc = rmdf_gather_shards_device(ctx, w, h, d_shard, d_gathered, stream);
+    if (rc != RMDF_OK) return rc;
+    if (ctx->comm_rank == 0) rc = rmdf_assemble_shards_device(ctx, w, h, ctx->comm_nranks, d_gathered, d_frame_rgba8, stream);
+    return rc;
 }
 
 int rmdf_resolve_box2_device(rmdf_ctx *ctx, const void *d_src_rgba8, int sw, int sh, void *d_dst_rgba8, void *stream)
@@ -918,6 +1402,7 @@ int rmdf_resolve_box2_device(rmdf_ctx *ctx, const void *d_src_rgba8, int sw, int
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
     if (!d_src_rgba8 || !d_dst_rgba8 || sw <= 0 || sh <= 0 || (sw & 1) || (sh & 1))
         return fail(ctx, RMDF_E_INVALID, "rmdf_resolve_box2_device: needs even, positive source sizes");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_resolve_box2((const uint32_t *)d_src_rgba8, sw, sh, (uint32_t *)d_dst_rgba8,
                                      stream ? (hipStream_t)stream : ctx->stream));
     return RMDF_OK;
@@ -929,6 +1414,7 @@ int rmdf_render_supersampled(rmdf_ctx *ctx, int scene, int w, int h, int levels,
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
     if (!out_rgba8 || levels < 0 || levels > 3 || w <= 0 || h <= 0)
         return fail(ctx, RMDF_E_INVALID, "rmdf_render_supersampled: bad argument (levels 0..3)");
+    RMDF_GUARD_BEGIN
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int sw = w << levels, sh = h << levels;
     FrameParams p;
@@ -951,6 +1437,7 @@ int rmdf_render_supersampled(rmdf_ctx *ctx, int scene, int w, int h, int levels,
     HIP_TRY(ctx, hipMemcpyAsync(out_rgba8, cur, (size_t)w * h * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RMDF_OK;
+    RMDF_GUARD_END(ctx)
 }
 
 int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[5])
@@ -981,6 +1468,8 @@ int rmdf_selftest_pinned_math(rmdf_ctx *ctx, uint64_t mismatches[7])
     return RMDF_OK;
 }
 
+
+#ifdef RMDF_XCHECK
 int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_waves)
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
@@ -1000,6 +1489,7 @@ int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_wav
     if (!enable && ctx->d_dbg) { (void)hipFree(ctx->d_dbg); ctx->d_dbg = nullptr; }
     return RMDF_OK;
 }
+#endif
 
 int rmdf_save_png(const char *path, const uint32_t *fb_rgba8, int w, int h)
 {
@@ -1045,6 +1535,7 @@ int rmdf_register_host_buffer(rmdf_ctx *ctx, void *ptr, size_t bytes)
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
     if (!ptr || bytes == 0) return fail(ctx, RMDF_E_INVALID, "rmdf_register_host_buffer: bad argument");
+    RMDF_GUARD_BEGIN
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (auto &r : ctx->host_regs) if (r.host == (char *)ptr && r.bytes == bytes) return RMDF_OK;
     HIP_TRY(ctx, hipHostRegister(ptr, bytes, hipHostRegisterMapped));
@@ -1056,6 +1547,7 @@ int rmdf_register_host_buffer(rmdf_ctx *ctx, void *ptr, size_t bytes)
     }
     ctx->host_regs.push_back(rmdf_ctx::HostReg{ (char *)ptr, bytes, (char *)dev });
     return RMDF_OK;
+    RMDF_GUARD_END(ctx)
 }
 
 int rmdf_unregister_host_buffer(rmdf_ctx *ctx, void *ptr)
@@ -1075,6 +1567,7 @@ int rmdf_unregister_host_buffer(rmdf_ctx *ctx, void *ptr)
 int rmdf_synchronize(rmdf_ctx *ctx, void *stream)
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
     return RMDF_OK;
 }

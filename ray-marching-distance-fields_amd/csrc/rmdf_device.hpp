@@ -500,36 +500,6 @@ __device__ __forceinline__ float de_test_scene(v3 pos)
     return smin_exp(d_box, gmin(d_sphere, d_torus), 64.0f);
 }
 
-// same, counting wave-level inner passes and the lanes active in them (measurement builds only)
-__device__ __forceinline__ float de_mandelbulb8_dbg(v3 pos, unsigned &iters, unsigned long long &passes, unsigned long long &lanes,
-                                                    unsigned long long *hist)
-{
-    pos = mk3(pos.z, pos.x, pos.y);
-    v3 w = pos;
-    float dr = 1.0f;
-    float r = 0.0f;
-    for (int i = 0; i < 25; i++) {
-        {
-            const unsigned long long am = __ballot(true);
-            const int na = __popcll(am);
-            passes++; lanes += na;
-            // histogram of the active-lane count of this pass, kept by the first active lane only
-            if (hist && __builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0)) == 0) {
-                const int b = na <= 2 ? 0 : na <= 4 ? 1 : na <= 8 ? 2 : na <= 16 ? 3 : na <= 32 ? 4 : na <= 48 ? 5 : 6;
-                atomicAdd(&hist[b], 1ull);
-            }
-        }
-        r = length3(w);
-        if (r > 4.0f) break;
-        w = triplex_pow8(w);
-        w = add3(w, pos);
-        float r2 = r * r, r4 = r2 * r2, r7 = (r4 * r2) * r;
-        dr = r7 * 8.0f * dr + 1.0f;
-        iters++;
-    }
-    return 0.5f * log_pinned(r) * r / dr;
-}
-
 // fragment.shd:312-321
 __device__ __forceinline__ float line_seg_min_dist_sq(v3 a, v3 b, v3 p)
 {

@@ -1,0 +1,293 @@
+// rmdf_env.hip -- gfx950 kernels of the environment-map preparation that the reference runs on the CPU
+// (HDREnvMap.hs): RGB16F cube upload with seamless border, lat/long -> cube faces, resizeHDRImage and the
+// cosine-lobe prefilter.  Every kernel here is BIT-EXACT against the oracle: the only transcendental values the
+// reference's formulas need (acos / atan of a face texel's direction, sin / cos of the row and column angles)
+// depend on image SIZES only, so the host computes them once with the libm the reference itself calls through GHC
+// (glibc) and the kernels do IEEE float arithmetic in the reference's operation order (-ffp-contract=off).
+#include "rmdf_internal.hpp"
+
+namespace rmdf {
+
+// ------------------------------------------------------------------------------------
+// RGB16F upload with seamless border (the texImage2D RGB16F of HDREnvMap.hs:160-161 +
+// GL_TEXTURE_CUBE_MAP_SEAMLESS, :126).  Border rule: DESIGN.md "spec pins".
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void cube_int_dir(int face, int W, int cw, int ch, int d[3])
+{
+    switch (face) {
+    case 0:  d[0] =  W;  d[1] = -ch; d[2] = -cw; break;
+    case 1:  d[0] = -W;  d[1] = -ch; d[2] =  cw; break;
+    case 2:  d[0] =  cw; d[1] =  W;  d[2] =  ch; break;
+    case 3:  d[0] =  cw; d[1] = -W;  d[2] = -ch; break;
+    case 4:  d[0] =  cw; d[1] = -ch; d[2] =  W;  break;
+    default: d[0] = -cw; d[1] = -ch; d[2] = -W;  break;
+    }
+}
+
+// texel (x,y) of `face` with exactly one coordinate out of range by one -> the texel
+// adjacent across the cube edge
+__device__ __forceinline__ void cube_fold(int face, int W, int x, int y, int &nf, int &nx, int &ny)
+{
+    int d[3];
+    cube_int_dir(face, W, 2 * x + 1 - W, 2 * y + 1 - W, d);
+    int major = face >> 1;
+    int over = -1;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        if (a != (face >> 1) && over < 0 && (d[a] > W || d[a] < -W)) over = a;
+    if (over >= 0) {
+        int keep = (d[major] > 0) ? W - 1 : -(W - 1);
+        int nd[3] = { d[0], d[1], d[2] };
+        nd[over] = (d[over] > 0) ? W : -W;
+        nd[major] = keep;
+        d[0] = nd[0]; d[1] = nd[1]; d[2] = nd[2];
+        major = over;
+    }
+    int f = major * 2 + (d[major] > 0 ? 0 : 1);
+    int cw, ch;
+    switch (f) {
+    case 0:  ch = -d[1]; cw = -d[2]; break;
+    case 1:  ch = -d[1]; cw =  d[2]; break;
+    case 2:  cw =  d[0]; ch =  d[2]; break;
+    case 3:  cw =  d[0]; ch = -d[2]; break;
+    case 4:  cw =  d[0]; ch = -d[1]; break;
+    default: cw = -d[0]; ch = -d[1]; break;
+    }
+    nf = f; nx = (cw + W - 1) / 2; ny = (ch + W - 1) / 2;
+}
+
+__device__ __forceinline__ __half src_half(const float *faces, int W, int f, int x, int y, int k)
+{
+    return __float2half_rn(faces[(((size_t)f * W + y) * W + x) * 3 + k]);
+}
+
+__global__ void k_cube_upload(const float *__restrict__ faces, int W, uint2 *__restrict__ padded)
+{
+    const int P = W + 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 6 * P * P) return;
+    const int X = i % P, Y = (i / P) % P, f = i / (P * P);
+    const int x = X - 1, y = Y - 1;
+    const bool ox = (x < 0 || x >= W), oy = (y < 0 || y >= W);
+    __half c[3];
+    if (!ox && !oy) {
+        for (int k = 0; k < 3; k++) c[k] = src_half(faces, W, f, x, y, k);
+    } else if (ox != oy) {
+        int nf, nx, ny;
+        cube_fold(f, W, x, y, nf, nx, ny);
+        for (int k = 0; k < 3; k++) c[k] = src_half(faces, W, nf, nx, ny, k);
+    } else {
+        const int cx = x < 0 ? 0 : W - 1, cy = y < 0 ? 0 : W - 1;
+        int f1, x1, y1, f2, x2, y2;
+        cube_fold(f, W, x, cy, f1, x1, y1);
+        cube_fold(f, W, cx, y, f2, x2, y2);
+        for (int k = 0; k < 3; k++) {
+            float a = __half2float(src_half(faces, W, f, cx, cy, k));
+            float b = __half2float(src_half(faces, W, f1, x1, y1, k));
+            float cc = __half2float(src_half(faces, W, f2, x2, y2, k));
+            c[k] = __float2half_rn(((a + b) + cc) / 3.0f);
+        }
+    }
+    uint2 t;
+    t.x = (uint32_t)__half_as_ushort(c[0]) | ((uint32_t)__half_as_ushort(c[1]) << 16);
+    t.y = (uint32_t)__half_as_ushort(c[2]);
+    padded[i] = t;
+}
+
+hipError_t launch_cube_upload(const float *d_faces_f32, int W, uint2 *d_padded, hipStream_t stream)
+{
+    const int n = 6 * (W + 2) * (W + 2);
+    hipLaunchKernelGGL(k_cube_upload, dim3((n + 255) / 256), dim3(256), 0, stream, d_faces_f32, W, d_padded);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// pixelAtBilinear, HDREnvMap.hs:91-113 (keeps the `mod (w-1)` / `min (h-1)` quirks)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ v3 pixel_at_bilinear(const float *__restrict__ img, int w, int h, float u, float v)
+{
+    const float upx = u * ((float)w - 1.0f), upy = v * ((float)h - 1.0f);
+    const int x = (int)floorf(upx), y = (int)floorf(upy);
+    const int m = w - 1;
+    int xp1 = (x + 1) % m;
+    if (xp1 < 0) xp1 += m;
+    const int yp1 = (y + 1 < h - 1) ? y + 1 : h - 1;
+    const float ur = upx - (float)x, vr = upy - (float)y;
+    const float uo = 1.0f - ur, vo = 1.0f - vr;
+    const float *a = img + ((size_t)x + (size_t)y * w) * 3, *b = img + ((size_t)xp1 + (size_t)y * w) * 3;
+    const float *c = img + ((size_t)x + (size_t)yp1 * w) * 3, *d = img + ((size_t)xp1 + (size_t)yp1 * w) * 3;
+    return mk3((a[0] * uo + b[0] * ur) * vo + (c[0] * uo + d[0] * ur) * vr,
+               (a[1] * uo + b[1] * ur) * vo + (c[1] * uo + d[1] * ur) * vr,
+               (a[2] * uo + b[2] * ur) * vo + (c[2] * uo + d[2] * ur) * vr);
+}
+
+// ------------------------------------------------------------------------------------
+// latLongHDREnvMapToCubeMap (HDREnvMap.hs:118-163): one thread per face texel.  The environment (u, v) of a face
+// texel -- cubeMapPixelToDir, worldToLocal, cartesianToSpherical (acos, atan2), sphericalToEnvironmentUV -- is a
+// function of (face, x, y, face size) alone: the host evaluates it once per face size with glibc's acosf / atanf
+// (cube_uv_table_host in rmdf_api.cpp) and the kernel only does the bilinear gather, so the faces carry the same
+// bits as the reference's CPU loop on this machine.
+// ------------------------------------------------------------------------------------
+__global__ void k_latlong_to_cube(const float *__restrict__ latlong, int w, int h, int cw,
+                                  const float2 *__restrict__ uv, float *__restrict__ faces)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 6 * cw * cw) return;
+    const float2 t = uv[i];
+    const v3 c = pixel_at_bilinear(latlong, w, h, t.x, t.y);
+    faces[(size_t)i * 3 + 0] = c.x; faces[(size_t)i * 3 + 1] = c.y; faces[(size_t)i * 3 + 2] = c.z;
+}
+
+hipError_t launch_latlong_to_cube(const float *d_latlong, int w, int h, const float2 *d_uv, float *d_faces_f32, hipStream_t stream)
+{
+    const int cw = w / 3, n = 6 * cw * cw;
+    if (n <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_latlong_to_cube, dim3((n + 255) / 256), dim3(256), 0, stream, d_latlong, w, h, cw, d_uv, d_faces_f32);
+    return hipGetLastError();
+}
+
+// resizeHDRImage (HDREnvMap.hs:169-195): one thread per destination pixel (no libm in it: bit-exact as written)
+__global__ void k_resize_latlong(const float *__restrict__ src, int sw, int sh, int dstw, int dsth, float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dstw * dsth) return;
+    const int dx = i % dstw, dy = i / dstw;
+    const float scale = (float)sw / (float)dstw;
+    const int taps = (int)ceilf(scale);
+    const float ntaps = (float)(taps * taps);
+    const float step = scale / (float)taps;
+    const float srcx1 = (float)dx * scale, srcy1 = (float)dy * scale;
+    float ar = 0.0f, ag = 0.0f, ab = 0.0f;
+    for (int y = 0; y < taps; y++)
+        for (int x = 0; x < taps; x++) {
+            const float sx = srcx1 + (float)x * step, sy = srcy1 + (float)y * step;
+            const v3 c = pixel_at_bilinear(src, sw, sh, sx / ((float)sw - 1.0f), sy / ((float)sh - 1.0f));
+            ar = ar + c.x; ag = ag + c.y; ab = ab + c.z;
+        }
+    out[(size_t)i * 3 + 0] = ar / ntaps; out[(size_t)i * 3 + 1] = ag / ntaps; out[(size_t)i * 3 + 2] = ab / ntaps;
+}
+
+hipError_t launch_resize_latlong(const float *d_src, int sw, int sh, int dstw, int dsth, float *d_out, hipStream_t stream)
+{
+    const int n = dstw * dsth;
+    if (n <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_resize_latlong, dim3((n + 255) / 256), dim3(256), 0, stream, d_src, sw, sh, dstw, dsth, d_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// cosineConvolveHDREnvMap (HDREnvMap.hs:217-254): O(n^4) -- every destination texel sums sin(theta) * cos^p over all
+// source texels with a positive cosine.  Float addition is not associative, so the only parallelism that keeps the
+// reference's bits is across DESTINATION texels: one lane per destination texel walks all source texels in the
+// reference's order (y outer, x inner) with its four accumulators (r, g, b, n).  One wavefront = 64 neighbouring
+// destination columns of one row; a workgroup = one wavefront (the machine holds two of them per CU at 256x128, more
+// at larger sizes; rmdf_prefilter_env_powers runs the four powers concurrently like the reference's mapConcurrently).
+//
+//   lutT[(blk * w + x) * 64 + lane] = cos |phi_L(blk*64+lane) - phi(x)|      (absPhiDiffCosLookup, host glibc cosf)
+//   tcs[y] = (cos theta_y, sin theta_y)                                        (host glibc cosf / sinf)
+// The wave's slice of lutT is staged in LDS when two workgroups per CU fit (w <= 256: 64 KiB each) and read from global
+// memory (L2-resident) otherwise; the source row, tcs[y] and the loop bounds are wave-uniform and arrive by scalar loads.
+//
+// cos^p: LOG2P >= 0 -> p = 2^LOG2P by LOG2P squarings in binary64 rounded once to binary32 -- the spec pin for the
+// reference's powers 1, 8, 64, 512 (FP64 vector multiplies issue at the FP32 rate on gfx950);
+// LOG2P = -1 -> device powf (any other power: tolerance parity only).
+// The inner loop is branch-free: texels with a non-positive cosine add a selected +0 (x + 0 == x: the same bits as
+// skipping them) and the sample count grows by a selected 1 or 0, so eight iterations' loads and multiplies are in
+// flight at once.
+// ------------------------------------------------------------------------------------
+template <int LOG2P, bool LUT_IN_LDS>
+__global__ __launch_bounds__(64) void k_prefilter(const float *__restrict__ src, int w, int h, float power,
+                                                  const float *__restrict__ lutT, const float2 *__restrict__ tcs,
+                                                  float *__restrict__ out)
+{
+    extern __shared__ float lds_lut[];                  // [w][64] when LUT_IN_LDS
+    const int lane = threadIdx.x;
+    const int blk = blockIdx.x, dy = blockIdx.y;
+    const int dx = blk * 64 + lane;
+    const float *glut = lutT + (size_t)blk * w * 64;
+    if (LUT_IN_LDS) {
+        for (int x = 0; x < w; x++) lds_lut[x * 64 + lane] = glut[x * 64 + lane];
+        __syncthreads();
+    }
+    typedef const float __attribute__((address_space(4))) cfloat;      // wave-uniform, read-only: scalar loads
+    const float lc = ((cfloat *)tcs)[2 * dy], ls = ((cfloat *)tcs)[2 * dy + 1];
+    float ar = 0.0f, ag = 0.0f, ab = 0.0f, n = 0.0f;
+    for (int y = 0; y < h; y++) {
+        const float pc = ((cfloat *)tcs)[2 * y], ps = ((cfloat *)tcs)[2 * y + 1];
+        const float lcpc = lc * pc, lsps = ls * ps;
+        cfloat *row = (cfloat *)(src + (size_t)y * w * 3);
+        if (LOG2P >= 0) {
+#pragma unroll 8
+            for (int x = 0; x < w; x++) {
+                const float l = LUT_IN_LDS ? lds_lut[x * 64 + lane] : glut[x * 64 + lane];
+                const float cos_angle = lcpc + lsps * l;
+                const bool pos = cos_angle > 0.0f;
+                float cp = cos_angle;
+                if (LOG2P > 0) {
+                    double cd = (double)cos_angle;
+#pragma unroll
+                    for (int k = 0; k < LOG2P; k++) cd = cd * cd;
+                    cp = (float)cd;
+                }
+                const float fac = ps * cp;
+                const float tr = row[x * 3] * fac, tg = row[x * 3 + 1] * fac, tb = row[x * 3 + 2] * fac;
+                ar = ar + (pos ? tr : 0.0f); ag = ag + (pos ? tg : 0.0f); ab = ab + (pos ? tb : 0.0f);
+                n = n + (pos ? 1.0f : 0.0f);
+            }
+        } else {
+            for (int x = 0; x < w; x++) {
+                const float l = LUT_IN_LDS ? lds_lut[x * 64 + lane] : glut[x * 64 + lane];
+                const float cos_angle = lcpc + lsps * l;
+                if (cos_angle > 0.0f) {
+                    const float fac = ps * powf(cos_angle, power);
+                    ar = ar + row[x * 3] * fac; ag = ag + row[x * 3 + 1] * fac; ab = ab + row[x * 3 + 2] * fac;
+                    n = n + 1.0f;
+                }
+            }
+        }
+    }
+    if (dx < w) {
+        float *o = out + ((size_t)dx + (size_t)dy * w) * 3;
+        o[0] = ar / n; o[1] = ag / n; o[2] = ab / n;
+    }
+}
+
+int prefilter_log2p(float power)
+{
+    if (power == 1.0f) return 0;
+    if (power == 8.0f) return 3;
+    if (power == 64.0f) return 6;
+    if (power == 512.0f) return 9;
+    return -1;
+}
+
+template <int LOG2P>
+static hipError_t launch_prefilter_t(const float *d_src, int w, int h, float power, const float *d_lutT, const float2 *d_tcs,
+                                     float *d_out, hipStream_t stream)
+{
+    const dim3 grid((w + 63) / 64, h), block(64);
+    const size_t lds = (size_t)w * 64 * sizeof(float);
+    if (lds <= 64 * 1024) {          // two workgroups per CU keep their slice in LDS; wider maps read it through L2
+        hipError_t e = hipFuncSetAttribute((const void *)k_prefilter<LOG2P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_prefilter<LOG2P, true>), grid, block, lds, stream, d_src, w, h, power, d_lutT, d_tcs, d_out);
+    } else {
+        hipLaunchKernelGGL((k_prefilter<LOG2P, false>), grid, block, 0, stream, d_src, w, h, power, d_lutT, d_tcs, d_out);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_prefilter(const float *d_src, int w, int h, float power, const float *d_lutT, const float2 *d_tcs,
+                            float *d_out, hipStream_t stream)
+{
+    if (w < 2 || h < 2) return hipErrorInvalidValue;
+    switch (prefilter_log2p(power)) {
+    case 0:  return launch_prefilter_t<0>(d_src, w, h, power, d_lutT, d_tcs, d_out, stream);
+    case 3:  return launch_prefilter_t<3>(d_src, w, h, power, d_lutT, d_tcs, d_out, stream);
+    case 6:  return launch_prefilter_t<6>(d_src, w, h, power, d_lutT, d_tcs, d_out, stream);
+    case 9:  return launch_prefilter_t<9>(d_src, w, h, power, d_lutT, d_tcs, d_out, stream);
+    default: return launch_prefilter_t<-1>(d_src, w, h, power, d_lutT, d_tcs, d_out, stream);
+    }
+}
+
+}  // namespace rmdf

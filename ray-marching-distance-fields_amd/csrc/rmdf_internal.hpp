@@ -37,8 +37,15 @@ struct FrameParams {
     float4   *rgba_f32;
     uint16_t *steps;
     uint16_t *iters;
-    // two-kernel Mandelbulb path (rmdf_march.hip): G-buffer written by k_march_mb8, read by k_shade.
-    // Indexed px + py*gw over the frame padded to even dimensions (helper pixels of odd sizes).
+    // cost-ordered dispatch of the render kernel (DESIGN.md 'critical path'): workgroup b renders strip block_order[b]
+    // (null = raster order) and writes its cost (largest escape-iteration + step total of one of its pixels) to block_cost[]
+    int merge_stragglers;     // k_render: pool the last rays of a workgroup's four packets in one wave (MERGE variant)
+    const unsigned *block_order;
+    unsigned *block_cost;
+#ifdef RMDF_XCHECK
+    // librmdf_xcheck.so only: the alternative schedules (xcheck/*.hip) and the measurement aids
+    // G-buffer written by k_march_mb8 / k_march_refill, read by k_shade; indexed px + py*gw over the frame padded to even
+    // dimensions (helper pixels of odd sizes)
     float4   *gbuf_nao;       // normal.xyz, ao (hit pixels only)
     unsigned *gbuf_meta;      // bits 0..14 steps, bit 15 hit, bits 16..31 escape iterations (saturated)
     int       gw;
@@ -47,15 +54,9 @@ struct FrameParams {
     int      *hit_list;       // G-buffer indices of the hit pixels, filled by k_march_refill
     const unsigned *tile_order;   // optional dispatch order of the 8x8 tiles (rmdf_pipeline.hip)
     int       total_items, items_per_shard_tile;
-    int       tail_t, shade_t, refill_t, chunk, pool_low;
-    // cost-ordered dispatch of the nested-loop kernel (see DESIGN.md 'critical path'): block b renders
-    // strip order[b] (null = raster order) and writes its cost (max escape iterations of a pixel) to cost[]
-    int dbg_skip;             // measurement knob: 1 = skip normal/AO + shading of k_render, 2 = skip only normal/AO
-    int merge_stragglers;     // k_render: pool the last rays of a workgroup's four packets in one wave (MERGE variant)
-    int prio_strips;          // the first prio_strips workgroups of an ordered launch raise their wave priority
-    const unsigned *block_order;
-    unsigned *block_cost;
-    unsigned long long *dbg;  // optional per-wave counters of k_march_mb8 (8 x u64 per wave), may be null   // scheduling thresholds of k_march_mb8 (see rmdf_march.hip)
+    int       tail_t, shade_t, refill_t, chunk, pool_low;   // scheduling thresholds of k_march_mb8 (rmdf_march.hip)
+    unsigned long long *dbg;  // optional per-wave counters (8 or 16 x u64 per wave), may be null
+#endif
 };
 
 // Which of the reference's 64 tiles rank `rank` of `nranks` renders, in slot order; returns how many (<= ceil(64/n)).
@@ -109,22 +110,28 @@ inline int shard_tiles_of_rank(int rank, int nranks, unsigned char tiles[64], co
 // tile idx -> pixel rectangle (ShaderRendering.hs:183-193), host copy in rmdf_api.cpp
 void tile_rect_host(int tile_idx, int w, int h, int *x0, int *y0, int *x1, int *y1);
 
-// kernels / launchers implemented in rmdf_kernels.hip
+// rmdf_render.hip
 hipError_t launch_render(int scene, const FrameParams &p, hipStream_t stream);
-hipError_t launch_march_stats(const FrameParams &p, hipStream_t stream);
-int render_grid_blocks(int scene, const FrameParams &p);   // number of 32x8 strips launch_render() uses for p
+int render_grid_blocks(const FrameParams &p);              // number of 32x8 strips launch_render() uses for p
 hipError_t launch_order_blocks(const unsigned *d_cost, int n, unsigned *d_order, hipStream_t stream);
-hipError_t launch_render_mb8(const FrameParams &p, hipStream_t stream, int num_cus);
-hipError_t launch_render_pipeline(int scene, const FrameParams &p, hipStream_t stream, int num_cus);   // rmdf_pipeline.hip
-hipError_t launch_march_pool(const FrameParams &p, int blocks, hipStream_t stream);   // rmdf_pool.hip
+// rmdf_util.hip
 hipError_t launch_resolve_box2(const uint32_t *d_src, int sw, int sh, uint32_t *d_dst, hipStream_t stream);
 hipError_t launch_selftest_exact_math(unsigned long long *d_counts, const float *d_cornell_tab, hipStream_t stream);
 hipError_t launch_selftest_pinned_math(unsigned long long *d_counts, hipStream_t stream);
 hipError_t launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t stream);
+// rmdf_env.hip: d_uv = per-texel environment (u, v) of the faces (host-built, cube_uv_table_host); d_lutT / d_tcs = the
+// prefilter's host-built cosine tables (prefilter_tables_host)
 hipError_t launch_cube_upload(const float *d_faces_f32, int W, uint2 *d_padded, hipStream_t stream);
-hipError_t launch_latlong_to_cube(const float *d_latlong, int w, int h, float *d_faces_f32, hipStream_t stream);
+hipError_t launch_latlong_to_cube(const float *d_latlong, int w, int h, const float2 *d_uv, float *d_faces_f32, hipStream_t stream);
 hipError_t launch_resize_latlong(const float *d_src, int sw, int sh, int dstw, int dsth, float *d_out, hipStream_t stream);
-hipError_t launch_prefilter(const float *d_src, int w, int h, float power, float *d_out, hipStream_t stream);
+hipError_t launch_prefilter(const float *d_src, int w, int h, float power, const float *d_lutT, const float2 *d_tcs,
+                            float *d_out, hipStream_t stream);
+#ifdef RMDF_XCHECK
+hipError_t launch_march_stats(const FrameParams &p, hipStream_t stream);                               // xcheck/rmdf_stats.hip
+hipError_t launch_render_mb8(const FrameParams &p, hipStream_t stream, int num_cus);                   // xcheck/rmdf_march.hip
+hipError_t launch_render_pipeline(int scene, const FrameParams &p, hipStream_t stream, int num_cus);   // xcheck/rmdf_pipeline.hip
+hipError_t launch_march_pool(const FrameParams &p, int blocks, hipStream_t stream);                    // xcheck/rmdf_pool.hip
+#endif
 // where[tile idx] = rank << 8 | slot under the deal in effect (built by the caller, cached per ctx)
 struct ShardWhere { unsigned short v[64]; };
 hipError_t launch_assemble_shards(const uint32_t *d_gathered, uint32_t *d_frame, int w, int h, int nranks, const ShardWhere &where,

@@ -1,0 +1,440 @@
+// rmdf_render.hip -- the sphere-tracing render kernel of librmdf.so (gfx950).
+//
+// Compile with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fast-math).
+// Geometry of the render kernel: one 64-lane wavefront = one 8x8 pixel packet
+// (16 GL-style 2x2 quads, 4 consecutive lanes = one quad so that the quad
+// neighbours needed by the cube-map min/mag decision are lane^1 and lane^2),
+// one 256-thread workgroup = a 32x8 pixel strip.  No MFMA: the path is scalar
+// per ray.  See DESIGN.md for the roofline that bounds it.
+#include "rmdf_internal.hpp"
+
+namespace rmdf {
+
+// ------------------------------------------------------------------------------------
+// tile -> pixel rectangle, ShaderRendering.hs:183-193 (centre-inside rasterisation of
+// the NDC rect; exact when 8 divides w and h)
+// ------------------------------------------------------------------------------------
+__host__ __device__ inline void tile_rect(int tile_idx, int w, int h, int &x0, int &y0, int &x1, int &y1)
+{
+    int midx = tile_idx % 64;
+    int tx = midx % 8, ty = midx / 8;
+    // pixel centre x+0.5 in [tx*w/8, (tx+1)*w/8)  <=>  x in [ceil(tx*w/8 - 0.5), ceil((tx+1)*w/8 - 0.5))
+    x0 = (2 * tx * w + 7) / 16;        // ceil((2*tx*w - 8) / 16) = floor((2*tx*w + 7) / 16)
+    x1 = (2 * (tx + 1) * w + 7) / 16;
+    y0 = (2 * ty * h + 7) / 16;
+    y1 = (2 * (ty + 1) * h + 7) / 16;
+}
+
+template <typename T>
+__device__ __forceinline__ T shfl_xor_w(T v, int mask) { return __shfl_xor(v, mask, 64); }
+
+__device__ __forceinline__ v3 shfl_xor3(v3 a, int mask)
+{
+    return mk3(__shfl_xor(a.x, mask, 64), __shfl_xor(a.y, mask, 64), __shfl_xor(a.z, mask, 64));
+}
+
+template <int SCENE>
+// hint: Cornell only -- the triangle that was nearest in this lane's previous estimate (evaluation order, not a result)
+__device__ __forceinline__ float distance_estimator(v3 pos, const FrameParams &p, unsigned &iters, int &hint)
+{
+    if (SCENE == 2)      return de_mandelbulb8(pos, iters);
+    else if (SCENE == 3) return de_mandelbulb_general(pos, p.power, iters);
+    else if (SCENE == 1) return de_test_scene(pos);
+    else                 return de_cornell_box_table(pos, p.cornell_tab, p.cornell_prune, hint);
+}
+
+template <int SCENE>
+__device__ __forceinline__ float bsphere_r() { return SCENE == 2 ? 1.15f : (SCENE == 3 ? 1.5f : 1.0f); }
+
+// ------------------------------------------------------------------------------------
+// v1 render kernel: per-lane nested loops (march loop around the DE loop)
+// ------------------------------------------------------------------------------------
+// MERGE = true: the four waves of a workgroup pool their last few rays.  A packet's march loop keeps running until
+// its slowest ray is done, and 29 % of all iteration passes of the headline frame run with <= 16 of 64 lanes.  So
+// the first wave of a workgroup that is down to <= MERGE_T active rays becomes the "host"; every other wave that
+// gets down to MERGE_T hands its remaining rays (strip pixel, t, steps, iterations) over through an LDS mailbox and
+// leaves the march; the host adopts them into its idle lanes and marches everything to the end.  Rays never wait:
+// they march in their own wave until handed over, then in the host.  Handed-over rays are all late, near-surface
+// rays with similar escape-iteration counts, so the packet coherence the nested loop lives on is kept.  Results go
+// through an LDS table indexed by strip pixel; ray arithmetic is untouched (bit-identical output).
+#define MERGE_T 32
+
+// OUT selects the planes an instantiation writes: OUT_RGBA8 = the product path (RGBA8 frame only), OUT_MIRROR = RGBA8 +
+// the same rows into a registered host buffer (rmdf_register_host_buffer), OUT_PLANES = RGBA8 + the float / steps /
+// iteration planes of rmdf_render_tile_ex (parity tests, cost probe).
+enum { OUT_RGBA8 = 0, OUT_MIRROR = 1, OUT_PLANES = 2 };
+#define WPB 4                       // waves per workgroup: a 32x8 strip
+
+template <int SCENE, bool MERGE, int OUT>
+__global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
+{
+    // Which strip this workgroup renders: raster order over (slot, row, column), or most expensive first
+    // (block_order, a permutation of the launch's linear workgroup ids -- it spans all tiles of a shard launch)
+    const unsigned strips_per_slot = gridDim.x * gridDim.y;
+    unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (p.block_order) lin = p.block_order[lin];
+    const unsigned strip = lin % strips_per_slot;
+    // rectangle of this launch / shard slot
+    int rx0, ry0, rx1, ry1, pitch, ox, oy;
+    size_t obase;
+    if (p.n_shard_tiles > 0) {
+        const int slot = (int)(lin / strips_per_slot);
+        tile_rect((int)p.shard_tile[slot], p.w, p.h, rx0, ry0, rx1, ry1);
+        pitch = rx1 - rx0; ox = rx0; oy = ry0;
+        obase = (size_t)slot * (size_t)(p.w / 8) * (size_t)(p.h / 8);
+    } else {
+        rx0 = p.x0; ry0 = p.y0; rx1 = p.x1; ry1 = p.y1;
+        pitch = p.w; ox = 0; oy = 0; obase = 0;
+    }
+    // GL quads are aligned to even window coordinates: helper pixels outside the
+    // rectangle are computed (not written) so that derivatives match a full-frame render
+    const int ex0 = rx0 & ~1, ey0 = ry0 & ~1;
+    const int ex1 = (rx1 + 1) & ~1, ey1 = (ry1 + 1) & ~1;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lx = (lane & 1) | (((lane >> 2) & 3) << 1);
+    const int ly = ((lane >> 1) & 1) | (((lane >> 4) & 3) << 1);
+    const int bx = strip % gridDim.x, by = strip / gridDim.x;
+    const int px = ex0 + bx * (WPB * 8) + wave * 8 + lx;
+    const int py = ey0 + by * 8 + ly;
+    const bool active = (px < ex1) && (py < ey1);
+#ifdef RMDF_XCHECK
+    const unsigned long long dbg_t0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;   // wave timeline (tools/nested_timeline.py)
+#endif
+
+    // generate_ray, perspective branch (fragment.shd:840-871)
+    const float ndcx = ((float)px + 0.5f) / p.wf * 2.0f - 1.0f;
+    const float ndcy = ((float)py + 0.5f) / p.hf * 2.0f - 1.0f;
+    const v3 dcam = normalize3(mk3(ndcx * p.fov_xs, ndcy * p.fov_xs / p.aspect, -1.0f));
+    const v3 dir = mk3(p.cam[0] * dcam.x + p.cam[3] * dcam.y + p.cam[6] * dcam.z,
+                       p.cam[1] * dcam.x + p.cam[4] * dcam.y + p.cam[7] * dcam.z,
+                       p.cam[2] * dcam.x + p.cam[5] * dcam.y + p.cam[8] * dcam.z);
+    const v3 origin = mk3(p.cam[9], p.cam[10], p.cam[11]);
+
+    // ray_march (fragment.shd:618-676)
+    bool hit = false;
+    int steps = 0;
+    unsigned iters = 0;
+    int tri_hint = 0;               // Cornell: evaluation-order hint of the distance estimate (never a result)
+    float t = 0.0f;
+    float tmin, tmax;
+    if (!MERGE) {
+        if (active && ray_sphere(origin, dir, bsphere_r<SCENE>(), tmin, tmax)) {
+            t = gmax(0.0f, tmin);
+            for (steps = 0; steps < p.max_steps; steps++) {
+                v3 pos = mk3(origin.x + t * dir.x, origin.y + t * dir.y, origin.z + t * dir.z);
+                float dist = distance_estimator<SCENE>(pos, p, iters, tri_hint);
+                t += dist;
+                if (t > tmax) break;
+                if (dist < 0.001f) { hit = true; break; }
+            }
+        }
+    } else {
+        __shared__ int    s_host, s_nreported;
+        __shared__ int    s_mb_n[WPB], s_mb_ready[WPB];
+        __shared__ float4 s_mb[WPB][MERGE_T];
+        __shared__ float4 s_res[WPB * 64];          // per strip pixel: t, steps | hit << 15, iterations
+        if (threadIdx.x == 0) { s_host = -1; s_nreported = 0; }
+        if (threadIdx.x < WPB) { s_mb_ready[threadIdx.x] = 0; s_mb_n[threadIdx.x] = 0; }
+        const int my_sp = ly * (WPB * 8) + wave * 8 + lx;
+        s_res[my_sp] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        __syncthreads();
+
+        // the ray this lane is marching right now (its own, or an adopted one when this wave is the host)
+        bool act = false;
+        int cur_sp = my_sp, st = 0;
+        unsigned it = 0;
+        float dx = dir.x, dy = dir.y, dz = dir.z, tt = 0.0f, tmx = 0.0f;
+        if (active && ray_sphere(origin, dir, bsphere_r<SCENE>(), tmin, tmax) && p.max_steps > 0) {
+            tt = gmax(0.0f, tmin); tmx = tmax; act = true;
+        }
+        bool is_host = false;
+        unsigned taken = 0u;
+        unsigned long long cursor = 0ull;      // per-mailbox: fully adopted flag, entries adopted so far (8 bits each)
+        const int merge_t = p.merge_stragglers < MERGE_T ? p.merge_stragglers : MERGE_T;
+        for (;;) {
+            unsigned long long am = __ballot(act);
+            int n_act = __popcll(am);
+            if (!is_host) {
+                if (n_act == 0) {
+                    if (lane == 0) __hip_atomic_fetch_add(&s_nreported, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    break;
+                }
+                if (n_act <= merge_t) {
+                    int h = 0;
+                    if (lane == 0) h = atomicCAS(&s_host, -1, wave);
+                    h = __builtin_amdgcn_readfirstlane(h);
+                    if (h == -1) {
+                        is_host = true;
+                    } else {
+                        if (act) {
+                            const int r = __builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0));
+                            s_mb[wave][r] = make_float4(__int_as_float(cur_sp), tt, __int_as_float(st), __uint_as_float(it));
+                        }
+                        if (lane == 0) {
+                            s_mb_n[wave] = n_act;
+                            __hip_atomic_store(&s_mb_ready[wave], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(&s_nreported, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        act = false;
+                        break;
+                    }
+                }
+            }
+            if (is_host) {
+                // adopt what the other waves have handed over so far, as far as idle lanes allow
+                for (int w = 0; w < WPB; w++) {
+                    if (w == wave || ((taken >> w) & 1u)) continue;
+                    if (__hip_atomic_load(&s_mb_ready[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) continue;
+                    const int n = s_mb_n[w], first = (int)((cursor >> (8 * w)) & 255ull);
+                    const unsigned long long idle = __ballot(!act);
+                    const int n_idle = __popcll(idle);
+                    const int r = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0));
+                    const int take = (n - first) < n_idle ? (n - first) : n_idle;
+                    if (!act && r < take) {
+                        const float4 e = s_mb[w][first + r];
+                        cur_sp = __float_as_int(e.x); tt = e.y; st = __float_as_int(e.z); it = __float_as_uint(e.w);
+                        const int qx = ex0 + bx * (WPB * 8) + (cur_sp % (WPB * 8)), qy = ey0 + by * 8 + (cur_sp / (WPB * 8));
+                        const float nx_ = ((float)qx + 0.5f) / p.wf * 2.0f - 1.0f, ny_ = ((float)qy + 0.5f) / p.hf * 2.0f - 1.0f;
+                        const v3 dc = normalize3(mk3(nx_ * p.fov_xs, ny_ * p.fov_xs / p.aspect, -1.0f));
+                        dx = p.cam[0] * dc.x + p.cam[3] * dc.y + p.cam[6] * dc.z;
+                        dy = p.cam[1] * dc.x + p.cam[4] * dc.y + p.cam[7] * dc.z;
+                        dz = p.cam[2] * dc.x + p.cam[5] * dc.y + p.cam[8] * dc.z;
+                        float tmin2;
+                        (void)ray_sphere(origin, mk3(dx, dy, dz), bsphere_r<SCENE>(), tmin2, tmx);
+                        act = true;
+                    }
+                    cursor += (unsigned long long)take << (8 * w);
+                    if (first + take >= n) taken |= 1u << w;
+                }
+                am = __ballot(act);
+                n_act = __popcll(am);
+                if (n_act == 0) {
+                    // nothing to march: done once the three other waves have left their march and all mail is taken
+                    bool all = __hip_atomic_load(&s_nreported, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == WPB - 1;
+                    if (all) {
+                        for (int w = 0; w < WPB; w++)
+                            if (w != wave && !((taken >> w) & 1u) &&
+                                __hip_atomic_load(&s_mb_ready[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) all = false;
+                    }
+                    if (all) break;
+                    __builtin_amdgcn_s_sleep(4);
+                    continue;
+                }
+            }
+            // one march step (fragment.shd:661-672) for the rays in flight
+            if (act) {
+                const v3 pos = mk3(origin.x + tt * dx, origin.y + tt * dy, origin.z + tt * dz);
+                const float dist = distance_estimator<SCENE>(pos, p, it, tri_hint);
+                tt += dist;
+                const bool out = tt > tmx;
+                const bool h2 = !out && (dist < 0.001f);
+                bool done = out || h2;
+                if (!done) { st++; done = st >= p.max_steps; }
+                if (done) {
+                    s_res[cur_sp] = make_float4(tt, __int_as_float(st | (h2 ? 0x8000 : 0)), __uint_as_float(it), 0.0f);
+                    act = false;
+                }
+            }
+        }
+        __syncthreads();
+        const float4 rr = s_res[my_sp];
+        t = rr.x;
+        const int sb = __float_as_int(rr.y);
+        steps = sb & 0x7fff;
+        hit = (sb >> 15) != 0;
+        iters = __float_as_uint(rr.z);
+    }
+
+    // render_ray hit branch up to the texture lookups (fragment.shd:743-799)
+    v3 n = mk3(0.0f, 0.0f, 0.0f), refl = mk3(0.0f, 0.0f, 0.0f);
+    float ao = 0.0f, fresnel = 0.0f;
+    if (hit) {
+        v3 isec = mk3(origin.x + dir.x * t, origin.y + dir.y * t, origin.z + dir.z * t);
+        v3 np = mk3(isec.x - dir.x * 0.00001f, isec.y - dir.y * 0.00001f, isec.z - dir.z * 0.00001f);
+        const float eps = 0.00001f;
+        float d0 = distance_estimator<SCENE>(np, p, iters, tri_hint);
+        float dx = distance_estimator<SCENE>(mk3(np.x - eps, np.y - 0.0f, np.z - 0.0f), p, iters, tri_hint);
+        float dy = distance_estimator<SCENE>(mk3(np.x - 0.0f, np.y - eps, np.z - 0.0f), p, iters, tri_hint);
+        float dz = distance_estimator<SCENE>(mk3(np.x - 0.0f, np.y - 0.0f, np.z - eps), p, iters, tri_hint);
+        n = normalize3(mk3(d0 - dx, d0 - dy, d0 - dz));
+        // distance_ao (fragment.shd:542-591)
+        float occl = 0.0f;
+        if (SCENE != 0) {
+            const float w0 = 0.5f, e0 = 0.016f, w1 = 0.25f, e1 = 0.081f;
+            occl += w0 * gclamp(1.0f - distance_estimator<SCENE>(mk3(isec.x + n.x * e0, isec.y + n.y * e0, isec.z + n.z * e0), p, iters, tri_hint) / e0, 0.0f, 1.0f);
+            occl += w1 * gclamp(1.0f - distance_estimator<SCENE>(mk3(isec.x + n.x * e1, isec.y + n.y * e1, isec.z + n.z * e1), p, iters, tri_hint) / e1, 0.0f, 1.0f);
+            occl = 1.0f - occl;
+            occl -= 0.29f;
+            occl *= 3.5f;
+            occl *= occl;
+            ao = gclamp(occl, 0.0f, 1.0f);
+        } else {
+            const float wt[4] = { 0.1f, 0.2f, 0.125f, 0.0625f }, dl[4] = { 0.1f, 0.2f, 0.4f, 0.5f };
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                occl += wt[k] * gclamp(1.0f - distance_estimator<SCENE>(mk3(isec.x + n.x * dl[k], isec.y + n.y * dl[k], isec.z + n.z * dl[k]), p, iters, tri_hint) / dl[k], 0.0f, 1.0f);
+            ao = 1.0f - occl;
+        }
+        fresnel = fresnel_conductor(dot3(mk3(-dir.x, -dir.y, -dir.z), n), 0.4f, 0.8f);
+        refl = reflect3(dir, n);
+    }
+
+    // quad neighbours (lane^1 = horizontal, lane^2 = vertical)
+    const int hit_i = hit ? 1 : 0;
+    const bool hit_h = shfl_xor_w(hit_i, 1) != 0, hit_v = shfl_xor_w(hit_i, 2) != 0;
+    const v3 n_h = shfl_xor3(n, 1), n_v = shfl_xor3(n, 2);
+    const v3 refl_h = shfl_xor3(refl, 1), refl_v = shfl_xor3(refl, 2);
+    const v3 dir_h = shfl_xor3(dir, 1), dir_v = shfl_xor3(dir, 2);
+
+    v3 color;
+    if (hit) {
+        // fragment.shd:799-810
+        v3 t1 = cube_texture(p.env_cos1, n, hit_h, n_h, hit_v, n_v);
+        v3 t8 = cube_texture(p.env_cos8, refl, hit_h, refl_h, hit_v, refl_v);
+        v3 tr = cube_texture(p.env_refl, refl, hit_h, refl_h, hit_v, refl_v);
+        const float diff_weight = 0.5f, spec_weight = 1.0f - 0.5f, npl = (8.0f + 2.0f) / 2.0f;
+        color.x = (t1.x * 1.0f * diff_weight + t8.x * 0.8f * npl * fresnel * spec_weight + tr.x * spec_weight * fresnel * 0.1f) * 3.0f * ao;
+        color.y = (t1.y * 0.8f * diff_weight + t8.y * 0.8f * npl * fresnel * spec_weight + tr.y * spec_weight * fresnel * 0.1f) * 3.0f * ao;
+        color.z = (t1.z * 0.8f * diff_weight + t8.z * 1.0f * npl * fresnel * spec_weight + tr.z * spec_weight * fresnel * 0.1f) * 3.0f * ao;
+    } else {
+        // fragment.shd:823
+        color = cube_texture(p.env_refl, dir, !hit_h, dir_h, !hit_v, dir_v);   // neighbours in the hit branch: undefined derivative -> minified
+    }
+
+    // fragment.shd:959-960 and the RGBA8 conversion of the colour attachment
+    const float inv_gamma = 1.0f / 2.2f;
+    const float gr = pow_pinned(color.x, inv_gamma), gg = pow_pinned(color.y, inv_gamma), gb = pow_pinned(color.z, inv_gamma);
+    // Stage the 32x8 strip in LDS so that every store instruction writes whole 128-byte lines (a wave's own
+    // 8x8 packet would write 32-byte pieces of 8 different rows).  Thread t stores pixel (t % 32, t / 32).
+    __shared__ uint32_t s_rgba8[8][WPB * 8];
+    __shared__ float4   s_f32[OUT == OUT_PLANES ? 8 : 1][WPB * 8];
+    __shared__ uint32_t s_meta[OUT == OUT_PLANES ? 8 : 1][WPB * 8];
+    {
+        const int sx = wave * 8 + lx;
+        s_rgba8[ly][sx] = to_unorm8(gr) | (to_unorm8(gg) << 8) | (to_unorm8(gb) << 16) | 0xff000000u;
+        if (OUT == OUT_PLANES) {
+            s_f32[ly][sx] = make_float4(gr, gg, gb, 1.0f);
+            s_meta[ly][sx] = (uint32_t)(steps | (hit_i << 15)) | ((iters > 65535u ? 65535u : iters) << 16);
+        }
+    }
+    __syncthreads();
+    {
+        const int ox_ = threadIdx.x % (WPB * 8), oy_ = threadIdx.x / (WPB * 8);
+        const int qx = ex0 + bx * (WPB * 8) + ox_, qy = ey0 + by * 8 + oy_;
+        if (qx >= rx0 && qx < rx1 && qy >= ry0 && qy < ry1) {
+            const size_t idx = obase + (size_t)(qx - ox) + (size_t)(qy - oy) * (size_t)pitch;
+            if (OUT != OUT_PLANES || p.rgba8) p.rgba8[idx] = s_rgba8[oy_][ox_];
+            if (OUT == OUT_MIRROR) p.rgba8_mirror[idx] = s_rgba8[oy_][ox_];
+            if (OUT == OUT_PLANES) {
+                if (p.rgba_f32) p.rgba_f32[idx] = s_f32[oy_][ox_];
+                const uint32_t m = s_meta[oy_][ox_];
+                if (p.steps) p.steps[idx] = (uint16_t)(m & 0xffffu);
+                if (p.iters) p.iters[idx] = (uint16_t)(m >> 16);
+            }
+        }
+    }
+    if (p.block_cost) {
+        // cost of the strip = the largest escape-iteration total of one of its pixels (proxy of its longest
+        // serial chain); only steers next frame's dispatch order, never the image
+        __shared__ unsigned s_cost;
+        if (threadIdx.x == 0) s_cost = 0u;
+        __syncthreads();
+        unsigned c = iters + (unsigned)steps;
+        for (int o = 32; o > 0; o >>= 1) { const unsigned v = __shfl_xor(c, o, 64); c = v > c ? v : c; }
+        if (lane == 0) atomicMax(&s_cost, c);
+        __syncthreads();
+        if (threadIdx.x == 0) p.block_cost[lin] = s_cost;
+    }
+#ifdef RMDF_XCHECK
+    if (p.dbg && lane == 0) {
+        const unsigned wid = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+        if (wid < 32768u * 2u) { p.dbg[wid * 8 + 6] = dbg_t0; p.dbg[wid * 8 + 7] = __builtin_amdgcn_s_memrealtime(); p.dbg[wid * 8] = (unsigned long long)steps; }
+    }
+#endif
+}
+static void render_grid(const FrameParams &p, dim3 &grid)
+{
+    int rx0, ry0, rx1, ry1, nz = 1;
+    if (p.n_shard_tiles > 0) {
+        // all tiles have the same size when 8 | w and 8 | h (required in shard mode); odd-sized tiles get one helper
+        // column / row, on one side only
+        rx0 = 0; ry0 = 0; rx1 = p.w / 8 + ((p.w / 8) & 1); ry1 = p.h / 8 + ((p.h / 8) & 1);
+        nz = p.n_shard_tiles;
+    } else {
+        rx0 = p.x0; ry0 = p.y0; rx1 = p.x1; ry1 = p.y1;
+    }
+    const int ex0 = rx0 & ~1, ey0 = ry0 & ~1, ex1 = (rx1 + 1) & ~1, ey1 = (ry1 + 1) & ~1;
+    if (ex1 <= ex0 || ey1 <= ey0) { grid = dim3(0, 0, 0); return; }
+    grid = dim3((ex1 - ex0 + WPB * 8 - 1) / (WPB * 8), (ey1 - ey0 + 7) / 8, nz);
+}
+
+int render_grid_blocks(const FrameParams &p)
+{
+    dim3 g;
+    render_grid(p, g);
+    return (int)(g.x * g.y * g.z);
+}
+
+// Counting sort of the strips by descending cost (256 logarithmic-ish bins): order[rank] = strip.
+// One workgroup; ~n/1024 elements per thread.  Longest-processing-time-first dispatch needs no exact order.
+__global__ __launch_bounds__(1024) void k_order_blocks(const unsigned *__restrict__ cost, int n, unsigned *__restrict__ order)
+{
+    __shared__ unsigned hist[256], base[256];
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0u;
+    __syncthreads();
+    auto bin_of = [](unsigned c) -> unsigned {
+        // 8 sub-bins per power of two: monotone in c, 0..255
+        if (c < 8u) return c;
+        const int e = 31 - __builtin_clz(c);              // >= 3
+        const unsigned b = (unsigned)(e - 2) * 8u + ((c >> (e - 3)) & 7u);
+        return b > 255u ? 255u : b;
+    };
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[bin_of(cost[i])], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        unsigned acc = 0u;
+        for (int b = 255; b >= 0; b--) { base[b] = acc; acc += hist[b]; }   // descending cost
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) order[atomicAdd(&base[bin_of(cost[i])], 1u)] = (unsigned)i;
+}
+
+hipError_t launch_order_blocks(const unsigned *d_cost, int n, unsigned *d_order, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, stream, d_cost, n, d_order);
+    return hipGetLastError();
+}
+
+template <int SCENE>
+static void launch_render_scene(const FrameParams &p, dim3 grid, hipStream_t stream)
+{
+    const bool merge = p.merge_stragglers != 0;
+    const int out = (p.rgba_f32 || p.steps || p.iters) ? OUT_PLANES : (p.rgba8_mirror ? OUT_MIRROR : OUT_RGBA8);
+#define RMDF_LAUNCH(O)                                                                                       \
+    do {                                                                                                     \
+        if (merge) hipLaunchKernelGGL((k_render<SCENE, true, O>), grid, dim3(WPB * 64), 0, stream, p);       \
+        else       hipLaunchKernelGGL((k_render<SCENE, false, O>), grid, dim3(WPB * 64), 0, stream, p);      \
+    } while (0)
+    if (out == OUT_PLANES)      RMDF_LAUNCH(OUT_PLANES);
+    else if (out == OUT_MIRROR) RMDF_LAUNCH(OUT_MIRROR);
+    else                        RMDF_LAUNCH(OUT_RGBA8);
+#undef RMDF_LAUNCH
+}
+
+hipError_t launch_render(int scene, const FrameParams &p, hipStream_t stream)
+{
+    dim3 grid;
+    render_grid(p, grid);
+    if (grid.x == 0) return hipSuccess;
+    if (!p.rgba8 && !(p.rgba_f32 || p.steps || p.iters)) return hipErrorInvalidValue;
+    if (scene == 2)      launch_render_scene<2>(p, grid, stream);
+    else if (scene == 0) launch_render_scene<0>(p, grid, stream);
+    else if (scene == 1) launch_render_scene<1>(p, grid, stream);
+    else if (scene == 3) launch_render_scene<3>(p, grid, stream);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace rmdf

@@ -1,0 +1,210 @@
+// rmdf_util.hip -- small gfx950 kernels around the render kernel: exhaustive self-tests of the short exact
+// arithmetic sequences, frame clear, shard assembly after the gather, super-sampling resolve.
+#include "rmdf_internal.hpp"
+
+namespace rmdf {
+
+// ------------------------------------------------------------------------------------
+// Self-test of the short correctly-rounded sequences of rmdf_device.hpp against hipcc's own IEEE expansions,
+// over ALL 2^32 float bit patterns: sqrt_rn vs sqrtf, rcp_rn vs 1.0f/x, log_pinned (whose internal quotient uses
+// div_known_range) vs the same algorithm with the compiler's division.  counts[k] = number of differing inputs
+// (NaN results compare equal to NaN).  ~1 s on an MI355X.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float log_ref_division(float x)
+{
+    const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
+    const float Lg1 = 0.66666662693f, Lg2 = 0.40000972152f, Lg3 = 0.28498786688f, Lg4 = 0.24279078841f;
+    int32_t ix = __float_as_int(x);
+    int32_t k = 0;
+    if (ix < 0x00800000) {
+        if ((ix & 0x7fffffff) == 0) return -__builtin_inff();
+        if (ix < 0) return __builtin_nanf("");
+        k = -25; x = x * 33554432.0f; ix = __float_as_int(x);
+    }
+    if (ix >= 0x7f800000) return x + x;
+    k += (ix >> 23) - 127;
+    ix &= 0x007fffff;
+    const int32_t i = (ix + 0x4afb20) & 0x800000;
+    x = __int_as_float(ix | (i ^ 0x3f800000));
+    k += (i >> 23);
+    const float f = x - 1.0f;
+    const float s = f / (2.0f + f);
+    const float dk = (float)k;
+    const float z = s * s, w = z * z;
+    const float t1 = w * (Lg2 + w * Lg4), t2 = z * (Lg1 + w * Lg3);
+    const float R = t2 + t1;
+    const float hfsq = (0.5f * f) * f;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+// div_by_table against the compiler's division: every numerator bit pattern x the 96 Cornell divisors
+__global__ void k_selftest_cornell_div(unsigned long long *counts, const float *__restrict__ tab)
+{
+    const int tri = blockIdx.y / 3, which = blockIdx.y % 3;
+    const float *t = tab + tri * CORNELL_STRIDE;
+    const float len = which == 0 ? t[15] : which == 1 ? t[17] : t[22];
+    const float rlen = which == 0 ? t[23] : which == 1 ? t[24] : t[25];
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long c = 0;
+    for (uint64_t i = tid; i < (1ull << 32); i += stride) {
+        const float x = __uint_as_float((uint32_t)i);
+        const float a = div_by_table(x, len, rlen), b = x / len;
+        c += !((__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b));
+    }
+    if (c) atomicAdd(&counts[4], c);
+}
+
+__global__ void k_selftest_exact_math(unsigned long long *counts)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (uint64_t i = tid; i < (1ull << 32); i += stride) {
+        const float x = __uint_as_float((uint32_t)i);
+        const float a0 = sqrt_rn(x), b0 = sqrtf(x);
+        const float a1 = rcp_rn(x), b1 = 1.0f / x;
+        const float a2 = log_pinned(x), b2 = log_ref_division(x);
+        const float a3 = rsqrt_ieee(x), b3 = 1.0f / sqrtf(x);
+        c0 += !((__float_as_uint(a0) == __float_as_uint(b0)) || (a0 != a0 && b0 != b0));
+        c1 += !((__float_as_uint(a1) == __float_as_uint(b1)) || (a1 != a1 && b1 != b1));
+        c2 += !((__float_as_uint(a2) == __float_as_uint(b2)) || (a2 != a2 && b2 != b2));
+        c3 += !((__float_as_uint(a3) == __float_as_uint(b3)) || (a3 != a3 && b3 != b3));
+    }
+    atomicAdd(&counts[0], c0); atomicAdd(&counts[1], c1); atomicAdd(&counts[2], c2); atomicAdd(&counts[3], c3);
+}
+
+// Self-test of the straight-line pinned functions (rmdf_device.hpp) against their branchy fdlibm-style forms, over ALL 2^32
+// float bit patterns: exp, acos, atan, sin, cos; atan2 and pow over 2^32 pseudo-random operand pairs (every bit pattern of y
+// paired with a hashed x).  counts[0..6] = differing inputs (NaN == NaN).
+__global__ void k_selftest_pinned_math(unsigned long long *counts)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long c[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    auto differ = [](float a, float b) { return !((__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b)); };
+    for (uint64_t i = tid; i < (1ull << 32); i += stride) {
+        const float x = __uint_as_float((uint32_t)i);
+        c[0] += differ(exp_pinned(x), exp_full(x));
+        c[1] += differ(acos_pinned(x), acos_full(x));
+        c[2] += differ(atan_pinned(x), atan_full(x));
+        float s0, c0, s1, c1;
+        sincos_pinned(x, s0, c0);
+        sincos_full(x, s1, c1);
+        c[3] += differ(s0, s1);
+        c[4] += differ(c0, c1);
+        uint32_t h = (uint32_t)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        // every fourth pair uses a "shader-like" second operand (finite, moderate) so that the main path is exercised densely
+        const float y = (i & 3) ? __uint_as_float(h) : (float)((int)(h >> 8) - 8388608) * (1.0f / 1048576.0f);
+        c[5] += differ(atan2_pinned(x, y), atan2_full(x, y));
+        const float pw = 2.0f + (float)(h & 1023u) * (4.5f / 1023.0f);         // the animated power range 2 .. 6.5
+        const float pr = !(x > 0.0f) ? 0.0f : exp_full(pw * log_ref_division(x));
+        c[6] += differ(pow_pinned(x, pw), pr);
+    }
+    for (int k = 0; k < 7; k++) if (c[k]) atomicAdd(&counts[k], c[k]);
+}
+
+hipError_t launch_selftest_pinned_math(unsigned long long *d_counts, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_selftest_pinned_math, dim3(8192), dim3(256), 0, stream, d_counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_selftest_exact_math(unsigned long long *d_counts, const float *d_cornell_tab, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_selftest_exact_math, dim3(8192), dim3(256), 0, stream, d_counts);
+    hipLaunchKernelGGL(k_selftest_cornell_div, dim3(256, 96), dim3(256), 0, stream, d_counts, d_cornell_tab);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// small utility kernels
+// ------------------------------------------------------------------------------------
+__global__ void k_fill_u32(uint32_t *dst, uint32_t value, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = value;
+}
+
+hipError_t launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, stream, dst, value, n);
+    return hipGetLastError();
+}
+
+// After the gather: shard r holds the tiles shard_tiles_of_rank(r, n) in slots 0,1,2,...; every rank's shard has
+// ceil(64/n) slots.  where.v[tile idx] = rank << 8 | slot.  One thread per frame pixel (coalesced writes).
+__global__ void k_assemble_shards(const uint32_t *__restrict__ gathered, uint32_t *__restrict__ frame,
+                                  int w, int h, int nranks, const ShardWhere where)
+{
+    const int tw = w / 8, th = h / 8;
+    const int slots = (64 + nranks - 1) / nranks;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)w * h, stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        int px = (int)(i % w), py = (int)(i / w);
+        int tx = px / tw, ty = py / th;
+        const int rs = where.v[tx + ty * 8];
+        const int rank = rs >> 8, slot = rs & 255;
+        size_t src = ((size_t)rank * slots + slot) * (size_t)tw * th + (size_t)(px - tx * tw) + (size_t)(py - ty * th) * tw;
+        frame[i] = gathered[src];
+    }
+}
+
+// same, four pixels per thread (16-byte loads and stores, one tile lookup per thread): tiles whose width is a multiple of 4.
+// HBM-bound: 8 B per pixel (4 read + 4 written).
+__global__ void k_assemble_shards_x4(const uint4 *__restrict__ gathered, uint4 *__restrict__ frame,
+                                     int w, int h, int nranks, const ShardWhere where)
+{
+    const int tw4 = w / 32, th = h / 8, w4 = w / 4;            // tile width and frame width in uint4 units
+    const int slots = (64 + nranks - 1) / nranks;
+    const int x4 = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y;
+    if (x4 >= w4) return;
+    const int tx = x4 / tw4, ty = py / th;
+    const int rs = where.v[tx + ty * 8];
+    const int rank = rs >> 8, slot = rs & 255;
+    const size_t src = ((size_t)rank * slots + slot) * (size_t)tw4 * th + (size_t)(x4 - tx * tw4) + (size_t)(py - ty * th) * tw4;
+    frame[(size_t)py * w4 + x4] = gathered[src];
+}
+
+hipError_t launch_assemble_shards(const uint32_t *d_gathered, uint32_t *d_frame, int w, int h, int nranks, const ShardWhere &where,
+                                  hipStream_t stream)
+{
+    if (w % 32 == 0 && ((uintptr_t)d_gathered % 16) == 0 && ((uintptr_t)d_frame % 16) == 0) {
+        hipLaunchKernelGGL(k_assemble_shards_x4, dim3((w / 4 + 255) / 256, h), dim3(256), 0, stream,
+                           (const uint4 *)d_gathered, (uint4 *)d_frame, w, h, nranks, where);
+        return hipGetLastError();
+    }
+    size_t n = (size_t)w * h;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_assemble_shards, dim3(blocks), dim3(256), 0, stream, d_gathered, d_frame, w, h, nranks, where);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// Super-sampling resolve: one glGenerateMipmap level of the RGBA8 frame (FrameBuffer.hs:153-154,187-195):
+// 2x2 box per channel, (a+b+c+d+2)>>2.  One lane per destination pixel; each lane reads two 8-byte
+// pairs (coalesced 512 B per wave-row) and writes 4 bytes.
+// ------------------------------------------------------------------------------------
+__global__ void k_resolve_box2(const uint2 *__restrict__ src, int dw, int dh, uint32_t *__restrict__ dst)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= dw || y >= dh) return;
+    const uint2 top = src[(size_t)(2 * y) * dw + x], bot = src[(size_t)(2 * y + 1) * dw + x];
+    // per-channel sums without carries between channels: split even / odd bytes
+    const uint32_t lo = (top.x & 0x00ff00ffu) + (top.y & 0x00ff00ffu) + (bot.x & 0x00ff00ffu) + (bot.y & 0x00ff00ffu) + 0x00020002u;
+    const uint32_t hi = ((top.x >> 8) & 0x00ff00ffu) + ((top.y >> 8) & 0x00ff00ffu) + ((bot.x >> 8) & 0x00ff00ffu) + ((bot.y >> 8) & 0x00ff00ffu) + 0x00020002u;
+    dst[(size_t)y * dw + x] = ((lo >> 2) & 0x00ff00ffu) | (((hi >> 2) & 0x00ff00ffu) << 8);
+}
+
+hipError_t launch_resolve_box2(const uint32_t *d_src, int sw, int sh, uint32_t *d_dst, hipStream_t stream)
+{
+    const int dw = sw / 2, dh = sh / 2;
+    if (dw <= 0 || dh <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_resolve_box2, dim3((dw + 255) / 256, dh), dim3(256), 0, stream, (const uint2 *)d_src, dw, dh, d_dst);
+    return hipGetLastError();
+}
+
+}  // namespace rmdf

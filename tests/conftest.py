@@ -29,19 +29,24 @@ def rmdf():
     return rmdf_amd
 
 
+ENV_CACHE = os.path.join(GOLD, "env_cache")        # the ORACLE's pre-convolved maps of uffizi_512 (make_fixtures.py --caches)
+
+
 @pytest.fixture(scope="session")
 def env_latlongs(orc, rmdf):
-    """uffizi_512 + its committed pre-convolved caches, decoded by the oracle."""
-    d = os.path.join(rmdf.DATA_DIR, "latlong_envmaps")
-    rd = lambda n: orc.hdr_decode(open(os.path.join(d, n), "rb").read())
-    return {"refl": rd("uffizi_512.hdr"), "cos1": rd("uffizi_512_cache_pow_1.0.hdr"),
-            "cos8": rd("uffizi_512_cache_pow_8.0.hdr")}
+    """uffizi_512 + the oracle's pre-convolved caches (committed fixtures, tests/golden/env_cache), decoded by the oracle."""
+    rd = lambda fn: orc.hdr_decode(open(fn, "rb").read())
+    return {"refl": rd(rmdf.DEFAULT_ENV_HDR),
+            "cos1": rd(os.path.join(ENV_CACHE, "uffizi_512_cache_pow_1.0.hdr")),
+            "cos8": rd(os.path.join(ENV_CACHE, "uffizi_512_cache_pow_8.0.hdr")),
+            "cos64": rd(os.path.join(ENV_CACHE, "uffizi_512_cache_pow_64.0.hdr")),
+            "cos512": rd(os.path.join(ENV_CACHE, "uffizi_512_cache_pow_512.0.hdr"))}
 
 
 @pytest.fixture(scope="session")
 def env_faces(orc, env_latlongs):
     """Oracle-built float32 cube faces (the input both sides share in strict parity tests)."""
-    return {k: orc.latlong_to_cube(v) for k, v in env_latlongs.items()}
+    return {k: orc.latlong_to_cube(env_latlongs[k]) for k in ("refl", "cos1", "cos8")}
 
 
 @pytest.fixture(scope="session")
@@ -63,7 +68,7 @@ def sr(rmdf, env_faces):
 
 @pytest.fixture(scope="session")
 def sr_alt(rmdf, env_faces):
-    """Same, but the Mandelbulb runs on the other schedule (flattened march + shade kernels)."""
+    """librmdf_xcheck.so: the Mandelbulb runs on the flattened march + shade kernels."""
     rmdf.build()
     r = rmdf.ShaderRenderer(0, flags=rmdf.FLAG_FLAT_MARCH)
     r.set_env_cube(rmdf.ENV_REFLECTION, env_faces["refl"])
@@ -75,7 +80,7 @@ def sr_alt(rmdf, env_faces):
 
 @pytest.fixture(scope="session")
 def sr_pipe(rmdf, env_faces):
-    """The three-kernel schedule (RMDF_FLAG_PIPELINE)."""
+    """librmdf_xcheck.so: the three-kernel schedule (RMDF_FLAG_PIPELINE)."""
     rmdf.build()
     r = rmdf.ShaderRenderer(0, flags=rmdf.FLAG_PIPELINE)
     r.set_env_cube(rmdf.ENV_REFLECTION, env_faces["refl"])

@@ -3,10 +3,15 @@
 
     python tests/golden/make_fixtures.py [--caches] [--renders] [--env] [--fractals]
 
-* --caches   ray-marching-distance-fields_amd/data/latlong_envmaps/uffizi_512_cache_pow_{1,8,64,512}.0.hdr:
-             the pre-convolved environment maps the reference keeps next to its .hdr
-             (buildPreConvolvedHDREnvMapCache, ShaderRendering.hs:131-149), produced by the oracle's
-             resizeHDRImage + cosineConvolveHDREnvMap + RGBE encode.
+* --caches   tests/golden/env_cache/uffizi_512_cache_pow_{1,8,64,512}.0.hdr: the pre-convolved environment maps the
+             reference keeps next to its .hdr (buildPreConvolvedHDREnvMapCache, ShaderRendering.hs:131-149), produced by
+             the ORACLE's resizeHDRImage + cosineConvolveHDREnvMap (pinned cos^p) + RGBE encode.  They are the expected
+             output of the product's rmdf_load_env_hdr cache-miss path (tests/test_gpu_env.py), not product data: the
+             product ships uffizi_512.hdr alone and builds its caches on the GPU at first load.
+* --cubes    tests/golden/env_cubes_uffizi.npz: the oracle-built padded RGB16F cube maps of the three sampled slots (so
+             that the full-size digests below do not depend on the libm of the box that checks them).
+* --digests  tests/golden/full_size_digests.json: sha256 of the oracle's rgba8 / steps / iters planes of BASELINE
+             configs 2 and 3 at full size (1280x720 @128 Cornell, 1920x1080 @256 Mandelbulb), from those cube maps.
 * --renders  tests/golden/render_<scene>_<w>x<h>_t<time>.npz : oracle float RGBA / RGBA8 / steps / iters.
 * --env      tests/golden/env_*.npz : cube faces for the procedural test env map, pixelAtBilinear probes,
              a 32x16 prefilter case.
@@ -26,8 +31,8 @@ sys.path.insert(0, ROOT)
 from oracle import orc  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
-ENVDIR = os.path.join(ROOT, "ray-marching-distance-fields_amd", "data", "latlong_envmaps")
-HDR = os.path.join(ENVDIR, "uffizi_512.hdr")
+ENVDIR = os.path.join(GOLD, "env_cache")
+HDR = os.path.join(ROOT, "ray-marching-distance-fields_amd", "data", "latlong_envmaps", "uffizi_512.hdr")
 POWERS = (1.0, 8.0, 64.0, 512.0)
 RENDER_CASES = [(scene, w, h, t, ms)
                 for scene, ms in ((orc.SCENE_MB_POWER8, 256), (orc.SCENE_CORNELL, 128))
@@ -55,11 +60,11 @@ def render_name(scene, w, h, t, ms):
 
 def main():
     ap = argparse.ArgumentParser()
-    for f in ("caches", "renders", "env", "fractals"):
+    for f in ("caches", "renders", "env", "fractals", "cubes", "digests"):
         ap.add_argument("--" + f, action="store_true")
     a = ap.parse_args()
-    if not (a.caches or a.renders or a.env or a.fractals):
-        a.caches = a.renders = a.env = a.fractals = True
+    if not (a.caches or a.renders or a.env or a.fractals or a.cubes or a.digests):
+        a.caches = a.renders = a.env = a.fractals = a.cubes = a.digests = True
 
     if a.caches:
         refl = orc.hdr_decode(open(HDR, "rb").read())
@@ -68,6 +73,26 @@ def main():
             conv = orc.cosine_convolve(small, p)
             open(cache_name(p), "wb").write(orc.hdr_encode(conv))
             print("wrote", cache_name(p))
+
+    if a.cubes:
+        env = load_env()
+        np.savez_compressed(os.path.join(GOLD, "env_cubes_uffizi.npz"), refl=env.reflection, cos1=env.cos_1, cos8=env.cos_8)
+        print("wrote env_cubes_uffizi.npz")
+
+    if a.digests:
+        import hashlib
+        import json
+        z = np.load(os.path.join(GOLD, "env_cubes_uffizi.npz"))
+        env = orc.EnvSet(z["refl"], z["cos1"], z["cos8"])
+        out = {}
+        for name, (scene, w, h, t, ms) in (("config2_cornell_1280x720_m128", (orc.SCENE_CORNELL, 1280, 720, 0.0, 128)),
+                                            ("config3_mandelbulb8_1920x1080_m256", (orc.SCENE_MB_POWER8, 1920, 1080, 0.0, 256))):
+            r = orc.render(scene, w, h, t, ms, env, want_f32=False)
+            out[name] = {"scene": scene, "w": w, "h": h, "time": t, "max_steps": ms,
+                         "sha256": {k: hashlib.sha256(np.ascontiguousarray(r[k]).tobytes()).hexdigest() for k in ("rgba8", "steps", "iters")},
+                         "counters": r["counters"]}
+            print(name, out[name])
+        json.dump(out, open(os.path.join(GOLD, "full_size_digests.json"), "w"), indent=1, sort_keys=True)
 
     if a.renders:
         env = load_env()

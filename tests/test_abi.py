@@ -22,13 +22,61 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(rmdf_[a-z0-9_]+)\s*\(", text)))
 
 
+def declared_xcheck_symbols():
+    text = open(os.path.join(ROOT, "include", "rmdf_xcheck.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rmdf_[a-z0-9_]+)\s*\(", text)))
+
+
 def test_header_and_binding_agree(rmdf):
     assert declared_symbols() == sorted(rmdf.ABI_SYMBOLS)
+    assert declared_xcheck_symbols() == sorted(rmdf.XCHECK_SYMBOLS)
 
 
-def test_every_declared_symbol_is_exported(lib):
+def test_every_declared_symbol_is_exported(lib, rmdf):
     for name in declared_symbols():
         assert hasattr(lib, name), name
+    xlib = rmdf.load_library(xcheck=True)
+    for name in declared_symbols() + declared_xcheck_symbols():
+        assert hasattr(xlib, name), name
+
+
+def test_product_library_holds_no_alternative_schedules_or_debug_knobs(rmdf):
+    """librmdf.so is the product: the slower alternative schedules, the per-wave statistics and every measurement knob
+    live in librmdf_xcheck.so (or nowhere)."""
+    syms = os.popen("nm -D --defined-only %s; strings -a %s" % (rmdf.LIB_PATH, rmdf.LIB_PATH)).read()
+    for word in ("rmdf_debug_march_stats", "k_march_mb8", "k_march_pool", "k_march_refill", "k_march_stats",
+                 "RMDF_DBG_SKIP", "RMDF_WPB", "RMDF_OCC_LDS", "RMDF_MERGE", "RMDF_PRIO_STRIPS", "RMDF_NESTED_STATS"):
+        assert word not in syms, word
+    xsyms = os.popen("strings -a %s" % rmdf.XCHECK_LIB_PATH).read()
+    assert "k_march_mb8" in xsyms and "k_march_refill" in xsyms
+
+
+def test_rccl_is_not_a_link_dependency(rmdf):
+    """RCCL is dlopen()ed by rmdf_comm_init: a single-GPU C host must not need it at load time."""
+    deps = os.popen("ldd %s" % rmdf.LIB_PATH).read()
+    assert "rccl" not in deps and "nccl" not in deps
+
+
+def test_last_error_without_ctx_is_process_wide(lib):
+    """rmdf_last_error(NULL) must work from another OS thread than the one the call failed on (a Haskell runtime may
+    migrate its threads): the message is process-wide, the returned pointer a per-thread copy."""
+    import threading
+    assert lib.rmdf_save_png(None, None, 0, 0) == -1
+    here = lib.rmdf_last_error(None)
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(lib.rmdf_last_error(None)))
+    t.start()
+    t.join()
+    assert here == seen[0] and b"rmdf_save_png" in here
+    err = C.create_string_buffer(256)
+    ctx = C.c_void_p()
+
+    class Cfg(C.Structure):
+        _fields_ = [("device", C.c_int), ("reserved", C.c_int * 7)]
+    cfg = Cfg(device=-5)
+    rc = lib.rmdf_create_ex(C.byref(ctx), C.byref(cfg), err, 256)
+    assert rc != 0 and not ctx.value and len(err.value) > 0
 
 
 def test_code_object_is_gfx950_only(rmdf):
@@ -67,6 +115,9 @@ def test_null_ctx_is_an_error_not_a_crash(lib):
     assert lib.rmdf_render_tile(None, 2, -1, 16, 16, 0.0, 16, None) == -1
     assert lib.rmdf_set_env_cube(None, 0, None, 4) == -1
     assert lib.rmdf_synchronize(None, None) == -1
+    assert lib.rmdf_comm_init(None, None, 0, 1) == -1 and lib.rmdf_gather_shards_device(None, 8, 8, None, None, None) == -1
+    assert lib.rmdf_comm_get_unique_id(None) == -1
+    assert lib.rmdf_prefilter_env_powers(None, None, 4, 4, None, 1, None) == -1
     lib.rmdf_destroy(None)
 
 
@@ -75,11 +126,16 @@ def test_product_never_touches_the_oracle(rmdf):
     pkg = os.path.dirname(rmdf.__file__)
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", ".hs")) or f == "Makefile":
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", ".hs", ".c")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in text and "rmdf_oracle" not in text and "from oracle" not in text, f
-    deps = os.popen("ldd %s" % rmdf.LIB_PATH).read()
-    assert "oracle" not in deps and "amdhip64" in deps
+    for lib_path in (rmdf.LIB_PATH, rmdf.XCHECK_LIB_PATH):
+        deps = os.popen("ldd %s" % lib_path).read()
+        assert "oracle" not in deps and "amdhip64" in deps
+    # the product data directory ships the reflection map alone: no oracle-generated cache files
+    # (cache files the product built at a first load may sit next to it; they are git-ignored)
+    tracked = os.popen("git -C %s ls-files %s" % (ROOT, os.path.join(rmdf.DATA_DIR, "latlong_envmaps"))).read().split()
+    assert [os.path.basename(t) for t in tracked] == ["uffizi_512.hdr"], tracked
 
 
 def _build_c_host(tmp_path):

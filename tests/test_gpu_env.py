@@ -1,0 +1,199 @@
+"""GPU tier (-m gpu): the product's own environment-map pipeline against the oracle, end to end.
+
+withShaderRenderer's env part (ShaderRendering.hs:65-91,131-149; HDREnvMap.hs:118-163,169-254): decode the Radiance file,
+resizeHDRImage to 256, cosineConvolveHDREnvMap for the powers 1/8/64/512, write + reload the RGBE cache files, convert the
+five lat/long maps to cube maps.  The kernels keep the reference's operation order and take every libm value from host
+tables (rmdf_env.hip), so the bar here is BIT equality -- of the cache-file bytes, of the padded RGB16F cube maps and of
+frames rendered from the product-built maps -- not a tolerance.  (cos^p for the four reference powers is the pinned
+binary64 squaring chain; tests/test_oracle_golden.py bounds its distance from libm powf.)"""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from conftest import ENV_CACHE, rel_err
+
+pytestmark = pytest.mark.gpu
+
+POWERS = (1.0, 8.0, 64.0, 512.0)
+
+
+def synthetic_latlong(w, h, seed):
+    """A seeded HDR-like lat/long map: smooth sky gradient + a few very bright lobes + texel noise, >= 0."""
+    rng = np.random.RandomState(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.empty((h, w, 3), np.float32)
+    for k in range(3):
+        base = 0.2 + 0.8 * (1.0 - y / h) ** (k + 1)
+        lobes = sum(a * np.exp(-(((x - cx) / sx) ** 2 + ((y - cy) / sy) ** 2))
+                    for a, cx, cy, sx, sy in zip(rng.uniform(2, 40, 5), rng.uniform(0, w, 5), rng.uniform(0, h, 5),
+                                                 rng.uniform(3, w / 8, 5), rng.uniform(3, h / 8, 5)))
+        img[..., k] = base + lobes + rng.uniform(0, 0.05, (h, w))
+    return img.astype(np.float32)
+
+
+def test_latlong_to_cube_is_bit_exact(rmdf, orc, env_latlongs):
+    """latLongHDREnvMapToCubeMap on the device (host-built (u,v) table + bilinear gather) + RGB16F upload with seamless
+    border == the oracle's, every texel, for the 512-wide reflection map, the 256-wide lobe maps and two odd sizes."""
+    fresh = rmdf.ShaderRenderer(0)
+    try:
+        cases = [(rmdf.ENV_REFLECTION, env_latlongs["refl"]), (rmdf.ENV_COS_1, env_latlongs["cos1"]),
+                 (rmdf.ENV_COS_8, env_latlongs["cos8"]), (rmdf.ENV_COS_64, synthetic_latlong(100, 37, 1)),
+                 (rmdf.ENV_COS_512, orc.build_test_latlong())]
+        for slot, ll in cases:
+            fresh.set_env_latlong(slot, ll)
+            got = fresh.get_env_cube_padded(slot)
+            ref = orc.cube_pad_f16(orc.latlong_to_cube(ll))
+            assert got.shape == ref.shape
+            assert np.array_equal(got, ref), (slot, int((got != ref).sum()))
+    finally:
+        fresh.close()
+
+
+@pytest.mark.parametrize("w,h", [(32, 16), (128, 64), (256, 128), (100, 37)])
+def test_lobe_prefilter_is_bit_exact(sr, orc, env_latlongs, w, h):
+    """cosineConvolveHDREnvMap at the reference's 256x128 and smaller / ragged sizes, all four reference powers at once
+    (rmdf_prefilter_env_powers, concurrent like mapConcurrently): bit-equal to the oracle's pinned form; <= 1e-6 from the
+    literal libm powf form; a power without a pin (3.0, device powf) within 2e-5."""
+    src = orc.resize_hdr(env_latlongs["refl"], w) if (w, h) != (100, 37) else synthetic_latlong(w, h, 7)
+    assert src.shape == (h, w, 3)
+    got = sr.prefilter_env_powers(src, POWERS)
+    for i, p in enumerate(POWERS):
+        ref = orc.cosine_convolve(src, p, pow_mode=1)
+        assert np.array_equal(got[i].view(np.uint32), ref.view(np.uint32)), (p, rel_err(got[i], ref).max())
+        assert np.array_equal(sr.prefilter_env(src, p).view(np.uint32), ref.view(np.uint32))        # single-power entry
+    if w <= 128:
+        assert rel_err(got[1], orc.cosine_convolve(src, 8.0, pow_mode=0)).max() <= 1e-6
+        e = rel_err(sr.prefilter_env(src, 3.0), orc.cosine_convolve(src, 3.0, pow_mode=0))
+        assert e.max() < 2e-5, e.max()
+
+
+def test_lobe_prefilter_wide_maps_and_device_entry(sr, orc):
+    """Maps wider than 256 texels read their cosine table through L2 instead of LDS (w = 640 > the old 600 limit, w = 1030
+    ragged); and the device-resident entry (rmdf_prefilter_env_device) gives the same bits as the host-pointer one."""
+    import torch
+    for (w, h, p) in ((640, 12, 8.0), (1030, 6, 1.0), (512, 24, 512.0)):
+        src = synthetic_latlong(w, h, w)
+        ref = orc.cosine_convolve(src, p, pow_mode=1)
+        got = sr.prefilter_env(src, p)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (w, h, p, rel_err(got, ref).max())
+        d_src = torch.from_numpy(src).cuda()
+        d_out = torch.empty_like(d_src)
+        st = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        sr.prefilter_env_device(d_src.data_ptr(), w, h, p, d_out.data_ptr(), stream=st.cuda_stream)
+        st.synchronize()
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+def test_config5_env_prefilter_chain_at_stated_size(sr, orc):
+    """BASELINE config 5 as written: a synthetic 2048x1024 lat/long map -> resizeHDRImage 256 -> the four
+    lobe powers at 256x128, each step bit-equal to the oracle; plus the cube conversion of the 2048-wide map (6 x 682^2)."""
+    big = synthetic_latlong(2048, 1024, 5)
+    small = sr.resize_latlong(big, 256)
+    assert small.shape == (128, 256, 3)
+    assert np.array_equal(small.view(np.uint32), orc.resize_hdr(big, 256).view(np.uint32))
+    got = sr.prefilter_env_powers(small, POWERS)
+    for i, p in enumerate(POWERS):
+        assert np.array_equal(got[i].view(np.uint32), orc.cosine_convolve(small, p, pow_mode=1).view(np.uint32)), p
+    sr.set_env_latlong(4, big)                                   # slot env_cos_512: never sampled by the renderer
+    assert np.array_equal(sr.get_env_cube_padded(4), orc.cube_pad_f16(orc.latlong_to_cube(big)))
+    # a true-resolution stress step: one power at 512x256 (16x the reference's work)
+    mid = sr.resize_latlong(big, 512)
+    assert np.array_equal(mid.view(np.uint32), orc.resize_hdr(big, 512).view(np.uint32))
+    assert np.array_equal(sr.prefilter_env(mid, 8.0).view(np.uint32), orc.cosine_convolve(mid, 8.0, pow_mode=1).view(np.uint32))
+
+
+def test_load_env_hdr_cache_miss_end_to_end(rmdf, orc, env_latlongs, tmp_path):
+    """uffizi_512.hdr ALONE in a fresh directory: rmdf_load_env_hdr takes the cache-miss branch (GPU resize -> GPU prefilter
+    at 256x128 -> RGBE encode -> write -> decode -> GPU cube conversion).
+      * the four cache files it writes == the oracle's, byte for byte (and == the committed oracle fixtures);
+      * all five padded RGB16F cube maps == the oracle's;
+      * a second renderer loading the same directory (cache hit) gets the same maps;
+      * frames of scenes 0 and 2 at 64x36 and 256x144 rendered from the PRODUCT-built maps hold the north-star bar against
+        the oracle rendering from the ORACLE-built maps: steps / hit mask / escape iterations bit-exact, colour <= 1e-4."""
+    from test_gpu_parity import assert_frame_parity
+    hdr = str(tmp_path / "uffizi_512.hdr")
+    shutil.copy(rmdf.DEFAULT_ENV_HDR, hdr)
+    assert sorted(os.listdir(tmp_path)) == ["uffizi_512.hdr"]
+    lat, files = orc.env_pipeline(open(hdr, "rb").read(), powers=POWERS)
+    a = rmdf.ShaderRenderer(0)
+    b = rmdf.ShaderRenderer(0)
+    try:
+        a.load_env_hdr(hdr)                                                       # cache miss
+        names = ["uffizi_512_cache_pow_%s.hdr" % repr(p) for p in POWERS]
+        assert sorted(os.listdir(tmp_path)) == sorted(["uffizi_512.hdr"] + names)
+        for p, n in zip(POWERS, names):
+            data = open(tmp_path / n, "rb").read()
+            assert data == files[p], "cache file for power %s differs from the oracle's" % p
+            assert data == open(os.path.join(ENV_CACHE, n), "rb").read()
+        b.load_env_hdr(hdr)                                                       # cache hit
+        keys = ["refl", "cos1", "cos8", "cos64", "cos512"]
+        for slot, k in enumerate(keys):
+            ref = orc.cube_pad_f16(orc.latlong_to_cube(lat[k]))
+            assert np.array_equal(a.get_env_cube_padded(slot), ref), k
+            assert np.array_equal(b.get_env_cube_padded(slot), ref), k
+        env = orc.EnvSet.from_latlongs(lat["refl"], lat["cos1"], lat["cos8"])
+        for scene, ms in ((2, 256), (0, 128)):
+            for (w, h) in ((64, 36), (256, 144)):
+                assert_frame_parity(a.render(scene, w, h, 0.0, max_steps=ms), orc.render(scene, w, h, 0.0, ms, env),
+                                    "product env pipeline, scene %d %dx%d" % (scene, w, h))
+    finally:
+        a.close()
+        b.close()
+
+
+def test_load_env_hdr_in_a_read_only_directory_and_concurrent_builders(rmdf, orc, tmp_path):
+    """(1) a directory that cannot be written: the cache images are used from memory, same cube maps, no error, nothing
+    left behind; (2) three renderers building the same cache one after the other and a truncated stale temp file next to it:
+    readers only ever see complete files (tmp + rename)."""
+    ro = tmp_path / "ro"
+    ro.mkdir()
+    hdr = str(ro / "uffizi_512.hdr")
+    shutil.copy(rmdf.DEFAULT_ENV_HDR, hdr)
+    lat, files = orc.env_pipeline(open(hdr, "rb").read(), powers=(1.0, 8.0))
+    os.chmod(ro, 0o555)
+    r = rmdf.ShaderRenderer(0)
+    try:
+        can_write = os.access(str(ro), os.W_OK)          # root ignores the mode bits: then this half checks nothing new
+        r.load_env_hdr(hdr)
+        if not can_write:
+            assert sorted(os.listdir(ro)) == ["uffizi_512.hdr"]
+        for slot, k in ((1, "cos1"), (2, "cos8")):
+            assert np.array_equal(r.get_env_cube_padded(slot), orc.cube_pad_f16(orc.latlong_to_cube(lat[k])))
+    finally:
+        os.chmod(ro, 0o755)
+        r.close()
+    rw = tmp_path / "rw"
+    rw.mkdir()
+    hdr2 = str(rw / "uffizi_512.hdr")
+    shutil.copy(rmdf.DEFAULT_ENV_HDR, hdr2)
+    open(str(rw / "uffizi_512_cache_pow_8.0.hdr.tmp.1"), "wb").write(b"#?RADIANCE\n")      # someone else's half-written file
+    rs = [rmdf.ShaderRenderer(0) for _ in range(3)]
+    try:
+        for x in rs:
+            x.load_env_hdr(hdr2)
+        assert open(rw / "uffizi_512_cache_pow_8.0.hdr", "rb").read() == files[8.0]
+        assert not [f for f in os.listdir(rw) if ".tmp." in f and not f.endswith(".tmp.1")]
+    finally:
+        for x in rs:
+            x.close()
+
+
+def test_malformed_hdr_files_fail_cleanly(rmdf, tmp_path):
+    """decode errors come back as RMDF_E_IO with a message (never an exception across the C ABI, never a huge allocation
+    from a size the file merely claims)."""
+    r = rmdf.ShaderRenderer(0)
+    try:
+        cases = {"huge.hdr": b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2000000000 +X 2000000000\n" + b"\0" * 64,
+                 "trunc.hdr": b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 128 +X 256\n" + b"\x10" * 100,
+                 "nohdr.hdr": b"not a radiance file", "tiny.hdr": b"#?RADIANCE\n\n-Y 1 +X 4\n" + b"\x80" * 16}
+        for n, data in cases.items():
+            fn = str(tmp_path / n)
+            open(fn, "wb").write(data)
+            with pytest.raises(rmdf.RmdfError) as e:
+                r.load_env_hdr(fn)
+            assert e.value.code == -4, (n, str(e.value))
+    finally:
+        r.close()

@@ -181,37 +181,6 @@ def test_error_convention(sr, rmdf):
     assert sr.render(2, 32, 18, 0.0)["rgba8"].shape == (18, 32)
 
 
-def test_gpu_env_pipeline_vs_oracle(sr, rmdf, orc, env_latlongs, env_faces):
-    """Device latlong->cube, resize and lobe prefilter against the oracle.  These call the device libm
-    (acosf/atanf/cosf/sinf/powf) where the reference calls glibc's, so the bar is a tolerance, stated here:
-    resize (no libm): bit-exact; cube faces: <= 2e-5 relative before f16 rounding except where a 1-ulp move of
-    (u,v) crosses a texel boundary (<= 0.1 % of texels, bounded by the local contrast); prefilter: <= 2e-5 + 2e-7*power."""
-    small = sr.resize_latlong(env_latlongs["refl"], 256)
-    assert np.array_equal(small, orc.resize_hdr(env_latlongs["refl"], 256))
-    fresh = rmdf.ShaderRenderer(0)
-    try:
-        fresh.set_env_latlong(rmdf.ENV_COS_1, env_latlongs["cos1"])
-        got = fresh.get_env_cube_padded(rmdf.ENV_COS_1).view(np.float16).astype(np.float32)
-        ref = orc.cube_pad_f16(env_faces["cos1"]).view(np.float16).astype(np.float32)
-        e = rel_err(got[..., :3], ref[..., :3], floor=1e-4)
-        assert (e > 2e-3).mean() < 1e-3 and np.median(e) == 0.0           # f16 ulp = 9.8e-4 relative
-        fresh.set_env_latlong(rmdf.ENV_REFLECTION, env_latlongs["refl"])
-        got = fresh.get_env_cube_padded(rmdf.ENV_REFLECTION).view(np.float16).astype(np.float32)
-        ref = orc.cube_pad_f16(env_faces["refl"]).view(np.float16).astype(np.float32)
-        e = rel_err(got[..., :3], ref[..., :3], floor=1e-4)
-        assert (e > 2e-3).mean() < 5e-3
-    finally:
-        fresh.close()
-    tiny = orc.resize_hdr(env_latlongs["refl"], 32)
-    for p in (1.0, 8.0, 64.0, 512.0, 3.0):          # powers of two by repeated squaring, others through powf
-        e = rel_err(sr.prefilter_env(tiny, p), orc.cosine_convolve(tiny, p))
-        # the device's cosf/sinf differ from glibc's by an ulp (6e-8) in cos(gamma); cos^p amplifies that p times
-        assert e.max() < 2e-5 + 2e-7 * p, (p, e.max())
-    mid = orc.resize_hdr(env_latlongs["refl"], 128)
-    e = rel_err(sr.prefilter_env(mid, 8.0), orc.cosine_convolve(mid, 8.0))
-    assert e.max() < 2e-5, e.max()
-
-
 def test_fresh_frame_is_cleared_to_opaque_black(rmdf, env_faces):
     """resizeFrameBuffer clears the new texture to (0,0,0,1) (FrameBuffer.hs:109-111): tiles that have not been
     drawn yet read 0xFF000000."""
@@ -562,3 +531,133 @@ def test_argument_limits(sr, rmdf):
         sr.render(2, 16, 8, 0.0, max_steps=32768)                 # the step counter shares a 16-bit plane with the hit bit
     assert e.value.code == -1
     assert sr.render(2, 16, 8, 0.0, max_steps=32767)["rgba8"].shape == (8, 16)
+
+
+def _committed_cube_renderer(rmdf):
+    """A renderer whose cube maps come from the committed oracle-built fixture (tests/golden/env_cubes_uffizi.npz): the
+    padded RGB16F texels are exact in float32, and the upload's RNE + border rule reproduces the fixture bit for bit."""
+    z = np.load(os.path.join(GOLD, "env_cubes_uffizi.npz"))
+    r = rmdf.ShaderRenderer(0)
+    for slot, k in ((rmdf.ENV_REFLECTION, "refl"), (rmdf.ENV_COS_1, "cos1"), (rmdf.ENV_COS_8, "cos8")):
+        faces = z[k].view(np.float16)[:, 1:-1, 1:-1, :3].astype(np.float32)
+        r.set_env_cube(slot, faces)
+        assert np.array_equal(r.get_env_cube_padded(slot), z[k]), k
+    return r
+
+
+@pytest.mark.parametrize("name", ["config2_cornell_1280x720_m128", "config3_mandelbulb8_1920x1080_m256"])
+def test_full_size_frames_match_the_committed_oracle_digests(rmdf, name):
+    """BASELINE configs 2 and 3 at FULL size, every pixel: sha256 of the rgba8 / steps / escape-iteration planes == the
+    digests of the oracle's planes (tests/golden/full_size_digests.json, written by make_fixtures.py --digests from the same
+    committed cube maps).  Rendered three ways: through the plane-writing kernel variant (rmdf_render_tile_ex), through the
+    RGBA8-only product variant (rmdf_render_tile), and again cost-ordered (second frame of the same configuration)."""
+    import hashlib
+    import json
+    d = json.load(open(os.path.join(GOLD, "full_size_digests.json")))[name]
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    r = _committed_cube_renderer(rmdf)
+    try:
+        for _ in range(2):
+            got = r.render(d["scene"], d["w"], d["h"], d["time"], max_steps=d["max_steps"], want_f32=False)
+            for k in ("rgba8", "steps", "iters"):
+                assert sha(got[k]) == d["sha256"][k], (name, k)
+            fb = np.zeros(d["w"] * d["h"], np.uint32)
+            r.draw_shader_tile(d["scene"], None, d["w"], d["h"], d["time"], fb, max_steps=d["max_steps"])
+            assert sha(fb) == d["sha256"]["rgba8"], (name, "rgba8-only variant")
+        hit = (got["steps"] >> 15).astype(np.int64).sum()
+        assert int(hit) == d["counters"]["hit_pixels"]
+        if d["scene"] == 2:
+            # march steps of the oracle's counters = DE calls made from ray_march: the loop counter + 1 per started step
+            assert int(got["iters"].astype(np.int64).sum()) == d["counters"]["triplex_iters"]
+    finally:
+        r.close()
+
+
+def test_extra_planes_are_allocated_on_demand_and_tiles_accumulate(rmdf, orc, env_oracle, env_faces):
+    """rmdf_render_tile keeps only the RGBA8 frame; the float / steps / iteration planes appear with the first
+    rmdf_render_tile_ex call and accumulate over the tiles rendered through it (zero elsewhere)."""
+    r = rmdf.ShaderRenderer(0)
+    try:
+        for slot, k in ((rmdf.ENV_REFLECTION, "refl"), (rmdf.ENV_COS_1, "cos1"), (rmdf.ENV_COS_8, "cos8")):
+            r.set_env_cube(slot, env_faces[k])
+        w, h = 96, 56
+        ref = orc.render(2, w, h, 0.5, 128, env_oracle)
+        fb = np.zeros(w * h, np.uint32)
+        for idx in range(0, 32):
+            r.draw_shader_tile(2, idx, w, h, 0.5, fb, max_steps=128)                       # RGBA8 only
+        part = None
+        for idx in range(32, 64):
+            part = r.render(2, w, h, 0.5, max_steps=128, tile_idx=idx)                      # planes from here on
+        assert np.array_equal(part["rgba8"], ref["rgba8"])
+        assert np.array_equal(part["steps"][h // 2:], ref["steps"][h // 2:]) and not part["steps"][:h // 2].any()
+        assert np.array_equal(part["iters"][h // 2:], ref["iters"][h // 2:])
+        assert np.array_equal(part["rgba_f32"][h // 2:].view(np.uint32), ref["rgba_f32"][h // 2:].view(np.uint32))
+    finally:
+        r.close()
+
+
+def test_alternative_schedules_live_in_the_xcheck_library_only(rmdf, sr_alt, sr_pipe):
+    """librmdf.so rejects the alternative-schedule flag bits; in librmdf_xcheck.so they keep one scratch set per ctx, so a
+    launch on another stream is refused (RMDF_E_UNSUPPORTED) instead of corrupting a frame in flight on the ctx stream."""
+    import ctypes as C
+    import torch
+    L = rmdf.load_library()
+
+    class Cfg(C.Structure):
+        _fields_ = [("device", C.c_int), ("reserved", C.c_int * 7)]
+    for flag in (rmdf.FLAG_FLAT_MARCH, rmdf.FLAG_PIPELINE, 1 << 20):
+        cfg = Cfg(device=0)
+        cfg.reserved[0] = flag
+        ctx = C.c_void_p()
+        assert L.rmdf_create(C.byref(ctx), C.byref(cfg)) == -6 and not ctx.value
+    assert sr_alt.xcheck and sr_pipe.xcheck
+    st = torch.cuda.Stream()
+    buf = torch.zeros((72, 128), dtype=torch.int32, device="cuda")
+    for r in (sr_alt, sr_pipe):
+        with pytest.raises(rmdf.RmdfError) as e:
+            r.render_rect_device(2, 128, 72, 0.0, 64, (0, 0, 128, 72), d_rgba8=buf.data_ptr(), stream=st.cuda_stream)
+        assert e.value.code == -6
+        r.render_rect_device(2, 128, 72, 0.0, 64, (0, 0, 128, 72), d_rgba8=buf.data_ptr())        # ctx stream: fine
+        r.synchronize()
+    with pytest.raises(rmdf.RmdfError):
+        rmdf.ShaderRenderer(0).debug_march_stats()
+
+
+def test_exchange_behind_the_c_abi_world_size_one(sr, rmdf):
+    """rmdf_comm_* + rmdf_render_frame_sharded_device with a communicator of ONE rank (all a 1-GPU box can hold: RCCL cannot
+    put two ranks on one device): unique id, ncclCommInitRank, the frame through shard render -> gather (the root's own
+    part: a copy, or nothing when it rendered into its slot) -> assemble == the plain full-frame render; error paths."""
+    import torch
+    w, h, ms = 640, 360, 256
+    full = sr.render(2, w, h, 0.0, max_steps=ms)["rgba8"]
+    r = rmdf.ShaderRenderer(0)
+    try:
+        for slot in range(3):
+            pad = sr.get_env_cube_padded(slot)
+            r.set_env_cube(slot, pad.view(np.float16)[:, 1:-1, 1:-1, :3].astype(np.float32))
+        assert r.comm_info() == (0, 0)
+        shard = torch.zeros((64, h // 8, w // 8), dtype=torch.int32, device="cuda")
+        gathered = torch.zeros((1, 64, h // 8, w // 8), dtype=torch.int32, device="cuda")
+        frame = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+        with pytest.raises(rmdf.RmdfError) as e:
+            r.render_frame_sharded_device(2, w, h, 0.0, ms, shard.data_ptr(), gathered.data_ptr(), frame.data_ptr())
+        assert e.value.code == -8                                                   # RMDF_E_COMM: no communicator yet
+        uid = rmdf.comm_get_unique_id()
+        assert len(uid) == rmdf.COMM_ID_BYTES and any(uid)
+        r.comm_init(uid, 0, 1)
+        assert r.comm_info() == (0, 1)
+        with pytest.raises(rmdf.RmdfError):
+            r.comm_init(uid, 0, 1)                                                  # already has one
+        st = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        r.render_frame_sharded_device(2, w, h, 0.0, ms, shard.data_ptr(), gathered.data_ptr(), frame.data_ptr(), stream=st.cuda_stream)
+        st.synchronize()
+        assert np.array_equal(frame.cpu().numpy().view(np.uint32), full)
+        frame.zero_()
+        r.render_frame_sharded_device(2, w, h, 0.0, ms, gathered[0].data_ptr(), gathered.data_ptr(), frame.data_ptr(), stream=st.cuda_stream)
+        st.synchronize()
+        assert np.array_equal(frame.cpu().numpy().view(np.uint32), full)              # rendered straight into its slot
+        r.comm_destroy()
+        assert r.comm_info() == (0, 0)
+    finally:
+        r.close()

@@ -6,7 +6,7 @@ os.environ["RMDF_NESTED_STATS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rmdf_amd
 w, h, ms = 1920, 1080, 256
-sr = rmdf_amd.ShaderRenderer(0)
+sr = rmdf_amd.ShaderRenderer(0, xcheck=True)
 sr.load_env_hdr(rmdf_amd.DEFAULT_ENV_HDR)
 sr.debug_march_stats(True)
 fb = np.empty(w * h, np.uint32)

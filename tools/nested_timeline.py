@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rmdf_amd
 w, h, ms = 1920, 1080, 256
 flags = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-sr = rmdf_amd.ShaderRenderer(0, flags=flags)
+sr = rmdf_amd.ShaderRenderer(0, flags=flags, xcheck=True)
 sr.load_env_hdr(rmdf_amd.DEFAULT_ENV_HDR)
 fb = np.empty(w * h, np.uint32)
 sr.draw_shader_tile(2, None, w, h, 0.0, fb, max_steps=ms)
