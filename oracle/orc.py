@@ -78,6 +78,7 @@ def lib():
         L.orc_f32_to_f16.argtypes = [C.c_float]
         L.orc_ray_sphere.argtypes = [fp, fp, C.c_float, fp, fp]
         L.orc_render.argtypes = [C.POINTER(Frame)] + [C.c_int] * 4 + [C.c_void_p] * 4 + [C.POINTER(Counters), C.c_int]
+        L.orc_render_ex.argtypes = [C.POINTER(Frame)] + [C.c_int] * 4 + [C.c_void_p] * 5 + [C.POINTER(Counters), C.c_int]
         L.orc_hdr_decode.argtypes = [u8p, C.c_long, ip, ip, C.c_void_p]
         L.orc_hdr_encode.restype = C.c_long
         L.orc_hdr_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -309,7 +310,7 @@ class EnvSet:
 
 
 def render(scene, w, h, time, max_steps, env: EnvSet, rect=None, nthreads=0, want_f32=True):
-    """Returns dict(rgba_f32, rgba8, steps, iters, counters); arrays are (h, w[,4]), row 0 = bottom."""
+    """Returns dict(rgba_f32, rgba8, steps, iters, iters_march, counters); arrays are (h, w[,4]), row 0 = bottom."""
     x0, y0, x1, y1 = rect if rect is not None else (0, 0, w, h)
     f = Frame()
     f.scene, f.w, f.h, f.time, f.max_steps = scene, w, h, float(time), max_steps
@@ -320,9 +321,10 @@ def render(scene, w, h, time, max_steps, env: EnvSet, rect=None, nthreads=0, wan
     rgba8 = np.zeros((h, w), np.uint32)
     steps = np.zeros((h, w), np.uint16)
     iters = np.zeros((h, w), np.uint16)
+    iters_march = np.zeros((h, w), np.uint16)
     ctr = Counters()
-    rc = lib().orc_render(C.byref(f), x0, y0, x1, y1, rgba.ctypes.data if want_f32 else None,
-                          rgba8.ctypes.data, steps.ctypes.data, iters.ctypes.data, C.byref(ctr), nthreads)
+    rc = lib().orc_render_ex(C.byref(f), x0, y0, x1, y1, rgba.ctypes.data if want_f32 else None,
+                             rgba8.ctypes.data, steps.ctypes.data, iters.ctypes.data, iters_march.ctypes.data, C.byref(ctr), nthreads)
     if rc != 0:
         raise RuntimeError("orc_render failed rc=%d" % rc)
-    return {"rgba_f32": rgba, "rgba8": rgba8, "steps": steps, "iters": iters, "counters": ctr.as_dict()}
+    return {"rgba_f32": rgba, "rgba8": rgba8, "steps": steps, "iters": iters, "iters_march": iters_march, "counters": ctr.as_dict()}

@@ -932,7 +932,7 @@ void orc_camera(int scene, float time, float out[12])
 typedef struct {
     v3       dir;
     int      hit, steps, entered;
-    unsigned iters;
+    unsigned iters, iters_march;
     v3       n, refl;
     float    ao, fresnel;
 } px_state;
@@ -942,7 +942,7 @@ typedef struct {
     int      x0, y0, x1, y1;
     float   *rgba_f32;
     uint32_t *rgba8;
-    uint16_t *steps, *iters;
+    uint16_t *steps, *iters, *iters_march;
     float    cam[12];
     float    fov_xs;
     int      qrow_lo, qrow_hi;      /* quad rows [lo,hi), in units of 2 pixel rows */
@@ -974,6 +974,7 @@ static void trace_pixel(render_job *j, int px, int py, px_state *s)
     memset(s, 0, sizeof *s);
     s->dir = generate_ray_dir(j, px, py);
     s->hit = ray_march(origin, s->dir, f->max_steps, &c, &t, &s->steps, &s->entered, &march_steps);
+    s->iters_march = (unsigned)c.triplex_iters;      /* iterations spent inside ray_march alone (normal / AO taps follow) */
     if (s->hit) {
         /* render_ray, fragment.shd:743-799 */
         v3 isec = V3(origin.x + s->dir.x * t, origin.y + s->dir.y * t, origin.z + s->dir.z * t);
@@ -1048,6 +1049,7 @@ static void *render_worker(void *arg)
                     j->rgba8[idx] = to_unorm8(g[0]) | (to_unorm8(g[1]) << 8) | (to_unorm8(g[2]) << 16) | 0xff000000u;
                 if (j->steps) j->steps[idx] = (uint16_t)(q[k].steps | (q[k].hit << 15));
                 if (j->iters) j->iters[idx] = (uint16_t)(q[k].iters > 65535u ? 65535u : q[k].iters);
+                if (j->iters_march) j->iters_march[idx] = (uint16_t)(q[k].iters_march > 65535u ? 65535u : q[k].iters_march);
             }
         }
     return NULL;
@@ -1103,6 +1105,12 @@ static void render_set_range(void *job, int lo, int hi)
 int orc_render(const orc_frame *f, int x0, int y0, int x1, int y1, float *rgba_f32, uint32_t *rgba8,
                uint16_t *steps, uint16_t *iters, orc_counters *ctr, int nthreads)
 {
+    return orc_render_ex(f, x0, y0, x1, y1, rgba_f32, rgba8, steps, iters, NULL, ctr, nthreads);
+}
+
+int orc_render_ex(const orc_frame *f, int x0, int y0, int x1, int y1, float *rgba_f32, uint32_t *rgba8,
+                  uint16_t *steps, uint16_t *iters, uint16_t *iters_march, orc_counters *ctr, int nthreads)
+{
     if (!f || f->w <= 0 || f->h <= 0 || f->max_steps < 0 || f->max_steps > 32767) return -1;
     if (f->scene < 0 || f->scene > 3) return -2;
     if (x0 < 0 || y0 < 0 || x1 > f->w || y1 > f->h || x0 > x1 || y0 > y1) return -3;
@@ -1110,7 +1118,7 @@ int orc_render(const orc_frame *f, int x0, int y0, int x1, int y1, float *rgba_f
     if (!jobs) return -4;
     jobs[0].f = f;
     jobs[0].x0 = x0; jobs[0].y0 = y0; jobs[0].x1 = x1; jobs[0].y1 = y1;
-    jobs[0].rgba_f32 = rgba_f32; jobs[0].rgba8 = rgba8; jobs[0].steps = steps; jobs[0].iters = iters;
+    jobs[0].rgba_f32 = rgba_f32; jobs[0].rgba8 = rgba8; jobs[0].steps = steps; jobs[0].iters = iters; jobs[0].iters_march = iters_march;
     orc_camera(f->scene, f->time, jobs[0].cam);
     jobs[0].fov_xs = orc_fov_xs();
     (void)cornell_table();

@@ -87,6 +87,13 @@ int orc_render(const orc_frame *f, int x0, int y0, int x1, int y1,
                float *rgba_f32, uint32_t *rgba8, uint16_t *steps, uint16_t *iters,
                orc_counters *ctr, int nthreads);
 
+/* Same, plus iters_march (may be NULL): the Mandelbulb iterations the pixel spent inside ray_march alone (the `iters`
+ * plane adds the four normal taps and the two AO taps of hit pixels).  Used to pin the escape-iteration counts against the
+ * reference shader run on SwiftShader, whose near-surface normal / AO taps are chaotic (tests/test_oracle_vs_glsl.py). */
+int orc_render_ex(const orc_frame *f, int x0, int y0, int x1, int y1,
+                  float *rgba_f32, uint32_t *rgba8, uint16_t *steps, uint16_t *iters, uint16_t *iters_march,
+                  orc_counters *ctr, int nthreads);
+
 /* Single-point probes for known-answer tests */
 float orc_de(int scene, float time, const float pos[3]);
 void  orc_triplex_pow8(const float w[3], float out[3]);

@@ -661,3 +661,30 @@ def test_exchange_behind_the_c_abi_world_size_one(sr, rmdf):
         assert r.comm_info() == (0, 0)
     finally:
         r.close()
+
+
+SS_CASES = sorted(glob.glob(os.path.join(GOLD, "swiftshader_s[0-2]_*.npz")))
+
+
+@pytest.mark.parametrize("fn", SS_CASES, ids=[os.path.basename(c)[:-4] for c in SS_CASES])
+def test_hip_planes_vs_reference_shader_fixtures(sr, fn):
+    """The HIP kernel's steps / hit / escape-iteration planes compared DIRECTLY with what the reference's own fragment.shd
+    produced on SwiftShader (tests/golden/swiftshader_*.npz, made by make_swiftshader_vectors.py from
+    /root/reference/fragment.shd; the oracle is not involved): hit mask identical, march step counts identical (<= 8 px off
+    by one), escape-iteration totals identical on every missed pixel and on >= 97 % of the hit pixels (whose normal / AO
+    taps sit on the fractal surface, see tests/test_oracle_vs_glsl.py)."""
+    m = re.match(r"swiftshader_s(\d)_(\d+)x(\d+)_t(\d+)p(\d+)_m(\d+)\.npz", os.path.basename(fn))
+    scene, w, h, t, ms = int(m.group(1)), int(m.group(2)), int(m.group(3)), float(m.group(4) + "." + m.group(5)), int(m.group(6))
+    g = np.load(fn)
+    got = sr.render(scene, w, h, t, max_steps=ms, want_f32=False)
+    hit = (got["steps"] >> 15).astype(bool)
+    ds = np.abs((got["steps"] & 0x7FFF).astype(int) - g["steps"].astype(int))
+    assert np.array_equal(hit, g["hit"])
+    assert (ds > 0).sum() <= 8 and ds.max() <= 1
+    di = got["iters"].astype(int) - g["iters"].astype(int)
+    if scene == 2:
+        assert not di[~hit].any()
+        assert (di[hit] != 0).mean() < 0.03
+        assert abs(int(got["iters"].sum()) - int(g["iters"].sum())) < 2e-4 * int(g["iters"].sum())
+    else:
+        assert not got["iters"].any() and not g["iters"].any()

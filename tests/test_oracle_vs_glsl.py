@@ -6,6 +6,12 @@ What this pins, with an actual execution of the reference shader:
   * the hit mask: identical, every pixel, every case of FSMBPower8Shader, FSDECornellBoxShader, FSDETestShader;
   * the march step count of every ray: identical (<= 3 pixels per frame may differ by one step -- SwiftShader's
     inversesqrt / log are approximations, so a ray that ends within an ulp of MIN_DIST can flip);
+  * the escape-iteration counts (north star: "bit-exact on escape-iteration counts"), read back from the shader's own
+    de_mandelbulb loop (fragment.shd:134-152) through a counter the fixture script adds: the iterations every ray spends
+    in ray_march are identical on every pixel of the power-8 frames (<= 8 pixels of 129 600 differ: rays that end within an
+    ulp of MIN_DIST); the per-pixel total that adds the four normal taps and two AO taps is identical on every missed
+    pixel and on ~99 % of the hit pixels (those taps sit on the fractal surface, where one differing last bit of
+    SwiftShader's approximate inversesqrt / log changes the escape iteration -- SURVEY.md H1);
   * the background colour (one cube-map lookup, gamma): equal to ~1e-6 wherever both sides magnify; the min/mag
     decision itself is implementation-defined near rho = 1, so low-resolution frames are checked statistically;
   * the surface colour statistically: the shader differentiates a fractal distance field with eps = 1e-5 in float32
@@ -53,6 +59,18 @@ def test_oracle_matches_reference_shader_on_swiftshader(orc, env_oracle, fn):
     else:
         assert np.array_equal(hit, g["hit"])                               # hit mask: identical
         assert (dsteps > 0).sum() <= 8 and dsteps.max() <= 1               # march length: identical (see docstring)
+    # escape-iteration counts, from the reference shader's own loop counter
+    di = r["iters"].astype(int) - g["iters"].astype(int)
+    dm = r["iters_march"].astype(int) - g["iters_march"].astype(int)
+    if scene in (0, 1):
+        assert not r["iters"].any() and not g["iters"].any()               # no Mandelbulb in these scenes
+    elif scene == 2:
+        assert (dm != 0).sum() <= 16, (dm != 0).sum()                       # march iterations: identical (observed <= 8 of 129 600)
+        assert not di[~(hit | g["hit"])].any()                              # totals on missed pixels: identical
+        assert (di[hit] != 0).mean() < 0.03                                 # + normal / AO taps on the surface (observed 1.3 %)
+        assert abs(int(r["iters"].sum()) - int(g["iters"].sum())) < 2e-4 * int(g["iters"].sum())
+    else:
+        assert (dm != 0).mean() < 0.08 and abs(int(r["iters"].sum()) - int(g["iters"].sum())) < 2e-3 * int(g["iters"].sum())
     rgb = r["rgba_f32"][..., :3]
     rel = _rel(rgb, g["rgb16"].astype(np.float32))
     # quads in which every pixel missed: the lookup derivative is well defined on both sides
