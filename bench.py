@@ -47,7 +47,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_TLANEOPS = 78.6       # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (157.3 TFLOPS only if every op were an FMA)
 VALU_ISSUE_PEAK = 0.93          # G wave-instructions/s/SIMD a stream of simple VALU instructions sustains (tools/ubench/valu_rates)
-MIN_WARM_SECONDS = 0.3
+MIN_WARM_SECONDS = float(os.environ.get("RMDF_BENCH_MIN_WARM", "0.3"))   # profiling runs shorten it
 
 # as-written operation counters of the headline frame (scene 2, 1920x1080, in_time 0, 256 steps), counted by the
 # instrumented oracle (tests/golden/full_size_digests.json holds the same numbers; `--check` or the cpu_baseline leg
@@ -299,6 +299,7 @@ def main():
         else:
             exchange = "torch.distributed gather (%s)" % ("gloo, host-staged: test aid" if share_gpu else "nccl = RCCL")
     frame = frames[0]
+    torch.cuda.synchronize(dev)                              # the zero fills above ran on torch's stream, not on the frame streams
 
     def resolve(src, sw, sh, dst, tmp, sp):
         """`L` box-filter levels from src (sw x sh) into dst, ping-ponging through tmp"""

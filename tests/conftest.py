@@ -4,6 +4,14 @@ import sys
 import numpy as np
 import pytest
 
+try:
+    # PyTorch bundles its own copy of the HIP runtime (same soname as the system's): it must be loaded BEFORE librmdf.so
+    # pulls in the system one, or the process ends up with two runtimes and torch finds no GPU afterwards.  The tests use
+    # torch only for device buffers and streams; the product never imports it.
+    import torch  # noqa: F401
+except Exception:                                       # noqa: BLE001
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

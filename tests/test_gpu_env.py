@@ -16,6 +16,15 @@ from conftest import ENV_CACHE, rel_err
 
 pytestmark = pytest.mark.gpu
 
+
+def dev_zeros(*a, **k):
+    """torch.zeros on the GPU, finished before it is handed to the library: torch fills on ITS current stream, the library
+    renders on its own non-blocking streams, which do not wait for it."""
+    import torch
+    t = torch.zeros(*a, **k)
+    torch.cuda.synchronize()
+    return t
+
 POWERS = (1.0, 8.0, 64.0, 512.0)
 
 

@@ -14,6 +14,15 @@ from conftest import GOLD, rel_err
 
 pytestmark = pytest.mark.gpu
 
+
+def dev_zeros(*a, **k):
+    """torch.zeros on the GPU, finished before it is handed to the library: torch fills on ITS current stream, the library
+    renders on its own non-blocking streams, which do not wait for it."""
+    import torch
+    t = torch.zeros(*a, **k)
+    torch.cuda.synchronize()
+    return t
+
 REL_TOL = 1e-4       # BASELINE.json: "within 1e-4 relative on float colour"
 
 
@@ -144,17 +153,17 @@ def test_device_resident_and_shard_paths(sr, rmdf):
     ts = torch.cuda.Stream(dev)
     torch.cuda.set_stream(ts)
     s = ts.cuda_stream
-    full = torch.zeros((h, w), dtype=torch.int32, device=dev)
+    full = dev_zeros((h, w), dtype=torch.int32, device=dev)
     sr.render_rect_device(2, w, h, 0.0, ms, (0, 0, w, h), d_rgba8=full.data_ptr(), stream=s)
     torch.cuda.synchronize()
     ref = sr.render(2, w, h, 0.0, max_steps=ms)["rgba8"]
     assert np.array_equal(full.cpu().numpy().view(np.uint32), ref)
     for n in (1, 2, 3, 8):
         slots = rmdf.shard_slots(n)
-        gathered = torch.zeros((n, slots, h // 8, w // 8), dtype=torch.int32, device=dev)
+        gathered = dev_zeros((n, slots, h // 8, w // 8), dtype=torch.int32, device=dev)
         for r in range(n):
             sr.render_shard_device(2, w, h, 0.0, ms, r, n, gathered[r].data_ptr(), stream=s)
-        frame = torch.zeros((h, w), dtype=torch.int32, device=dev)
+        frame = dev_zeros((h, w), dtype=torch.int32, device=dev)
         sr.assemble_shards_device(w, h, n, gathered.data_ptr(), frame.data_ptr(), stream=s)
         torch.cuda.synchronize()
         assert np.array_equal(frame.cpu().numpy().view(np.uint32), ref), "nranks=%d" % n
@@ -237,12 +246,12 @@ def test_supersample_resolve(sr, orc, rmdf):
     dev = torch.device("cuda", 0)
     ts = torch.cuda.Stream(dev); torch.cuda.set_stream(ts); s = ts.cuda_stream
     slots = rmdf.shard_slots(n)
-    gathered = torch.zeros((n, slots, H // 8, W // 8), dtype=torch.int32, device=dev)
+    gathered = dev_zeros((n, slots, H // 8, W // 8), dtype=torch.int32, device=dev)
     for r in range(n):
-        big = torch.zeros((slots, 2 * H // 8, 2 * W // 8), dtype=torch.int32, device=dev)
+        big = dev_zeros((slots, 2 * H // 8, 2 * W // 8), dtype=torch.int32, device=dev)
         sr.render_shard_device(2, 2 * W, 2 * H, 0.0, ms, r, n, big.data_ptr(), stream=s)
         sr.resolve_box2_device(big.data_ptr(), 2 * W // 8, slots * 2 * H // 8, gathered[r].data_ptr(), stream=s)
-    frame = torch.zeros((H, W), dtype=torch.int32, device=dev)
+    frame = dev_zeros((H, W), dtype=torch.int32, device=dev)
     sr.assemble_shards_device(W, H, n, gathered.data_ptr(), frame.data_ptr(), stream=s)
     torch.cuda.synchronize()
     assert np.array_equal(frame.cpu().numpy().view(np.uint32), sr.render_supersampled(2, W, H, 1, 0.0, max_steps=ms))
@@ -302,7 +311,7 @@ def test_frames_in_flight_and_ordered_shards(sr, rmdf):
     dev = torch.device("cuda", 0)
     ref = sr.render(2, w, h, 0.0, max_steps=ms)["rgba8"]
     streams = [torch.cuda.Stream(dev) for _ in range(3)]
-    bufs = [torch.zeros((h, w), dtype=torch.int32, device=dev) for _ in range(3)]
+    bufs = [dev_zeros((h, w), dtype=torch.int32, device=dev) for _ in range(3)]
     for rep in range(3):                 # rep 0: raster order on every stream; later: ordered, overlapping launches
         for b in bufs:
             b.zero_()
@@ -316,7 +325,7 @@ def test_frames_in_flight_and_ordered_shards(sr, rmdf):
     n = 2
     slots = rmdf.shard_slots(n)
     for rep in range(3):
-        gathered = torch.zeros((n, slots, h // 8, w // 8), dtype=torch.int32, device=dev)
+        gathered = dev_zeros((n, slots, h // 8, w // 8), dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
         for r in range(n):
             sr.render_shard_device(2, w, h, 0.0, ms, r, n, gathered[r].data_ptr(), stream=streams[r].cuda_stream)
@@ -325,7 +334,7 @@ def test_frames_in_flight_and_ordered_shards(sr, rmdf):
     # 8 ranks on ONE stream: the key (first tile, stride) changes every launch -> raster; then the same rank twice -> ordered
     n = 8
     slots = rmdf.shard_slots(n)
-    gathered = torch.zeros((n, slots, h // 8, w // 8), dtype=torch.int32, device=dev)
+    gathered = dev_zeros((n, slots, h // 8, w // 8), dtype=torch.int32, device=dev)
     s = streams[0].cuda_stream
     for r in range(n):
         for _ in range(2):
@@ -354,10 +363,10 @@ def test_cost_aware_tile_deal(sr, rmdf):
             load = lambda deal: max(sum(cost[t] for t in ts) for ts in deal)
             assert load(tiles) <= load([rmdf.shard_tiles(r, n) for r in range(n)])
             slots = rmdf.shard_slots(n)
-            gathered = torch.zeros((n, slots, h // 8, w // 8), dtype=torch.int32, device=dev)
+            gathered = dev_zeros((n, slots, h // 8, w // 8), dtype=torch.int32, device=dev)
             for r in range(n):
                 sr.render_shard_device(2, w, h, 0.0, ms, r, n, gathered[r].data_ptr())
-            frame = torch.zeros((h, w), dtype=torch.int32, device=dev)
+            frame = dev_zeros((h, w), dtype=torch.int32, device=dev)
             sr.assemble_shards_device(w, h, n, gathered.data_ptr(), frame.data_ptr())
             sr.synchronize()
             assert np.array_equal(frame.cpu().numpy().view(np.uint32), ref), n
@@ -407,12 +416,12 @@ def test_config4_full_size_sharded_supersample(sr, rmdf, orc, env_oracle):
     try:
         sr.set_shard_costs(sr.probe_tile_costs(2, 2 * W, 2 * H, 0.0, ms))
         slots = rmdf.shard_slots(n)
-        gathered = torch.zeros((n, slots, H // 8, W // 8), dtype=torch.int32, device=dev)
-        big = torch.zeros((slots, 2 * H // 8, 2 * W // 8), dtype=torch.int32, device=dev)
+        gathered = dev_zeros((n, slots, H // 8, W // 8), dtype=torch.int32, device=dev)
+        big = dev_zeros((slots, 2 * H // 8, 2 * W // 8), dtype=torch.int32, device=dev)
         for r in range(n):
             sr.render_shard_device(2, 2 * W, 2 * H, 0.0, ms, r, n, big.data_ptr())
             sr.resolve_box2_device(big.data_ptr(), 2 * W // 8, slots * 2 * H // 8, gathered[r].data_ptr())
-        frame = torch.zeros((H, W), dtype=torch.int32, device=dev)
+        frame = dev_zeros((H, W), dtype=torch.int32, device=dev)
         sr.assemble_shards_device(W, H, n, gathered.data_ptr(), frame.data_ptr())
         sr.synchronize()
         assert np.array_equal(frame.cpu().numpy().view(np.uint32), ref)
@@ -612,7 +621,7 @@ def test_alternative_schedules_live_in_the_xcheck_library_only(rmdf, sr_alt, sr_
         assert L.rmdf_create(C.byref(ctx), C.byref(cfg)) == -6 and not ctx.value
     assert sr_alt.xcheck and sr_pipe.xcheck
     st = torch.cuda.Stream()
-    buf = torch.zeros((72, 128), dtype=torch.int32, device="cuda")
+    buf = dev_zeros((72, 128), dtype=torch.int32, device="cuda")
     for r in (sr_alt, sr_pipe):
         with pytest.raises(rmdf.RmdfError) as e:
             r.render_rect_device(2, 128, 72, 0.0, 64, (0, 0, 128, 72), d_rgba8=buf.data_ptr(), stream=st.cuda_stream)
@@ -636,9 +645,9 @@ def test_exchange_behind_the_c_abi_world_size_one(sr, rmdf):
             pad = sr.get_env_cube_padded(slot)
             r.set_env_cube(slot, pad.view(np.float16)[:, 1:-1, 1:-1, :3].astype(np.float32))
         assert r.comm_info() == (0, 0)
-        shard = torch.zeros((64, h // 8, w // 8), dtype=torch.int32, device="cuda")
-        gathered = torch.zeros((1, 64, h // 8, w // 8), dtype=torch.int32, device="cuda")
-        frame = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+        shard = dev_zeros((64, h // 8, w // 8), dtype=torch.int32, device="cuda")
+        gathered = dev_zeros((1, 64, h // 8, w // 8), dtype=torch.int32, device="cuda")
+        frame = dev_zeros((h, w), dtype=torch.int32, device="cuda")
         with pytest.raises(rmdf.RmdfError) as e:
             r.render_frame_sharded_device(2, w, h, 0.0, ms, shard.data_ptr(), gathered.data_ptr(), frame.data_ptr())
         assert e.value.code == -8                                                   # RMDF_E_COMM: no communicator yet
