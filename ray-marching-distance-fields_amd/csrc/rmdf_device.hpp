@@ -726,6 +726,15 @@ __device__ __forceinline__ void cube_project(int face, v3 q, float &sc, float &t
 
 __device__ __forceinline__ float cube_texcoord(float c, float ama, float W) { return (0.5f * (c / ama + 1.0f)) * W; }
 
+// RMDF_AB_NO_TEXEL_FETCH (tools/abtest only, never defined in the product build): every texel read is replaced by a value
+// made from its address -- no memory access at all.  The frame is wrong, of course; the build exists to measure an UPPER
+// BOUND of what any staging of env-map texels (LDS or otherwise) could save: DESIGN.md 4.1.
+#ifdef RMDF_AB_NO_TEXEL_FETCH
+#define RMDF_TEXEL(ptr) make_uint2((unsigned)(size_t)(ptr) & 0x3bff3bffu, 0x3c00u)
+#else
+#define RMDF_TEXEL(ptr) (*(ptr))
+#endif
+
 __device__ __forceinline__ v3 texel_rgb(uint2 t)
 {
     __half2 rg = *reinterpret_cast<__half2 *>(&t.x);
@@ -742,7 +751,7 @@ __device__ __forceinline__ v3 cube_fetch_nearest(const CubeDev &c, int face, flo
     if (!(fj >= 0.0f)) fj = 0.0f;
     if (fj > Wm1) fj = Wm1;
     int P = c.W + 2;
-    return texel_rgb(c.texels[(face * P + ((int)fj + 1)) * P + ((int)fi + 1)]);
+    return texel_rgb(RMDF_TEXEL(&c.texels[(face * P + ((int)fj + 1)) * P + ((int)fi + 1)]));
 }
 
 __device__ __forceinline__ v3 cube_fetch_linear(const CubeDev &c, int face, float u, float v)
@@ -758,8 +767,8 @@ __device__ __forceinline__ v3 cube_fetch_linear(const CubeDev &c, int face, floa
     float gu = 1.0f - fu, gv = 1.0f - fv;
     int P = c.W + 2;
     const uint2 *row0 = c.texels + (face * P + ((int)fj + 1)) * P + ((int)fi + 1);
-    v3 t00 = texel_rgb(row0[0]), t10 = texel_rgb(row0[1]);
-    v3 t01 = texel_rgb(row0[P]), t11 = texel_rgb(row0[P + 1]);
+    v3 t00 = texel_rgb(RMDF_TEXEL(row0)), t10 = texel_rgb(RMDF_TEXEL(row0 + 1));
+    v3 t01 = texel_rgb(RMDF_TEXEL(row0 + P)), t11 = texel_rgb(RMDF_TEXEL(row0 + P + 1));
     v3 o;
     o.x = (t00.x * gu + t10.x * fu) * gv + (t01.x * gu + t11.x * fu) * fv;
     o.y = (t00.y * gu + t10.y * fu) * gv + (t01.y * gu + t11.y * fu) * fv;

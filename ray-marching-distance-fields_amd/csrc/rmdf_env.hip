@@ -180,8 +180,11 @@ hipError_t launch_resize_latlong(const float *d_src, int sw, int sh, int dstw, i
 // source texels with a positive cosine.  Float addition is not associative, so the only parallelism that keeps the
 // reference's bits is across DESTINATION texels: one lane per destination texel walks all source texels in the
 // reference's order (y outer, x inner) with its four accumulators (r, g, b, n).  One wavefront = 64 neighbouring
-// destination columns of one row; a workgroup = one wavefront (the machine holds two of them per CU at 256x128, more
-// at larger sizes; rmdf_prefilter_env_powers runs the four powers concurrently like the reference's mapConcurrently).
+// destination columns of one row; a workgroup = four wavefronts = four rows of the same columns, which share the staged
+// cosine table and land on the four SIMDs of a CU (single-wave workgroups were all placed on the same SIMD of their CU and
+// shared its issue slots: 1.16 ms per power at 256x128 instead of 0.6).  At 256x128 one power is 512 waves, half the
+// machine's SIMDs; rmdf_prefilter_env_powers runs the four powers concurrently (the reference's mapConcurrently), which
+// fills it.
 //
 //   lutT[(blk * w + x) * 64 + lane] = cos |phi_L(blk*64+lane) - phi(x)|      (absPhiDiffCosLookup, host glibc cosf)
 //   tcs[y] = (cos theta_y, sin theta_y)                                        (host glibc cosf / sinf)
@@ -191,61 +194,105 @@ hipError_t launch_resize_latlong(const float *d_src, int sw, int sh, int dstw, i
 // cos^p: LOG2P >= 0 -> p = 2^LOG2P by LOG2P squarings in binary64 rounded once to binary32 -- the spec pin for the
 // reference's powers 1, 8, 64, 512 (FP64 vector multiplies issue at the FP32 rate on gfx950);
 // LOG2P = -1 -> device powf (any other power: tolerance parity only).
-// The inner loop is branch-free: texels with a non-positive cosine add a selected +0 (x + 0 == x: the same bits as
-// skipping them) and the sample count grows by a selected 1 or 0, so eight iterations' loads and multiplies are in
-// flight at once.
+// The inner loop is branch-free (see the comment in the kernel), so eight iterations' loads and multiplies are in flight at once.
 // ------------------------------------------------------------------------------------
+#define PREFILTER_WAVES 4            // destination rows (waves) per workgroup; they share the staged cosine table
+
 template <int LOG2P, bool LUT_IN_LDS>
-__global__ __launch_bounds__(64) void k_prefilter(const float *__restrict__ src, int w, int h, float power,
+__global__ __launch_bounds__(64 * PREFILTER_WAVES) void k_prefilter(const float *__restrict__ src, int w, int h, float power,
                                                   const float *__restrict__ lutT, const float2 *__restrict__ tcs,
                                                   float *__restrict__ out)
 {
     extern __shared__ float lds_lut[];                  // [w][64] when LUT_IN_LDS
-    const int lane = threadIdx.x;
-    const int blk = blockIdx.x, dy = blockIdx.y;
+    // the wave index is wave-uniform, but the compiler cannot know that of threadIdx.x >> 6: say so, or every address
+    // derived from it is treated as divergent and read with per-lane vector loads
+    const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int blk = blockIdx.x, dy = blockIdx.y * PREFILTER_WAVES + g;
     const int dx = blk * 64 + lane;
     const float *glut = lutT + (size_t)blk * w * 64;
     if (LUT_IN_LDS) {
-        for (int x = 0; x < w; x++) lds_lut[x * 64 + lane] = glut[x * 64 + lane];
+        for (int i = threadIdx.x; i < w * 64; i += 64 * PREFILTER_WAVES) lds_lut[i] = glut[i];
         __syncthreads();
     }
+    if (dy >= h) return;
     typedef const float __attribute__((address_space(4))) cfloat;      // wave-uniform, read-only: scalar loads
     const float lc = ((cfloat *)tcs)[2 * dy], ls = ((cfloat *)tcs)[2 * dy + 1];
-    float ar = 0.0f, ag = 0.0f, ab = 0.0f, n = 0.0f;
+    // A lone wave issues one instruction every ~5 cycles whatever it is, so the inner loop is written for few instructions:
+    //   * the branch `if cosAngle > 0` becomes a clamp: c0 = max(cosAngle, 0) makes cos^p, the factor and the three products
+    //     +-0, and x + (+-0) == x -- the same bits as skipping the texel (finite texels: Radiance RGBE cannot encode others);
+    //   * (r, g) accumulate as one packed pair (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per instruction);
+    //   * the sample count n is an integer add-with-carry on the compare's mask (the reference counts in Float: exact below
+    //     2^24, where a Float counter stops growing -- restored at the end).
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 arg = { 0.0f, 0.0f };
+    float ab = 0.0f;
+    unsigned ni = 0u;
     for (int y = 0; y < h; y++) {
         const float pc = ((cfloat *)tcs)[2 * y], ps = ((cfloat *)tcs)[2 * y + 1];
         const float lcpc = lc * pc, lsps = ls * ps;
         cfloat *row = (cfloat *)(src + (size_t)y * w * 3);
         if (LOG2P >= 0) {
-#pragma unroll 8
-            for (int x = 0; x < w; x++) {
-                const float l = LUT_IN_LDS ? lds_lut[x * 64 + lane] : glut[x * 64 + lane];
+            // one texel: the reference's arithmetic, operation for operation
+            auto texel = [&](float l, float r, float g, float b) {
                 const float cos_angle = lcpc + lsps * l;
-                const bool pos = cos_angle > 0.0f;
-                float cp = cos_angle;
+                ni += (cos_angle > 0.0f) ? 1u : 0u;
+                const float c0 = __builtin_fmaxf(cos_angle, 0.0f);
+                float cp = c0;
                 if (LOG2P > 0) {
-                    double cd = (double)cos_angle;
+                    double cd = (double)c0;
 #pragma unroll
                     for (int k = 0; k < LOG2P; k++) cd = cd * cd;
                     cp = (float)cd;
                 }
                 const float fac = ps * cp;
-                const float tr = row[x * 3] * fac, tg = row[x * 3 + 1] * fac, tb = row[x * 3 + 2] * fac;
-                ar = ar + (pos ? tr : 0.0f); ag = ag + (pos ? tg : 0.0f); ab = ab + (pos ? tb : 0.0f);
-                n = n + (pos ? 1.0f : 0.0f);
+                const f2 rg = { r, g };
+                const f2 fac2 = { fac, fac };
+                arg = arg + rg * fac2;
+                ab = ab + b * fac;
+            };
+            // Eight texels per trip, software-pipelined: the scalar loads of the source row and the cosine-table reads of
+            // trip i + 1 are issued before trip i computes, so a lone wave does not sit through their latency every trip
+            // (scalar loads of the next ROW's first chunk are harmless: the last row is followed by w * 3 floats of padding
+            // only when another row exists, so the prefetch is skipped on the last trip of the last row).
+            const int w8 = w & ~7;
+            float rn[24], ln[8];
+            if (w8 > 0) {
+#pragma unroll
+                for (int k = 0; k < 24; k++) rn[k] = row[k];
+#pragma unroll
+                for (int k = 0; k < 8; k++) ln[k] = LUT_IN_LDS ? lds_lut[k * 64 + lane] : glut[k * 64 + lane];
             }
+            for (int x = 0; x < w8; x += 8) {
+                float rc[24], lc8[8];
+#pragma unroll
+                for (int k = 0; k < 24; k++) rc[k] = rn[k];
+#pragma unroll
+                for (int k = 0; k < 8; k++) lc8[k] = ln[k];
+                if (x + 8 < w8) {
+#pragma unroll
+                    for (int k = 0; k < 24; k++) rn[k] = row[(x + 8) * 3 + k];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) ln[k] = LUT_IN_LDS ? lds_lut[(x + 8 + k) * 64 + lane] : glut[(x + 8 + k) * 64 + lane];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) texel(lc8[k], rc[3 * k], rc[3 * k + 1], rc[3 * k + 2]);
+            }
+            for (int x = w8; x < w; x++)
+                texel(LUT_IN_LDS ? lds_lut[x * 64 + lane] : glut[x * 64 + lane], row[x * 3], row[x * 3 + 1], row[x * 3 + 2]);
         } else {
             for (int x = 0; x < w; x++) {
                 const float l = LUT_IN_LDS ? lds_lut[x * 64 + lane] : glut[x * 64 + lane];
                 const float cos_angle = lcpc + lsps * l;
                 if (cos_angle > 0.0f) {
                     const float fac = ps * powf(cos_angle, power);
-                    ar = ar + row[x * 3] * fac; ag = ag + row[x * 3 + 1] * fac; ab = ab + row[x * 3 + 2] * fac;
-                    n = n + 1.0f;
+                    arg.x = arg.x + row[x * 3] * fac; arg.y = arg.y + row[x * 3 + 1] * fac; ab = ab + row[x * 3 + 2] * fac;
+                    ni++;
                 }
             }
         }
     }
+    const float ar = arg.x, ag = arg.y;
+    const float n = (float)(ni < 16777216u ? ni : 16777216u);       // a Float counter: n + 1 == n from 2^24 on
     if (dx < w) {
         float *o = out + ((size_t)dx + (size_t)dy * w) * 3;
         o[0] = ar / n; o[1] = ag / n; o[2] = ab / n;
@@ -265,7 +312,7 @@ template <int LOG2P>
 static hipError_t launch_prefilter_t(const float *d_src, int w, int h, float power, const float *d_lutT, const float2 *d_tcs,
                                      float *d_out, hipStream_t stream)
 {
-    const dim3 grid((w + 63) / 64, h), block(64);
+    const dim3 grid((w + 63) / 64, (h + PREFILTER_WAVES - 1) / PREFILTER_WAVES), block(64 * PREFILTER_WAVES);
     const size_t lds = (size_t)w * 64 * sizeof(float);
     if (lds <= 64 * 1024) {          // two workgroups per CU keep their slice in LDS; wider maps read it through L2
         hipError_t e = hipFuncSetAttribute((const void *)k_prefilter<LOG2P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense the raw rocprofv3 output of tools/profile.sh into the files kept under profiles/.
 usage: pmc_summary.py gpurun_out/prof_<tag> <tag>   -> gpurun_out/prof_<tag>/summary/{<tag>_*.csv, pmc_traffic.json}"""
-import csv, glob, json, os, shutil, statistics, sys
+import csv, glob, hashlib, json, os, shutil, statistics, sys
 
 src, tag = sys.argv[1], sys.argv[2]
 dst = os.path.join(src, "summary")
@@ -26,6 +26,17 @@ for name in ("bench_s1.json", "bench_default.json"):
             open(os.path.join(dst, "%s_%s" % (tag, name)), "w").write(lines[-1])
 
 counters = {}
+# Cornell box (config 2): the SQ counters of k_render<0, ...>
+f = one("pmc_sq_cornell/**/*_counter_collection.csv")
+cornell = {}
+if f:
+    per = {}
+    for r in csv.DictReader(open(f)):
+        if "k_render<0" in r["Kernel_Name"]:
+            per.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+            per[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    cornell = {c: statistics.median(d.values()) for c, d in per.items()}
+
 for grp in ("pmc_fetch", "pmc_write", "pmc_sq"):
     f = one(grp + "/**/*_counter_collection.csv")
     if not f:
@@ -51,7 +62,10 @@ for grp in ("pmc_fetch", "pmc_write", "pmc_sq"):
                                            "SGPR_Count": rows[0]["SGPR_Count"], "LDS_Block_Size": rows[0]["LDS_Block_Size"],
                                            "Workgroup_Size": rows[0]["Workgroup_Size"], "Grid_Size": rows[0]["Grid_Size"]})
 
-out = {"workload": [2, 1920, 1080, 256], "kernel": "rmdf::k_render<2, true, 4>",
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "ray-marching-distance-fields_amd", "librmdf.so")
+out = {"workload": [2, 1920, 1080, 256], "kernel": "rmdf::k_render<2, true, 0> (scene 2, MERGE, OUT_RGBA8)",
+       "lib_sha256": hashlib.sha256(open(LIB, "rb").read()).hexdigest(),
        "command": "tools/profile.sh %s (rocprofv3 --pmc <one group per run> -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --streams 1)" % tag,
        "counters_per_launch": counters}
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
@@ -67,5 +81,8 @@ if "SQ_INSTS_VALU" in counters and "SQ_THREAD_CYCLES_VALU" in counters:
     out["valu"] = {"SQ_INSTS_VALU_per_launch": counters["SQ_INSTS_VALU"]["median"],
                    "lane_utilisation": counters["SQ_THREAD_CYCLES_VALU"]["median"] / (64.0 * counters["SQ_ACTIVE_INST_VALU"]["median"])
                    if "SQ_ACTIVE_INST_VALU" in counters else None}
+if cornell:
+    out["cornell_1280x720_m128"] = {"counters_per_launch_median": cornell,
+                                    "lane_utilisation": cornell.get("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * cornell["SQ_ACTIVE_INST_VALU"]) if cornell.get("SQ_ACTIVE_INST_VALU") else None}
 json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: (v["median"] if isinstance(v, dict) and "median" in v else v) for k, v in counters.items()}, indent=1))
