@@ -265,6 +265,13 @@ int rmdf_unregister_host_buffer(rmdf_ctx *ctx, void *ptr);
  * as an 8-bit RGBA PNG.  Host-only (no ctx, no device); errors are reported through rmdf_last_error(NULL). */
 int rmdf_save_png(const char *path, const uint32_t *fb_rgba8, int w, int h);
 
+/* Device memory for hosts without a HIP binding of their own (the Haskell viewer, a plain-C host): buffers for the
+ * device-resident entry points above.  rmdf_device_malloc / rmdf_device_free: hipMalloc / hipFree on the ctx's device.
+ * rmdf_copy_to_host: asynchronous device-to-host copy on `stream` (NULL = ctx stream) followed by a wait for it. */
+int rmdf_device_malloc(rmdf_ctx *ctx, size_t bytes, void **d_ptr);
+int rmdf_device_free(rmdf_ctx *ctx, void *d_ptr);
+int rmdf_copy_to_host(rmdf_ctx *ctx, void *host_dst, const void *d_src, size_t bytes, void *stream);
+
 /* Block until everything queued on `stream` (NULL = ctx stream) has finished. */
 int rmdf_synchronize(rmdf_ctx *ctx, void *stream);
 

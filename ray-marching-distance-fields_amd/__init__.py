@@ -52,7 +52,8 @@ ABI_SYMBOLS = (
     "rmdf_get_shard_tiles", "rmdf_save_png", "rmdf_register_host_buffer", "rmdf_unregister_host_buffer",
     "rmdf_selftest_pinned_math", "rmdf_set_shard_root_handicap", "rmdf_create_ex", "rmdf_prefilter_env_powers",
     "rmdf_prefilter_env_device", "rmdf_comm_get_unique_id", "rmdf_comm_init", "rmdf_comm_destroy", "rmdf_comm_info",
-    "rmdf_gather_shards_device", "rmdf_render_frame_sharded_device",
+    "rmdf_gather_shards_device", "rmdf_render_frame_sharded_device", "rmdf_device_malloc", "rmdf_device_free",
+    "rmdf_copy_to_host",
 )
 XCHECK_SYMBOLS = ("rmdf_debug_march_stats",)      # include/rmdf_xcheck.h
 
@@ -161,6 +162,9 @@ def load_library(xcheck=False):
     L.rmdf_set_shard_root_handicap.argtypes = [vp, C.c_float]
     L.rmdf_assemble_shards_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.rmdf_synchronize.argtypes = [vp, vp]
+    L.rmdf_device_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.rmdf_device_free.argtypes = [vp, vp]
+    L.rmdf_copy_to_host.argtypes = [vp, vp, vp, C.c_size_t, vp]
     L.rmdf_device_info.argtypes = [vp, C.c_char_p, C.c_int, ip]
     if xcheck:
         L.rmdf_debug_march_stats.argtypes = [vp, C.c_int, vp, C.c_int]

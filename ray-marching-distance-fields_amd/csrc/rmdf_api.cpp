@@ -1564,6 +1564,36 @@ int rmdf_unregister_host_buffer(rmdf_ctx *ctx, void *ptr)
     return fail(ctx, RMDF_E_INVALID, "rmdf_unregister_host_buffer: not registered");
 }
 
+int rmdf_device_malloc(rmdf_ctx *ctx, size_t bytes, void **d_ptr)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!d_ptr || bytes == 0) return fail(ctx, RMDF_E_INVALID, "rmdf_device_malloc: bad argument");
+    *d_ptr = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMalloc(d_ptr, bytes));
+    return RMDF_OK;
+}
+
+int rmdf_device_free(rmdf_ctx *ctx, void *d_ptr)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!d_ptr) return RMDF_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipFree(d_ptr));
+    return RMDF_OK;
+}
+
+int rmdf_copy_to_host(rmdf_ctx *ctx, void *host_dst, const void *d_src, size_t bytes, void *stream)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!host_dst || !d_src) return fail(ctx, RMDF_E_INVALID, "rmdf_copy_to_host: null pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return RMDF_OK;
+}
+
 int rmdf_synchronize(rmdf_ctx *ctx, void *stream)
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");

@@ -138,14 +138,14 @@ def test_product_never_touches_the_oracle(rmdf):
     assert [os.path.basename(t) for t in tracked] == ["uffizi_512.hdr"], tracked
 
 
-def _build_c_host(tmp_path):
+def _build_c_host(tmp_path, name="c_host"):
     import subprocess
     import rmdf_amd
     rmdf_amd.build()
-    exe = str(tmp_path / "c_host")
+    exe = str(tmp_path / name)
     libdir = os.path.dirname(rmdf_amd.LIB_PATH)
     subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-std=c99", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "examples", "c_host.c"), "-o", exe, "-L", libdir, "-lrmdf", "-Wl,-rpath," + libdir])
+                           os.path.join(ROOT, "examples", name + ".c"), "-o", exe, "-L", libdir, "-lrmdf", "-Wl,-rpath," + libdir])
     return exe
 
 
@@ -154,6 +154,8 @@ def test_c_host_compiles_against_the_header(tmp_path):
     App.draw does (64 drawShaderTile calls into a Word32 buffer, then the screenshot) builds without a GPU."""
     exe = _build_c_host(tmp_path)
     assert os.path.exists(exe)
+    # the multi-GPU host: one process per GPU, unique id through a shared page, rmdf_comm_init, one call per frame
+    assert os.path.exists(_build_c_host(tmp_path, "c_host_multi"))
 
 
 @pytest.mark.gpu
@@ -172,4 +174,23 @@ def test_c_host_runs(tmp_path):
     with rmdf_amd.with_shader_renderer() as sr:
         fb = rmdf_amd.FrameBuffer(320, 184)
         sr.draw_shader_tile(2, None, 320, 184, 1.5, fb.vec, max_steps=256)
+    assert np.array_equal(np.asarray(Image.open(png)), fb.to_image_rows_top_down())
+
+
+@pytest.mark.gpu
+def test_c_host_multi_runs_with_one_rank(tmp_path):
+    """examples/c_host_multi.c -- the N > 1 path (cost-aware deal, RCCL communicator, rmdf_render_frame_sharded_device) from
+    plain C with no Python in the process -- with the one rank a 1-GPU box can hold: the sharded frame equals the
+    single-launch frame (it checks that itself) and the PNG decodes to the frame the Python mirror renders."""
+    import subprocess
+    from PIL import Image
+    import rmdf_amd
+    exe = _build_c_host(tmp_path, "c_host_multi")
+    png = str(tmp_path / "multi.png")
+    out = subprocess.run([exe, rmdf_amd.DEFAULT_ENV_HDR, png, "1", "640", "360", "5"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "sharded == single launch: yes" in out.stdout and "rank 0 of 1" in out.stdout
+    with rmdf_amd.with_shader_renderer() as sr:
+        fb = rmdf_amd.FrameBuffer(640, 360)
+        sr.draw_shader_tile(2, None, 640, 360, 0.0, fb.vec, max_steps=256)
     assert np.array_equal(np.asarray(Image.open(png)), fb.to_image_rows_top_down())
