@@ -86,7 +86,10 @@ def main():
         env = orc.EnvSet(z["refl"], z["cos1"], z["cos8"])
         out = {}
         for name, (scene, w, h, t, ms) in (("config2_cornell_1280x720_m128", (orc.SCENE_CORNELL, 1280, 720, 0.0, 128)),
-                                            ("config3_mandelbulb8_1920x1080_m256", (orc.SCENE_MB_POWER8, 1920, 1080, 0.0, 256))):
+                                            ("config3_mandelbulb8_1920x1080_m256", (orc.SCENE_MB_POWER8, 1920, 1080, 0.0, 256)),
+                                            ("detest_1280x720_t2p5_m128", (orc.SCENE_DETEST, 1280, 720, 2.5, 128)),
+                                            ("mbgeneral_1280x720_t3p0_m128", (orc.SCENE_MB_GENERAL, 1280, 720, 3.0, 128)),
+                                            ("mandelbulb8_1920x1080_t7p0_m256", (orc.SCENE_MB_POWER8, 1920, 1080, 7.0, 256))):
             r = orc.render(scene, w, h, t, ms, env, want_f32=False)
             out[name] = {"scene": scene, "w": w, "h": h, "time": t, "max_steps": ms,
                          "sha256": {k: hashlib.sha256(np.ascontiguousarray(r[k]).tobytes()).hexdigest() for k in ("rgba8", "steps", "iters")},
