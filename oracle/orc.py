@@ -79,6 +79,7 @@ def lib():
         L.orc_ray_sphere.argtypes = [fp, fp, C.c_float, fp, fp]
         L.orc_render.argtypes = [C.POINTER(Frame)] + [C.c_int] * 4 + [C.c_void_p] * 4 + [C.POINTER(Counters), C.c_int]
         L.orc_render_ex.argtypes = [C.POINTER(Frame)] + [C.c_int] * 4 + [C.c_void_p] * 5 + [C.POINTER(Counters), C.c_int]
+        L.orc_shade_gbuffer.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_hdr_decode.argtypes = [u8p, C.c_long, ip, ip, C.c_void_p]
         L.orc_hdr_encode.restype = C.c_long
         L.orc_hdr_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -328,3 +329,19 @@ def render(scene, w, h, time, max_steps, env: EnvSet, rect=None, nthreads=0, wan
     if rc != 0:
         raise RuntimeError("orc_render failed rc=%d" % rc)
     return {"rgba_f32": rgba, "rgba8": rgba8, "steps": steps, "iters": iters, "iters_march": iters_march, "counters": ctr.as_dict()}
+
+
+def shade_gbuffer(scene, w, h, time, max_steps, env: EnvSet, nao, hit):
+    """Shading alone: colour (h, w, 4) from per-pixel hit flags and (normal, ao) -- see orc_shade_gbuffer."""
+    f = Frame()
+    f.scene, f.w, f.h, f.time, f.max_steps = scene, w, h, float(time), max_steps
+    for name in ("reflection", "cos_1", "cos_8"):
+        arr = getattr(env, name)
+        setattr(f, "env_" + name, Cube(arr.shape[1] - 2, arr.ctypes.data))
+    nao = np.ascontiguousarray(nao, np.float32)
+    hit = np.ascontiguousarray(hit, np.uint8)
+    out = np.zeros((h, w, 4), np.float32)
+    rc = lib().orc_shade_gbuffer(C.byref(f), nao.ctypes.data, hit.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("orc_shade_gbuffer failed rc=%d" % rc)
+    return out

@@ -1055,6 +1055,46 @@ static void *render_worker(void *arg)
     return NULL;
 }
 
+/* Shading alone (fragment.shd:788-823, 956-960): the colour of every pixel of the frame given, per pixel, the hit flag and
+ * the (normal, ao) pair the hit branch computed -- e.g. as exported from the reference shader itself run on SwiftShader
+ * (tests/golden/make_swiftshader_vectors.py, "gbuffer" program).  Everything downstream of the normal is done here exactly as
+ * orc_render does it: ray direction, Fresnel, reflect, the three cube-map lookups with the quad filter rule, gamma. */
+int orc_shade_gbuffer(const orc_frame *f, const float *nao /* w*h*4 */, const uint8_t *hit /* w*h */, float *rgba_f32)
+{
+    if (!f || !nao || !hit || !rgba_f32 || f->w <= 0 || f->h <= 0 || (f->w & 1) || (f->h & 1)) return -1;
+    render_job j;
+    memset(&j, 0, sizeof j);
+    j.f = f;
+    orc_camera(f->scene, f->time, j.cam);
+    j.fov_xs = orc_fov_xs();
+    for (int qy = 0; qy < f->h / 2; qy++)
+        for (int qx = 0; qx < f->w / 2; qx++) {
+            px_state q[4];
+            for (int k = 0; k < 4; k++) {
+                const int px = qx * 2 + (k & 1), py = qy * 2 + (k >> 1);
+                const size_t idx = (size_t)px + (size_t)py * f->w;
+                memset(&q[k], 0, sizeof q[k]);
+                q[k].dir = generate_ray_dir(&j, px, py);
+                q[k].hit = hit[idx] != 0;
+                if (q[k].hit) {
+                    q[k].n = V3(nao[idx * 4], nao[idx * 4 + 1], nao[idx * 4 + 2]);
+                    q[k].ao = nao[idx * 4 + 3];
+                    q[k].fresnel = fresnel_conductor(rm_dot(rm_neg(q[k].dir), q[k].n), 0.4f, 0.8f);
+                    q[k].refl = rm_reflect(q[k].dir, q[k].n);
+                }
+            }
+            for (int k = 0; k < 4; k++) {
+                const int px = qx * 2 + (k & 1), py = qy * 2 + (k >> 1);
+                const size_t idx = (size_t)px + (size_t)py * f->w;
+                float rgb[3];
+                shade_pixel(&j, q, k, rgb);
+                for (int c = 0; c < 3; c++) rgba_f32[idx * 4 + c] = rm_powf(rgb[c], 1.0f / 2.2f);
+                rgba_f32[idx * 4 + 3] = 1.0f;
+            }
+        }
+    return 0;
+}
+
 int orc_num_processors(void)
 {
     long n = sysconf(_SC_NPROCESSORS_ONLN);

@@ -94,6 +94,10 @@ int orc_render_ex(const orc_frame *f, int x0, int y0, int x1, int y1,
                   float *rgba_f32, uint32_t *rgba8, uint16_t *steps, uint16_t *iters, uint16_t *iters_march,
                   orc_counters *ctr, int nthreads);
 
+/* Shading alone: colour of every pixel given its hit flag and the (normal, ao) the hit branch produced (w*h*4 floats);
+ * w, h even.  Used to compare the shading with the reference shader's, its own normals fed back (tests/test_oracle_vs_glsl.py). */
+int orc_shade_gbuffer(const orc_frame *f, const float *nao, const uint8_t *hit, float *rgba_f32);
+
 /* Single-point probes for known-answer tests */
 float orc_de(int scene, float time, const float pos[3]);
 void  orc_triplex_pow8(const float w[3], float out[3]);

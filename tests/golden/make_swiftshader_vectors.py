@@ -17,6 +17,11 @@ The patch:
     iterations that ran triplex_pow -- over the march, the four normal taps and the two AO taps -- i.e. the escape-iteration
     counts the north star wants bit-exact, read back from the reference shader itself (g_iters_march: the part spent inside
     ray_march, snapshotted at its three exits).
+  * a third program ("gbuffer") exports what the shader's hit branch feeds into its shading: `g_n = isec_n; g_ao = ao;` behind
+    `float ao = distance_ao(isec_pos, isec_n);` (fragment.shd:769) and writes (g_n, g_ao) instead of the colour.  Given these,
+    shading is a short deterministic function -- Fresnel, reflect, three cube-map lookups, gamma -- so
+    tests/test_oracle_vs_glsl.py can compare the oracle's SHADING with the reference shader's colour tightly, with the chaotic
+    eps = 1e-5 normal differentiation taken out of the comparison (frames *_gbuf.npz, float32 colour kept).
 SwiftShader's float math is its own (its inversesqrt/pow/log/exp are approximations, its texture filter uses
 fixed-point weights), so this is a tolerance-level cross-check of the RESTATEMENT, not a bit-level oracle.
 """
@@ -42,7 +47,7 @@ INT_LITERAL_LINES = [113, 116, 118, 119, 121, 318, 340, 345, 363, 400, 487, 537,
 VARIANTS = {0: "#define CORNELL_BOX_SCENE\n", 1: "", 2: "#define MANDELBULB_SCENE\n#define POWER8\n", 3: "#define MANDELBULB_SCENE\n"}
 
 
-def patched_shader(scene, max_steps, counters=False):
+def patched_shader(scene, max_steps, counters=False, gbuffer=False):
     lines = open(REF_SHADER).read().split("\n")
     lit = re.compile(r"(?<![\w.])(\d+)(?![\w.])")
     for ln in INT_LITERAL_LINES + (list(range(448, 457)) if scene == 1 else []):
@@ -59,7 +64,12 @@ def patched_shader(scene, max_steps, counters=False):
     src = src.replace("            step_gradient = 1.0 - float(steps) / float(MAX_STEPS);\n            return true;",
                       "            step_gradient = 1.0 - float(steps) / float(MAX_STEPS);\n            g_steps = float(steps); g_hit = 1.0; return true;")
     src = src.replace("    }\n\n    return false;\n}\n\nvec3 soft_lam", "    }\n\n    g_steps = float(MAX_STEPS); return false;\n}\n\nvec3 soft_lam")
-    if counters:
+    if gbuffer:
+        assert src.count("        float ao = distance_ao(isec_pos, isec_n);\n") == 1
+        src = src.replace("out vec4 frag_color;", "out vec4 frag_color;\nvec3 g_n = vec3(0.0);\nfloat g_ao = 0.0;", 1)
+        src = src.replace("        float ao = distance_ao(isec_pos, isec_n);\n", "        float ao = distance_ao(isec_pos, isec_n); g_n = isec_n; g_ao = ao;\n")
+        src = src.replace("    frag_color = vec4(gamma, 1);", "    frag_color = vec4(g_n, g_ao + 0.0 * gamma.x);")
+    elif counters:
         assert src.count("        w += pos;\n") == 1
         src = src.replace("out vec4 frag_color;", "out vec4 frag_color;\nfloat g_iters = 0.0;\nfloat g_iters_march = 0.0;", 1)
         src = src.replace("        w += pos;\n", "        w += pos; g_iters += 1.0;\n")
@@ -217,6 +227,9 @@ CASES = [(2, 96, 54, 0.0, 128), (2, 96, 54, 2.5, 256), (2, 192, 108, 0.0, 256), 
          (1, 96, 54, 0.0, 128), (1, 320, 180, 3.0, 128), (3, 96, 54, 0.0, 128), (3, 320, 180, 3.0, 128), (3, 160, 90, 11.0, 128)]
 
 
+GBUF_CASES = [(2, 192, 108, 0.0, 256), (2, 96, 54, 2.5, 256), (0, 128, 72, 1.0, 128), (1, 96, 54, 0.0, 128)]
+
+
 def main():
     rd = lambda n: orc.hdr_decode(open(os.path.join(ENVDIR, n), "rb").read())
     faces = {"env_reflection": orc.latlong_to_cube(orc.hdr_decode(open(HDR, "rb").read())),
@@ -247,6 +260,12 @@ def main():
         np.savez_compressed(fn, rgb16=img[..., :3].astype(np.float16), steps=steps, hit=hit, iters=iters.astype(np.uint16), iters_march=iters_march.astype(np.uint16),
                             rows_f32=np.concatenate([img[:8, :, :3], img[-8:, :, :3]]).astype(np.float32))
         print("wrote", fn, "hit fraction %.4f" % hit.mean(), "max steps", steps.max(), "iterations", int(iters.sum()))
+        if (scene, w, h, t, ms) in GBUF_CASES:
+            gprog = gl.program(patched_shader(scene, ms, gbuffer=True))
+            gb = gl.render(gprog, w, h, t, tex)
+            fn2 = fn[:-4] + "_gbuf.npz"
+            np.savez_compressed(fn2, nao=gb.astype(np.float32), rgb=img[..., :3].astype(np.float32), hit=hit, steps=steps)
+            print("wrote", fn2)
 
 
 if __name__ == "__main__":
