@@ -62,38 +62,38 @@ def env_oracle(orc, env_faces):
     return orc.EnvSet(*(orc.cube_pad_f16(env_faces[k]) for k in ("refl", "cos1", "cos8")))
 
 
-@pytest.fixture(scope="session")
-def sr(rmdf, env_faces):
-    """A ShaderRenderer on cuda:0 whose cube maps were uploaded from the oracle-built faces."""
+def _renderer_with_product_env(rmdf, env_oracle, **kw):
+    """A ShaderRenderer whose cube maps come from the PRODUCT's own env pipeline (rmdf_load_env_hdr on the shipped uffizi_512.hdr:
+    GPU resize, GPU lobe prefilter, RGBE cache files, GPU cube conversion) -- checked here, once per renderer, to be bit-equal
+    to the oracle-built maps every parity test compares against."""
     rmdf.build()
-    r = rmdf.ShaderRenderer(0)
-    r.set_env_cube(rmdf.ENV_REFLECTION, env_faces["refl"])
-    r.set_env_cube(rmdf.ENV_COS_1, env_faces["cos1"])
-    r.set_env_cube(rmdf.ENV_COS_8, env_faces["cos8"])
+    r = rmdf.ShaderRenderer(0, **kw)
+    r.load_env_hdr(rmdf.DEFAULT_ENV_HDR)
+    for slot, ref in ((rmdf.ENV_REFLECTION, env_oracle.reflection), (rmdf.ENV_COS_1, env_oracle.cos_1), (rmdf.ENV_COS_8, env_oracle.cos_8)):
+        assert np.array_equal(r.get_env_cube_padded(slot), ref), "product-built cube map %d differs from the oracle's" % slot
+    return r
+
+
+@pytest.fixture(scope="session")
+def sr(rmdf, env_oracle):
+    """The product renderer on cuda:0, environment built by its own pipeline."""
+    r = _renderer_with_product_env(rmdf, env_oracle)
     yield r
     r.close()
 
 
 @pytest.fixture(scope="session")
-def sr_alt(rmdf, env_faces):
+def sr_alt(rmdf, env_oracle):
     """librmdf_xcheck.so: the Mandelbulb runs on the flattened march + shade kernels."""
-    rmdf.build()
-    r = rmdf.ShaderRenderer(0, flags=rmdf.FLAG_FLAT_MARCH)
-    r.set_env_cube(rmdf.ENV_REFLECTION, env_faces["refl"])
-    r.set_env_cube(rmdf.ENV_COS_1, env_faces["cos1"])
-    r.set_env_cube(rmdf.ENV_COS_8, env_faces["cos8"])
+    r = _renderer_with_product_env(rmdf, env_oracle, flags=rmdf.FLAG_FLAT_MARCH)
     yield r
     r.close()
 
 
 @pytest.fixture(scope="session")
-def sr_pipe(rmdf, env_faces):
+def sr_pipe(rmdf, env_oracle):
     """librmdf_xcheck.so: the three-kernel schedule (RMDF_FLAG_PIPELINE)."""
-    rmdf.build()
-    r = rmdf.ShaderRenderer(0, flags=rmdf.FLAG_PIPELINE)
-    r.set_env_cube(rmdf.ENV_REFLECTION, env_faces["refl"])
-    r.set_env_cube(rmdf.ENV_COS_1, env_faces["cos1"])
-    r.set_env_cube(rmdf.ENV_COS_8, env_faces["cos8"])
+    r = _renderer_with_product_env(rmdf, env_oracle, flags=rmdf.FLAG_PIPELINE)
     yield r
     r.close()
 

@@ -1,8 +1,8 @@
 """GPU tier (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same inputs.
 
 Bars (BASELINE.json north_star): step counts, hit mask and escape-iteration counts BIT-EXACT; float colour within
-1e-4 relative (absolute floor 1e-6).  Both sides receive identical float32 cube faces; the f16 rounding, border
-padding and everything after it is done independently by each side."""
+1e-4 relative (absolute floor 1e-6).  The renderer under test (`sr`) builds its environment with the product's own pipeline
+(rmdf_load_env_hdr); the oracle side builds its own (tests/conftest.py checks the two sets of cube maps are bit-equal)."""
 import glob
 import os
 import re
