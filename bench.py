@@ -282,21 +282,35 @@ def main():
         # joins the library's communicator.  Any failure (all ranks decide together) falls back to dist.gather.
         use_abi_comm = not share_gpu and os.environ.get("RMDF_BENCH_TORCH_GATHER") != "1"
         if use_abi_comm:
-            ok = 1
+            # every step that can fail on ONE rank is followed by an all-reduce of the outcome before the next collective
+            # starts, so a rank that cannot load RCCL makes all ranks fall back together instead of leaving the others waiting
+            def all_ok(ok):
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cdev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return int(flag.item()) == 1
+            uid = torch.zeros(rmdf_amd.COMM_ID_BYTES, dtype=torch.uint8, device=cdev)
             try:
-                uid = torch.zeros(rmdf_amd.COMM_ID_BYTES, dtype=torch.uint8, device=cdev)
+                my_id = rmdf_amd.comm_get_unique_id()          # on every rank: proves librccl loads here (only rank 0's is used)
                 if rank == 0:
-                    uid.copy_(torch.frombuffer(bytearray(rmdf_amd.comm_get_unique_id()), dtype=torch.uint8))
-                dist.broadcast(uid, src=0)
-                sr.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+                    uid.copy_(torch.frombuffer(bytearray(my_id), dtype=torch.uint8))
+                ok = True
             except Exception as e:                              # noqa: BLE001
-                print("rank %d: rmdf_comm_init failed (%s); falling back to torch.distributed gather" % (rank, e), file=sys.stderr)
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            use_abi_comm = int(flag.item()) == 1
-            if not use_abi_comm and ok:
-                sr.comm_destroy()
+                print("rank %d: rmdf_comm_get_unique_id failed (%s)" % (rank, e), file=sys.stderr)
+                ok = False
+            use_abi_comm = all_ok(ok)
+            if use_abi_comm:
+                dist.broadcast(uid, src=0)
+                try:
+                    sr.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+                    ok = True
+                except Exception as e:                          # noqa: BLE001
+                    print("rank %d: rmdf_comm_init failed (%s)" % (rank, e), file=sys.stderr)
+                    ok = False
+                use_abi_comm = all_ok(ok)
+                if not use_abi_comm and ok:
+                    sr.comm_destroy()
+            if not use_abi_comm:
+                print("rank %d: falling back to the torch.distributed gather" % rank, file=sys.stderr)
         if use_abi_comm:
             rccl_ranks = sr.comm_info()[1]
             exchange = "librmdf: rmdf_render_frame_sharded_device (grouped ncclSend/ncclRecv fan-in to rank 0), RCCL communicator of %d ranks" % rccl_ranks
