@@ -542,6 +542,40 @@ def test_argument_limits(sr, rmdf):
     assert sr.render(2, 16, 8, 0.0, max_steps=32767)["rgba8"].shape == (8, 16)
 
 
+def test_argument_limits_of_the_round_two_entry_points(sr, rmdf, orc):
+    """Bad arguments to the env / exchange / device-memory entry points come back as RMDF_E_INVALID (or RMDF_E_COMM without a
+    communicator) with a message, and leave the renderer usable; sixteen powers in one concurrent call work."""
+    import ctypes as C
+    L, ctx = rmdf.load_library(), sr.handle
+    img = np.ones((4, 8, 3), np.float32)
+    out = np.empty((17, 4, 8, 3), np.float32)
+    pw = np.ones(17, np.float32)
+    assert L.rmdf_prefilter_env_powers(ctx, img.ctypes.data, 8, 4, pw.ctypes.data, 17, out.ctypes.data) == -1      # > 16 powers
+    assert L.rmdf_prefilter_env_powers(ctx, img.ctypes.data, 8, 4, pw.ctypes.data, 0, out.ctypes.data) == -1
+    assert L.rmdf_prefilter_env_powers(ctx, img.ctypes.data, 8200, 4, pw.ctypes.data, 1, out.ctypes.data) == -1    # w > 8192
+    assert L.rmdf_prefilter_env_powers(ctx, img.ctypes.data, 1, 4, pw.ctypes.data, 1, out.ctypes.data) == -1
+    assert b"rmdf_prefilter_env_powers" in L.rmdf_last_error(ctx)
+    assert L.rmdf_prefilter_env_device(ctx, None, 8, 4, C.c_float(1.0), None, None) == -1
+    assert L.rmdf_set_env_latlong(ctx, 0, img.ctypes.data, 5, 4) == -1                                             # w < 6: no cube face
+    assert L.rmdf_gather_shards_device(ctx, 64, 64, None, None, None) in (-1, -8)
+    assert L.rmdf_render_frame_sharded_device(ctx, 2, 64, 64, C.c_double(0.0), 64, None, None, None, None) == -8   # no communicator
+    assert L.rmdf_comm_init(ctx, None, 0, 1) == -1 and L.rmdf_comm_init(ctx, out.ctypes.data, 3, 2) == -1
+    p = C.c_void_p()
+    assert L.rmdf_device_malloc(ctx, 0, C.byref(p)) == -1 and L.rmdf_device_malloc(ctx, 16, None) == -1
+    assert L.rmdf_device_malloc(ctx, 1 << 20, C.byref(p)) == 0 and p.value
+    assert L.rmdf_copy_to_host(ctx, None, p, 16, None) == -1
+    host = np.zeros(4, np.uint32)
+    assert L.rmdf_copy_to_host(ctx, host.ctypes.data, p, 16, None) == 0
+    assert L.rmdf_device_free(ctx, p) == 0 and L.rmdf_device_free(ctx, None) == 0
+    # sixteen powers at once (four streams, four rounds): the pinned ones bit-equal to the oracle
+    src = orc.resize_hdr(orc.build_test_latlong(), 32)
+    powers = [1.0, 8.0, 64.0, 512.0] * 4
+    got = sr.prefilter_env_powers(src, powers)
+    for i, pwr in enumerate(powers):
+        assert np.array_equal(got[i].view(np.uint32), orc.cosine_convolve(src, pwr, pow_mode=1).view(np.uint32)), (i, pwr)
+    assert sr.render(2, 16, 8, 0.0)["rgba8"].shape == (8, 16)
+
+
 def _committed_cube_renderer(rmdf):
     """A renderer whose cube maps come from the committed oracle-built fixture (tests/golden/env_cubes_uffizi.npz): the
     padded RGB16F texels are exact in float32, and the upload's RNE + border rule reproduces the fixture bit for bit."""
