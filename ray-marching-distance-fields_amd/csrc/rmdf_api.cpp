@@ -9,6 +9,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <exception>
 #include <mutex>
 #include <new>
@@ -544,7 +545,8 @@ void encode_hdr(const std::vector<float> &rgb, int w, int h, std::vector<uint8_t
 // name and rename() into place, so a reader sees either no file or a complete one.
 bool write_file_atomic(const std::string &path, const std::vector<uint8_t> &data)
 {
-    const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+    static std::atomic<unsigned> serial{ 0 };                 // several renderers of one process may build the same cache
+    const std::string tmp = path + ".tmp." + std::to_string((long)getpid()) + "." + std::to_string(serial.fetch_add(1));
     FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return false;
     bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
