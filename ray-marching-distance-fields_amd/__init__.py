@@ -89,16 +89,31 @@ def tile_rect(tile_idx, w, h):
     return ((2 * tx * w + 7) // 16, (2 * ty * h + 7) // 16, (2 * (tx + 1) * w + 7) // 16, (2 * (ty + 1) * h + 7) // 16)
 
 
+def _source_digest():
+    """sha256 over the contents of everything the two libraries are built from (csrc/**, the two headers)."""
+    import hashlib
+    files = sorted(os.path.join(r, f) for r, _, fs in os.walk(CSRC) for f in fs)
+    files += [os.path.join(_HERE, "..", "include", h) for h in ("rmdf.h", "rmdf_xcheck.h")]
+    h = hashlib.sha256()
+    for fn in files:
+        h.update(os.path.relpath(fn, _HERE).encode() + b"\0")
+        with open(fn, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
-    """Compile librmdf.so for gfx950 with hipcc (cross-compiles without a GPU).  Serialised with a file lock:
-    several ranks of one node may call this at the same time."""
+    """Compile librmdf.so and librmdf_xcheck.so for gfx950 with hipcc (cross-compiles without a GPU).  Serialised with a file
+    lock: several ranks of one node may call this at the same time.  Whether the libraries are current is decided by a digest
+    of the source CONTENTS kept next to them (librmdf.stamp), not by file times: a copied tree (the GPU box's snapshot) keeps
+    the prebuilt libraries instead of rebuilding them because a copy happened to reorder mtimes."""
     import fcntl
-    srcs = [os.path.join(r, f) for r, _, fs in os.walk(CSRC) for f in fs]
-    srcs += [os.path.join(_HERE, "..", "include", h) for h in ("rmdf.h", "rmdf_xcheck.h")]
+    stamp = os.path.join(_HERE, "librmdf.stamp")
 
     def stale():
-        return any((not os.path.exists(lib)) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs)
-                   for lib in (LIB_PATH, XCHECK_LIB_PATH))
+        if not (os.path.exists(LIB_PATH) and os.path.exists(XCHECK_LIB_PATH) and os.path.exists(stamp)):
+            return True
+        return open(stamp).read().strip() != _source_digest()
     if not (force or stale()):
         return LIB_PATH
     with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
@@ -107,6 +122,9 @@ def build(force=False, verbose=False):
             if force or stale():
                 out = None if verbose else subprocess.DEVNULL
                 subprocess.check_call(["make", "-C", CSRC] + (["-B"] if force else []), stdout=out)
+                with open(stamp + ".tmp", "w") as f:
+                    f.write(_source_digest() + "\n")
+                os.replace(stamp + ".tmp", stamp)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
