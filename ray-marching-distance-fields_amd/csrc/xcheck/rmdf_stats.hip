@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_march_stats(const FrameParams p)
                        p.cam[1] * dcam.x + p.cam[4] * dcam.y + p.cam[7] * dcam.z,
                        p.cam[2] * dcam.x + p.cam[5] * dcam.y + p.cam[8] * dcam.z);
     const v3 origin = mk3(p.cam[9], p.cam[10], p.cam[11]);
-    unsigned long long passes = 0, lanes = 0, wsteps = 0, wlanes = 0;
+    unsigned long long passes = 0, lanes = 0, wsteps = 0;
     unsigned iters = 0;
     float t = 0.0f, tmin, tmax;
     int steps = 0;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_march_stats(const FrameParams p)
     if (active && ray_sphere(origin, dir, 1.15f, tmin, tmax)) {
         t = gmax(0.0f, tmin);
         for (steps = 0; steps < p.max_steps; steps++) {
-            wsteps++; wlanes += __popcll(__ballot(true));
+            wsteps++;
             v3 pos = mk3(origin.x + t * dir.x, origin.y + t * dir.y, origin.z + t * dir.z);
             float dist = de_mandelbulb8_dbg(pos, iters, passes, lanes, p.dbg ? p.dbg + 8 : nullptr);
             t += dist;
