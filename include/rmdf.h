@@ -243,8 +243,10 @@ int rmdf_render_frame_sharded_device(rmdf_ctx *ctx, int scene, int w, int h, dou
 /* Self-test of the kernels' short correctly-rounded sequences (sqrt, reciprocal, 1/sqrt, and the known-range
  * division inside log) against the compiler's IEEE expansions for ALL 2^32 float inputs on the device.
  * mismatches[0..3] = sqrt, reciprocal, log, 1/sqrt; mismatches[4] = the table-driven division of the Cornell
- * distance estimator against the compiler's for every numerator and each of its 96 divisors.  All must be 0. */
-int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[5]);
+ * distance estimator against the compiler's for every numerator and each of its 96 divisors; mismatches[5..7] = the
+ * Mandelbulb loop's forms: the bailout test taken on the squared radius, the in-loop root of the radius and the in-loop
+ * 1/sqrt(k3^7) (one transcendental each, one shared guard) against the written sqrt / inversesqrt.  All must be 0. */
+int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[8]);
 /* Self-test of the straight-line device forms of the pinned GLSL built-ins (exp, acos, atan, sin, cos: all 2^32 inputs;
  * atan(y,x) and pow(x,y): 2^32 operand pairs) against the branchy fdlibm-style forms they restate.
  * mismatches[0..6] = exp, acos, atan, sin, cos, atan2, pow.  All must be 0. */

@@ -396,8 +396,9 @@ class ShaderRenderer:
         return out
 
     def selftest_exact_math(self):
-        """Mismatch counts (sqrt, rcp, log, rsqrt) of the short exact sequences vs the compiler's, all 2^32 inputs."""
-        out = np.zeros(5, np.uint64)
+        """Mismatch counts (sqrt, rcp, log, rsqrt, Cornell division, Mandelbulb bailout test / in-loop sqrt / in-loop rsqrt) of
+        the short exact sequences vs the compiler's, all 2^32 inputs."""
+        out = np.zeros(8, np.uint64)
         self._check(self._lib.rmdf_selftest_exact_math(self._ctx, out.ctypes.data))
         return out
 

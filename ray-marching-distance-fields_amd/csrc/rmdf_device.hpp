@@ -36,15 +36,27 @@ __device__ __forceinline__ bool in_core_range(float x)
     // 2^-100 <= |x| <= 2^100 as one unsigned compare on the exponent field (NaN, inf, 0, subnormals fail)
     return ((__float_as_uint(x) & 0x7fffffffu) - 0x0d800000u) <= (0x71800000u - 0x0d800000u);
 }
-__device__ __forceinline__ float sqrt_core(float x)        // x in [2^-100, 2^100]
+// y = v_rsq_f32(x) (<= 1 ulp), s0 = RN(x*y), one correction s0 + (x - s0^2) * (y/2): the correctly rounded root for EVERY
+// x in [2^-100, 2^100] with ONE transcendental instruction (round 2 used v_sqrt_f32 + a neighbour test: 9 instructions; in
+// this kernel's mix a transcendental costs ~4.6 simple issue slots, so sequences that bought fewer instructions with a second
+// transcendental did not pay -- DESIGN.md 4.1).  y is handed out: it also seeds the reciprocal of the root (rsqrt_ieee).
+__device__ __forceinline__ float sqrt_core_y(float x, float &y)       // x in [2^-100, 2^100]
 {
-    float s = __builtin_amdgcn_sqrtf(x);                                  // <= 1 ulp
-    const float s_dn = __int_as_float(__float_as_int(s) - 1), s_up = __int_as_float(__float_as_int(s) + 1);
-    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
-    s = (r_dn <= 0.0f) ? s_dn : s;
-    s = (r_up > 0.0f) ? s_up : s;
-    return s;
+    y = __builtin_amdgcn_rsqf(x);
+    const float s0 = x * y, h = 0.5f * y;
+    return __builtin_fmaf(__builtin_fmaf(-s0, s0, x), h, s0);
 }
+__device__ __forceinline__ float sqrt_core(float x) { float y; return sqrt_core_y(x, y); }
+// RN(1 / s) for s = RN(sqrt x) from the same y: one Newton step.  Correctly rounded for every x in [2^-100, 2^100] except
+// where the root's mantissa is all ones (s = 2^k - ulp: the classical exception of Newton reciprocals -- 200 inputs); the
+// callers route lanes whose root has its low 16 mantissa bits set (a superset, one 16-bit compare, 2^-16 of all roots)
+// through the compiler's expansion together with the out-of-range lanes.
+__device__ __forceinline__ float rcp_of_root(float s, float y)
+{
+    const float e = __builtin_fmaf(-s, y, 1.0f);
+    return __builtin_fmaf(e, y, y);
+}
+__device__ __forceinline__ bool root_needs_slow_rcp(float s) { return (uint16_t)__float_as_uint(s) == (uint16_t)0xffffu; }
 __device__ __forceinline__ float rcp_core(float x)         // |x| in [2^-100, 2^100]
 {
     const float y0 = __builtin_amdgcn_rcpf(x);                            // <= 1 ulp
@@ -83,8 +95,10 @@ __device__ __forceinline__ float length3(v3 a) { return sqrt_rn(dot3(a, a)); }
 // inversesqrt := 1/sqrt, two roundings.  If x is in the core range so is sqrt(x) (2^-50 .. 2^50): one range test.
 __device__ __forceinline__ float rsqrt_ieee(float x)
 {
-    float y = rcp_core(sqrt_core(x));
-    const bool bad = (__float_as_uint(x) - 0x0d800000u) > (0x71800000u - 0x0d800000u);
+    float y0;
+    const float s = sqrt_core_y(x, y0);
+    float y = rcp_of_root(s, y0);
+    const bool bad = (int)((__float_as_uint(x) - 0x0d800000u) > (0x71800000u - 0x0d800000u)) | (int)root_needs_slow_rcp(s);
     if (__builtin_expect(__ballot(bad) != 0ull, 0)) { if (bad) y = 1.0f / sqrtf(x); }
     return y;
 }
@@ -206,22 +220,61 @@ __device__ __forceinline__ v3 triplex_pow8(v3 w)
                -16.0f * z2 * k3 * k4 * k4 + k1 * k1);
 }
 
-// fragment.shd:101-158 (POWER8); iters counts the iterations that ran triplex_pow8
+// fragment.shd:101-158 (POWER8); iters counts the iterations that ran triplex_pow8.
+// The loop is the shader's, statement for statement and rounding for rounding; what differs is how three of its operations are
+// evaluated, each with the bits of the written one (rmdf_selftest_exact_math checks all three against the written forms for all
+// 2^32 inputs on the device):
+//  * `r > bailout` (bailout = 4) is decided on d = dot(w,w): RN(sqrt d) > 4  <=>  d > 16 + 2^-19 (the correctly rounded root is
+//    monotone; the root of 16 + 2^-19 lies below the midpoint of 4 and its successor, that of 16 + 2^-18 above) -- the root
+//    leaves the branch's dependency chain, and a lane that escapes takes its root once, after the loop;
+//  * inside the loop d lies in [k3, 16 + 2^-19] and k3^7 in [2^-98, 2^29] once k3 >= 2^-14 is known, so both roots run the bare
+//    core sequences and ONE guard per iteration (k3 < 2^-14, or the root of k3^7 ends in sixteen one-bits: rcp_of_root) sends
+//    lanes through the compiler's expansions instead of a range test per root;
+//  * triplex_pow8 is inlined so that its x^2 + y^2 is shared with the dot product (the same two products, one addition).
+#define RMDF_MB8_D4   16.000001907348633f      /* 16 + 2^-19 = 0x41800001 */
+#define RMDF_MB8_K3MIN 0x1p-14f
+// The two roots of one Mandelbulb iteration that did not escape: r = RN(sqrt d), k2 = RN(1 / RN(sqrt q)) with q = k3^7,
+// k3 <= d <= 16 + 2^-19.  One guard for both (see de_mandelbulb8).
+__device__ __forceinline__ void mb8_roots(float d, float k3, float q, float &r, float &k2)
+{
+    r = sqrt_core(d);
+    float y0;
+    const float sq = sqrt_core_y(q, y0);
+    k2 = rcp_of_root(sq, y0);
+    const bool slow = (int)(k3 < RMDF_MB8_K3MIN) | (int)root_needs_slow_rcp(sq);
+    if (__builtin_expect(__ballot(slow) != 0ull, 0)) { if (slow) { r = sqrtf(d); k2 = 1.0f / sqrtf(q); } }
+}
 __device__ __forceinline__ float de_mandelbulb8(v3 pos, unsigned &iters)
 {
     pos = mk3(pos.z, pos.x, pos.y);
     v3 w = pos;
     float dr = 1.0f;
-    float r = 0.0f;
+    float r = 0.0f, d = 0.0f;
+    bool escaped = false;
     for (int i = 0; i < 25; i++) {
-        r = length3(w);
-        if (r > 4.0f) break;
-        w = triplex_pow8(w);
-        w = add3(w, pos);
-        float r2 = r * r, r4 = r2 * r2, r7 = (r4 * r2) * r;
+        // r = length(w); if (r > bailout) break;                                    fragment.shd:137-139
+        const float x = w.x, y = w.y, z = w.z;
+        const float x2 = x * x, y2 = y * y, z2 = z * z;
+        const float k3 = y2 + x2;                       // = x*x + y*y of the dot product (addition commutes bit for bit)
+        d = k3 + z2;
+        if (d > RMDF_MB8_D4) { escaped = true; break; }
+        // w = triplex_pow8(w)                                                       fragment.shd:74-99
+        const float x4 = x2 * x2, y4 = y2 * y2, z4 = z2 * z2;
+        const float q = k3 * k3 * k3 * k3 * k3 * k3 * k3;
+        float k2;
+        mb8_roots(d, k3, q, r, k2);                     // r = sqrt(d), k2 = inversesqrt(q)
+        const float k1 = y4 + z4 + x4 - 6.0f * z2 * x2 - 6.0f * y2 * z2 + 2.0f * x2 * y2;
+        const float k4 = y2 - z2 + x2;
+        const float wx = -8.0f * z * k4 * (y4 * y4 - 28.0f * y4 * y2 * x2 + 70.0f * y4 * x4 - 28.0f * y2 * x2 * x4 + x4 * x4) * k1 * k2;
+        const float wy = 64.0f * y * z * x * (y2 - x2) * k4 * (y4 - 6.0f * y2 * x2 + x4) * k1 * k2;
+        const float wz = -16.0f * z2 * k3 * k4 * k4 + k1 * k1;
+        w = add3(mk3(wx, wy, wz), pos);
+        // dr = pow(r, power - 1) * power * dr + 1                                   fragment.shd:148
+        const float r2 = r * r, r4 = r2 * r2, r7 = (r4 * r2) * r;
         dr = r7 * 8.0f * dr + 1.0f;
         iters++;
     }
+    if (escaped) r = sqrt_rn(d);
     return 0.5f * log_pinned(r) * r / dr;
 }
 

@@ -7,7 +7,8 @@ namespace rmdf {
 // ------------------------------------------------------------------------------------
 // Self-test of the short correctly-rounded sequences of rmdf_device.hpp against hipcc's own IEEE expansions,
 // over ALL 2^32 float bit patterns: sqrt_rn vs sqrtf, rcp_rn vs 1.0f/x, log_pinned (whose internal quotient uses
-// div_known_range) vs the same algorithm with the compiler's division.  counts[k] = number of differing inputs
+// div_known_range) vs the same algorithm with the compiler's division; counts[5..7]: the Mandelbulb loop's bailout test on
+// the squared radius and its two in-loop roots vs the written forms.  counts[k] = number of differing inputs
 // (NaN results compare equal to NaN).  ~1 s on an MI355X.
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ float log_ref_division(float x)
@@ -57,9 +58,20 @@ __global__ void k_selftest_cornell_div(unsigned long long *counts, const float *
 __global__ void k_selftest_exact_math(unsigned long long *counts)
 {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
-    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c5 = 0, c6 = 0, c7 = 0;
     for (uint64_t i = tid; i < (1ull << 32); i += stride) {
         const float x = __uint_as_float((uint32_t)i);
+        // the Mandelbulb loop's forms (de_mandelbulb8): the bailout test on the squared radius, and the two roots of an
+        // iteration that did not escape (d = x with k3 = x covers every d and every k3 the loop can hold)
+        c5 += (sqrtf(x) > 4.0f) != (x > RMDF_MB8_D4);
+        if (!(x > RMDF_MB8_D4)) {
+            const float q = x * x * x * x * x * x * x;
+            float r, k2;
+            mb8_roots(x, x, q, r, k2);
+            const float rr = sqrtf(x), kk = 1.0f / sqrtf(q);
+            c6 += !((__float_as_uint(r) == __float_as_uint(rr)) || (r != r && rr != rr));
+            c7 += !((__float_as_uint(k2) == __float_as_uint(kk)) || (k2 != k2 && kk != kk));
+        }
         const float a0 = sqrt_rn(x), b0 = sqrtf(x);
         const float a1 = rcp_rn(x), b1 = 1.0f / x;
         const float a2 = log_pinned(x), b2 = log_ref_division(x);
@@ -70,6 +82,7 @@ __global__ void k_selftest_exact_math(unsigned long long *counts)
         c3 += !((__float_as_uint(a3) == __float_as_uint(b3)) || (a3 != a3 && b3 != b3));
     }
     atomicAdd(&counts[0], c0); atomicAdd(&counts[1], c1); atomicAdd(&counts[2], c2); atomicAdd(&counts[3], c3);
+    atomicAdd(&counts[5], c5); atomicAdd(&counts[6], c6); atomicAdd(&counts[7], c7);
 }
 
 // Self-test of the straight-line pinned functions (rmdf_device.hpp) against their branchy fdlibm-style forms, over ALL 2^32

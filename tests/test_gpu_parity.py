@@ -282,7 +282,7 @@ def test_exact_math_exhaustive(sr, orc):
     on the device for all 2^32 float inputs.  The compiler's own sqrtf / division are then tied to the host's IEEE
     arithmetic (what the oracle runs on) through sampled comparisons of the functions built from them."""
     mism = sr.selftest_exact_math()
-    assert mism.tolist() == [0, 0, 0, 0, 0], mism
+    assert mism.tolist() == [0] * 8, mism
 
 
 def test_straggler_pooling_is_invisible(rmdf, sr, env_faces):

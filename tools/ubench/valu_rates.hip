@@ -69,6 +69,43 @@ __global__ void k_scalar(float *out, float c)
         if (K == 20) { asm volatile("v_sub_f32 %0, %0, %4\n\tv_sub_f32 %1, %1, %4\n\tv_sub_f32 %2, %2, %4\n\tv_sub_f32 %3, %3, %4\n\t"
                                    "v_mul_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_mul_f32 %2, %2, %4\n\tv_mul_f32 %3, %3, %4"
                                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c)); }
+        if (K == 21) { // float / integer interleaved: do they share one issue port?
+            asm volatile("v_mul_f32 %0, %0, %8\n\tv_add_u32 %4, %4, %8\n\tv_mul_f32 %1, %1, %8\n\tv_add_u32 %5, %5, %8\n\t"
+                         "v_mul_f32 %2, %2, %8\n\tv_add_u32 %6, %6, %8\n\tv_mul_f32 %3, %3, %8\n\tv_add_u32 %7, %7, %8"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c)); }
+        if (K == 22) { // float / transcendental interleaved 7:1
+            asm volatile("v_mul_f32 %0, %0, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_rsq_f32 %7, %7\n\t"
+                         "v_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c)); }
+        if (K == 23) { // float / compare+select interleaved
+            asm volatile("v_mul_f32 %0, %0, %8\n\tv_cmp_lt_f32 vcc, %4, %8\n\tv_mul_f32 %1, %1, %8\n\tv_cndmask_b32 %5, %5, %8, vcc\n\t"
+                         "v_mul_f32 %2, %2, %8\n\tv_cmp_lt_f32 vcc, %6, %8\n\tv_mul_f32 %3, %3, %8\n\tv_cndmask_b32 %7, %7, %8, vcc"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c) : "vcc"); }
+        if (K == 24) { // VOP2 fma with a literal multiplier: D = S0 * K + S1
+            asm volatile("v_fmamk_f32 %0, %0, 0xc1000000, %8\n\tv_fmamk_f32 %1, %1, 0xc1000000, %8\n\tv_fmamk_f32 %2, %2, 0xc1000000, %8\n\tv_fmamk_f32 %3, %3, 0xc1000000, %8\n\t"
+                         "v_fmamk_f32 %4, %4, 0xc1000000, %8\n\tv_fmamk_f32 %5, %5, 0xc1000000, %8\n\tv_fmamk_f32 %6, %6, 0xc1000000, %8\n\tv_fmamk_f32 %7, %7, 0xc1000000, %8"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c)); }
+        if (K == 25) { // VOP3 fma with an inline constant and two VGPRs
+            asm volatile("v_fma_f32 %0, %0, 2.0, %8\n\tv_fma_f32 %1, %1, 2.0, %8\n\tv_fma_f32 %2, %2, 2.0, %8\n\tv_fma_f32 %3, %3, 2.0, %8\n\t"
+                         "v_fma_f32 %4, %4, 2.0, %8\n\tv_fma_f32 %5, %5, 2.0, %8\n\tv_fma_f32 %6, %6, 2.0, %8\n\tv_fma_f32 %7, %7, 2.0, %8"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c)); }
+        if (K == 26) { // the iteration's mix: 6 mul/add : 1 three-source fma with distinct registers
+            asm volatile("v_mul_f32 %0, %0, %8\n\tv_add_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_fma_f32 %3, %4, %5, %3\n\t"
+                         "v_mul_f32 %4, %4, %8\n\tv_add_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %7, %7, %8"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c)); }
+        if (K == 27) { // 15 mul : 1 rsq
+            asm volatile("v_mul_f32 %0, %0, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_rsq_f32 %7, %7\n\t"
+                         "v_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\t"
+                         "v_mul_f32 %0, %0, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\t"
+                         "v_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %0, %0, %8"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c)); }
+        if (K == 28) { // 31 mul : 1 rsq
+            asm volatile("v_rsq_f32 %7, %7\n\t"
+                         "v_mul_f32 %0, %0, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\t"
+                         "v_mul_f32 %0, %0, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %0, %0, %8\n\t"
+                         "v_mul_f32 %0, %0, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %0, %0, %8\n\t"
+                         "v_mul_f32 %0, %0, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %0, %0, %8"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c)); }
         if (K == 9) { // dependent chain of v_mul (latency)
             asm volatile("v_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\t"
                          "v_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1" : "+v"(a0) : "v"(c)); }
@@ -95,7 +132,7 @@ __global__ void k_packed(float *out, float cc)
 }
 
 template <typename F>
-static void run(const char *name, F launch, int ops_per_instr)
+static void run(const char *name, F launch, int ops_per_instr, double instr_scale = 1.0)
 {
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
@@ -115,7 +152,7 @@ static void run(const char *name, F launch, int ops_per_instr)
         hipEventSynchronize(e1);
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
-        double winstr = (double)blocks * 4 * REPS * 8;
+        double winstr = (double)blocks * 4 * REPS * 8 * instr_scale;
         double per_simd_per_s = winstr / (cus * 4.0) / (ms * 1e-3);
         printf("  wps%d: %6.3f ms %6.2f Ginstr/s/SIMD (%5.1f Tlaneops/s)", wps, ms, per_simd_per_s / 1e9,
                winstr * 64 * ops_per_instr / (ms * 1e-3) / 1e12);
@@ -129,6 +166,8 @@ int main()
 #define S(K, NAME) run(NAME, [](int b, int t, float *o) { hipLaunchKernelGGL(k_scalar<K>, dim3(b), dim3(t), 0, 0, o, 1.0001f); }, 1)
 #define P(K, NAME) run(NAME, [](int b, int t, float *o) { hipLaunchKernelGGL(k_packed<K>, dim3(b), dim3(t), 0, 0, o, 1.0001f); }, 2)
     S(0, "v_mul_f32"); S(1, "v_add_f32"); S(2, "v_fma_f32"); P(0, "v_pk_mul_f32"); P(1, "v_pk_add_f32"); P(2, "v_pk_fma_f32");
-    S(3, "v_sqrt_f32"); S(4, "v_rcp_f32"); S(5, "v_rsq_f32"); S(6, "v_log_f32"); S(7, "v_max_f32"); S(8, "v_cndmask vcc"); S(10, "v_cndmask e64"); S(11, "v_cmp_lt_f32"); S(12, "v_fma 3src"); S(13, "v_fmac_f32"); S(14, "v_add_u32"); S(15, "v_mul 2vsrc"); S(9, "dep v_mul"); S(16, "cmp+cnd vcc"); S(17, "cmp+cnd sgpr"); S(18, "cmp,2mul,cnd,4mul"); S(19, "v_min_f32"); S(20, "sub/mul mix");
+    S(3, "v_sqrt_f32"); S(4, "v_rcp_f32"); S(5, "v_rsq_f32"); S(6, "v_log_f32"); S(7, "v_max_f32"); S(8, "v_cndmask vcc"); S(10, "v_cndmask e64"); S(11, "v_cmp_lt_f32"); S(12, "v_fma 3src"); S(13, "v_fmac_f32"); S(14, "v_add_u32"); S(15, "v_mul 2vsrc"); S(9, "dep v_mul"); S(16, "cmp+cnd vcc"); S(17, "cmp+cnd sgpr"); S(18, "cmp,2mul,cnd,4mul"); S(19, "v_min_f32"); S(20, "sub/mul mix"); S(21, "mul/add_u32 1:1"); S(22, "7 mul : 1 rsq"); S(23, "mul/cmp/mul/cnd"); S(24, "v_fmamk literal"); S(25, "v_fma inline k"); S(26, "7 mul/add : 1 fma3");
+    run("15 mul : 1 rsq", [](int b, int t, float *o) { hipLaunchKernelGGL(k_scalar<27>, dim3(b), dim3(t), 0, 0, o, 1.0001f); }, 1, 2.0);
+    run("31 mul : 1 rsq", [](int b, int t, float *o) { hipLaunchKernelGGL(k_scalar<28>, dim3(b), dim3(t), 0, 0, o, 1.0001f); }, 1, 4.0);
     return 0;
 }
