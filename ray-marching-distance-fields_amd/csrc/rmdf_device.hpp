@@ -250,31 +250,29 @@ __device__ __forceinline__ float de_mandelbulb8(v3 pos, unsigned &iters)
     v3 w = pos;
     float dr = 1.0f;
     float r = 0.0f, d = 0.0f;
-    bool escaped = false;
     for (int i = 0; i < 25; i++) {
         // r = length(w); if (r > bailout) break;                                    fragment.shd:137-139
         const float x = w.x, y = w.y, z = w.z;
         const float x2 = x * x, y2 = y * y, z2 = z * z;
         const float k3 = y2 + x2;                       // = x*x + y*y of the dot product (addition commutes bit for bit)
         d = k3 + z2;
-        if (d > RMDF_MB8_D4) { escaped = true; break; }
+        if (d > RMDF_MB8_D4) break;
         // w = triplex_pow8(w)                                                       fragment.shd:74-99
         const float x4 = x2 * x2, y4 = y2 * y2, z4 = z2 * z2;
         const float q = k3 * k3 * k3 * k3 * k3 * k3 * k3;
-        float k2;
-        mb8_roots(d, k3, q, r, k2);                     // r = sqrt(d), k2 = inversesqrt(q)
         const float k1 = y4 + z4 + x4 - 6.0f * z2 * x2 - 6.0f * y2 * z2 + 2.0f * x2 * y2;
         const float k4 = y2 - z2 + x2;
-        const float wx = -8.0f * z * k4 * (y4 * y4 - 28.0f * y4 * y2 * x2 + 70.0f * y4 * x4 - 28.0f * y2 * x2 * x4 + x4 * x4) * k1 * k2;
-        const float wy = 64.0f * y * z * x * (y2 - x2) * k4 * (y4 - 6.0f * y2 * x2 + x4) * k1 * k2;
+        const float wx_ = -8.0f * z * k4 * (y4 * y4 - 28.0f * y4 * y2 * x2 + 70.0f * y4 * x4 - 28.0f * y2 * x2 * x4 + x4 * x4) * k1;
+        const float wy_ = 64.0f * y * z * x * (y2 - x2) * k4 * (y4 - 6.0f * y2 * x2 + x4) * k1;
         const float wz = -16.0f * z2 * k3 * k4 * k4 + k1 * k1;
-        w = add3(mk3(wx, wy, wz), pos);
-        // dr = pow(r, power - 1) * power * dr + 1                                   fragment.shd:148
+        float k2;
+        mb8_roots(d, k3, q, r, k2);
         const float r2 = r * r, r4 = r2 * r2, r7 = (r4 * r2) * r;
         dr = r7 * 8.0f * dr + 1.0f;
+        w = add3(mk3(wx_ * k2, wy_ * k2, wz), pos);
         iters++;
     }
-    if (escaped) r = sqrt_rn(d);
+    if (d > RMDF_MB8_D4) r = sqrt_rn(d);           // the lanes that left through the break (d keeps its last value)
     return 0.5f * log_pinned(r) * r / dr;
 }
 

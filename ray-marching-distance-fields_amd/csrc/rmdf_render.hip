@@ -100,6 +100,7 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
     const bool active = (px < ex1) && (py < ey1);
 #ifdef RMDF_XCHECK
     const unsigned long long dbg_t0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;   // wave timeline (tools/nested_timeline.py)
+    const unsigned long long dbg_c0 = p.dbg ? __builtin_amdgcn_s_memtime() : 0ull;       // shader cycles: the clock the kernel really runs at
 #endif
 
     // generate_ray, perspective branch (fragment.shd:840-871)
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
 #ifdef RMDF_XCHECK
     if (p.dbg && lane == 0) {
         const unsigned wid = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
-        if (wid < 32768u * 2u) { p.dbg[wid * 8 + 6] = dbg_t0; p.dbg[wid * 8 + 7] = __builtin_amdgcn_s_memrealtime(); p.dbg[wid * 8] = (unsigned long long)steps; }
+        if (wid < 32768u * 2u) { p.dbg[wid * 8 + 4] = dbg_c0; p.dbg[wid * 8 + 5] = __builtin_amdgcn_s_memtime(); p.dbg[wid * 8 + 6] = dbg_t0; p.dbg[wid * 8 + 7] = __builtin_amdgcn_s_memrealtime(); p.dbg[wid * 8] = (unsigned long long)steps; }
     }
 #endif
 }

@@ -22,6 +22,11 @@ d = e - b
 print("flags %d: waves recorded %d, span %.1f us" % (flags, len(st), e.max()))
 print("wave duration us: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f ; sum %.3e us (= %.1f us x 8192 wave slots)" %
       (d.mean(), *np.percentile(d, [50, 90, 99]), d.max(), d.sum(), d.sum() / 8192))
+long_w = d > 20.0
+if long_w.any():
+    # shader clock while the kernel runs: s_memtime ticks (shader cycles) per s_memrealtime tick (100 MHz), waves that lived > 20 us
+    print("shader clock during the launch: %.0f MHz (s_memtime / s_memrealtime over %d waves)" %
+          ((st[long_w, 5] - st[long_w, 4]).sum() / (st[long_w, 7] - st[long_w, 6]).sum() * 100.0, long_w.sum()))
 print("start time us: p50 %.1f p90 %.1f max %.1f" % (*np.percentile(b, [50, 90]), b.max()))
 for q in range(25, int(e.max()) + 25, 25):
     print("  resident at t=%d us: %d waves" % (q, ((b <= q) & (e > q)).sum()))

@@ -131,6 +131,17 @@ __global__ void k_packed(float *out, float cc)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y;
 }
 
+// shader clock under a full VALU load: s_memtime ticks (shader cycles) per s_memrealtime tick (100 MHz), lane 0 of every workgroup
+__global__ void k_clock(float *out, float c, unsigned long long *stamps)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < REPS; i++) { CHAIN8("v_mul_f32") }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { stamps[blockIdx.x * 2] = t1 - t0; stamps[blockIdx.x * 2 + 1] = r1 - r0; }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
 template <typename F>
 static void run(const char *name, F launch, int ops_per_instr, double instr_scale = 1.0)
 {
@@ -161,8 +172,32 @@ static void run(const char *name, F launch, int ops_per_instr, double instr_scal
     hipFree(out);
 }
 
+static void clock_under_load()
+{
+    hipDeviceProp_t prop;
+    (void)hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount;
+    for (int wps : { 1, 2, 4, 8 }) {
+        const int blocks = cus * wps;
+        float *out; unsigned long long *st;
+        (void)hipMalloc(&out, (size_t)blocks * 256 * 4); (void)hipMalloc(&st, (size_t)blocks * 16);
+        for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL(k_clock, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, st);
+        (void)hipDeviceSynchronize();
+        std::vector<unsigned long long> h(blocks * 2);
+        (void)hipMemcpy(h.data(), st, (size_t)blocks * 16, hipMemcpyDeviceToHost);
+        double cyc = 0, real = 0;
+        for (int b = 0; b < blocks; b++) { cyc += (double)h[b * 2]; real += (double)h[b * 2 + 1]; }
+        const double mhz = cyc / real * 100.0;
+        // instructions per wave = REPS * 8; four waves per block on four SIMDs, wps blocks per CU
+        printf("clock under v_mul load, %d waves/SIMD: s_memtime/s_memrealtime -> %.0f MHz; %.2f shader cycles per wave-instruction per SIMD\n",
+               wps, mhz, cyc / blocks / ((double)REPS * 8 * wps));
+        (void)hipFree(out); (void)hipFree(st);
+    }
+}
+
 int main()
 {
+    clock_under_load();
 #define S(K, NAME) run(NAME, [](int b, int t, float *o) { hipLaunchKernelGGL(k_scalar<K>, dim3(b), dim3(t), 0, 0, o, 1.0001f); }, 1)
 #define P(K, NAME) run(NAME, [](int b, int t, float *o) { hipLaunchKernelGGL(k_packed<K>, dim3(b), dim3(t), 0, 0, o, 1.0001f); }, 2)
     S(0, "v_mul_f32"); S(1, "v_add_f32"); S(2, "v_fma_f32"); P(0, "v_pk_mul_f32"); P(1, "v_pk_add_f32"); P(2, "v_pk_fma_f32");
