@@ -244,7 +244,8 @@ int rmdf_render_frame_sharded_device(rmdf_ctx *ctx, int scene, int w, int h, dou
  * division inside log) against the compiler's IEEE expansions for ALL 2^32 float inputs on the device.
  * mismatches[0..3] = sqrt, reciprocal, log, 1/sqrt; mismatches[4] = the table-driven division of the Cornell
  * distance estimator against the compiler's for every numerator and each of its 96 divisors; mismatches[5..7] = the
- * Mandelbulb loop's forms: the bailout test taken on the squared radius, the in-loop root of the radius and the in-loop
+ * Mandelbulb loop's forms: the bailout test taken on the squared radius together with the estimate's final division
+ * (Markstein on the reciprocal of dr, 2^33 operand pairs), the in-loop root of the radius and the in-loop
  * 1/sqrt(k3^7) (one transcendental each, one shared guard) against the written sqrt / inversesqrt.  All must be 0. */
 int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[8]);
 /* Self-test of the straight-line device forms of the pinned GLSL built-ins (exp, acos, atan, sin, cos: all 2^32 inputs;

@@ -64,6 +64,16 @@ __global__ void k_selftest_exact_math(unsigned long long *counts)
         // the Mandelbulb loop's forms (de_mandelbulb8): the bailout test on the squared radius, and the two roots of an
         // iteration that did not escape (d = x with k3 = x covers every d and every k3 the loop can hold)
         c5 += (sqrtf(x) > 4.0f) != (x > RMDF_MB8_D4);
+        {
+            // the estimate's final division: every bit pattern as the numerator against a hashed dr >= 1 (exponents 0..75 densely,
+            // the guard's edge and beyond now and then), and every bit pattern as dr against a hashed numerator
+            uint32_t h = (uint32_t)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            const float dr1 = __uint_as_float((h & 0x007fffffu) | ((127u + (h >> 23) % ((h >> 31) ? 128u : 76u)) << 23));
+            const float a2 = __uint_as_float((h & 0x807fffffu) | ((127u - 40u + (h >> 24) % 48u) << 23));
+            const float q1 = div_by_dr(x, dr1), e1 = x / dr1, q2 = div_by_dr(a2, x), e2 = a2 / x;
+            c5 += !((__float_as_uint(q1) == __float_as_uint(e1)) || (q1 != q1 && e1 != e1));
+            c5 += !((__float_as_uint(q2) == __float_as_uint(e2)) || (q2 != q2 && e2 != e2));
+        }
         if (!(x > RMDF_MB8_D4)) {
             const float q = x * x * x * x * x * x * x;
             float r, k2;
