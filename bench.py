@@ -533,7 +533,7 @@ def main():
                                   "kernel_ms_avg": round(kern_ms, 4), "kernel_ms_min": round(kern_ms_min, 4),
                                   "kernel_ms_note": "HIP events on the launch stream around one frame's launches, one frame at a time: k_render "
                                                     "plus the single-workgroup k_order_blocks (~0.009 ms) that follows it; rocprofv3 of this "
-                                                    "command (profiles/r02_kernel_stats_s1.csv): k_render alone 0.461 ms",
+                                                    "command (profiles/r02_kernel_stats_s1.csv): k_render alone 0.433 ms",
                                   "ops_per_launch": F, "op_counters": ctr, "op_counters_source": ctr_src,
                                   "note": "binding roof = FP32 vector-ALU issue (SURVEY 8d): as-written IEEE operations (sqrt, 1/sqrt, "
                                           "log, pow, / each 1; no FMA contraction by the parity contract) per second against 256 CU x "
