@@ -260,13 +260,12 @@ __device__ __forceinline__ void mb8_roots(float d, float k3, float q, float &r, 
     const bool slow = (int)(k3 < RMDF_MB8_K3MIN) | (int)root_needs_slow_rcp(sq);
     if (__builtin_expect(__ballot(slow) != 0ull, 0)) { if (slow) { r = sqrtf(d); k2 = 1.0f / sqrtf(q); } }
 }
-__device__ __forceinline__ float de_mandelbulb8(v3 pos, unsigned &iters)
+// Iterations i0 .. i1-1 of the loop (i1 <= 25) on the state (w, dr, r, d); a lane whose squared radius d exceeds the bailout
+// leaves early.  Afterwards the estimate is complete iff d > RMDF_MB8_D4 (escaped) or i1 == 25; otherwise mb8_iterate(.., i1, 25, ..)
+// resumes it -- on any lane: the distance-AO estimates of k_render are finished that way (rmdf_render.hip).
+__device__ __forceinline__ void mb8_iterate(v3 &w, const v3 pos, float &dr, float &r, float &d, int i0, int i1, unsigned &iters)
 {
-    pos = mk3(pos.z, pos.x, pos.y);
-    v3 w = pos;
-    float dr = 1.0f;
-    float r = 0.0f, d = 0.0f;
-    for (int i = 0; i < 25; i++) {
+    for (int i = i0; i < i1; i++) {
         // r = length(w); if (r > bailout) break;                                    fragment.shd:137-139
         const float x = w.x, y = w.y, z = w.z;
         const float x2 = x * x, y2 = y * y, z2 = z * z;
@@ -283,13 +282,26 @@ __device__ __forceinline__ float de_mandelbulb8(v3 pos, unsigned &iters)
         const float wz = -16.0f * z2 * k3 * k4 * k4 + k1 * k1;
         float k2;
         mb8_roots(d, k3, q, r, k2);
+        // dr = pow(r, power - 1) * power * dr + 1                                   fragment.shd:148
         const float r2 = r * r, r4 = r2 * r2, r7 = (r4 * r2) * r;
         dr = r7 * 8.0f * dr + 1.0f;
         w = add3(mk3(wx_ * k2, wy_ * k2, wz), pos);
         iters++;
     }
-    if (d > RMDF_MB8_D4) r = sqrt_rn(d);           // the lanes that left through the break (d keeps its last value)
+}
+// fragment.shd:157 -- the lanes that left through the break take their root now (d keeps its last value)
+__device__ __forceinline__ float mb8_finish(float dr, float r, float d)
+{
+    if (d > RMDF_MB8_D4) r = sqrt_rn(d);
     return div_by_dr(0.5f * log_pinned(r) * r, dr);
+}
+__device__ __forceinline__ float de_mandelbulb8(v3 pos, unsigned &iters)
+{
+    pos = mk3(pos.z, pos.x, pos.y);
+    v3 w = pos;
+    float dr = 1.0f, r = 0.0f, d = 0.0f;
+    mb8_iterate(w, pos, dr, r, d, 0, 25, iters);
+    return mb8_finish(dr, r, d);
 }
 
 // ---- pinned sin / cos / acos / atan / mod (FSMBGeneralShader, FSDETestShader) ------------------------

@@ -58,6 +58,14 @@ __device__ __forceinline__ float bsphere_r() { return SCENE == 2 ? 1.15f : (SCEN
 // rays with similar escape-iteration counts, so the packet coherence the nested loop lives on is kept.  Results go
 // through an LDS table indexed by strip pixel; ray arithmetic is untouched (bit-identical output).
 #define MERGE_T 32
+// Distance-AO estimates of the power-8 Mandelbulb (MERGE variant): a sample point 0.016 / 0.081 off the surface lands INSIDE another
+// part of the set for 0.7 % / 4.2 % of the hit pixels and then runs all 25 iterations, while the mean is 3.8 -- so nearly every
+// wave's two AO estimates ran ~21 passes for ~7.5 lanes' worth of work (tools/ubench/surface_k.hip).  Every lane therefore
+// iterates at most AO_CUT passes in place; estimates still iterating then are set aside in an LDS queue (their state: w, pos,
+// dr, r) and the workgroup finishes them together, 64 per wave, with the same code (mb8_iterate resumes anywhere: bit-identical).
+// A full queue is not an error: those lanes finish in place.
+#define AO_CUT 5
+#define AO_CAP 128
 
 // OUT selects the planes an instantiation writes: OUT_RGBA8 = the product path (RGBA8 frame only), OUT_MIRROR = RGBA8 +
 // the same rows into a registered host buffer (rmdf_register_host_buffer), OUT_PLANES = RGBA8 + the float / steps /
@@ -68,6 +76,10 @@ enum { OUT_RGBA8 = 0, OUT_MIRROR = 1, OUT_PLANES = 2 };
 template <int SCENE, bool MERGE, int OUT>
 __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
 {
+    constexpr bool AO_POOL = (SCENE == 2) && MERGE;
+    __shared__ unsigned s_ao_cnt;
+    __shared__ float4   s_ao_q[AO_POOL ? AO_CAP : 1][2];      // w.xyz, dr | pos.xyz, r
+    __shared__ float2   s_ao_out[AO_POOL ? AO_CAP : 1];       // distance, iterations run after the hand-over
     // Which strip this workgroup renders: raster order over (slot, row, column), or most expensive first
     // (block_order, a permutation of the launch's linear workgroup ids -- it spans all tiles of a shard launch)
     const unsigned strips_per_slot = gridDim.x * gridDim.y;
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
         __shared__ int    s_mb_n[WPB], s_mb_ready[WPB];
         __shared__ float4 s_mb[WPB][MERGE_T];
         __shared__ float4 s_res[WPB * 64];          // per strip pixel: t, steps | hit << 15, iterations
-        if (threadIdx.x == 0) { s_host = -1; s_nreported = 0; }
+        if (threadIdx.x == 0) { s_host = -1; s_nreported = 0; s_ao_cnt = 0u; }
         if (threadIdx.x < WPB) { s_mb_ready[threadIdx.x] = 0; s_mb_n[threadIdx.x] = 0; }
         const int my_sp = ly * (WPB * 8) + wave * 8 + lx;
         s_res[my_sp] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -250,8 +262,9 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
     // render_ray hit branch up to the texture lookups (fragment.shd:743-799)
     v3 n = mk3(0.0f, 0.0f, 0.0f), refl = mk3(0.0f, 0.0f, 0.0f);
     float ao = 0.0f, fresnel = 0.0f;
+    v3 isec = mk3(0.0f, 0.0f, 0.0f);
     if (hit) {
-        v3 isec = mk3(origin.x + dir.x * t, origin.y + dir.y * t, origin.z + dir.z * t);
+        isec = mk3(origin.x + dir.x * t, origin.y + dir.y * t, origin.z + dir.z * t);
         v3 np = mk3(isec.x - dir.x * 0.00001f, isec.y - dir.y * 0.00001f, isec.z - dir.z * 0.00001f);
         const float eps = 0.00001f;
         float d0 = distance_estimator<SCENE>(np, p, iters, tri_hint);
@@ -259,12 +272,71 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
         float dy = distance_estimator<SCENE>(mk3(np.x - 0.0f, np.y - eps, np.z - 0.0f), p, iters, tri_hint);
         float dz = distance_estimator<SCENE>(mk3(np.x - 0.0f, np.y - 0.0f, np.z - eps), p, iters, tri_hint);
         n = normalize3(mk3(d0 - dx, d0 - dy, d0 - dz));
-        // distance_ao (fragment.shd:542-591)
+    }
+    // distance_ao (fragment.shd:542-591)
+    const float w0 = 0.5f, e0 = 0.016f, w1 = 0.25f, e1 = 0.081f;
+    float ao_dist[2] = { 0.0f, 0.0f };
+    if (AO_POOL) {
+        // the two estimates with their stragglers set aside (see AO_CUT above); every wave of the workgroup comes through here
+        int slot[2] = { -1, -1 };
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const float e = k == 0 ? e0 : e1;
+            v3 pos = mk3(isec.x + n.x * e, isec.y + n.y * e, isec.z + n.z * e);
+            pos = mk3(pos.z, pos.x, pos.y);                     // de_mandelbulb8's own first statement
+            v3 w = pos;
+            float dr = 1.0f, r = 0.0f, d = 0.0f;
+            bool pend = false;
+            if (hit) {
+                mb8_iterate(w, pos, dr, r, d, 0, AO_CUT, iters);
+                pend = !(d > RMDF_MB8_D4);
+            }
+            // one LDS atomic per wave: queue slots for its pending estimates
+            const unsigned long long pm = __ballot(pend);
+            if (pm != 0ull) {
+                unsigned base = 0u;
+                if (lane == 0) base = atomicAdd(&s_ao_cnt, (unsigned)__popcll(pm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const unsigned mine = base + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0));
+                if (pend) {
+                    if (mine < (unsigned)AO_CAP) {
+                        slot[k] = (int)mine;
+                        s_ao_q[mine][0] = make_float4(w.x, w.y, w.z, dr);
+                        s_ao_q[mine][1] = make_float4(pos.x, pos.y, pos.z, r);
+                    } else {
+                        mb8_iterate(w, pos, dr, r, d, AO_CUT, 25, iters);      // queue full: finish in place
+                    }
+                }
+            }
+            if (hit && slot[k] < 0) ao_dist[k] = mb8_finish(dr, r, d);
+        }
+        __syncthreads();
+        const unsigned n_q = s_ao_cnt < (unsigned)AO_CAP ? s_ao_cnt : (unsigned)AO_CAP;     // the same for every wave
+        if (n_q != 0u) {
+            for (unsigned tsk = threadIdx.x; tsk < n_q; tsk += WPB * 64) {
+                const float4 a = s_ao_q[tsk][0], b = s_ao_q[tsk][1];
+                v3 w = mk3(a.x, a.y, a.z);
+                const v3 pos = mk3(b.x, b.y, b.z);
+                float dr = a.w, r = b.w, d = 0.0f;
+                unsigned it2 = 0u;
+                mb8_iterate(w, pos, dr, r, d, AO_CUT, 25, it2);
+                s_ao_out[tsk] = make_float2(mb8_finish(dr, r, d), __uint_as_float(it2));
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+                if (slot[k] >= 0) { const float2 o = s_ao_out[slot[k]]; ao_dist[k] = o.x; iters += __float_as_uint(o.y); }
+        }
+    }
+    if (hit) {
         float occl = 0.0f;
         if (SCENE != 0) {
-            const float w0 = 0.5f, e0 = 0.016f, w1 = 0.25f, e1 = 0.081f;
-            occl += w0 * gclamp(1.0f - distance_estimator<SCENE>(mk3(isec.x + n.x * e0, isec.y + n.y * e0, isec.z + n.z * e0), p, iters, tri_hint) / e0, 0.0f, 1.0f);
-            occl += w1 * gclamp(1.0f - distance_estimator<SCENE>(mk3(isec.x + n.x * e1, isec.y + n.y * e1, isec.z + n.z * e1), p, iters, tri_hint) / e1, 0.0f, 1.0f);
+            if (!AO_POOL) {
+                ao_dist[0] = distance_estimator<SCENE>(mk3(isec.x + n.x * e0, isec.y + n.y * e0, isec.z + n.z * e0), p, iters, tri_hint);
+                ao_dist[1] = distance_estimator<SCENE>(mk3(isec.x + n.x * e1, isec.y + n.y * e1, isec.z + n.z * e1), p, iters, tri_hint);
+            }
+            occl += w0 * gclamp(1.0f - ao_dist[0] / e0, 0.0f, 1.0f);
+            occl += w1 * gclamp(1.0f - ao_dist[1] / e1, 0.0f, 1.0f);
             occl = 1.0f - occl;
             occl -= 0.29f;
             occl *= 3.5f;
