@@ -64,8 +64,8 @@ __device__ __forceinline__ float bsphere_r() { return SCENE == 2 ? 1.15f : (SCEN
 // iterates at most AO_CUT passes in place; estimates still iterating then are set aside in an LDS queue (their state: w, pos,
 // dr, r) and the workgroup finishes them together, 64 per wave, with the same code (mb8_iterate resumes anywhere: bit-identical).
 // A full queue is not an error: those lanes finish in place.
-#define AO_CUT 5
-#define AO_CAP 128
+#define AO_CUT 6
+#define AO_CAP 256
 
 // OUT selects the planes an instantiation writes: OUT_RGBA8 = the product path (RGBA8 frame only), OUT_MIRROR = RGBA8 +
 // the same rows into a registered host buffer (rmdf_register_host_buffer), OUT_PLANES = RGBA8 + the float / steps /
