@@ -156,6 +156,30 @@ int main()
     printf("cost model: wave-step = %.0f * max k + %.0f wave instructions\n", A, B);
     printf("%-28s %10.1f M wave-instr  (x%.3f of nested)\n", "ideal (all lanes busy)", ideal / 1e6, ideal / c_nested);
     printf("%-28s %10.1f M wave-instr  lane utilisation %.3f\n", "nested 8x8 packets", c_nested / 1e6, ideal / c_nested);
+    // Upper bound of what setting aside long ESTIMATES of the march could save (what k_render does for the distance-AO estimates since
+    // round 2): every lane iterates at most `cut` passes per wave-step in place; the iterations beyond that are assumed to run elsewhere at
+    // full lane utilisation, for `xch` instructions per wave-step that has any.  Nested packets, no ray pooling.  Ignores that a ray
+    // whose estimate is set aside cannot take its next step until it returns -- a bound, not a schedule.
+    {
+        const double A2 = 91.0, B2 = 100.0, xch = 40.0;
+        std::vector<Ray> r;
+        double base = 0.0, bound[5] = { 0, 0, 0, 0, 0 };
+        const int cuts[5] = { 3, 4, 5, 6, 8 };
+        for (int by = 0; by < PY; by++) for (int bx = 0; bx < PX; bx++) {
+            packet(bx, by, r);
+            for (;;) {
+                int act = 0, mk = 0; int over[5] = { 0, 0, 0, 0, 0 };
+                for (auto &x : r) if (x.step < g_n[x.pix]) { act++; const int k = kof(x.pix, x.step); if (k > mk) mk = k; for (int c = 0; c < 5; c++) if (k > cuts[c]) over[c] += k - cuts[c]; }
+                if (!act) break;
+                base += A2 * mk + B2;
+                for (int c = 0; c < 5; c++) bound[c] += A2 * std::min(mk, cuts[c]) + B2 + (over[c] ? xch + A2 * over[c] / 64.0 : 0.0);
+                for (auto &x : r) if (x.step < g_n[x.pix]) x.step++;
+            }
+        }
+        printf("march estimates with long ones set aside (bound; A = %.0f, B = %.0f): nested %.1f M;", A2, B2, base / 1e6);
+        for (int c = 0; c < 5; c++) printf("  cut %d: %.1f M (x%.3f)", cuts[c], bound[c] / 1e6, bound[c] / base);
+        printf("\n");
+    }
     for (int T : { 16, 24, 32, 40 }) {
         // workgroup pooling: the four packets of a 32x8 strip; survivors of each (<= T) go to one host wave, which
         // takes them 64 at a time in hand-over order and runs them to the end
