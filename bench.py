@@ -184,7 +184,7 @@ def main():
                     "resolved on the GPU before the gather (BASELINE config 4: --width 3840 --height 2160 --supersample 1)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("RMDF_BENCH_STREAMS", "0")),
                     help="frames kept in flight (one HIP stream + buffer set each); 1 = one frame at a time; "
-                         "0 = default: 2 on one GPU, 8 on N GPUs")
+                         "0 = default: 3 on one GPU, 8 on N GPUs")
     ap.add_argument("--animate", type=float, default=0.0, help="advance in_time by this many seconds per frame (the viewer's "
                     "animation: the cost-ordered dispatch then works from the previous frame's costs of a slightly different view)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -250,7 +250,7 @@ def main():
     # i % S.  On one GPU this overlaps the thin tail of a frame -- the launch cannot end before its longest ray has
     # finished a ~0.45 ms serial chain -- with the bulk of the next; on N GPUs it also overlaps the gather of frame i
     # with the render of frame i+1.  --streams 1 = strictly one frame at a time.
-    S = a.streams if a.streams > 0 else (2 if not sharded else 8)
+    S = a.streams if a.streams > 0 else (3 if not sharded else 8)
     if int(os.environ.get("RMDF_FLAGS", "0")) & (rmdf_amd.FLAG_FLAT_MARCH | rmdf_amd.FLAG_PIPELINE):
         # the alternative schedules of librmdf_xcheck.so keep one scratch set per ctx and render on the ctx stream only
         raise SystemExit("RMDF_FLAGS selects an alternative schedule (librmdf_xcheck.so): those support neither frames in flight nor "
