@@ -63,6 +63,7 @@ struct rmdf_ctx {
     hipEvent_t   ev_fork = nullptr, ev_join[4] = { nullptr, nullptr, nullptr, nullptr };
     float       *d_cornell = nullptr;
     float       *d_cornell_tab = nullptr;
+    uint32_t    *d_cornell_grid = nullptr;
     CubeSlot     env[RMDF_ENV_SLOTS];
     std::vector<UvTable>   uv_tables;
     std::vector<LobeTable> lobe_tables;
@@ -251,6 +252,59 @@ void cornell_table(const float tri[96 * 3], float tab[CORNELL_TAB_FLOATS])
         for (int k = 0; k < 8; k++) tab[32 * CORNELL_STRIDE + i * 8 + k] = tab[i * CORNELL_STRIDE + 26 + k];
 }
 
+// Candidate grid of de_cornell_box_table (rmdf_device.hpp: cornell_cell_mask).  Per cell: the triangles t with
+//   d(centre, t) <= min_s d(centre, s) + 2 * rho,   rho = half diagonal of the cell + margin,
+// in double arithmetic on the float vertices.  |d(p, t) - d(centre, t)| <= |p - centre| <= rho for every p of the cell, so a triangle
+// outside the mask is farther than the nearest one everywhere in the cell; the margin (1e-4, scene size ~1) covers the float rounding of
+// the cell index at cell borders and of the reference's own distance formulas (1e-7).
+static double point_triangle_distance(const double p[3], const double a[3], const double b[3], const double c[3])
+{
+    // closest point on triangle abc to p (Ericson, Real-Time Collision Detection 5.1.5)
+    double ab[3], ac[3], ap[3];
+    for (int k = 0; k < 3; k++) { ab[k] = b[k] - a[k]; ac[k] = c[k] - a[k]; ap[k] = p[k] - a[k]; }
+    auto dot = [](const double *u, const double *v) { return u[0] * v[0] + u[1] * v[1] + u[2] * v[2]; };
+    double q[3];
+    const double d1 = dot(ab, ap), d2 = dot(ac, ap);
+    double bp[3], cp[3];
+    for (int k = 0; k < 3; k++) { bp[k] = p[k] - b[k]; cp[k] = p[k] - c[k]; }
+    const double d3 = dot(ab, bp), d4 = dot(ac, bp), d5 = dot(ab, cp), d6 = dot(ac, cp);
+    const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    if (d1 <= 0.0 && d2 <= 0.0) { for (int k = 0; k < 3; k++) q[k] = a[k]; }
+    else if (d3 >= 0.0 && d4 <= d3) { for (int k = 0; k < 3; k++) q[k] = b[k]; }
+    else if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) { const double v = d1 / (d1 - d3); for (int k = 0; k < 3; k++) q[k] = a[k] + v * ab[k]; }
+    else if (d6 >= 0.0 && d5 <= d6) { for (int k = 0; k < 3; k++) q[k] = c[k]; }
+    else if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) { const double w = d2 / (d2 - d6); for (int k = 0; k < 3; k++) q[k] = a[k] + w * ac[k]; }
+    else if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) {
+        const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        for (int k = 0; k < 3; k++) q[k] = b[k] + w * (c[k] - b[k]);
+    } else {
+        const double den = 1.0 / (va + vb + vc), v = vb * den, w = vc * den;
+        for (int k = 0; k < 3; k++) q[k] = a[k] + ab[k] * v + ac[k] * w;
+    }
+    double s2 = 0.0;
+    for (int k = 0; k < 3; k++) s2 += (p[k] - q[k]) * (p[k] - q[k]);
+    return sqrt(s2);
+}
+
+void cornell_grid(const float tri[96 * 3], uint32_t masks[CORNELL_GRID_N * CORNELL_GRID_N * CORNELL_GRID_N])
+{
+    const int N = CORNELL_GRID_N;
+    const double H = (double)CORNELL_GRID_H, cell = 2.0 * H / N, rho = 0.5 * cell * sqrt(3.0) + 1e-4;
+    for (int iz = 0; iz < N; iz++) for (int iy = 0; iy < N; iy++) for (int ix = 0; ix < N; ix++) {
+        const double c[3] = { -H + (ix + 0.5) * cell, -H + (iy + 0.5) * cell, -H + (iz + 0.5) * cell };
+        double d[32], dmin = 1e30;
+        for (int t = 0; t < 32; t++) {
+            double v[3][3];
+            for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) v[j][k] = (double)tri[t * 9 + j * 3 + k];
+            d[t] = point_triangle_distance(c, v[0], v[1], v[2]);
+            if (d[t] < dmin) dmin = d[t];
+        }
+        uint32_t m = 0u;
+        for (int t = 0; t < 32; t++) if (d[t] <= dmin + 2.0 * rho) m |= 1u << t;
+        masks[(iz * N + iy) * N + ix] = m;
+    }
+}
+
 int ensure_frame(rmdf_ctx *ctx, int w, int h, bool planes)
 {
     const size_t npx = (size_t)w * (size_t)h;
@@ -421,6 +475,7 @@ int fill_params(rmdf_ctx *ctx, int scene, int w, int h, float time, int max_step
     // it costs 6 % for the Cornell box, whose distance estimate has the same cost for every ray
     p.merge_stragglers = ((ctx->flags & RMDF_FLAG_NO_MERGE) || scene == RMDF_FS_DE_CORNELL_BOX) ? 0 : 32;
     p.cornell_tab = ctx->d_cornell_tab;
+    p.cornell_grid = ctx->d_cornell_grid;
     p.cornell_prune = (ctx->flags & RMDF_FLAG_NO_PRUNE) ? 0 : 1;
 #ifdef RMDF_XCHECK
     p.dbg = ctx->d_dbg;
@@ -904,12 +959,16 @@ int rmdf_create(rmdf_ctx **out, const rmdf_config *cfg)
     cornell_triangles(tri);
     float tab[CORNELL_TAB_FLOATS];
     cornell_table(tri, tab);
+    std::vector<uint32_t> cgrid((size_t)CORNELL_GRID_N * CORNELL_GRID_N * CORNELL_GRID_N);
+    cornell_grid(tri, cgrid.data());
     if ((e = hipSetDevice(dev)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc((void **)&ctx->d_cornell, sizeof tri)) != hipSuccess ||
         (e = hipMemcpy(ctx->d_cornell, tri, sizeof tri, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMalloc((void **)&ctx->d_cornell_tab, sizeof tab)) != hipSuccess ||
         (e = hipMemcpy(ctx->d_cornell_tab, tab, sizeof tab, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMalloc((void **)&ctx->d_cornell_grid, cgrid.size() * 4)) != hipSuccess ||
+        (e = hipMemcpy(ctx->d_cornell_grid, cgrid.data(), cgrid.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) {
         std::string msg = std::string("device init: ") + hipGetErrorString(e);
         rmdf_destroy(ctx);
@@ -938,6 +997,7 @@ void rmdf_destroy(rmdf_ctx *ctx)
     for (auto &t : ctx->lobe_tables) { (void)hipFree(t.d_lutT); (void)hipFree(t.d_tcs); }
     if (ctx->d_cornell) (void)hipFree(ctx->d_cornell);
     if (ctx->d_cornell_tab) (void)hipFree(ctx->d_cornell_tab);
+    if (ctx->d_cornell_grid) (void)hipFree(ctx->d_cornell_grid);
     if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
     if (ctx->d_rgba_f32) (void)hipFree(ctx->d_rgba_f32);
     if (ctx->d_steps) (void)hipFree(ctx->d_steps);

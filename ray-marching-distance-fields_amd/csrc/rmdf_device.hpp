@@ -696,7 +696,34 @@ __device__ __forceinline__ float cornell_tri_dist2(v3 pos, cfloat *t)
     return gmin(s01, gmin(s02, s12));
 }
 
-__device__ __forceinline__ float de_cornell_box_table(v3 pos, const float *__restrict__ tab, int prune, int &hint)
+// Candidate grid (round 2).  A host-built grid of CORNELL_GRID_N^3 cells over [-CORNELL_GRID_H, CORNELL_GRID_H]^3 holds, per cell, the
+// bit mask of the triangles that can be the nearest one for SOME point of the cell: the point-triangle distance is 1-Lipschitz, so
+// triangle t can win only if d(centre, t) <= min_s d(centre, s) + 2 * (half diagonal + margin) (rmdf_api.cpp: cornell_grid, double
+// arithmetic).  The kernel keeps the grid in LDS; a wave ORs the masks of its lanes' cells (rays of a packet are close together: one or
+// two cells) and the bound tests and row loads below run only for the triangles of that mask -- min() does not care which provably
+// losing triangles are left out.  Points outside the grid (and the NO_PRUNE loop) take every triangle.
+#define CORNELL_GRID_N 16
+#define CORNELL_GRID_H 1.1f
+__device__ __forceinline__ unsigned cornell_cell_mask(v3 p, const unsigned *grid)
+{
+    const float s = (float)CORNELL_GRID_N / (2.0f * CORNELL_GRID_H);
+    const int ix = (int)floorf((p.x + CORNELL_GRID_H) * s), iy = (int)floorf((p.y + CORNELL_GRID_H) * s), iz = (int)floorf((p.z + CORNELL_GRID_H) * s);
+    if ((unsigned)ix >= (unsigned)CORNELL_GRID_N || (unsigned)iy >= (unsigned)CORNELL_GRID_N || (unsigned)iz >= (unsigned)CORNELL_GRID_N) return 0xffffffffu;
+    return grid[(iz * CORNELL_GRID_N + iy) * CORNELL_GRID_N + ix];
+}
+// OR of `m` over the active lanes of the wave (exec-safe: reads only lanes that are active, one per distinct missing bit set)
+__device__ __forceinline__ unsigned wave_or_active(unsigned m)
+{
+    unsigned acc = 0u;
+    for (;;) {
+        const unsigned long long need = __ballot((m & ~acc) != 0u);
+        if (need == 0ull) break;
+        acc |= (unsigned)__builtin_amdgcn_readlane((int)m, (int)__builtin_ctzll(need));
+    }
+    return acc;
+}
+
+__device__ __forceinline__ float de_cornell_box_table(v3 pos, const float *__restrict__ tab, int prune, int &hint, const unsigned *grid = nullptr)
 {
     float dist2 = 998001.0f;                                   // 999^2
     // The table is read-only for the whole launch and every index below is wave-uniform: address it through the
@@ -712,8 +739,12 @@ __device__ __forceinline__ float de_cornell_box_table(v3 pos, const float *__res
         }
         return sqrt_rn(dist2);
     }
-    // the triangle that was nearest last time first, unconditionally
-    const int g = __builtin_amdgcn_readfirstlane(hint) & 31;
+    // candidates of this wave's cells (all 32 without a grid)
+    unsigned cand = grid ? wave_or_active(cornell_cell_mask(pos, grid)) : 0xffffffffu;
+    if (cand == 0u) cand = 0xffffffffu;                        // cannot happen with a well-formed grid (the nearest triangle is always in)
+    // the triangle that was nearest last time first, unconditionally (if it is a candidate; else the first candidate)
+    int g = __builtin_amdgcn_readfirstlane(hint) & 31;
+    if (!((cand >> g) & 1u)) g = (int)__builtin_ctz(cand);
     dist2 = cornell_tri_dist2(pos, ctab + g * CORNELL_STRIDE);
     float dmax = __builtin_amdgcn_sqrtf(dist2) * 1.001f + 1e-5f;
     hint = g;
@@ -722,6 +753,7 @@ __device__ __forceinline__ float de_cornell_box_table(v3 pos, const float *__res
     cfloat *btab = ctab + 32 * CORNELL_STRIDE;
 #pragma unroll 1
     for (int c = 0; c < 8; c++) {
+        if (((cand >> (4 * c)) & 15u & ~((1u << g) >> (4 * c))) == 0u) continue;      // no candidate but possibly g in this chunk
         cfloat *b = btab + c * 32;
         float bb[32];
 #pragma unroll
@@ -729,7 +761,7 @@ __device__ __forceinline__ float de_cornell_box_table(v3 pos, const float *__res
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int i = c * 4 + k;
-            if (i == g) continue;
+            if (i == g || !((cand >> i) & 1u)) continue;
             const float pd = fabsf(((bb[8 * k] * pos.x + bb[8 * k + 1] * pos.y) + bb[8 * k + 2] * pos.z) - bb[8 * k + 3]);
             const v3 dc = mk3(pos.x - bb[8 * k + 4], pos.y - bb[8 * k + 5], pos.z - bb[8 * k + 6]);
             const float rs = bb[8 * k + 7] + dmax;

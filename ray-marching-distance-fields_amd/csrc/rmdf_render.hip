@@ -35,12 +35,12 @@ __device__ __forceinline__ v3 shfl_xor3(v3 a, int mask)
 
 template <int SCENE>
 // hint: Cornell only -- the triangle that was nearest in this lane's previous estimate (evaluation order, not a result)
-__device__ __forceinline__ float distance_estimator(v3 pos, const FrameParams &p, unsigned &iters, int &hint)
+__device__ __forceinline__ float distance_estimator(v3 pos, const FrameParams &p, unsigned &iters, int &hint, const unsigned *cgrid = nullptr)
 {
     if (SCENE == 2)      return de_mandelbulb8(pos, iters);
     else if (SCENE == 3) return de_mandelbulb_general(pos, p.power, iters);
     else if (SCENE == 1) return de_test_scene(pos);
-    else                 return de_cornell_box_table(pos, p.cornell_tab, p.cornell_prune, hint);
+    else                 return de_cornell_box_table(pos, p.cornell_tab, p.cornell_prune, hint, cgrid);
 }
 
 template <int SCENE>
@@ -77,6 +77,14 @@ template <int SCENE, bool MERGE, int OUT>
 __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
 {
     constexpr bool AO_POOL = (SCENE == 2) && MERGE;
+    // Cornell box: the candidate grid (rmdf_device.hpp) lives in LDS for the whole launch
+    __shared__ unsigned s_cgrid[SCENE == 0 ? CORNELL_GRID_N * CORNELL_GRID_N * CORNELL_GRID_N : 1];
+    const unsigned *cgrid = nullptr;
+    if (SCENE == 0 && p.cornell_prune && p.cornell_grid) {
+        for (int i = threadIdx.x; i < CORNELL_GRID_N * CORNELL_GRID_N * CORNELL_GRID_N; i += WPB * 64) s_cgrid[i] = p.cornell_grid[i];
+        __syncthreads();
+        cgrid = s_cgrid;
+    }
     __shared__ unsigned s_ao_cnt;
     __shared__ float4   s_ao_q[AO_POOL ? AO_CAP : 1][2];      // w.xyz, dr | pos.xyz, r
     __shared__ float2   s_ao_out[AO_POOL ? AO_CAP : 1];       // distance, iterations run after the hand-over
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
             t = gmax(0.0f, tmin);
             for (steps = 0; steps < p.max_steps; steps++) {
                 v3 pos = mk3(origin.x + t * dir.x, origin.y + t * dir.y, origin.z + t * dir.z);
-                float dist = distance_estimator<SCENE>(pos, p, iters, tri_hint);
+                float dist = distance_estimator<SCENE>(pos, p, iters, tri_hint, cgrid);
                 t += dist;
                 if (t > tmax) break;
                 if (dist < 0.001f) { hit = true; break; }
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
             // one march step (fragment.shd:661-672) for the rays in flight
             if (act) {
                 const v3 pos = mk3(origin.x + tt * dx, origin.y + tt * dy, origin.z + tt * dz);
-                const float dist = distance_estimator<SCENE>(pos, p, it, tri_hint);
+                const float dist = distance_estimator<SCENE>(pos, p, it, tri_hint, cgrid);
                 tt += dist;
                 const bool out = tt > tmx;
                 const bool h2 = !out && (dist < 0.001f);
@@ -267,10 +275,10 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
         isec = mk3(origin.x + dir.x * t, origin.y + dir.y * t, origin.z + dir.z * t);
         v3 np = mk3(isec.x - dir.x * 0.00001f, isec.y - dir.y * 0.00001f, isec.z - dir.z * 0.00001f);
         const float eps = 0.00001f;
-        float d0 = distance_estimator<SCENE>(np, p, iters, tri_hint);
-        float dx = distance_estimator<SCENE>(mk3(np.x - eps, np.y - 0.0f, np.z - 0.0f), p, iters, tri_hint);
-        float dy = distance_estimator<SCENE>(mk3(np.x - 0.0f, np.y - eps, np.z - 0.0f), p, iters, tri_hint);
-        float dz = distance_estimator<SCENE>(mk3(np.x - 0.0f, np.y - 0.0f, np.z - eps), p, iters, tri_hint);
+        float d0 = distance_estimator<SCENE>(np, p, iters, tri_hint, cgrid);
+        float dx = distance_estimator<SCENE>(mk3(np.x - eps, np.y - 0.0f, np.z - 0.0f), p, iters, tri_hint, cgrid);
+        float dy = distance_estimator<SCENE>(mk3(np.x - 0.0f, np.y - eps, np.z - 0.0f), p, iters, tri_hint, cgrid);
+        float dz = distance_estimator<SCENE>(mk3(np.x - 0.0f, np.y - 0.0f, np.z - eps), p, iters, tri_hint, cgrid);
         n = normalize3(mk3(d0 - dx, d0 - dy, d0 - dz));
     }
     // distance_ao (fragment.shd:542-591)
@@ -332,8 +340,8 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
         float occl = 0.0f;
         if (SCENE != 0) {
             if (!AO_POOL) {
-                ao_dist[0] = distance_estimator<SCENE>(mk3(isec.x + n.x * e0, isec.y + n.y * e0, isec.z + n.z * e0), p, iters, tri_hint);
-                ao_dist[1] = distance_estimator<SCENE>(mk3(isec.x + n.x * e1, isec.y + n.y * e1, isec.z + n.z * e1), p, iters, tri_hint);
+                ao_dist[0] = distance_estimator<SCENE>(mk3(isec.x + n.x * e0, isec.y + n.y * e0, isec.z + n.z * e0), p, iters, tri_hint, cgrid);
+                ao_dist[1] = distance_estimator<SCENE>(mk3(isec.x + n.x * e1, isec.y + n.y * e1, isec.z + n.z * e1), p, iters, tri_hint, cgrid);
             }
             occl += w0 * gclamp(1.0f - ao_dist[0] / e0, 0.0f, 1.0f);
             occl += w1 * gclamp(1.0f - ao_dist[1] / e1, 0.0f, 1.0f);
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
             const float wt[4] = { 0.1f, 0.2f, 0.125f, 0.0625f }, dl[4] = { 0.1f, 0.2f, 0.4f, 0.5f };
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                occl += wt[k] * gclamp(1.0f - distance_estimator<SCENE>(mk3(isec.x + n.x * dl[k], isec.y + n.y * dl[k], isec.z + n.z * dl[k]), p, iters, tri_hint) / dl[k], 0.0f, 1.0f);
+                occl += wt[k] * gclamp(1.0f - distance_estimator<SCENE>(mk3(isec.x + n.x * dl[k], isec.y + n.y * dl[k], isec.z + n.z * dl[k]), p, iters, tri_hint, cgrid) / dl[k], 0.0f, 1.0f);
             ao = 1.0f - occl;
         }
         fresnel = fresnel_conductor(dot3(mk3(-dir.x, -dir.y, -dir.z), n), 0.4f, 0.8f);
