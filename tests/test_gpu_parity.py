@@ -385,16 +385,19 @@ def test_cost_aware_tile_deal(sr, rmdf):
 
 
 def test_cornell_pruning_is_invisible(rmdf, sr, orc, env_oracle, env_faces):
-    """The Cornell distance estimate skips triangles whose lower bounds (plane distance, bounding sphere) exceed the
-    running minimum by a safety margin (rmdf_device.hpp: de_cornell_box_table).  min() is exact and order-independent,
-    so the result must be the same bits as evaluating all 32 triangles (RMDF_FLAG_NO_PRUNE) -- checked on whole frames
-    (march positions, the 1e-5 finite-difference normals, the four AO taps) at several camera positions, and against
-    the oracle."""
+    """The Cornell distance estimate looks at the triangles of its cell's candidate mask only (host-built 16^3 grid, 1-Lipschitz
+    bound) and among those skips triangles whose lower bounds (plane distance, bounding sphere) exceed the running minimum by a
+    safety margin (rmdf_device.hpp: de_cornell_box_table, cornell_cell_mask).  min() is exact and order-independent, so the
+    result must be the same bits as evaluating all 32 triangles (RMDF_FLAG_NO_PRUNE) -- checked on whole frames (march
+    positions, the 1e-5 finite-difference normals, the four AO taps, which reach 0.5 beyond the surfaces) at camera positions
+    around the whole orbit (period 4 pi), and against the oracle."""
     plain = rmdf.ShaderRenderer(0, flags=rmdf.FLAG_NO_PRUNE)
     try:
         for slot, k in ((rmdf.ENV_REFLECTION, "refl"), (rmdf.ENV_COS_1, "cos1"), (rmdf.ENV_COS_8, "cos8")):
             plain.set_env_cube(slot, env_faces[k])
-        for (w, h, t, ms) in ((1280, 720, 0.0, 128), (640, 360, 1.3, 128), (640, 360, 4.0, 128), (250, 130, 9.7, 64), (33, 17, 2.0, 128)):
+        views = [(1280, 720, 0.0, 128), (640, 360, 1.3, 128), (640, 360, 4.0, 128), (250, 130, 9.7, 64), (33, 17, 2.0, 128)]
+        views += [(640, 360, t, 128) for t in (0.7, 2.6, 5.5, 6.3, 7.9, 10.2, 11.4, 12.0)] + [(1920, 1080, 3.3, 256)]
+        for (w, h, t, ms) in views:
             a, b = sr.render(0, w, h, t, max_steps=ms), plain.render(0, w, h, t, max_steps=ms)
             for k in ("rgba8", "steps", "iters"):
                 assert np.array_equal(a[k], b[k]), (k, w, h, t)
