@@ -204,6 +204,49 @@ int main()
         }
         printf("wg-pool T=%-2d %26.1f M wave-instr  (x%.3f of nested)  lane utilisation %.3f\n", T, c / 1e6, c / c_nested, ideal / c);
     }
+    // Generations (what a march split into launches with a global hand-over between them could reach): generation 0 = the product's
+    // workgroup pooling (T = 32), but a host wave that has taken all mail and is down to <= T2 rays appends them to a global list and
+    // stops; generation g + 1 packs that list 64 rays per wave in list order (4 waves per workgroup, the same pooling) and does the same;
+    // the last generation runs to the end.  Q = instructions charged per handed-over ray (queue write + read, ray set-up again), per 64.
+    for (int T2 : { 8, 16, 24, 32 }) for (int ngen : { 2, 3 }) {
+        const double A2 = 91.0, B2 = 100.0, Q = 120.0;
+        const int T = 32;
+        double c = 0.0; size_t moved = 0;
+        // one workgroup: up to 4 waves' rays; returns the survivors handed to the global list
+        auto run_wg = [&](std::vector<Ray> wv[4], int nw, bool last, std::vector<Ray> &out) {
+            std::vector<Ray> pool;
+            for (int q = 0; q < nw; q++) { c += run_wave(wv[q], T, A2, B2, &dummy); pool.insert(pool.end(), wv[q].begin(), wv[q].end()); }
+            std::vector<Ray> host; size_t next = 0;
+            for (;;) {
+                while (host.size() < 64 && next < pool.size()) host.push_back(pool[next++]);
+                if (host.empty()) break;
+                if (!last && next >= pool.size() && (int)host.size() <= T2) { out.insert(out.end(), host.begin(), host.end()); break; }
+                int mk = 0;
+                for (auto &x : host) { int k = kof(x.pix, x.step); if (k > mk) mk = k; }
+                c += A2 * mk + B2;
+                std::vector<Ray> s2;
+                for (auto &x : host) { x.step++; if (x.step < g_n[x.pix]) s2.push_back(x); }
+                host.swap(s2);
+            }
+        };
+        std::vector<Ray> glob, nextglob, wv[4];
+        for (int by = 0; by < PY; by++) for (int sx = 0; sx < (PX + 3) / 4; sx++) {
+            int nw = 0;
+            for (int q = 0; q < 4; q++) { const int bx = sx * 4 + q; if (bx >= PX) break; packet(bx, by, wv[q]); nw++; }
+            run_wg(wv, nw, ngen == 1, glob);
+        }
+        for (int g = 1; g < ngen; g++) {
+            moved += glob.size(); c += Q * glob.size() / 64.0;
+            nextglob.clear();
+            for (size_t i = 0; i < glob.size(); i += 256) {
+                int nw = 0;
+                for (int q = 0; q < 4 && i + 64 * q < glob.size(); q++) { wv[q].assign(glob.begin() + i + 64 * q, glob.begin() + std::min(glob.size(), i + 64 * q + 64)); nw++; }
+                run_wg(wv, nw, g == ngen - 1, nextglob);
+            }
+            glob.swap(nextglob);
+        }
+        printf("generations: T2=%-2d %d launches %14.1f M wave-instr (A = 91, B = 100; %zu rays handed over)\n", T2, ngen, c / 1e6, moved);
+    }
     for (int T : { 16, 24, 32, 40, 48 }) {
         // global pool: generations; a generation's waves are formed of 64 consecutive pooled rays (hand-over order keeps
         // neighbours together), marched until <= T are left, survivors re-pooled; the last generation runs to the end
