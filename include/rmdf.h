@@ -253,6 +253,13 @@ int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[8]);
  * mismatches[0..6] = exp, acos, atan, sin, cos, atan2, pow.  All must be 0. */
 int rmdf_selftest_pinned_math(rmdf_ctx *ctx, uint64_t mismatches[7]);
 
+/* The clock the shader engines run at right now: one wave (issuing vector instructions) stamps the shader-cycle counter against the
+ * 100 MHz real-time counter over `spin_us` microseconds, on a highest-priority stream of the library's own -- launched while the
+ * caller's frames run on other streams it reports the clock under that load.  MI355X, measured with this renderer: 2.4 GHz idle and
+ * under sustained load, but 2.06-2.1 GHz for the first milliseconds of a load that starts from idle (it ramps back up over ~20 ms):
+ * a lone frame rendered from idle runs at the lower clock.  Blocks until the probe has finished. */
+int rmdf_probe_shader_clock(rmdf_ctx *ctx, double spin_us, double *mhz);
+
 /* Optional: pin a host buffer the caller reuses from frame to frame (page-locks it and maps it into the GPU's address
  * space).  A whole-frame rmdf_render_tile (tile_idx = -1) whose out_rgba8 lies inside a registered range is then
  * written by the render kernel itself, row by row while it renders, instead of being copied after the launch: the PCIe

@@ -53,7 +53,7 @@ ABI_SYMBOLS = (
     "rmdf_selftest_pinned_math", "rmdf_set_shard_root_handicap", "rmdf_create_ex", "rmdf_prefilter_env_powers",
     "rmdf_prefilter_env_device", "rmdf_comm_get_unique_id", "rmdf_comm_init", "rmdf_comm_destroy", "rmdf_comm_info",
     "rmdf_gather_shards_device", "rmdf_render_frame_sharded_device", "rmdf_device_malloc", "rmdf_device_free",
-    "rmdf_copy_to_host",
+    "rmdf_copy_to_host", "rmdf_probe_shader_clock",
 )
 XCHECK_SYMBOLS = ("rmdf_debug_march_stats",)      # include/rmdf_xcheck.h
 
@@ -180,6 +180,7 @@ def load_library(xcheck=False):
     L.rmdf_set_shard_root_handicap.argtypes = [vp, C.c_float]
     L.rmdf_assemble_shards_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.rmdf_synchronize.argtypes = [vp, vp]
+    L.rmdf_probe_shader_clock.argtypes = [vp, C.c_double, C.POINTER(C.c_double)]
     L.rmdf_device_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.rmdf_device_free.argtypes = [vp, vp]
     L.rmdf_copy_to_host.argtypes = [vp, vp, vp, C.c_size_t, vp]
@@ -401,6 +402,12 @@ class ShaderRenderer:
         out = np.zeros(8, np.uint64)
         self._check(self._lib.rmdf_selftest_exact_math(self._ctx, out.ctypes.data))
         return out
+
+    def probe_shader_clock(self, spin_us=300.0):
+        """MHz of the shader engines over the next `spin_us` microseconds (under whatever load other streams provide)."""
+        mhz = C.c_double(0.0)
+        self._check(self._lib.rmdf_probe_shader_clock(self._ctx, float(spin_us), C.byref(mhz)))
+        return mhz.value
 
     def selftest_pinned_math(self):
         """Mismatch counts (exp, acos, atan, sin, cos, atan2, pow) of the straight-line device forms vs the branchy ones."""

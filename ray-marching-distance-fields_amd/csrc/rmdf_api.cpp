@@ -64,6 +64,8 @@ struct rmdf_ctx {
     float       *d_cornell = nullptr;
     float       *d_cornell_tab = nullptr;
     uint32_t    *d_cornell_grid = nullptr;
+    hipStream_t  probe_stream = nullptr;   // rmdf_probe_shader_clock: highest priority, created on first use
+    unsigned long long *probe_host = nullptr;   // ... and its two counters, in mapped host memory
     CubeSlot     env[RMDF_ENV_SLOTS];
     std::vector<UvTable>   uv_tables;
     std::vector<LobeTable> lobe_tables;
@@ -998,6 +1000,8 @@ void rmdf_destroy(rmdf_ctx *ctx)
     if (ctx->d_cornell) (void)hipFree(ctx->d_cornell);
     if (ctx->d_cornell_tab) (void)hipFree(ctx->d_cornell_tab);
     if (ctx->d_cornell_grid) (void)hipFree(ctx->d_cornell_grid);
+    if (ctx->probe_stream) (void)hipStreamDestroy(ctx->probe_stream);
+    if (ctx->probe_host) (void)hipHostFree(ctx->probe_host);
     if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
     if (ctx->d_rgba_f32) (void)hipFree(ctx->d_rgba_f32);
     if (ctx->d_steps) (void)hipFree(ctx->d_steps);
@@ -1513,6 +1517,29 @@ int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[8])
     HIP_TRY(ctx, launch_selftest_exact_math((unsigned long long *)d.p, ctx->d_cornell_tab, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(mismatches, d.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RMDF_OK;
+}
+
+int rmdf_probe_shader_clock(rmdf_ctx *ctx, double spin_us, double *mhz)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!mhz || !(spin_us >= 1.0) || spin_us > 1e6) return fail(ctx, RMDF_E_INVALID, "rmdf_probe_shader_clock: null output or spin outside 1 us .. 1 s");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // a stream of its own (highest priority) and a buffer kept for the ctx's life: no allocation, no free -- both may wait for the
+    // device to drain -- so that the probe runs BESIDE whatever the caller has in flight on other streams
+    if (!ctx->probe_stream) {
+        int least = 0, greatest = 0;
+        HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->probe_stream, hipStreamNonBlocking, greatest));
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->probe_host, 4 * sizeof(unsigned long long), hipHostMallocMapped));
+    }
+    hipStream_t st = ctx->probe_stream;
+    volatile unsigned long long *h = ctx->probe_host;
+    h[0] = 0; h[1] = 0;
+    HIP_TRY(ctx, launch_clock_probe((unsigned long long *)ctx->probe_host, (unsigned long long)(spin_us * 100.0), 1, st));   // the wave writes host memory itself
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (h[1] == 0) return fail(ctx, RMDF_E_HIP, "rmdf_probe_shader_clock: the probe did not run");
+    *mhz = (double)h[0] / (double)h[1] * 100.0;
     return RMDF_OK;
 }
 

@@ -137,6 +137,33 @@ hipError_t launch_selftest_exact_math(unsigned long long *d_counts, const float 
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------
+// Shader-clock probe: one wave stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) around a spin of `ticks` real-time
+// ticks.  Launched beside running frames it reports the clock the shader engines sustain under THAT load (rmdf_probe_shader_clock).
+// ------------------------------------------------------------------------------------
+__global__ void k_clock_probe(unsigned long long *out, unsigned long long ticks, int busy)
+{
+    float a = (float)threadIdx.x, b = 1.0001f;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) {
+        if (busy) { for (int i = 0; i < 256; i++) a = a * b + 0.5f; }      // a wave that keeps issuing vector instructions
+        else      __builtin_amdgcn_s_sleep(8);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+    if (a == 12345.678f) out[2] = 1ull;                                    // keeps the arithmetic alive
+}
+
+hipError_t launch_clock_probe(unsigned long long *d_out, unsigned long long ticks, int busy, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, stream, d_out, ticks, busy);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------
 // small utility kernels
 // ------------------------------------------------------------------------------------

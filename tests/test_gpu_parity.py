@@ -285,6 +285,15 @@ def test_exact_math_exhaustive(sr, orc):
     assert mism.tolist() == [0] * 8, mism
 
 
+def test_shader_clock_probe(sr):
+    """rmdf_probe_shader_clock: shader cycles per 100 MHz real-time tick on one wave -- a plausible MI355X clock, idle or loaded."""
+    for spin in (50.0, 300.0):
+        mhz = sr.probe_shader_clock(spin)
+        assert 300.0 < mhz < 3000.0, mhz
+    with pytest.raises(Exception):
+        sr.probe_shader_clock(0.0)
+
+
 def test_straggler_pooling_is_invisible(rmdf, sr, env_faces):
     """The default kernels of both Mandelbulbs and of the test scene pool the last rays of a workgroup's four packets in one
     wave; a renderer with RMDF_FLAG_NO_MERGE must produce the same bits."""

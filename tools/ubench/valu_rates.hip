@@ -195,9 +195,41 @@ static void clock_under_load()
     }
 }
 
+// the same v_mul stream after ~50 ms of continuous load: the clock of a load that starts from idle is ~2.0-2.1 GHz and ramps to 2.4 GHz
+// over ~20 ms (tools/clock_probe_check.py), so the one-launch figures above are taken at the LOW clock
+static void sustained()
+{
+    hipDeviceProp_t prop;
+    (void)hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount;
+    for (int wps : { 2, 4, 8 }) {
+        const int blocks = cus * wps;
+        float *out; unsigned long long *st;
+        (void)hipMalloc(&out, (size_t)blocks * 256 * 4); (void)hipMalloc(&st, (size_t)blocks * 16);
+        const int warm = 120 / wps;
+        for (int rep = 0; rep < warm; rep++) hipLaunchKernelGGL(k_clock, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, st);
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0);
+        const int n = 10;
+        for (int rep = 0; rep < n; rep++) hipLaunchKernelGGL(k_clock, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, st);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        std::vector<unsigned long long> h(blocks * 2);
+        (void)hipMemcpy(h.data(), st, (size_t)blocks * 16, hipMemcpyDeviceToHost);
+        double cyc = 0, real = 0;
+        for (int b = 0; b < blocks; b++) { cyc += (double)h[b * 2]; real += (double)h[b * 2 + 1]; }
+        const double winstr = (double)blocks * 4 * REPS * 8 * n;
+        printf("sustained v_mul, %d waves/SIMD: %.2f G instructions/s/SIMD at %.0f MHz (s_memtime / s_memrealtime) = one per %.2f cycles\n",
+               wps, winstr / (cus * 4.0) / (ms * 1e-3) / 1e9, cyc / real * 100.0, (cyc / real * 1e8) / (winstr / (cus * 4.0) / (ms * 1e-3)));
+        (void)hipFree(out); (void)hipFree(st);
+    }
+}
+
 int main()
 {
     clock_under_load();
+    sustained();
 #define S(K, NAME) run(NAME, [](int b, int t, float *o) { hipLaunchKernelGGL(k_scalar<K>, dim3(b), dim3(t), 0, 0, o, 1.0001f); }, 1)
 #define P(K, NAME) run(NAME, [](int b, int t, float *o) { hipLaunchKernelGGL(k_packed<K>, dim3(b), dim3(t), 0, 0, o, 1.0001f); }, 2)
     S(0, "v_mul_f32"); S(1, "v_add_f32"); S(2, "v_fma_f32"); P(0, "v_pk_mul_f32"); P(1, "v_pk_add_f32"); P(2, "v_pk_fma_f32");
