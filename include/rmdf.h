@@ -246,8 +246,11 @@ int rmdf_render_frame_sharded_device(rmdf_ctx *ctx, int scene, int w, int h, dou
  * distance estimator against the compiler's for every numerator and each of its 96 divisors; mismatches[5..7] = the
  * Mandelbulb loop's forms: the bailout test taken on the squared radius together with the estimate's final division
  * (Markstein on the reciprocal of dr, 2^33 operand pairs), the in-loop root of the radius and the in-loop
- * 1/sqrt(k3^7) (one transcendental each, one shared guard) against the written sqrt / inversesqrt.  All must be 0. */
-int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[8]);
+ * 1/sqrt(k3^7) (one transcendental each, one shared guard) against the written sqrt / inversesqrt; mismatches[8] = whole
+ * Mandelbulb estimates with the power-of-two scalings folded into FMAs (behind their underflow guard, written passes as the
+ * fall-back) against the written loop on 2^28 points, half of them with coordinates down to 2^-150.  [0..8] must be 0;
+ * mismatches[9] = how many of those estimates took the fall-back (informational: the test must reach it, so > 0). */
+int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[10]);
 /* Self-test of the straight-line device forms of the pinned GLSL built-ins (exp, acos, atan, sin, cos: all 2^32 inputs;
  * atan(y,x) and pow(x,y): 2^32 operand pairs) against the branchy fdlibm-style forms they restate.
  * mismatches[0..6] = exp, acos, atan, sin, cos, atan2, pow.  All must be 0. */

@@ -398,8 +398,9 @@ class ShaderRenderer:
 
     def selftest_exact_math(self):
         """Mismatch counts (sqrt, rcp, log, rsqrt, Cornell division, Mandelbulb bailout test / in-loop sqrt / in-loop rsqrt) of
-        the short exact sequences vs the compiler's, all 2^32 inputs."""
-        out = np.zeros(8, np.uint64)
+        the short exact sequences vs the compiler's, all 2^32 inputs; [8] folded vs written Mandelbulb estimates (2^28 points), [9] how many
+        of those took the written fall-back (informational)."""
+        out = np.zeros(10, np.uint64)
         self._check(self._lib.rmdf_selftest_exact_math(self._ctx, out.ctypes.data))
         return out
 

@@ -1506,16 +1506,16 @@ int rmdf_render_supersampled(rmdf_ctx *ctx, int scene, int w, int h, int levels,
     RMDF_GUARD_END(ctx)
 }
 
-int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[8])
+int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[10])
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
     if (!mismatches) return fail(ctx, RMDF_E_INVALID, "null output");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf d;
-    HIP_TRY(ctx, hipMalloc(&d.p, 8 * sizeof(unsigned long long)));
-    HIP_TRY(ctx, hipMemsetAsync(d.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMalloc(&d.p, 10 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(d.p, 0, 10 * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, launch_selftest_exact_math((unsigned long long *)d.p, ctx->d_cornell_tab, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(mismatches, d.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(mismatches, d.p, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RMDF_OK;
 }

@@ -246,7 +246,8 @@ __device__ __forceinline__ float div_by_dr(float a, float dr)
 //  * inside the loop d lies in [k3, 16 + 2^-19] and k3^7 in [2^-98, 2^29] once k3 >= 2^-14 is known, so both roots run the bare
 //    core sequences and ONE guard per iteration (k3 < 2^-14, or the root of k3^7 ends in sixteen one-bits: rcp_of_root) sends
 //    lanes through the compiler's expansions instead of a range test per root;
-//  * triplex_pow8 is inlined so that its x^2 + y^2 is shared with the dot product (the same two products, one addition).
+//  * triplex_pow8 is inlined so that its x^2 + y^2 is shared with the dot product (the same two products, one addition);
+//  * the five scalings by a power of two ride on FMAs at the end of their chains, behind an underflow guard (mb8_iterate_t).
 #define RMDF_MB8_D4   16.000001907348633f      /* 16 + 2^-19 = 0x41800001 */
 #define RMDF_MB8_K3MIN 0x1p-14f
 // The two roots of one Mandelbulb iteration that did not escape: r = RN(sqrt d), k2 = RN(1 / RN(sqrt q)) with q = k3^7,
@@ -261,9 +262,24 @@ __device__ __forceinline__ void mb8_roots(float d, float k3, float q, float &r, 
     if (__builtin_expect(__ballot(slow) != 0ull, 0)) { if (slow) { r = sqrtf(d); k2 = 1.0f / sqrtf(q); } }
 }
 // Iterations i0 .. i1-1 of the loop (i1 <= 25) on the state (w, dr, r, d); a lane whose squared radius d exceeds the bailout
-// leaves early.  Afterwards the estimate is complete iff d > RMDF_MB8_D4 (escaped) or i1 == 25; otherwise mb8_iterate(.., i1, 25, ..)
-// resumes it -- on any lane: the distance-AO estimates of k_render are finished that way (rmdf_render.hip).
-__device__ __forceinline__ void mb8_iterate(v3 &w, const v3 pos, float &dr, float &r, float &d, int i0, int i1, unsigned &iters)
+// leaves early.  Afterwards the estimate is complete iff d > RMDF_MB8_D4 (escaped) or i1 == 25; otherwise the same function
+// resumes it from i1 -- on any lane: the distance-AO estimates of k_render are finished that way (rmdf_render.hip).
+//
+// FOLD = false is the shader's arithmetic operation for operation.  FOLD = true pulls the five scalings by a power of two to the
+// end of their chains, where an FMA takes them for nothing:
+//     -8 z k4 P8 k1 k2 + pos.x  ->  fma(-8, A, pos.x),  A = ((((z k4) P8) k1) k2)          64 y z x (y2-x2) k4 P4 k1 k2 + pos.y  ->  fma(64, B, pos.y)
+//     -16 z2 k3 k4 k4 + k1 k1   ->  fma(-16, C, k1 k1), C = ((z2 k3) k4) k4                  ... + 2 x2 y2  ->  fma(2, t, ...), t = x2 y2
+//     r7 8 dr + 1               ->  fma(8, r7 dr, 1)
+// Scaling by a power of two commutes with rounding unless a product underflows (or overflows: excluded by k3 >= 2^-14, d <= 16), so
+// the folded pass has the bits of the written one whenever every partial product of the four chains is a normal number.  That is
+// implied by |A|, |B|, C, t >= 2^-40: the factors still to come are bounded (|k2| <= 2^49, |k1| <= 2^13, |P8| <= k3^4 <= 2^16,
+// |P4| <= 2^9, |k4| <= 2^5, |y2 - x2| <= 2^4, |x|, |z| <= 2^2.01), which puts the smallest partial product of the longest chain
+// at >= 2^-122.  `m` accumulates the minimum of those four over the passes (two instructions per pass); the CALLER compares it
+// with RMDF_MB8_FOLD_MIN once per call and runs the call again with FOLD = false from the same state if any lane fell below
+// (never in the frames measured so far; lanes with k3 < 2^-14, where r^7 dr may underflow too, force it through m = 0).
+#define RMDF_MB8_FOLD_MIN 0x1p-40f
+template <bool FOLD>
+__device__ __forceinline__ void mb8_iterate_t(v3 &w, const v3 pos, float &dr, float &r, float &d, int i0, int i1, unsigned &iters, float &m)
 {
     for (int i = i0; i < i1; i++) {
         // r = length(w); if (r > bailout) break;                                    fragment.shd:137-139
@@ -275,33 +291,74 @@ __device__ __forceinline__ void mb8_iterate(v3 &w, const v3 pos, float &dr, floa
         // w = triplex_pow8(w)                                                       fragment.shd:74-99
         const float x4 = x2 * x2, y4 = y2 * y2, z4 = z2 * z2;
         const float q = k3 * k3 * k3 * k3 * k3 * k3 * k3;
-        const float k1 = y4 + z4 + x4 - 6.0f * z2 * x2 - 6.0f * y2 * z2 + 2.0f * x2 * y2;
         const float k4 = y2 - z2 + x2;
-        const float wx_ = -8.0f * z * k4 * (y4 * y4 - 28.0f * y4 * y2 * x2 + 70.0f * y4 * x4 - 28.0f * y2 * x2 * x4 + x4 * x4) * k1;
-        const float wy_ = 64.0f * y * z * x * (y2 - x2) * k4 * (y4 - 6.0f * y2 * x2 + x4) * k1;
-        const float wz = -16.0f * z2 * k3 * k4 * k4 + k1 * k1;
-        float k2;
-        mb8_roots(d, k3, q, r, k2);
-        // dr = pow(r, power - 1) * power * dr + 1                                   fragment.shd:148
-        const float r2 = r * r, r4 = r2 * r2, r7 = (r4 * r2) * r;
-        dr = r7 * 8.0f * dr + 1.0f;
-        w = add3(mk3(wx_ * k2, wy_ * k2, wz), pos);
+        const float p8 = y4 * y4 - 28.0f * y4 * y2 * x2 + 70.0f * y4 * x4 - 28.0f * y2 * x2 * x4 + x4 * x4;
+        const float p4 = y4 - 6.0f * y2 * x2 + x4;
+        if (!FOLD) {
+            const float k1 = y4 + z4 + x4 - 6.0f * z2 * x2 - 6.0f * y2 * z2 + 2.0f * x2 * y2;
+            const float wx_ = -8.0f * z * k4 * p8 * k1;
+            const float wy_ = 64.0f * y * z * x * (y2 - x2) * k4 * p4 * k1;
+            const float wz = -16.0f * z2 * k3 * k4 * k4 + k1 * k1;
+            float k2;
+            mb8_roots(d, k3, q, r, k2);
+            // dr = pow(r, power - 1) * power * dr + 1                               fragment.shd:148
+            const float r2 = r * r, r4 = r2 * r2, r7 = (r4 * r2) * r;
+            dr = r7 * 8.0f * dr + 1.0f;
+            w = add3(mk3(wx_ * k2, wy_ * k2, wz), pos);
+        } else {
+            const float t = x2 * y2;
+            const float k1 = __builtin_fmaf(2.0f, t, y4 + z4 + x4 - 6.0f * z2 * x2 - 6.0f * y2 * z2);
+            const float a_ = z * k4 * p8 * k1;
+            const float b_ = y * z * x * (y2 - x2) * k4 * p4 * k1;
+            const float c = z2 * k3 * k4 * k4;
+            const float wz = __builtin_fmaf(-16.0f, c, k1 * k1);
+            // the two roots, as in mb8_roots; a lane with k3 < 2^-14 also gives up the folds (m = 0)
+            r = sqrt_core(d);
+            float y0;
+            const float sq = sqrt_core_y(q, y0);
+            float k2 = rcp_of_root(sq, y0);
+            const bool small = k3 < RMDF_MB8_K3MIN;
+            const bool slow = (int)small | (int)root_needs_slow_rcp(sq);
+            if (__builtin_expect(__ballot(slow) != 0ull, 0)) { if (slow) { r = sqrtf(d); k2 = 1.0f / sqrtf(q); if (small) m = 0.0f; } }
+            const float a = a_ * k2, b = b_ * k2;
+            m = __builtin_fminf(__builtin_fminf(m, __builtin_fabsf(a)), __builtin_fabsf(b));     // v_min3_f32 with |.| modifiers
+            m = __builtin_fminf(__builtin_fminf(m, c), t);                                       // c, t >= 0
+            const float r2 = r * r, r4 = r2 * r2, r7 = (r4 * r2) * r;
+            dr = __builtin_fmaf(8.0f, r7 * dr, 1.0f);
+            w = mk3(__builtin_fmaf(-8.0f, a, pos.x), __builtin_fmaf(64.0f, b, pos.y), wz + pos.z);
+        }
         iters++;
     }
 }
+// does the folded call have to be run again in written form (any lane of the wave decides for itself; the branch is wave-uniform)
+__device__ __forceinline__ bool mb8_fold_failed(float m) { return !(m >= RMDF_MB8_FOLD_MIN); }
 // fragment.shd:157 -- the lanes that left through the break take their root now (d keeps its last value)
 __device__ __forceinline__ float mb8_finish(float dr, float r, float d)
 {
     if (d > RMDF_MB8_D4) r = sqrt_rn(d);
     return div_by_dr(0.5f * log_pinned(r) * r, dr);
 }
-__device__ __forceinline__ float de_mandelbulb8(v3 pos, unsigned &iters)
+// the written loop (reference of the device self-test, and the fall-back of the folded one)
+__device__ __noinline__ float de_mandelbulb8_written(v3 pos, unsigned &iters)
 {
     pos = mk3(pos.z, pos.x, pos.y);
     v3 w = pos;
-    float dr = 1.0f, r = 0.0f, d = 0.0f;
-    mb8_iterate(w, pos, dr, r, d, 0, 25, iters);
+    float dr = 1.0f, r = 0.0f, d = 0.0f, m = 1.0f;
+    mb8_iterate_t<false>(w, pos, dr, r, d, 0, 25, iters, m);
     return mb8_finish(dr, r, d);
+}
+__device__ __forceinline__ float de_mandelbulb8(v3 pos, unsigned &iters)
+{
+    const v3 p = mk3(pos.z, pos.x, pos.y);
+    v3 w = p;
+    float dr = 1.0f, r = 0.0f, d = 0.0f, m = 1.0f;
+    unsigned n = 0u;
+    mb8_iterate_t<true>(w, p, dr, r, d, 0, 25, n, m);
+    float dist = mb8_finish(dr, r, d);
+    const bool redo = mb8_fold_failed(m);
+    if (__builtin_expect(__ballot(redo) != 0ull, 0)) { if (redo) { n = 0u; dist = de_mandelbulb8_written(pos, n); } }
+    iters += n;
+    return dist;
 }
 
 // ---- pinned sin / cos / acos / atan / mod (FSMBGeneralShader, FSDETestShader) ------------------------

@@ -74,7 +74,7 @@ enum { OUT_RGBA8 = 0, OUT_MIRROR = 1, OUT_PLANES = 2 };
 #define WPB 4                       // waves per workgroup: a 32x8 strip
 
 template <int SCENE, bool MERGE, int OUT>
-__global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
+__global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : 1) void k_render(const FrameParams p)
 {
     constexpr bool AO_POOL = (SCENE == 2) && MERGE;
     // Cornell box: the candidate grid (rmdf_device.hpp) lives in LDS for the whole launch
@@ -296,7 +296,14 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
             float dr = 1.0f, r = 0.0f, d = 0.0f;
             bool pend = false;
             if (hit) {
-                mb8_iterate(w, pos, dr, r, d, 0, AO_CUT, iters);
+                float m = 1.0f;
+                unsigned n = 0u;
+                mb8_iterate_t<true>(w, pos, dr, r, d, 0, AO_CUT, n, m);
+                const bool redo = mb8_fold_failed(m);             // rmdf_device.hpp: the folded passes need the written ones' range
+                if (__builtin_expect(__ballot(redo) != 0ull, 0)) {
+                    if (redo) { w = pos; dr = 1.0f; r = 0.0f; d = 0.0f; n = 0u; mb8_iterate_t<false>(w, pos, dr, r, d, 0, AO_CUT, n, m); }
+                }
+                iters += n;
                 pend = !(d > RMDF_MB8_D4);
             }
             // one LDS atomic per wave: queue slots for its pending estimates
@@ -312,7 +319,8 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
                         s_ao_q[mine][0] = make_float4(w.x, w.y, w.z, dr);
                         s_ao_q[mine][1] = make_float4(pos.x, pos.y, pos.z, r);
                     } else {
-                        mb8_iterate(w, pos, dr, r, d, AO_CUT, 25, iters);      // queue full: finish in place
+                        float m = 1.0f;
+                        mb8_iterate_t<false>(w, pos, dr, r, d, AO_CUT, 25, iters, m);      // queue full: finish in place (written form)
                     }
                 }
             }
@@ -327,7 +335,12 @@ __global__ __launch_bounds__(WPB * 64) void k_render(const FrameParams p)
                 const v3 pos = mk3(b.x, b.y, b.z);
                 float dr = a.w, r = b.w, d = 0.0f;
                 unsigned it2 = 0u;
-                mb8_iterate(w, pos, dr, r, d, AO_CUT, 25, it2);
+                float m = 1.0f;
+                mb8_iterate_t<true>(w, pos, dr, r, d, AO_CUT, 25, it2, m);
+                const bool redo = mb8_fold_failed(m);
+                if (__builtin_expect(__ballot(redo) != 0ull, 0)) {
+                    if (redo) { w = mk3(a.x, a.y, a.z); dr = a.w; r = b.w; d = 0.0f; it2 = 0u; mb8_iterate_t<false>(w, pos, dr, r, d, AO_CUT, 25, it2, m); }
+                }
                 s_ao_out[tsk] = make_float2(mb8_finish(dr, r, d), __uint_as_float(it2));
             }
             __syncthreads();

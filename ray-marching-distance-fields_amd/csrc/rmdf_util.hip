@@ -95,6 +95,44 @@ __global__ void k_selftest_exact_math(unsigned long long *counts)
     atomicAdd(&counts[5], c5); atomicAdd(&counts[6], c6); atomicAdd(&counts[7], c7);
 }
 
+// The folded Mandelbulb passes (rmdf_device.hpp: mb8_iterate_t<true> behind its running-minimum guard, with the written passes as
+// the fall-back) against the written loop, on 2^28 hashed points: uniform in the bounding cube, and with one, two or three
+// coordinates scaled down to 2^-20 .. 2^-150 -- where partial products DO underflow and the guard has to send the estimate back
+// through the written form.  counts[8] = estimates that differ in distance bits or iteration count (must be 0), counts[9] = estimates
+// that took the fall-back (must not be 0: the test has to reach it).
+__global__ void k_selftest_mb8_folds(unsigned long long *counts)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long bad = 0, fell = 0;
+    for (uint64_t i = tid; i < (1ull << 28); i += stride) {
+        uint32_t h = (uint32_t)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        uint32_t g = (h ^ 0x9e3779b9u) * 3266489917u; g ^= g >> 16;
+        uint32_t f = (g + 0x7f4a7c15u) * 668265263u; f ^= f >> 15;
+        float c[3] = { ((float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f) * 1.3f, ((float)(g >> 8) * (1.0f / 8388608.0f) - 1.0f) * 1.3f,
+                       ((float)(f >> 8) * (1.0f / 8388608.0f) - 1.0f) * 1.3f };
+        const unsigned mode = (unsigned)(i & 7u);                       // 0..3: plain; 4..7: some coordinates tiny
+        if (mode >= 4u) {
+            const int e = -20 - (int)((h & 0xffu) % 131u);              // 2^-20 .. 2^-150
+            const float sc = __builtin_ldexpf(1.0f, e);
+            if (mode == 4u || mode == 7u) c[h % 3u] *= sc;
+            if (mode == 5u) { c[0] *= sc; c[1] *= sc; }
+            if (mode == 6u) { c[1] *= sc; c[2] *= sc; }
+            if (mode == 7u) c[(h + 1u) % 3u] *= __builtin_ldexpf(1.0f, -(int)(g & 63u));
+        }
+        const v3 pos = mk3(c[0], c[1], c[2]);
+        unsigned ia = 0u, ib = 0u;
+        const float a = de_mandelbulb8(pos, ia), b = de_mandelbulb8_written(pos, ib);
+        bad += !(((__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b)) && ia == ib);
+        // did it fall back?  the same folded call once more, looking at its guard
+        const v3 p2 = mk3(pos.z, pos.x, pos.y);
+        v3 w = p2; float dr = 1.0f, r = 0.0f, d = 0.0f, m = 1.0f; unsigned n = 0u;
+        mb8_iterate_t<true>(w, p2, dr, r, d, 0, 25, n, m);
+        fell += mb8_fold_failed(m) ? 1u : 0u;
+    }
+    if (bad) atomicAdd(&counts[8], bad);
+    if (fell) atomicAdd(&counts[9], fell);
+}
+
 // Self-test of the straight-line pinned functions (rmdf_device.hpp) against their branchy fdlibm-style forms, over ALL 2^32
 // float bit patterns: exp, acos, atan, sin, cos; atan2 and pow over 2^32 pseudo-random operand pairs (every bit pattern of y
 // paired with a hashed x).  counts[0..6] = differing inputs (NaN == NaN).
@@ -134,6 +172,7 @@ hipError_t launch_selftest_exact_math(unsigned long long *d_counts, const float 
 {
     hipLaunchKernelGGL(k_selftest_exact_math, dim3(8192), dim3(256), 0, stream, d_counts);
     hipLaunchKernelGGL(k_selftest_cornell_div, dim3(256, 96), dim3(256), 0, stream, d_counts, d_cornell_tab);
+    hipLaunchKernelGGL(k_selftest_mb8_folds, dim3(4096), dim3(256), 0, stream, d_counts);
     return hipGetLastError();
 }
 
