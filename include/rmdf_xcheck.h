@@ -21,6 +21,8 @@ extern "C" {
 #define RMDF_FLAG_NESTED_LOOPS 1   /* no-op (the default render kernel)                                                      */
 #define RMDF_FLAG_FLAT_MARCH   2   /* Mandelbulb power 8: flattened march kernel + shade kernel (xcheck/rmdf_march.hip, rmdf_pool.hip) */
 #define RMDF_FLAG_PIPELINE     8   /* all scenes: march-with-refill + normal/AO-on-hit-list + shade kernels (xcheck/rmdf_pipeline.hip) */
+#define RMDF_FLAG_FORCE_WRITTEN 64 /* power-8 Mandelbulb: the folded iteration passes' underflow guard always trips, so every ray, normal and
+                                      AO estimate of the product kernel takes its written fall-back (tests: the frame must not change) */
 
 /* Measurement aid: per-wave counters of the Mandelbulb march kernels.  enable != 0 switches collection on
  * (off: frees the buffer); out (may be NULL) receives 16 uint64 per wave for the launches since the last read:

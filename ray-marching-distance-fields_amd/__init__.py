@@ -36,6 +36,7 @@ TILES_X, TILES_Y, N_TILES = 8, 8, 64          # ShaderRendering.hs:49-52
 ENV_REFLECTION, ENV_COS_1, ENV_COS_8, ENV_COS_64, ENV_COS_512 = range(5)
 FLAG_RASTER_ORDER, FLAG_NO_MERGE, FLAG_NO_PRUNE = 4, 16, 32          # rmdf.h RMDF_FLAG_*
 FLAG_NESTED_LOOPS, FLAG_FLAT_MARCH, FLAG_PIPELINE = 1, 2, 8         # rmdf_xcheck.h: librmdf_xcheck.so only
+FLAG_FORCE_WRITTEN = 64                                              # rmdf_xcheck.h: every folded Mandelbulb pass takes its written fall-back
 COMM_ID_BYTES = 128
 
 _ERRORS = {-1: "RMDF_E_INVALID", -2: "RMDF_E_NO_DEVICE", -3: "RMDF_E_HIP", -4: "RMDF_E_IO",
@@ -208,8 +209,8 @@ class ShaderRenderer:
     the Cornell geometry table and the accumulating frame."""
 
     def __init__(self, device=0, flags=0, xcheck=False):
-        """xcheck=True (implied by FLAG_FLAT_MARCH / FLAG_PIPELINE): run on librmdf_xcheck.so, the cross-check build."""
-        self.xcheck = bool(xcheck or (flags & (FLAG_FLAT_MARCH | FLAG_PIPELINE)))
+        """xcheck=True (implied by FLAG_FLAT_MARCH / FLAG_PIPELINE / FLAG_FORCE_WRITTEN): run on librmdf_xcheck.so, the cross-check build."""
+        self.xcheck = bool(xcheck or (flags & (FLAG_FLAT_MARCH | FLAG_PIPELINE | FLAG_FORCE_WRITTEN)))
         self._lib = load_library(self.xcheck)
         self._ctx = C.c_void_p()
         cfg = _Config(device=device)

@@ -481,6 +481,7 @@ int fill_params(rmdf_ctx *ctx, int scene, int w, int h, float time, int max_step
     p.cornell_prune = (ctx->flags & RMDF_FLAG_NO_PRUNE) ? 0 : 1;
 #ifdef RMDF_XCHECK
     p.dbg = ctx->d_dbg;
+    p.fold_min = (ctx->flags & RMDF_FLAG_FORCE_WRITTEN) ? __builtin_inff() : RMDF_MB8_FOLD_MIN;
 #endif
     return RMDF_OK;
 }

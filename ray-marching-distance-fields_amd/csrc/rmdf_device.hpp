@@ -138,7 +138,8 @@ __device__ __forceinline__ float log_core(float x, int32_t k0)
     return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
 }
 // zero, negative, subnormal, inf, NaN
-__device__ __noinline__ float log_special(float x)
+// (inlined: a call inside k_render made every value that lives across it occupy a callee-saved register)
+__device__ __forceinline__ float log_special(float x)
 {
     int32_t ix = __float_as_int(x);
     if ((ix & 0x7fffffff) == 0) return -__builtin_inff();
@@ -276,7 +277,8 @@ __device__ __forceinline__ void mb8_roots(float d, float k3, float q, float &r, 
 // |P4| <= 2^9, |k4| <= 2^5, |y2 - x2| <= 2^4, |x|, |z| <= 2^2.01), which puts the smallest partial product of the longest chain
 // at >= 2^-122.  `m` accumulates the minimum of those four over the passes (two instructions per pass); the CALLER compares it
 // with RMDF_MB8_FOLD_MIN once per call and runs the call again with FOLD = false from the same state if any lane fell below
-// (never in the frames measured so far; lanes with k3 < 2^-14, where r^7 dr may underflow too, force it through m = 0).
+// (it does happen: a few thousand estimates of the headline frame -- points within 2^-7 of the bulb's axis, where k3 < 2^-14 forces
+// it through m = 0 because r^7 dr may underflow too, and rays that cross a coordinate plane within ~2^-20).
 #define RMDF_MB8_FOLD_MIN 0x1p-40f
 template <bool FOLD>
 __device__ __forceinline__ void mb8_iterate_t(v3 &w, const v3 pos, float &dr, float &r, float &d, int i0, int i1, unsigned &iters, float &m)
@@ -331,15 +333,15 @@ __device__ __forceinline__ void mb8_iterate_t(v3 &w, const v3 pos, float &dr, fl
     }
 }
 // does the folded call have to be run again in written form (any lane of the wave decides for itself; the branch is wave-uniform)
-__device__ __forceinline__ bool mb8_fold_failed(float m) { return !(m >= RMDF_MB8_FOLD_MIN); }
+__device__ __forceinline__ bool mb8_fold_failed(float m, float fold_min = RMDF_MB8_FOLD_MIN) { return !(m >= fold_min); }
 // fragment.shd:157 -- the lanes that left through the break take their root now (d keeps its last value)
 __device__ __forceinline__ float mb8_finish(float dr, float r, float d)
 {
     if (d > RMDF_MB8_D4) r = sqrt_rn(d);
     return div_by_dr(0.5f * log_pinned(r) * r, dr);
 }
-// the written loop (reference of the device self-test, and the fall-back of the folded one)
-__device__ __noinline__ float de_mandelbulb8_written(v3 pos, unsigned &iters)
+// the written loop (the fall-back of the folded one; de_mandelbulb8_written = the reference of the device self-test)
+__device__ __forceinline__ float de_mandelbulb8_written_inl(v3 pos, unsigned &iters)
 {
     pos = mk3(pos.z, pos.x, pos.y);
     v3 w = pos;
@@ -347,7 +349,12 @@ __device__ __noinline__ float de_mandelbulb8_written(v3 pos, unsigned &iters)
     mb8_iterate_t<false>(w, pos, dr, r, d, 0, 25, iters, m);
     return mb8_finish(dr, r, d);
 }
-__device__ __forceinline__ float de_mandelbulb8(v3 pos, unsigned &iters)
+__device__ __noinline__ float de_mandelbulb8_written(v3 pos, unsigned &iters) { return de_mandelbulb8_written_inl(pos, iters); }
+// The fall-back is inlined (round 2 called it: every value of k_render that lives across the call site then had to sit in a
+// callee-saved register, and two VGPRs went to scratch).  It starts from a LAUNDERED copy of the position: otherwise the compiler
+// shares the first pass's squares and sums with the folded loop, keeps them alive across it, and pays five register copies per
+// estimate in the hot path for a block that runs a few hundred times per frame (measured: 2 %).
+__device__ __forceinline__ float de_mandelbulb8(v3 pos, unsigned &iters, float fold_min = RMDF_MB8_FOLD_MIN, unsigned *n_redone = nullptr)
 {
     const v3 p = mk3(pos.z, pos.x, pos.y);
     v3 w = p;
@@ -355,8 +362,16 @@ __device__ __forceinline__ float de_mandelbulb8(v3 pos, unsigned &iters)
     unsigned n = 0u;
     mb8_iterate_t<true>(w, p, dr, r, d, 0, 25, n, m);
     float dist = mb8_finish(dr, r, d);
-    const bool redo = mb8_fold_failed(m);
-    if (__builtin_expect(__ballot(redo) != 0ull, 0)) { if (redo) { n = 0u; dist = de_mandelbulb8_written(pos, n); } }
+    const bool redo = mb8_fold_failed(m, fold_min);
+    if (__builtin_expect(__ballot(redo) != 0ull, 0)) {
+        if (redo) {
+            v3 q = pos;
+            asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z));
+            n = 0u;
+            dist = de_mandelbulb8_written_inl(q, n);
+            if (n_redone) ++*n_redone;
+        }
+    }
     iters += n;
     return dist;
 }

@@ -57,6 +57,7 @@ struct FrameParams {
     int       total_items, items_per_shard_tile;
     int       tail_t, shade_t, refill_t, chunk, pool_low;   // scheduling thresholds of k_march_mb8 (rmdf_march.hip)
     unsigned long long *dbg;  // optional per-wave counters (8 or 16 x u64 per wave), may be null
+    float     fold_min;       // underflow bound of the folded Mandelbulb passes (RMDF_MB8_FOLD_MIN; +inf under RMDF_FLAG_FORCE_WRITTEN)
 #endif
 };
 

@@ -33,11 +33,22 @@ __device__ __forceinline__ v3 shfl_xor3(v3 a, int mask)
     return mk3(__shfl_xor(a.x, mask, 64), __shfl_xor(a.y, mask, 64), __shfl_xor(a.z, mask, 64));
 }
 
+// The underflow bound of the folded Mandelbulb passes (rmdf_device.hpp).  A constant in the product; the cross-check build reads it
+// from the frame parameters so that a test can force every estimate through its written fall-back (RMDF_FLAG_FORCE_WRITTEN).
+__device__ __forceinline__ float fold_min_of(const FrameParams &p)
+{
+#ifdef RMDF_XCHECK
+    return p.fold_min;
+#else
+    return RMDF_MB8_FOLD_MIN;
+#endif
+}
+
 template <int SCENE>
 // hint: Cornell only -- the triangle that was nearest in this lane's previous estimate (evaluation order, not a result)
 __device__ __forceinline__ float distance_estimator(v3 pos, const FrameParams &p, unsigned &iters, int &hint, const unsigned *cgrid = nullptr)
 {
-    if (SCENE == 2)      return de_mandelbulb8(pos, iters);
+    if (SCENE == 2)      return de_mandelbulb8(pos, iters, fold_min_of(p));
     else if (SCENE == 3) return de_mandelbulb_general(pos, p.power, iters);
     else if (SCENE == 1) return de_test_scene(pos);
     else                 return de_cornell_box_table(pos, p.cornell_tab, p.cornell_prune, hint, cgrid);
@@ -73,8 +84,59 @@ __device__ __forceinline__ float bsphere_r() { return SCENE == 2 ? 1.15f : (SCEN
 enum { OUT_RGBA8 = 0, OUT_MIRROR = 1, OUT_PLANES = 2 };
 #define WPB 4                       // waves per workgroup: a 32x8 strip
 
+// Everything a lane derives from (strip, thread id): the rectangle of its launch / shard slot, its pixel, its primary ray.
+// (Deriving it a second time after the march from laundered inputs, so that none of it occupies registers across the march
+// loop, was measured in round 3: 1.5 % slower -- the kernel needs 53 VGPRs, nothing is short.)
+struct PixelGeom {
+    int rx0, ry0, rx1, ry1, pitch, ox, oy;
+    size_t obase;
+    int ex0, ey0, bx, by;
+    int lane, wave, lx, ly;
+    bool active;
+    v3 dir;
+};
+__device__ __forceinline__ v3 primary_dir(const FrameParams &p, int px, int py)
+{
+    // generate_ray, perspective branch (fragment.shd:840-871)
+    const float ndcx = ((float)px + 0.5f) / p.wf * 2.0f - 1.0f;
+    const float ndcy = ((float)py + 0.5f) / p.hf * 2.0f - 1.0f;
+    const v3 dcam = normalize3(mk3(ndcx * p.fov_xs, ndcy * p.fov_xs / p.aspect, -1.0f));
+    return mk3(p.cam[0] * dcam.x + p.cam[3] * dcam.y + p.cam[6] * dcam.z,
+               p.cam[1] * dcam.x + p.cam[4] * dcam.y + p.cam[7] * dcam.z,
+               p.cam[2] * dcam.x + p.cam[5] * dcam.y + p.cam[8] * dcam.z);
+}
+__device__ __forceinline__ PixelGeom pixel_geom(const FrameParams &p, unsigned lin, unsigned tid)
+{
+    PixelGeom g;
+    const unsigned strips_per_slot = gridDim.x * gridDim.y;
+    const unsigned strip = lin % strips_per_slot;
+    // rectangle of this launch / shard slot
+    if (p.n_shard_tiles > 0) {
+        const int slot = (int)(lin / strips_per_slot);
+        tile_rect((int)p.shard_tile[slot], p.w, p.h, g.rx0, g.ry0, g.rx1, g.ry1);
+        g.pitch = g.rx1 - g.rx0; g.ox = g.rx0; g.oy = g.ry0;
+        g.obase = (size_t)slot * (size_t)(p.w / 8) * (size_t)(p.h / 8);
+    } else {
+        g.rx0 = p.x0; g.ry0 = p.y0; g.rx1 = p.x1; g.ry1 = p.y1;
+        g.pitch = p.w; g.ox = 0; g.oy = 0; g.obase = 0;
+    }
+    // GL quads are aligned to even window coordinates: helper pixels outside the
+    // rectangle are computed (not written) so that derivatives match a full-frame render
+    g.ex0 = g.rx0 & ~1; g.ey0 = g.ry0 & ~1;
+    const int ex1 = (g.rx1 + 1) & ~1, ey1 = (g.ry1 + 1) & ~1;
+    g.lane = (int)(tid & 63u); g.wave = (int)(tid >> 6);
+    g.lx = (g.lane & 1) | (((g.lane >> 2) & 3) << 1);
+    g.ly = ((g.lane >> 1) & 1) | (((g.lane >> 4) & 3) << 1);
+    g.bx = (int)(strip % gridDim.x); g.by = (int)(strip / gridDim.x);
+    const int px = g.ex0 + g.bx * (WPB * 8) + g.wave * 8 + g.lx;
+    const int py = g.ey0 + g.by * 8 + g.ly;
+    g.active = (px < ex1) && (py < ey1);
+    g.dir = primary_dir(p, px, py);
+    return g;
+}
+
 template <int SCENE, bool MERGE, int OUT>
-__global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : 1) void k_render(const FrameParams p)
+__device__ __forceinline__ void render_body(const FrameParams &p)
 {
     constexpr bool AO_POOL = (SCENE == 2) && MERGE;
     // Cornell box: the candidate grid (rmdf_device.hpp) lives in LDS for the whole launch
@@ -90,46 +152,13 @@ __global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : 1
     __shared__ float2   s_ao_out[AO_POOL ? AO_CAP : 1];       // distance, iterations run after the hand-over
     // Which strip this workgroup renders: raster order over (slot, row, column), or most expensive first
     // (block_order, a permutation of the launch's linear workgroup ids -- it spans all tiles of a shard launch)
-    const unsigned strips_per_slot = gridDim.x * gridDim.y;
     unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (p.block_order) lin = p.block_order[lin];
-    const unsigned strip = lin % strips_per_slot;
-    // rectangle of this launch / shard slot
-    int rx0, ry0, rx1, ry1, pitch, ox, oy;
-    size_t obase;
-    if (p.n_shard_tiles > 0) {
-        const int slot = (int)(lin / strips_per_slot);
-        tile_rect((int)p.shard_tile[slot], p.w, p.h, rx0, ry0, rx1, ry1);
-        pitch = rx1 - rx0; ox = rx0; oy = ry0;
-        obase = (size_t)slot * (size_t)(p.w / 8) * (size_t)(p.h / 8);
-    } else {
-        rx0 = p.x0; ry0 = p.y0; rx1 = p.x1; ry1 = p.y1;
-        pitch = p.w; ox = 0; oy = 0; obase = 0;
-    }
-    // GL quads are aligned to even window coordinates: helper pixels outside the
-    // rectangle are computed (not written) so that derivatives match a full-frame render
-    const int ex0 = rx0 & ~1, ey0 = ry0 & ~1;
-    const int ex1 = (rx1 + 1) & ~1, ey1 = (ry1 + 1) & ~1;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int lx = (lane & 1) | (((lane >> 2) & 3) << 1);
-    const int ly = ((lane >> 1) & 1) | (((lane >> 4) & 3) << 1);
-    const int bx = strip % gridDim.x, by = strip / gridDim.x;
-    const int px = ex0 + bx * (WPB * 8) + wave * 8 + lx;
-    const int py = ey0 + by * 8 + ly;
-    const bool active = (px < ex1) && (py < ey1);
+    const PixelGeom g = pixel_geom(p, lin, threadIdx.x);
 #ifdef RMDF_XCHECK
     const unsigned long long dbg_t0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;   // wave timeline (tools/nested_timeline.py)
     const unsigned long long dbg_c0 = p.dbg ? __builtin_amdgcn_s_memtime() : 0ull;       // shader cycles: the clock the kernel really runs at
 #endif
-
-    // generate_ray, perspective branch (fragment.shd:840-871)
-    const float ndcx = ((float)px + 0.5f) / p.wf * 2.0f - 1.0f;
-    const float ndcy = ((float)py + 0.5f) / p.hf * 2.0f - 1.0f;
-    const v3 dcam = normalize3(mk3(ndcx * p.fov_xs, ndcy * p.fov_xs / p.aspect, -1.0f));
-    const v3 dir = mk3(p.cam[0] * dcam.x + p.cam[3] * dcam.y + p.cam[6] * dcam.z,
-                       p.cam[1] * dcam.x + p.cam[4] * dcam.y + p.cam[7] * dcam.z,
-                       p.cam[2] * dcam.x + p.cam[5] * dcam.y + p.cam[8] * dcam.z);
     const v3 origin = mk3(p.cam[9], p.cam[10], p.cam[11]);
 
     // ray_march (fragment.shd:618-676)
@@ -140,10 +169,10 @@ __global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : 1
     float t = 0.0f;
     float tmin, tmax;
     if (!MERGE) {
-        if (active && ray_sphere(origin, dir, bsphere_r<SCENE>(), tmin, tmax)) {
+        if (g.active && ray_sphere(origin, g.dir, bsphere_r<SCENE>(), tmin, tmax)) {
             t = gmax(0.0f, tmin);
             for (steps = 0; steps < p.max_steps; steps++) {
-                v3 pos = mk3(origin.x + t * dir.x, origin.y + t * dir.y, origin.z + t * dir.z);
+                v3 pos = mk3(origin.x + t * g.dir.x, origin.y + t * g.dir.y, origin.z + t * g.dir.z);
                 float dist = distance_estimator<SCENE>(pos, p, iters, tri_hint, cgrid);
                 t += dist;
                 if (t > tmax) break;
@@ -157,16 +186,20 @@ __global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : 1
         __shared__ float4 s_res[WPB * 64];          // per strip pixel: t, steps | hit << 15, iterations
         if (threadIdx.x == 0) { s_host = -1; s_nreported = 0; s_ao_cnt = 0u; }
         if (threadIdx.x < WPB) { s_mb_ready[threadIdx.x] = 0; s_mb_n[threadIdx.x] = 0; }
-        const int my_sp = ly * (WPB * 8) + wave * 8 + lx;
-        s_res[my_sp] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        {
+            const int my_sp = g.ly * (WPB * 8) + g.wave * 8 + g.lx;
+            s_res[my_sp] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
         __syncthreads();
 
         // the ray this lane is marching right now (its own, or an adopted one when this wave is the host)
         bool act = false;
-        int cur_sp = my_sp, st = 0;
+        int cur_sp = g.ly * (WPB * 8) + g.wave * 8 + g.lx, st = 0;
         unsigned it = 0;
-        float dx = dir.x, dy = dir.y, dz = dir.z, tt = 0.0f, tmx = 0.0f;
-        if (active && ray_sphere(origin, dir, bsphere_r<SCENE>(), tmin, tmax) && p.max_steps > 0) {
+        float dx = g.dir.x, dy = g.dir.y, dz = g.dir.z, tt = 0.0f, tmx = 0.0f;
+        const int lane = g.lane, wave = __builtin_amdgcn_readfirstlane(g.wave);
+        const int sx0 = g.ex0 + g.bx * (WPB * 8), sy0 = g.ey0 + g.by * 8;        // strip origin (wave-uniform)
+        if (g.active && ray_sphere(origin, g.dir, bsphere_r<SCENE>(), tmin, tmax) && p.max_steps > 0) {
             tt = gmax(0.0f, tmin); tmx = tmax; act = true;
         }
         bool is_host = false;
@@ -215,12 +248,8 @@ __global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : 1
                     if (!act && r < take) {
                         const float4 e = s_mb[w][first + r];
                         cur_sp = __float_as_int(e.x); tt = e.y; st = __float_as_int(e.z); it = __float_as_uint(e.w);
-                        const int qx = ex0 + bx * (WPB * 8) + (cur_sp % (WPB * 8)), qy = ey0 + by * 8 + (cur_sp / (WPB * 8));
-                        const float nx_ = ((float)qx + 0.5f) / p.wf * 2.0f - 1.0f, ny_ = ((float)qy + 0.5f) / p.hf * 2.0f - 1.0f;
-                        const v3 dc = normalize3(mk3(nx_ * p.fov_xs, ny_ * p.fov_xs / p.aspect, -1.0f));
-                        dx = p.cam[0] * dc.x + p.cam[3] * dc.y + p.cam[6] * dc.z;
-                        dy = p.cam[1] * dc.x + p.cam[4] * dc.y + p.cam[7] * dc.z;
-                        dz = p.cam[2] * dc.x + p.cam[5] * dc.y + p.cam[8] * dc.z;
+                        const v3 dq = primary_dir(p, sx0 + (cur_sp % (WPB * 8)), sy0 + (cur_sp / (WPB * 8)));
+                        dx = dq.x; dy = dq.y; dz = dq.z;
                         float tmin2;
                         (void)ray_sphere(origin, mk3(dx, dy, dz), bsphere_r<SCENE>(), tmin2, tmx);
                         act = true;
@@ -259,7 +288,7 @@ __global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : 1
             }
         }
         __syncthreads();
-        const float4 rr = s_res[my_sp];
+        const float4 rr = s_res[g.ly * (WPB * 8) + g.wave * 8 + g.lx];
         t = rr.x;
         const int sb = __float_as_int(rr.y);
         steps = sb & 0x7fff;
@@ -268,6 +297,8 @@ __global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : 1
     }
 
     // render_ray hit branch up to the texture lookups (fragment.shd:743-799)
+    const v3 dir = g.dir;
+    const int lane = g.lane, wave = g.wave, lx = g.lx, ly = g.ly;
     v3 n = mk3(0.0f, 0.0f, 0.0f), refl = mk3(0.0f, 0.0f, 0.0f);
     float ao = 0.0f, fresnel = 0.0f;
     v3 isec = mk3(0.0f, 0.0f, 0.0f);
@@ -299,7 +330,7 @@ __global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : 1
                 float m = 1.0f;
                 unsigned n = 0u;
                 mb8_iterate_t<true>(w, pos, dr, r, d, 0, AO_CUT, n, m);
-                const bool redo = mb8_fold_failed(m);             // rmdf_device.hpp: the folded passes need the written ones' range
+                const bool redo = mb8_fold_failed(m, fold_min_of(p));   // rmdf_device.hpp: the folded passes need the written ones' range
                 if (__builtin_expect(__ballot(redo) != 0ull, 0)) {
                     if (redo) { w = pos; dr = 1.0f; r = 0.0f; d = 0.0f; n = 0u; mb8_iterate_t<false>(w, pos, dr, r, d, 0, AO_CUT, n, m); }
                 }
@@ -337,7 +368,7 @@ __global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : 1
                 unsigned it2 = 0u;
                 float m = 1.0f;
                 mb8_iterate_t<true>(w, pos, dr, r, d, AO_CUT, 25, it2, m);
-                const bool redo = mb8_fold_failed(m);
+                const bool redo = mb8_fold_failed(m, fold_min_of(p));
                 if (__builtin_expect(__ballot(redo) != 0ull, 0)) {
                     if (redo) { w = mk3(a.x, a.y, a.z); dr = a.w; r = b.w; d = 0.0f; it2 = 0u; mb8_iterate_t<false>(w, pos, dr, r, d, AO_CUT, 25, it2, m); }
                 }
@@ -415,9 +446,9 @@ __global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : 1
     __syncthreads();
     {
         const int ox_ = threadIdx.x % (WPB * 8), oy_ = threadIdx.x / (WPB * 8);
-        const int qx = ex0 + bx * (WPB * 8) + ox_, qy = ey0 + by * 8 + oy_;
-        if (qx >= rx0 && qx < rx1 && qy >= ry0 && qy < ry1) {
-            const size_t idx = obase + (size_t)(qx - ox) + (size_t)(qy - oy) * (size_t)pitch;
+        const int qx = g.ex0 + g.bx * (WPB * 8) + ox_, qy = g.ey0 + g.by * 8 + oy_;
+        if (qx >= g.rx0 && qx < g.rx1 && qy >= g.ry0 && qy < g.ry1) {
+            const size_t idx = g.obase + (size_t)(qx - g.ox) + (size_t)(qy - g.oy) * (size_t)g.pitch;
             if (OUT != OUT_PLANES || p.rgba8) p.rgba8[idx] = s_rgba8[oy_][ox_];
             if (OUT == OUT_MIRROR) p.rgba8_mirror[idx] = s_rgba8[oy_][ox_];
             if (OUT == OUT_PLANES) {
@@ -447,6 +478,13 @@ __global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : 1
     }
 #endif
 }
+// The power-8 Mandelbulb's product variants are held to 64 VGPRs = 8 waves per SIMD (the kernel is latency-sensitive: the eighth
+// wave is worth 3 %).  The same bound caps the SGPRs at 80 (8 x (80 + the 16 of the trap handler) <= the 800 of a SIMD -- stating
+// 96 through amdgpu_num_sgpr instead was measured: the hardware then runs 7 waves); what does not fit lives in lanes of a spare
+// VGPR (v_writelane, prologue and epilogue only).  No scratch: `make resources`.
+template <int SCENE, bool MERGE, int OUT>
+__global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : 1) void k_render(const FrameParams p) { render_body<SCENE, MERGE, OUT>(p); }
+
 static void render_grid(const FrameParams &p, dim3 &grid)
 {
     int rx0, ry0, rx1, ry1, nz = 1;

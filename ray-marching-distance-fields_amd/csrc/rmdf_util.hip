@@ -121,13 +121,10 @@ __global__ void k_selftest_mb8_folds(unsigned long long *counts)
         }
         const v3 pos = mk3(c[0], c[1], c[2]);
         unsigned ia = 0u, ib = 0u;
-        const float a = de_mandelbulb8(pos, ia), b = de_mandelbulb8_written(pos, ib);
+        unsigned nw = 0u;                                               // did the folded estimate fall back to the written form?
+        const float a = de_mandelbulb8(pos, ia, RMDF_MB8_FOLD_MIN, &nw), b = de_mandelbulb8_written(pos, ib);
         bad += !(((__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b)) && ia == ib);
-        // did it fall back?  the same folded call once more, looking at its guard
-        const v3 p2 = mk3(pos.z, pos.x, pos.y);
-        v3 w = p2; float dr = 1.0f, r = 0.0f, d = 0.0f, m = 1.0f; unsigned n = 0u;
-        mb8_iterate_t<true>(w, p2, dr, r, d, 0, 25, n, m);
-        fell += mb8_fold_failed(m) ? 1u : 0u;
+        fell += nw ? 1u : 0u;
     }
     if (bad) atomicAdd(&counts[8], bad);
     if (fell) atomicAdd(&counts[9], fell);

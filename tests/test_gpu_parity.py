@@ -312,6 +312,30 @@ def test_straggler_pooling_is_invisible(rmdf, sr, env_faces):
         plain.close()
 
 
+def test_folded_passes_fall_back_invisibly(rmdf, sr, env_faces):
+    """The power-8 Mandelbulb's iteration passes fold five power-of-two scalings into FMAs behind an underflow guard; a lane that
+    trips it recomputes THAT pass as written (rmdf_device.hpp: mb8_iterate_t).  It does happen in ordinary frames (rays crossing a
+    coordinate plane within ~2^-20), so the fall-back has to be invisible: the cross-check build with RMDF_FLAG_FORCE_WRITTEN
+    trips the guard in EVERY pass of the march, the normals and the pooled and unpooled distance-AO estimates -- same bits,
+    with and without workgroup pooling."""
+    forced = [rmdf.ShaderRenderer(0, flags=rmdf.FLAG_FORCE_WRITTEN), rmdf.ShaderRenderer(0, flags=rmdf.FLAG_FORCE_WRITTEN | rmdf.FLAG_NO_MERGE)]
+    try:
+        for f in forced:
+            assert f.xcheck
+            for slot, k in ((rmdf.ENV_REFLECTION, "refl"), (rmdf.ENV_COS_1, "cos1"), (rmdf.ENV_COS_8, "cos8")):
+                f.set_env_cube(slot, env_faces[k])
+        for (w, h, t, ms) in ((480, 270, 0.0, 256), (250, 130, 2.5, 64), (33, 17, 1.0, 256), (1280, 720, 7.0, 256)):
+            a = sr.render(2, w, h, t, max_steps=ms)
+            for f in forced:
+                b = f.render(2, w, h, t, max_steps=ms)
+                for k in ("rgba8", "steps", "iters"):
+                    assert np.array_equal(a[k], b[k]), (k, w, h)
+                assert np.array_equal(a["rgba_f32"].view(np.uint32), b["rgba_f32"].view(np.uint32))
+    finally:
+        for f in forced:
+            f.close()
+
+
 def test_frames_in_flight_and_ordered_shards(sr, rmdf):
     """Pipelined rendering (bench.py --streams S): frames on different HIP streams run concurrently, each stream with its
     own cost/order tables, and shard launches are cost-ordered across all their tiles from the second frame on.  None of
@@ -662,7 +686,7 @@ def test_alternative_schedules_live_in_the_xcheck_library_only(rmdf, sr_alt, sr_
 
     class Cfg(C.Structure):
         _fields_ = [("device", C.c_int), ("reserved", C.c_int * 7)]
-    for flag in (rmdf.FLAG_FLAT_MARCH, rmdf.FLAG_PIPELINE, 1 << 20):
+    for flag in (rmdf.FLAG_FLAT_MARCH, rmdf.FLAG_PIPELINE, rmdf.FLAG_FORCE_WRITTEN, 1 << 20):
         cfg = Cfg(device=0)
         cfg.reserved[0] = flag
         ctx = C.c_void_p()

@@ -1,0 +1,10 @@
+#!/bin/bash
+# A/B of alternative builds of librmdf (tools/abtest/*.so): headline frame with 3 frames in flight and one at a time
+shopt -s nullglob
+for s in 3 1; do
+  for lib in tools/abtest/*.so; do
+    export RMDF_LIB=$PWD/$lib
+    python bench.py --no-cpu-baseline --no-secondary --streams $s --steps 100 2>/dev/null > /tmp/ab.json
+    python tools/show_bench.py /tmp/ab.json | sed "s|/tmp/ab.json|$lib S=$s|"
+  done
+done
