@@ -130,6 +130,37 @@ def max_over_ranks(seconds, dist, device):
     return float(t.item())
 
 
+class Watchdog:
+    """A collective that never completes (a peer that died, a mismatched send / receive) would leave the driver waiting for its own
+    timeout with nothing on stderr.  arm(what) starts a countdown, disarm() stops it; when it runs out the thread says which rank
+    was stuck in what and ends the process with exit code 3 (os._exit: no re-exec, no atexit handlers that could block again)."""
+
+    def __init__(self, rank, seconds):
+        import threading
+        self.rank, self.seconds, self.what, self.deadline = rank, seconds, None, None
+        self.lock = threading.Lock()
+        t = threading.Thread(target=self._run, daemon=True)
+        t.start()
+
+    def arm(self, what, seconds=None):
+        with self.lock:
+            self.what, self.deadline = what, time.monotonic() + (seconds or self.seconds)
+
+    def disarm(self):
+        with self.lock:
+            self.what, self.deadline = None, None
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                what, dl = self.what, self.deadline
+            if dl is not None and time.monotonic() > dl:
+                sys.stderr.write("bench.py watchdog: rank %d has been stuck in %r for more than %.0f s -- giving up (exit 3)\n" % (self.rank, what, self.seconds))
+                sys.stderr.flush()
+                os._exit(3)
+
+
 def flops_model(c):
     """F = 79 I + 11 E + 9 S + 150 H + 30 P  (as-written IEEE op counts)."""
     return 79 * c["triplex_iters"] + 11 * c["de_evals"] + 9 * c["march_steps"] + 150 * c["hit_pixels"] + 30 * c["pixels"]
@@ -218,13 +249,16 @@ def main():
     # the N > 1 path (shard render, RCCL gather, assemble); RMDF_BENCH_FORCE_DIST=1 runs it with world size 1 so that a
     # 1-GPU box can smoke-test it
     sharded = world > 1 or os.environ.get("RMDF_BENCH_FORCE_DIST") == "1"
+    dog = Watchdog(rank, float(os.environ.get("RMDF_BENCH_WATCHDOG_S", "180")))
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        dog.arm("torch.distributed.init_process_group")
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dog.disarm()
 
     # one rank builds (a no-op when librmdf.so is current), the others wait: N ranks must not run make at once
     if local_rank == 0:
@@ -302,7 +336,9 @@ def main():
             if use_abi_comm:
                 dist.broadcast(uid, src=0)
                 try:
+                    dog.arm("rmdf_comm_init (ncclCommInitRank, %d ranks)" % world)
                     sr.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+                    dog.disarm()
                     ok = True
                 except Exception as e:                          # noqa: BLE001
                     print("rank %d: rmdf_comm_init failed (%s)" % (rank, e), file=sys.stderr)
@@ -311,6 +347,22 @@ def main():
                 if not use_abi_comm and ok:
                     sr.comm_destroy()
             if not use_abi_comm:
+                print("rank %d: falling back to the torch.distributed gather" % rank, file=sys.stderr)
+        dog.disarm()
+        if use_abi_comm:
+            # the exchange's own calls against this rank itself before any peer is involved: a grouped ncclRecv + ncclSend of one
+            # shard's size on a frame stream (the lines that move the tiles have no other single-GPU coverage)
+            dog.arm("rmdf_comm_selftest_loopback")
+            try:
+                sr.comm_selftest_loopback(slots * (h // 8) * (w // 8) * 4, stream=streams[0].cuda_stream)
+                ok = True
+            except Exception as e:                              # noqa: BLE001
+                print("rank %d: rmdf_comm_selftest_loopback failed (%s)" % (rank, e), file=sys.stderr)
+                ok = False
+            dog.disarm()
+            use_abi_comm = all_ok(ok)
+            if not use_abi_comm:
+                sr.comm_destroy()
                 print("rank %d: falling back to the torch.distributed gather" % rank, file=sys.stderr)
         if use_abi_comm:
             rccl_ranks = sr.comm_info()[1]
@@ -347,9 +399,11 @@ def main():
             sr.assemble_shards_device(w, h, world, g.data_ptr(), frames[k].data_ptr(), stream=sp)
 
     def step(i=0):
+        step_at(i, a.time + a.animate * i)
+
+    def step_at(i, t):
         k = i % S
         sp = streams[k].cuda_stream
-        t = a.time + a.animate * i
         if not sharded:
             render_only(k, t)
             if L:
@@ -380,6 +434,7 @@ def main():
         return float(np.mean(ts)), float(np.min(ts))
 
     deal = "single GPU"
+    shard_split = None
     if sharded:
         # cost-aware deal of the 64 tiles: every rank probes the view at 256 x 144 on its own GPU (bit-reproducible
         # kernels -> identical costs, no exchange) and deals longest-processing-time-first.  Outside the timed region
@@ -389,10 +444,12 @@ def main():
         # the exchange + assembly alone on rank 0's stream (all ranks send at once, so the root sees transfer + launch cost,
         # not waiting) against the mean render time of a rank's shard; the deal starts rank 0 with that share of load.
         # RMDF_ROOT_HANDICAP overrides (a fraction of a rank's fair share).
+        dog.arm("the first exchange of the run (shard render + gather to rank 0 + assemble, 3 frames)")
         for _ in range(3):
             render_only(0)
             exchange_only(0)
         barrier()
+        dog.disarm()
         t_render = event_ms(lambda: render_only(0), 10)[0]
         barrier()
         t_exch = event_ms(lambda: exchange_only(0), 10)[0]
@@ -400,6 +457,9 @@ def main():
         tt = torch.tensor([t_render, t_exch if rank == 0 else 0.0], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         mean_render, root_exchange = float(tt[0].item()) / world, float(tt[1].item())
+        shard_split = {"shard_render_ms_mean_over_ranks": round(mean_render, 4), "exchange_plus_assemble_ms_rank0": round(root_exchange, 4),
+                       "note": "measured before the timed region, one frame at a time on stream 0: every rank's shard render (HIP events), and on "
+                               "rank 0 the gather + assembly alone while all peers send at once"}
         measured = min(0.5, root_exchange / max(mean_render, 1e-6))
         handicap = float(os.environ.get("RMDF_ROOT_HANDICAP", measured))
         sr.set_shard_root_handicap(handicap)
@@ -413,6 +473,8 @@ def main():
             deal = "static (ranks disagreed on the probed costs)"
 
     # warm-up: W steps, then keep stepping until MIN_WARM_SECONDS have passed (all ranks decide together)
+    if sharded:
+        dog.arm("warm-up and timed blocks", seconds=max(dog.seconds, 600.0))
     for i in range(a.warmup):
         step(i)
     barrier()
@@ -425,15 +487,56 @@ def main():
         barrier()
         if max_over_ranks(time.perf_counter() - t_w0, dist, cdev) >= MIN_WARM_SECONDS or extra_warm >= 100000:
             break
-    blocks, host_enqueue = [], []
-    for _ in range(max(1, a.repeats)):
+    # RMDF_BENCH_MARK=1 (tools/profile.sh): a one-thread marker kernel (k_resolve_box2 on a 2x2 image, used by nothing else in this
+    # run) is launched BEFORE the opening barrier of every timed block and after the closing barrier of the last one, so that a
+    # rocprofv3 kernel trace of this command can be cut into the timed blocks (tools/pmc_summary.py: first dispatch start -> last
+    # dispatch end of a block / steps = the figure `ms_per_step` should reproduce).  Nothing is added inside the timed region.
+    mark = None
+    if os.environ.get("RMDF_BENCH_MARK") == "1" and rank == 0:
+        m_src, m_dst = torch.zeros((2, 2), **i32), torch.zeros((1, 1), **i32)
+        torch.cuda.synchronize(dev)
+        mark = lambda: sr.resolve_box2_device(m_src.data_ptr(), 2, 2, m_dst.data_ptr(), stream=streams[0].cuda_stream)
+
+    def timed_block(n_steps, first_i=0, dt_anim=None):
+        """EXACTLY n_steps steps between barrier + synchronize on both sides.  Returns (wall seconds, max over ranks; host seconds
+        this rank spent issuing; device span in ms: first stream-start event -> last stream-end event of the block)."""
+        if mark:
+            mark()
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
         barrier()
         t0 = time.perf_counter()
-        for i in range(a.steps):
-            step(i)
-        host_enqueue.append((time.perf_counter() - t0) / a.steps * 1e3)      # host time to issue one step (this rank)
+        for k in range(S):
+            ev0[k].record(streams[k])
+        for i in range(n_steps):
+            step(first_i + i) if dt_anim is None else step_at(first_i + i, a.time + dt_anim * (first_i + i))
+        t_issue = time.perf_counter() - t0
+        for k in range(S):
+            ev1[k].record(streams[k])
         barrier()
-        blocks.append(max_over_ranks(time.perf_counter() - t0, dist, cdev))
+        wall = max_over_ranks(time.perf_counter() - t0, dist, cdev)
+        span = max(e0.elapsed_time(e1) for e0 in ev0 for e1 in ev1)
+        return wall, t_issue, span
+
+    blocks, host_enqueue, spans = [], [], []
+    for _ in range(max(1, a.repeats)):
+        wall, t_issue, span = timed_block(a.steps)
+        blocks.append(wall)
+        host_enqueue.append(t_issue / a.steps * 1e3)                             # host time to issue one step (this rank)
+        spans.append(span / a.steps)
+    # the same block with the viewer's animation (in_time advances 1/60 s per frame): the cost-ordered dispatch then works from
+    # the costs of a slightly different view instead of a perfect table
+    anim_ms = None
+    if a.animate == 0.0:
+        timed_block(max(a.warmup, 10), dt_anim=1.0 / 60.0)
+        anim_ms = timed_block(a.steps, dt_anim=1.0 / 60.0)[0] / a.steps * 1e3
+        for i in range(S):                                         # every frame buffer holds the in_time = a.time frame again (--check)
+            step(i)
+        barrier()
+    if mark:
+        mark()
+        torch.cuda.synchronize(dev)
+    dog.disarm()
     order = sorted(range(len(blocks)), key=lambda i: blocks[i])
     med = order[len(order) // 2]
     dt = blocks[med]
@@ -513,10 +616,21 @@ def main():
                                        (world, "ranks sharing one GPU (test aid)" if share_gpu else "GPUs")) +
                                       ", %d frame(s) in flight" % S,
                        "exchange": exchange, "rccl_ranks": rccl_ranks,
+                       "exchange_ms": None if shard_split is None else shard_split["exchange_plus_assemble_ms_rank0"],
+                       "shard_render_ms": None if shard_split is None else shard_split["shard_render_ms_mean_over_ranks"],
                        "frames_in_flight": S, "tile_deal": deal, "animate_dt": a.animate,
                        "device": dev_name, "compute_units": cus},
             "repeats": len(blocks), "ms_per_step_blocks": [round(b / a.steps * 1e3, 4) for b in blocks],
             "ms_per_step_min": round(min(blocks) / a.steps * 1e3, 4),
+            "device_span_ms_per_step": round(spans[med], 4),
+            "device_span_note": "the median block again, measured on the device: HIP events recorded on every frame stream at the start and "
+                                "at the end of the block, latest end - earliest start, / steps (rank 0's streams); the tracked counterpart "
+                                "from a rocprofv3 kernel trace of this command is profiles/*_schedule_default.json",
+            "value_animated": None if anim_ms is None else round(mpix / (anim_ms * 1e-3), 2),
+            "ms_per_step_animated": None if anim_ms is None else round(anim_ms, 4),
+            "animated_note": "one more block of `steps` steps with in_time advancing 1/60 s per frame (the viewer's animation): the cost-"
+                             "ordered dispatch then runs on the previous frame's costs of a slightly different view; `value` renders the "
+                             "same frame every step",
             "timing_note": "value / ms_per_step = the median of `repeats` blocks of exactly `steps` steps, each bracketed by "
                            "barrier + synchronize; %d + %d untimed warm-up steps (>= %.1f s) ran before the first block" % (a.warmup, extra_warm, MIN_WARM_SECONDS),
             "hbm_roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
@@ -554,8 +668,8 @@ def main():
                                   "clock_note": "peak is priced at 2.4 GHz; the shader engines sustain less under this load (rmdf_probe_shader_clock: "
                                                 "s_memtime against s_memrealtime on one wave beside the running frames, median of 3 probes of 0.3 ms)",
                                   "kernel_ms_note": "HIP events on the launch stream around one frame's launches, one frame at a time: k_render "
-                                                    "plus the single-workgroup k_order_blocks (~0.009 ms) that follows it; rocprofv3 of this "
-                                                    "command (profiles/r02_kernel_stats_s1.csv): k_render alone 0.433 ms",
+                                                    "plus the single-workgroup k_order_blocks (~0.009 ms) that follows it; the rocprofv3 "
+                                                    "average of k_render alone is in profiles/*_kernel_stats_s1.csv (same command with --streams 1)",
                                   "ops_per_launch": F, "op_counters": ctr, "op_counters_source": ctr_src,
                                   "note": "binding roof = FP32 vector-ALU issue (SURVEY 8d): as-written IEEE operations (sqrt, 1/sqrt, "
                                           "log, pow, / each 1; no FMA contraction by the parity contract) per second against 256 CU x "
@@ -568,10 +682,23 @@ def main():
                                                "achieved": round(rate, 3), "peak": VALU_ISSUE_PEAK, "frac": round(rate / VALU_ISSUE_PEAK, 3),
                                                "unit": "G wave-instructions/s/SIMD",
                                                "lane_utilisation": (pmc.get("valu") or {}).get("lane_utilisation")}
+        elif ctr is not None and sharded and L == 0:
+            # N GPUs: the frame's as-written operations against the job's N vector-ALU roofs, at the whole-job rate the timed region
+            # measured (the per-launch kernel time of one rank's shard is kernel_ms_avg; sharding adds helper rows and the exchange)
+            F = flops_model(ctr)
+            ach = F / (ms_per_step * 1e-3) / 1e12
+            result["roofline"] = {"bound": "valu", "kernel": kname + " (one shard launch per rank and frame)", "achieved": round(ach, 3),
+                                  "peak": round(VALU_PEAK_TLANEOPS * world, 1), "unit": "T lane-ops/s", "frac": round(ach / (VALU_PEAK_TLANEOPS * world), 4),
+                                  "traffic": None, "kernel_ms_avg": round(kern_ms, 4), "kernel_ms_min": round(kern_ms_min, 4),
+                                  "ops_per_launch": F, "op_counters": ctr, "op_counters_source": ctr_src,
+                                  "exchange": shard_split,
+                                  "note": "aggregate: as-written IEEE operations of the whole frame / ms_per_step against n_gpus x 78.6 T "
+                                          "lane-ops/s; kernel_ms_avg = rank 0's shard launch alone (HIP events)"}
         else:
             result["roofline"] = {"bound": "valu", "kernel": kname, "achieved": None, "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
                                   "frac": None, "traffic": None, "kernel_ms_avg": round(kern_ms, 4), "kernel_ms_min": round(kern_ms_min, 4),
-                                  "note": "operation counters are only known for the headline workload on one GPU (or after the "
+                                  "exchange": shard_split,
+                                  "note": "operation counters are only known for the headline workload (or after the "
                                           "cpu_baseline leg counted them)"}
         if not a.no_secondary and world == 1 and not sharded and L == 0:
             result["secondary"] = secondary_workloads(sr, torch, dev, stream, cus)
@@ -583,11 +710,23 @@ def main():
             # thread per power (ShaderRendering.hs:142) -- one power timed on one thread -- and split over all cores
             small = orc.resize_hdr(oracle_env_latlongs(orc)["refl"], 256)
             tj0 = time.perf_counter(); orc.julia_animated(512, 512, 0, 0.0); tj = time.perf_counter() - tj0
+            tj0 = time.perf_counter(); orc.julia_animated(512, 512, 1, 0.0); tjs = time.perf_counter() - tj0
+            tj0 = time.perf_counter(); orc.julia_animated(1920, 1080, 0, 0.0); tjb = time.perf_counter() - tj0
+            tj0 = time.perf_counter(); orc.julia_animated(1920, 1080, 1, 0.0); tjbs = time.perf_counter() - tj0
+            refl_ll = oracle_env_latlongs(orc)["refl"]
+            orc.latlong_to_cube(refl_ll)                           # first call builds nothing persistent, but warms the pool
+            tq0 = time.perf_counter(); orc.latlong_to_cube(refl_ll); tq = time.perf_counter() - tq0
             tc0 = time.perf_counter(); orc.cosine_convolve(small, 8.0, nthreads=1, pow_mode=0); tc1 = time.perf_counter() - tc0
             tc0 = time.perf_counter(); orc.cosine_convolve(small, 8.0, nthreads=0, pow_mode=0); tca = time.perf_counter() - tc0
             result["cpu_reference_paths"] = {
                 "cores": orc.num_processors(), "kind": "port",
                 "julia_animated_512x512_ms": round(tj * 1e3, 2), "julia_animated_mpixels_s": round(0.262144 / tj, 1),
+                "julia_animated_512x512_smooth_ms": round(tjs * 1e3, 2),
+                "julia_animated_1920x1080_ms": round(tjb * 1e3, 2), "julia_animated_1920x1080_smooth_ms": round(tjbs * 1e3, 2),
+                "latlong_to_cube_512x256_to_6x170x170_all_cores_ms": round(tq * 1e3, 2),
+                "note": "C restatements with the reference's threading: juliaAnimated and latLongHDREnvMapToCubeMap in nproc row "
+                        "segments (ConcurrentSegments.hs:14-28, Fractal2D.hs:98, HDREnvMap.hs:139); cosineConvolveHDREnvMap one power "
+                        "per thread (ShaderRendering.hs:142) and, labelled, split over all cores; literal libm powf (pow_mode 0)",
                 "cosine_convolve_256x128_power8_one_thread_s": round(tc1, 3),
                 "cosine_convolve_256x128_power8_all_cores_s": round(tca, 3)}
             if a.check:
@@ -603,8 +742,10 @@ def main():
 
 
 def secondary_workloads(sr, torch, dev, stream, cus):
-    """The other single-GPU configurations of BASELINE.json, timed with HIP events after the headline run (device-resident,
-    one frame at a time): config 2 (Cornell box 1280x720 @128) and config 5 (lobe prefilter 256x128, the four powers)."""
+    """The other configurations SURVEY.md 8(d) lists, timed after the headline run (device-resident unless said otherwise): config 2
+    (Cornell box 1280x720 @128), config 5 (lobe prefilter 256x128, the four powers), config 4 on one GPU (3840x2160 output from
+    7680x4320 rays, box-resolved on the GPU), the reference's 64-tile mode through the boundary call (rmdf_render_tile into a host
+    buffer, 64 calls per frame), and the headline scene at in_time 1, 2.5 and 7."""
     out = {}
     fb = torch.empty((720, 1280), dtype=torch.int32, device=dev)
     sp = stream.cuda_stream
@@ -654,6 +795,46 @@ def secondary_workloads(sr, torch, dev, stream, cus):
     t0 = time.perf_counter()
     sr.prefilter_env_powers(src, (1.0, 8.0, 64.0, 512.0))
     four = time.perf_counter() - t0
+    # config 4 on ONE GPU: frame-buffer scale 2 (App.hs:105-106,131-133) = 7680x4320 rays, one launch, then one mip level of the
+    # RGBA8 frame (k_resolve_box2).  Two frames in flight like the headline's schedule would need 2 x 133 MB more; one at a time.
+    big = torch.empty((4320, 7680), dtype=torch.int32, device=dev)
+    fb4 = torch.empty((2160, 3840), dtype=torch.int32, device=dev)
+    c4_render = lambda: sr.render_rect_device(2, 7680, 4320, 0.0, 256, (0, 0, 7680, 4320), d_rgba8=big.data_ptr(), stream=sp)
+    c4_resolve = lambda: sr.resolve_box2_device(big.data_ptr(), 7680, 4320, fb4.data_ptr(), stream=sp)
+    for _ in range(3):
+        c4_render(); c4_resolve()
+    t_r, t_s = ev(c4_render, 8), ev(c4_resolve, 8)
+    out["config4_mandelbulb_3840x2160_x4rays_one_gpu"] = {
+        "render_ms": round(t_r, 4), "resolve_ms": round(t_s, 4), "ms_per_frame": round(t_r + t_s, 4),
+        "mrays_s": round(33.1776 / ((t_r + t_s) * 1e-3), 1), "mpixels_s": round(8.2944 / ((t_r + t_s) * 1e-3), 1),
+        "note": "BASELINE config 4's work on one GPU (the 8-GPU form shards the 64 tiles and resolves before the gather); "
+                "7680x4320 rays @256 steps in one launch + k_resolve_box2, HIP events, one frame at a time"}
+    del big, fb4
+    # the reference's tiled dispatch (ShaderRendering.hs:181-193): 64 drawShaderTile calls per frame through the boundary,
+    # each returning the whole accumulated frame into the caller's Word32 buffer (the PBO is orphaned every call)
+    host = np.empty(1920 * 1080, np.uint32)
+    for tidx in range(64):
+        sr.draw_shader_tile(2, tidx, 1920, 1080, 0.0, host, max_steps=256)
+    t0 = time.perf_counter()
+    n_tf = 2
+    for f in range(n_tf):
+        for tidx in range(64):
+            sr.draw_shader_tile(2, 64 * (f + 1) + tidx, 1920, 1080, 0.0, host, max_steps=256)
+    t_tile = (time.perf_counter() - t0) / (64 * n_tf) * 1e3
+    out["tile_mode_64_calls_1920x1080"] = {"ms_per_tile_call": round(t_tile, 4), "ms_per_frame": round(64 * t_tile, 3),
+                                           "mpixels_s": round(2.0736 / (64 * t_tile * 1e-3), 1),
+                                           "note": "rmdf_render_tile with tile_idx 0..63, host buffer handed back whole on every call "
+                                                   "(FrameBuffer.hs:129,207-213), wall clock, PCIe included"}
+    # the headline scene from the SURVEY's other camera times
+    fbv = torch.empty((1080, 1920), dtype=torch.int32, device=dev)
+    views = {}
+    for tv in (1.0, 2.5, 7.0):
+        fv = lambda tv=tv: sr.render_rect_device(2, 1920, 1080, tv, 256, (0, 0, 1920, 1080), d_rgba8=fbv.data_ptr(), stream=sp)
+        for _ in range(5):
+            fv()
+        tt = ev(fv, 20)
+        views["in_time_%g" % tv] = {"kernel_ms_avg": round(tt, 4), "mpixels_s": round(2.0736 / (tt * 1e-3), 1)}
+    out["headline_scene_other_views_1920x1080_m256"] = views
     out["config5_lobe_prefilter_256x128"] = {"per_power": per, "four_powers_concurrent_host_in_out_ms": round(four * 1e3, 3),
                                              "pair_terms_per_power": pair_terms,
                                              "note": "one lane per destination texel, source summed serially in the reference's order "

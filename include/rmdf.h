@@ -228,8 +228,13 @@ int rmdf_render_supersampled(rmdf_ctx *ctx, int scene, int w, int h, int levels,
  *   per frame:   rmdf_render_frame_sharded_device(...)            -- = rmdf_render_shard_device + rmdf_gather_shards_device
  *                                                                    + (rank 0) rmdf_assemble_shards_device, all on `stream`
  * rmdf_gather_shards_device: every rank's packed shard (ceil(64/nranks) tile slots of (w/8)*(h/8) uint32) lands in
- * d_gathered[rank] on rank 0 (grouped ncclRecv fan-in; the other ranks ncclSend).  Rank 0 may pass d_shard == d_gathered (it
- * rendered straight into its own slot).  d_gathered is ignored on the other ranks. */
+ * d_gathered[rank] on rank 0 (grouped ncclRecv fan-in; the other ranks ncclSend).  Only the tiles a rank owns under the deal in
+ * effect travel (the root derives every peer's count from the same deal: ALL ranks must have set the same costs / handicap, or
+ * none -- rmdf_set_shard_costs).  Rank 0 may pass d_shard == d_gathered (it rendered straight into its own slot).  d_gathered is
+ * ignored on the other ranks.
+ * rmdf_comm_selftest_loopback: the exchange's own calls against this rank itself -- a grouped ncclRecv from self + ncclSend to
+ * self of `bytes` bytes on `stream` (NULL = ctx stream), compared word for word; on the ctx's communicator, or on a private
+ * one-rank communicator when the ctx has none (a single-GPU box can run it).  *mismatches (may be NULL) = differing words. */
 #define RMDF_COMM_ID_BYTES 128
 int rmdf_comm_get_unique_id(void *id);
 int rmdf_comm_init(rmdf_ctx *ctx, const void *id, int rank, int nranks);
@@ -237,6 +242,7 @@ int rmdf_comm_destroy(rmdf_ctx *ctx);
 /* *nranks = 0 when the ctx has no communicator */
 int rmdf_comm_info(rmdf_ctx *ctx, int *rank, int *nranks);
 int rmdf_gather_shards_device(rmdf_ctx *ctx, int w, int h, const void *d_shard, void *d_gathered, void *stream);
+int rmdf_comm_selftest_loopback(rmdf_ctx *ctx, size_t bytes, void *stream, uint64_t *mismatches);
 int rmdf_render_frame_sharded_device(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps,
                                      void *d_shard, void *d_gathered, void *d_frame_rgba8, void *stream);
 

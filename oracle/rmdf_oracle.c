@@ -1385,17 +1385,22 @@ static void spherical_to_env_uv(float theta, float phi, float *u, float *v)
     *v = theta / PI_F;
 }
 
-/* HDREnvMap.hs:91-113, including its `mod (w-1)` and min(h-1) quirks */
+/* HDREnvMap.hs:91-113, including its `mod (w-1)` and min(h-1) quirks.
+ * The reference fetches with unsafePixelAt (HDREnvMap.hs:106-109) and reads past the pixel vector when (u, v) leaves [0, 1] --
+ * resizeHDRImage (169-195) does for maps that are not 2:1 (1024x510 -> 256: dsth = round(127.5) = 128, last tap row = source
+ * row 511).  Undefined in the reference; pinned here (and in the device kernel) by clamping the integer texel into the image
+ * before the fetch, weights unchanged.  Inside the image nothing changes. */
 static void pixel_at_bilinear(const float *img, int w, int h, float u, float v, float rgb[3])
 {
     float upx = u * ((float)w - 1.0f);
     float upy = v * ((float)h - 1.0f);
-    int x = (int)floorf(upx), y = (int)floorf(upy);
+    int xf = (int)floorf(upx), yf = (int)floorf(upy);
+    int x = xf < 0 ? 0 : (xf > w - 1 ? w - 1 : xf), y = yf < 0 ? 0 : (yf > h - 1 ? h - 1 : yf);
     int m = w - 1;
     int xp1 = (x + 1) % m;
     if (xp1 < 0) xp1 += m;                /* Haskell mod is floored */
     int yp1 = (y + 1 < h - 1) ? y + 1 : h - 1;
-    float ur = upx - (float)x, vr = upy - (float)y;
+    float ur = upx - (float)xf, vr = upy - (float)yf;
     float uo = 1.0f - ur, vo = 1.0f - vr;
     const float *a = img + ((size_t)x + (size_t)y * w) * 3, *b = img + ((size_t)xp1 + (size_t)y * w) * 3;
     const float *c = img + ((size_t)x + (size_t)yp1 * w) * 3, *d = img + ((size_t)xp1 + (size_t)yp1 * w) * 3;

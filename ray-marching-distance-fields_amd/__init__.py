@@ -54,7 +54,7 @@ ABI_SYMBOLS = (
     "rmdf_selftest_pinned_math", "rmdf_set_shard_root_handicap", "rmdf_create_ex", "rmdf_prefilter_env_powers",
     "rmdf_prefilter_env_device", "rmdf_comm_get_unique_id", "rmdf_comm_init", "rmdf_comm_destroy", "rmdf_comm_info",
     "rmdf_gather_shards_device", "rmdf_render_frame_sharded_device", "rmdf_device_malloc", "rmdf_device_free",
-    "rmdf_copy_to_host", "rmdf_probe_shader_clock",
+    "rmdf_copy_to_host", "rmdf_probe_shader_clock", "rmdf_comm_selftest_loopback",
 )
 XCHECK_SYMBOLS = ("rmdf_debug_march_stats",)      # include/rmdf_xcheck.h
 
@@ -122,7 +122,9 @@ def build(force=False, verbose=False):
         try:
             if force or stale():
                 out = None if verbose else subprocess.DEVNULL
-                subprocess.check_call(["make", "-C", CSRC] + (["-B"] if force else []), stdout=out)
+                # the digest is the authority, not make's file times: a tree restored with its mtimes (cp -p, rsync) would make a
+                # plain `make` a no-op and the new digest would then bless stale libraries
+                subprocess.check_call(["make", "-B", "-C", CSRC], stdout=out)
                 with open(stamp + ".tmp", "w") as f:
                     f.write(_source_digest() + "\n")
                 os.replace(stamp + ".tmp", stamp)
@@ -164,6 +166,7 @@ def load_library(xcheck=False):
     L.rmdf_comm_destroy.argtypes = [vp]
     L.rmdf_comm_info.argtypes = [vp, ip, ip]
     L.rmdf_gather_shards_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+    L.rmdf_comm_selftest_loopback.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_uint64)]
     L.rmdf_render_frame_sharded_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp]
     L.rmdf_is_tile_idx_first_tile.argtypes = [C.c_int]
     L.rmdf_is_tile_idx_last_tile.argtypes = [C.c_int]
@@ -310,6 +313,13 @@ class ShaderRenderer:
         r, n = C.c_int(), C.c_int()
         self._check(self._lib.rmdf_comm_info(self._ctx, C.byref(r), C.byref(n)))
         return r.value, n.value
+
+    def comm_selftest_loopback(self, nbytes, stream=0):
+        """The exchange's own RCCL calls against this rank itself (grouped ncclRecv from self + ncclSend to self of nbytes on
+        `stream`), compared word for word; returns the number of differing words (raises RMDF_E_COMM if any)."""
+        bad = C.c_uint64(0)
+        self._check(self._lib.rmdf_comm_selftest_loopback(self._ctx, int(nbytes), stream or None, C.byref(bad)))
+        return bad.value
 
     def gather_shards_device(self, w, h, d_shard, d_gathered=0, stream=0):
         self._check(self._lib.rmdf_gather_shards_device(self._ctx, w, h, d_shard, d_gathered or None, stream or None))

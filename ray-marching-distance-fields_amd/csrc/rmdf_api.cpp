@@ -1093,12 +1093,14 @@ int rmdf_get_env_cube_padded(rmdf_ctx *ctx, int slot, uint16_t *out, int *face_w
 int rmdf_resize_latlong(rmdf_ctx *ctx, const float *rgb, int w, int h, int dstw, float *out, int *dsth)
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
-    if (!rgb || w < 2 || h < 2 || dstw < 1 || !dsth) return fail(ctx, RMDF_E_INVALID, "rmdf_resize_latlong: bad argument");
+    if (!rgb || w < 2 || h < 2 || w > 32768 || h > 16384 || dstw < 1 || dstw > 32768 || !dsth)
+        return fail(ctx, RMDF_E_INVALID, "rmdf_resize_latlong: bad argument (2 <= w <= 32768, 2 <= h <= 16384, 1 <= dstw <= 32768)");
     // dsth = round (srch / srcw * dstw) in Float, Haskell round = half-to-even (HDREnvMap.hs:173)
     const int dh = (int)rintf((float)h / (float)w * (float)dstw);
     *dsth = dh;
     if (!out) return RMDF_OK;
     if (dh < 1) return fail(ctx, RMDF_E_INVALID, "destination height < 1");
+    if ((long long)dstw * dh > (1ll << 28)) return fail(ctx, RMDF_E_INVALID, "rmdf_resize_latlong: destination larger than 2^28 texels");
     RMDF_GUARD_BEGIN
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf src, dst;
@@ -1432,20 +1434,71 @@ int rmdf_gather_shards_device(rmdf_ctx *ctx, int w, int h, const void *d_shard, 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     const size_t slots = (size_t)((64 + n - 1) / n);
-    const size_t bytes = slots * (size_t)(w / 8) * (size_t)(h / 8) * 4;          // every rank's shard has the same size
+    const size_t tile_bytes = (size_t)(w / 8) * (size_t)(h / 8) * 4;
+    const size_t bytes = slots * tile_bytes;                                       // the stride of a rank's region in d_gathered
+    // A rank sends the tiles it OWNS under the deal in effect (ensure_deal: static, or by the costs every rank has set alike -- the
+    // deal is a pure function of them, so the root knows every peer's count without asking); unused slots stay where they are.
+    ensure_deal(ctx, n);
     if (rank == 0) {
         // fan-in: one receive per peer, grouped so that they progress together over the seven xGMI links of the root
         if (n > 1) {
             RCCL_TRY(ctx, g_rccl.GroupStart());
             for (int r = 1; r < n; r++)
-                RCCL_TRY(ctx, g_rccl.Recv((char *)d_gathered + (size_t)r * bytes, bytes, ncclChar, r, ctx->comm, st));
+                if (ctx->deal_count[r] > 0)
+                    RCCL_TRY(ctx, g_rccl.Recv((char *)d_gathered + (size_t)r * bytes, (size_t)ctx->deal_count[r] * tile_bytes, ncclChar, r, ctx->comm, st));
             RCCL_TRY(ctx, g_rccl.GroupEnd());
         }
         if ((const char *)d_shard != (const char *)d_gathered)     // the root may render straight into its own slot
-            HIP_TRY(ctx, hipMemcpyAsync(d_gathered, d_shard, bytes, hipMemcpyDeviceToDevice, st));
-    } else {
-        RCCL_TRY(ctx, g_rccl.Send(d_shard, bytes, ncclChar, 0, ctx->comm, st));
+            HIP_TRY(ctx, hipMemcpyAsync(d_gathered, d_shard, (size_t)ctx->deal_count[0] * tile_bytes, hipMemcpyDeviceToDevice, st));
+    } else if (ctx->deal_count[rank] > 0) {
+        RCCL_TRY(ctx, g_rccl.Send(d_shard, (size_t)ctx->deal_count[rank] * tile_bytes, ncclChar, 0, ctx->comm, st));
     }
+    return RMDF_OK;
+    RMDF_GUARD_END(ctx)
+}
+
+int rmdf_comm_selftest_loopback(rmdf_ctx *ctx, size_t bytes, void *stream, uint64_t *mismatches)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (bytes < 4 || bytes > ((size_t)1 << 28) || (bytes & 3)) return fail(ctx, RMDF_E_INVALID, "rmdf_comm_selftest_loopback: 4 <= bytes <= 2^28, a multiple of 4");
+    if (mismatches) *mismatches = 0;
+    RMDF_GUARD_BEGIN
+    int rc = load_rccl(ctx);
+    if (rc != RMDF_OK) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    // the ctx's communicator if it has one (any size: a rank talks to itself), else a private one-rank communicator
+    ncclComm_t comm = ctx->comm;
+    int me = ctx->comm_rank;
+    struct TmpComm {
+        ncclComm_t c = nullptr;
+        ~TmpComm() { if (c) g_rccl.CommDestroy(c); }
+    } tmp;
+    if (!comm) {
+        ncclUniqueId uid;
+        RCCL_TRY(ctx, g_rccl.GetUniqueId(&uid));
+        RCCL_TRY(ctx, g_rccl.CommInitRank(&tmp.c, 1, uid, 0));
+        comm = tmp.c; me = 0;
+    }
+    const size_t nw = bytes / 4;
+    std::vector<uint32_t> host(nw), back(nw);
+    for (size_t i = 0; i < nw; i++) { uint32_t h = (uint32_t)i * 2654435761u + 0x9e3779b9u; h ^= h >> 15; h *= 2246822519u; host[i] = h ^ (h >> 13); }
+    DevBuf src, dst;
+    HIP_TRY(ctx, hipMalloc(&src.p, bytes));
+    HIP_TRY(ctx, hipMalloc(&dst.p, bytes));
+    HIP_TRY(ctx, hipMemcpyAsync(src.p, host.data(), bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(dst.p, 0, bytes, st));
+    // exactly the calls of the exchange step: a grouped receive (the root's side) and a send (a peer's side), on the caller's stream
+    RCCL_TRY(ctx, g_rccl.GroupStart());
+    RCCL_TRY(ctx, g_rccl.Recv(dst.p, bytes, ncclChar, me, comm, st));
+    RCCL_TRY(ctx, g_rccl.Send(src.p, bytes, ncclChar, me, comm, st));
+    RCCL_TRY(ctx, g_rccl.GroupEnd());
+    HIP_TRY(ctx, hipMemcpyAsync(back.data(), dst.p, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    uint64_t bad = 0;
+    for (size_t i = 0; i < nw; i++) bad += back[i] != host[i];
+    if (mismatches) *mismatches = bad;
+    if (bad) return fail(ctx, RMDF_E_COMM, "rmdf_comm_selftest_loopback: " + std::to_string(bad) + " of " + std::to_string(nw) + " words differ after ncclSend/ncclRecv to self");
     return RMDF_OK;
     RMDF_GUARD_END(ctx)
 }

@@ -103,16 +103,21 @@ hipError_t launch_cube_upload(const float *d_faces_f32, int W, uint2 *d_padded, 
 
 // ------------------------------------------------------------------------------------
 // pixelAtBilinear, HDREnvMap.hs:91-113 (keeps the `mod (w-1)` / `min (h-1)` quirks)
+// The reference fetches with unsafePixelAt and steps past the image when (u, v) leaves [0, 1]: resizeHDRImage does that for maps
+// that are not 2:1 (1024x510 -> 256: dsth rounds up to 128 and the last tap row asks for source row 511), where the reference
+// reads whatever follows the pixel vector.  Pin (oracle and device alike): the integer texel (x, y) is clamped into the image
+// before the fetch -- the weights keep their values; inside the image nothing changes.
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ v3 pixel_at_bilinear(const float *__restrict__ img, int w, int h, float u, float v)
 {
     const float upx = u * ((float)w - 1.0f), upy = v * ((float)h - 1.0f);
-    const int x = (int)floorf(upx), y = (int)floorf(upy);
+    const int xf = (int)floorf(upx), yf = (int)floorf(upy);
+    const int x = xf < 0 ? 0 : (xf > w - 1 ? w - 1 : xf), y = yf < 0 ? 0 : (yf > h - 1 ? h - 1 : yf);
     const int m = w - 1;
     int xp1 = (x + 1) % m;
     if (xp1 < 0) xp1 += m;
     const int yp1 = (y + 1 < h - 1) ? y + 1 : h - 1;
-    const float ur = upx - (float)x, vr = upy - (float)y;
+    const float ur = upx - (float)xf, vr = upy - (float)yf;
     const float uo = 1.0f - ur, vo = 1.0f - vr;
     const float *a = img + ((size_t)x + (size_t)y * w) * 3, *b = img + ((size_t)xp1 + (size_t)y * w) * 3;
     const float *c = img + ((size_t)x + (size_t)yp1 * w) * 3, *d = img + ((size_t)xp1 + (size_t)yp1 * w) * 3;

@@ -24,7 +24,7 @@ module RmdfFFI ( HipRenderer
                ) where
 
 import Control.Exception (bracket)
-import Control.Monad (when)
+import Control.Monad (void, when)
 import qualified Data.ByteString as B
 import qualified Data.ByteString.Unsafe as BU
 import Data.Word (Word32, Word8)
@@ -130,6 +130,8 @@ foreign import ccall safe "rmdf_set_shard_costs"
     c_rmdf_set_shard_costs :: Ptr RmdfCtx -> Ptr Float -> IO CInt
 foreign import ccall safe "rmdf_device_malloc"
     c_rmdf_device_malloc :: Ptr RmdfCtx -> CSize -> Ptr (Ptr ()) -> IO CInt
+foreign import ccall safe "rmdf_device_free"
+    c_rmdf_device_free :: Ptr RmdfCtx -> Ptr () -> IO CInt
 foreign import ccall safe "rmdf_render_frame_sharded_device"
     c_rmdf_render_frame_sharded_device :: Ptr RmdfCtx -> CInt -> CInt -> CInt -> CDouble -> CInt
                                        -> Ptr () -> Ptr () -> Ptr () -> Ptr () -> IO CInt
@@ -143,36 +145,43 @@ hipCommGetUniqueId = allocaBytes 128 $ \p -> do
                else Left <$> rmdfLastError nullPtr
 
 -- | withHipRenderer for rank `rank` of `nranks` (GPU ordinal = rank): environment, cost-aware deal of the 64 tiles for the
---   view (w, h, time) -- every rank computes the same deal by itself --, RCCL communicator, device buffers.
+--   view that will be drawn (shader `shd`, w, h, `time`, `maxSteps` -- every rank computes the same deal by itself from a probe
+--   frame of THAT view), RCCL communicator, device buffers (released with the renderer).
 --   The action gets the renderer and a per-frame draw function (rank 0 receives the whole frame in its vector, the other
 --   ranks pass a dummy vector and get nothing back).
-withHipRendererOnRank :: FilePath -> HipCommId -> Int -> Int -> Int -> Int
+withHipRendererOnRank :: FilePath -> HipCommId -> Int -> Int -> FragmentShader -> Int -> Int -> Double -> Int
                       -> (HipRenderer -> (FragmentShader -> Double -> VSM.IOVector Word32 -> IO (Either String ())) -> IO a) -> IO a
-withHipRendererOnRank reflMapFn commId rank nranks w h f =
-    alloca $ \pcfg -> withHipRenderer' pcfg $ \hr@(HipRenderer ctx) -> do
+withHipRendererOnRank reflMapFn commId rank nranks shd0 w h time0 maxSteps f =
+    withRenderer $ \hr@(HipRenderer ctx) -> do
         let slots = (64 + nranks - 1) `div` nranks
             tile  = (w `div` 8) * (h `div` 8) * 4
             check what rc = when (rc /= 0) $ rmdfLastError ctx >>= \e -> traceAndThrow (what ++ ": " ++ e)
         allocaBytes (64 * 4) $ \cost -> do
-            c_rmdf_probe_tile_costs ctx (fromIntegral $ fromEnum FSMBPower8Shader) (fromIntegral w) (fromIntegral h) 0 128 cost
+            c_rmdf_probe_tile_costs ctx (fromIntegral $ fromEnum shd0) (fromIntegral w) (fromIntegral h) (realToFrac time0)
+                                    (fromIntegral maxSteps) cost
                 >>= check "rmdf_probe_tile_costs"
             c_rmdf_set_shard_costs ctx cost >>= check "rmdf_set_shard_costs"
         BU.unsafeUseAsCString commId $ \p ->
             c_rmdf_comm_init ctx (castPtr p) (fromIntegral rank) (fromIntegral nranks) >>= check "rmdf_comm_init"
         let dmalloc n = alloca $ \pp -> c_rmdf_device_malloc ctx (fromIntegral n) pp >>= check "rmdf_device_malloc" >> peek pp
-        dGathered <- if rank == 0 then dmalloc (nranks * slots * tile) else return nullPtr
-        dFrame    <- if rank == 0 then dmalloc (w * h * 4) else return nullPtr
-        dShard    <- if rank == 0 then return dGathered else dmalloc (slots * tile)   -- the root renders into its own slot
-        f hr $ \shd time fbVec -> do
-            rc <- c_rmdf_render_frame_sharded_device ctx (fromIntegral $ fromEnum shd) (fromIntegral w) (fromIntegral h)
-                                                     (realToFrac time) 128 dShard dGathered dFrame nullPtr
-            rc' <- if rc == 0 && rank == 0
-                       then VSM.unsafeWith fbVec $ \p -> c_rmdf_copy_to_host ctx (castPtr p) dFrame (fromIntegral $ w * h * 4) nullPtr
-                       else return rc
-            if rc' == 0 then return $ Right () else Left <$> rmdfLastError ctx
+            dfree p   = when (p /= nullPtr) $ void $ c_rmdf_device_free ctx p
+        -- rmdf_device_malloc is a bare device allocation: rmdf_destroy does not own it, so the bracket releases it
+        bracket (do g  <- if rank == 0 then dmalloc (nranks * slots * tile) else return nullPtr
+                    fr <- if rank == 0 then dmalloc (w * h * 4) else return nullPtr
+                    sh <- if rank == 0 then return nullPtr else dmalloc (slots * tile)
+                    return (g, fr, sh))
+                (\(g, fr, sh) -> dfree g >> dfree fr >> dfree sh) $ \(dGathered, dFrame, dOwn) -> do
+            let dShard = if rank == 0 then dGathered else dOwn                -- the root renders into its own slot
+            f hr $ \shd time fbVec -> do
+                rc <- c_rmdf_render_frame_sharded_device ctx (fromIntegral $ fromEnum shd) (fromIntegral w) (fromIntegral h)
+                                                         (realToFrac time) (fromIntegral maxSteps) dShard dGathered dFrame nullPtr
+                rc' <- if rc == 0 && rank == 0
+                           then VSM.unsafeWith fbVec $ \p -> c_rmdf_copy_to_host ctx (castPtr p) dFrame (fromIntegral $ w * h * 4) nullPtr
+                           else return rc
+                if rc' == 0 then return $ Right () else Left <$> rmdfLastError ctx
   where
     -- rmdf_config { device = rank, reserved = 0 }: eight C ints
-    withHipRenderer' _ g = allocaBytes 32 $ \cfg -> do
+    withRenderer g = allocaBytes 32 $ \cfg -> do
         mapM_ (\i -> pokeElemOff' cfg i (if i == 0 then fromIntegral rank else 0)) [0 .. 7 :: Int]
         bracket (open cfg) (\(HipRenderer ctx) -> c_rmdf_destroy ctx) g
     pokeElemOff' :: Ptr CInt -> Int -> CInt -> IO ()

@@ -137,6 +137,17 @@ def test_load_env_hdr_cache_miss_end_to_end(rmdf, orc, env_latlongs, tmp_path):
             data = open(tmp_path / n, "rb").read()
             assert data == files[p], "cache file for power %s differs from the oracle's" % p
             assert data == open(os.path.join(ENV_CACHE, n), "rb").read()
+        # ... and against the REFERENCE's arithmetic rather than the pin: the oracle's literal `cosAngle ** power` through
+        # glibc powf (pow_mode 0; the pinned form is a binary64 squaring chain).  powf is not correctly
+        # rounded and depends on the libm build, so the bar is a tolerance: every RGBE byte of the product's cache files within one
+        # step of the powf pipeline's, on at most 0.01 % of the bytes (observed for uffizi_512 with glibc 2.35: identical files).
+        _, files_powf = orc.env_pipeline(open(hdr, "rb").read(), powers=POWERS, pow_mode=0)
+        for p, n in zip(POWERS, names):
+            x = np.frombuffer(open(tmp_path / n, "rb").read(), np.uint8).astype(np.int16)
+            y = np.frombuffer(files_powf[p], np.uint8).astype(np.int16)
+            assert x.size == y.size
+            diff = np.abs(x - y)
+            assert diff.max() <= 1 and (diff != 0).mean() <= 1e-4, (p, int(diff.max()), float((diff != 0).mean()))
         b.load_env_hdr(hdr)                                                       # cache hit
         keys = ["refl", "cos1", "cos8", "cos64", "cos512"]
         for slot, k in enumerate(keys):
@@ -206,3 +217,18 @@ def test_malformed_hdr_files_fail_cleanly(rmdf, tmp_path):
             assert e.value.code == -4, (n, str(e.value))
     finally:
         r.close()
+@pytest.mark.gpu
+def test_resize_of_a_map_that_is_not_2_to_1(sr, orc):
+    """1024x510 -> 256 makes resizeHDRImage's last tap rows ask for source rows past the image (dsth = round(127.5) = 128); the
+    reference reads out of bounds there, oracle and kernel clamp the texel (rmdf_env.hip: pixel_at_bilinear).  Bit-equal, finite,
+    and the argument bounds of rmdf_resize_latlong hold."""
+    src = synthetic_latlong(1024, 510, 5)
+    got = sr.resize_latlong(src, 256)
+    ref = orc.resize_hdr(src, 256)
+    assert got.shape == (128, 256, 3) and np.isfinite(got).all()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    src2 = synthetic_latlong(300, 155, 6)                                 # taps 2, odd geometry
+    assert np.array_equal(sr.resize_latlong(src2, 200).view(np.uint32), orc.resize_hdr(src2, 200).view(np.uint32))
+    with pytest.raises(Exception):
+        sr.resize_latlong(src2, 40000)
+

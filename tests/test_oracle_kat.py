@@ -294,6 +294,27 @@ def test_hdr_rle_and_flat_decode_agree(orc):
         orc.hdr_decode(b"not an hdr file at all")
 
 
+def test_resize_of_a_map_that_is_not_2_to_1_stays_inside_the_image(orc):
+    """resizeHDRImage (HDREnvMap.hs:169-195) of 1024x510 -> 256: dsth = round(127.5) = 128 (half to even), so the last rows' taps ask
+    pixelAtBilinear for source rows 510/511 -- past the image, where the reference's unsafePixelAt reads whatever follows.  Pin: the
+    integer texel is clamped into the image (oracle and device kernel alike).  The map is embedded in a larger allocation filled with
+    NaN behind it: no NaN may come out, and the last output rows equal the resize of a copy extended by replicated rows."""
+    rng = np.random.RandomState(11)
+    h, w = 510, 1024
+    arena = np.full((h + 8, w, 3), np.nan, np.float32)
+    arena[:h] = rng.uniform(0.0, 4.0, (h, w, 3)).astype(np.float32)
+    out = orc.resize_hdr(arena[:h], 256)
+    assert out.shape == (128, 256, 3) and np.isfinite(out).all()
+    # rows whose taps stay inside are untouched by the pin: identical to resizing with the map's true geometry cut differently
+    again = orc.resize_hdr(arena[:h].copy(), 256)
+    assert np.array_equal(out.view(np.uint32), again.view(np.uint32))
+    # u, v outside [0, 1] directly
+    img = arena[:h]
+    for (u, v) in ((1.2, 0.5), (-0.2, 0.5), (0.5, 1.01), (0.5, -0.3), (1.5, 1.5)):
+        assert np.isfinite(orc.pixel_at_bilinear(img, u, v)).all()
+    assert np.array_equal(orc.pixel_at_bilinear(img, 0.5, 1.01), orc.pixel_at_bilinear(img, 0.5, 1.0))
+
+
 def test_resize_dimensions(orc):
     src = np.ones((256, 512, 3), np.float32)
     assert orc.resize_hdr(src, 256).shape == (128, 256, 3)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of alternative builds of librmdf (tools/abtest/*.so): headline frame, two frames in flight (the bench default), then one
+# A/B of alternative builds of librmdf (tools/abtest/*.so): headline frame, two frames in flight (the bench default is three: run4.sh / run5.sh), then one
 shopt -s nullglob
 for s in 2 1; do
   for lib in tools/abtest/*.so; do

@@ -84,5 +84,54 @@ if "SQ_INSTS_VALU" in counters and "SQ_THREAD_CYCLES_VALU" in counters:
 if cornell:
     out["cornell_1280x720_m128"] = {"counters_per_launch_median": cornell,
                                     "lane_utilisation": cornell.get("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * cornell["SQ_ACTIVE_INST_VALU"]) if cornell.get("SQ_ACTIVE_INST_VALU") else None}
+# VGPR_Count / SGPR_Count as rocprofv3 prints them are allocation figures of the dispatch packet, not the compiler's register counts
+if "_resources" in counters:
+    counters["_resources"]["note"] = ("as printed by rocprofv3 for the dispatch (allocation units of the packet); the compiler's counts are in "
+                                      "`make -C ray-marching-distance-fields_amd/csrc resources`: 53 VGPRs, 78 SGPRs, scratch 0 for k_render<2, true, 0>")
 json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+
+
+# The schedule the bench times (frames in flight on several streams): cut the kernel trace into the timed blocks at the marker
+# dispatches (bench.py, RMDF_BENCH_MARK=1: k_resolve_box2 before the opening barrier of every block and after the last one) and
+# report, per block, (last k_render end - first k_render start) / number of k_render dispatches.
+def schedule(name):
+    f = one(name + "/**/*_kernel_trace.csv")
+    if not f:
+        return None
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    # (the 2x2 marker launches are one workgroup; config 4's resolve in the secondary workloads is a real one)
+    marks = [int(r["Start_Timestamp"]) for r in rows if "k_resolve_box2" in r["Kernel_Name"]
+             and int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) <= 1024]
+    if len(marks) < 2:
+        return None
+    ren = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if KERNEL in r["Kernel_Name"] and "true, 0>" in r["Kernel_Name"]]
+    blocks = []
+    for a, b in zip(marks[:-1], marks[1:]):
+        d = [x for x in ren if a <= x[0] < b]
+        if d:
+            span = max(e for _, e in d) - min(st for st, _ in d)
+            busy = sum(e - st for st, e in d)
+            blocks.append({"k_render_dispatches": len(d), "span_ms": round(span / 1e6, 4),
+                           "span_ms_per_frame": round(span / 1e6 / len(d), 5),
+                           "sum_of_kernel_durations_ms_per_frame": round(busy / 1e6 / len(d), 5)})
+    return blocks
+
+
+for name in ("trace_s1", "trace_default"):
+    b = schedule(name)
+    if b:
+        bj = os.path.join(src, "bench_%s.json" % name[6:])
+        line = [l for l in open(bj) if l.startswith("{")][-1] if os.path.exists(bj) else None
+        bench = json.loads(line) if line else {}
+        json.dump({"command": "RMDF_BENCH_MARK=1 rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline"
+                              + (" --streams 1" if name == "trace_s1" else ""),
+                   "what": "timed blocks of the run cut out of the kernel trace at the marker dispatches: first k_render<2, true, 0> start -> last "
+                           "end, per frame.  With frames in flight the kernels overlap, so the per-kernel durations of the same trace "
+                           "(kernel_stats) do NOT add up to the block; span / frames is the figure bench.py's ms_per_step reproduces "
+                           "(plus the host's barrier + synchronize around the block). The first blocks are warm-up / animated blocks as "
+                           "bench.py orders them: `repeats` timed blocks, then (animate 0) one short and one full animated block.",
+                   "blocks": b,
+                   "bench_line_of_the_same_run": {k: bench.get(k) for k in ("ms_per_step", "ms_per_step_blocks", "device_span_ms_per_step",
+                                                                            "ms_per_step_animated", "value", "value_animated")}},
+                  open(os.path.join(dst, "%s_schedule_%s.json" % (tag, name[6:])), "w"), indent=1)
 print(json.dumps({k: (v["median"] if isinstance(v, dict) and "median" in v else v) for k, v in counters.items()}, indent=1))

@@ -14,9 +14,11 @@ mkdir -p "$out"
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 args="--steps 100 --warmup 10 --no-cpu-baseline"
+export RMDF_BENCH_MARK=1     # marker dispatches around the timed blocks (tools/pmc_summary.py cuts the trace there)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_s1" -- python3 bench.py $args --streams 1 > "$out/bench_s1.json" 2> "$out/trace_s1.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_default" -- python3 bench.py $args > "$out/bench_default.json" 2> "$out/trace_default.log"
 export RMDF_BENCH_MIN_WARM=0
+unset RMDF_BENCH_MARK
 pmc_args="--steps 20 --warmup 2 --repeats 1 --no-cpu-baseline --no-secondary --streams 1"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py $pmc_args > /dev/null 2> "$out/pmc_fetch.log"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py $pmc_args > /dev/null 2> "$out/pmc_write.log"
