@@ -219,6 +219,8 @@ def main():
                          "0 = default: 3 on one GPU, 8 on N GPUs")
     ap.add_argument("--animate", type=float, default=0.0, help="advance in_time by this many seconds per frame (the viewer's "
                     "animation: the cost-ordered dispatch then works from the previous frame's costs of a slightly different view)")
+    ap.add_argument("--no-animated", action="store_true", help="skip the extra animated block behind `value_animated` (profiling runs whose "
+                    "per-kernel averages should cover the headline frame only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (Cornell config 2, env prefilter config 5)")
     ap.add_argument("--check", action="store_true", help="also compare the frame with the oracle (slow)")
@@ -527,7 +529,7 @@ def main():
     # the same block with the viewer's animation (in_time advances 1/60 s per frame): the cost-ordered dispatch then works from
     # the costs of a slightly different view instead of a perfect table
     anim_ms = None
-    if a.animate == 0.0:
+    if a.animate == 0.0 and not a.no_animated:
         timed_block(max(a.warmup, 10), dt_anim=1.0 / 60.0)
         anim_ms = timed_block(a.steps, dt_anim=1.0 / 60.0)[0] / a.steps * 1e3
         for i in range(S):                                         # every frame buffer holds the in_time = a.time frame again (--check)

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace rmdf {
 
@@ -744,8 +745,10 @@ __device__ __forceinline__ float seg_dist_sq_table(v3 a, v3 ab, float len, float
 // table reads stay scalar) is evaluated first, then the rest in table order.
 typedef const float __attribute__((address_space(4))) cfloat;     // constant address space: wave-uniform reads become s_loads
 
-// squared distance to triangle row t (de_triangle, fragment.shd:348-372, constants from the table)
-__device__ __forceinline__ float cornell_tri_dist2(v3 pos, cfloat *t)
+// squared distance to triangle row t (de_triangle, fragment.shd:348-372, constants from the table); PTR = the constant-address-space
+// pointer of the wave-uniform path (rows by scalar loads) or a plain pointer into an LDS copy (one row per lane: cornell_group_dist2)
+template <typename PTR>
+__device__ __forceinline__ float cornell_tri_dist2(v3 pos, PTR t)
 {
     const v3 v0 = mk3(t[0], t[1], t[2]), v1 = mk3(t[3], t[4], t[5]), v2 = mk3(t[6], t[7], t[8]);
     const v3 e0 = mk3(t[9], t[10], t[11]), e1 = mk3(t[12], t[13], t[14]);
@@ -793,6 +796,40 @@ __device__ __forceinline__ unsigned wave_or_active(unsigned m)
         acc |= (unsigned)__builtin_amdgcn_readlane((int)m, (int)__builtin_ctzll(need));
     }
     return acc;
+}
+
+// Lane-parallel form for the LAST rays of a wave (rmdf_render.hip: cornell_straggler_march): the wave's lanes are split into groups
+// of G, a group works on ONE ray, lane `sub` of the group evaluates the candidates i == sub (mod G) of the ray's own cell mask -- each
+// from its own row of an LDS copy of the table -- and the group takes the minimum (min is exact and order-independent, and the cell's
+// candidates contain the nearest triangle: same bits as the loop below).  One estimate is then ONE triangle evaluation deep
+// instead of a chain of scalar loads, bound tests and evaluations: what a wave's last, long rays need is latency, not throughput.
+template <int G>
+__device__ __forceinline__ float cornell_group_dist2(v3 pos, const float *lds_tab, const unsigned *grid, int sub)
+{
+    static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "group size");
+    const unsigned residue = (G == 1 ? 0xffffffffu : (G == 2 ? 0x55555555u : (G == 4 ? 0x11111111u : (G == 8 ? 0x01010101u : 0x00010001u)))) << sub;
+    unsigned my = cornell_cell_mask(pos, grid) & residue;
+    float best = 998001.0f;                                    // 999^2
+    while (__ballot(my != 0u) != 0ull) {
+        if (my != 0u) {
+            const int i = (int)__builtin_ctz(my);
+            my &= my - 1u;
+            const float x = cornell_tri_dist2(pos, lds_tab + i * CORNELL_STRIDE);
+            best = (x < best) ? x : best;
+        }
+    }
+    // minimum over the group's G consecutive lanes by DPP (no LDS round trip as __shfl_xor would take): quad_perm for the lanes
+    // 1 and 2 apart, then -- the quads being uniform by now -- row_half_mirror (lane i <-> 7 - i) and row_mirror (i <-> 15 - i)
+    // swap the quads of a group of 8 and the halves of a group of 16 (a disabled source lane leaves the lane's own value: `old` = v)
+    auto dpp_min = [](float v, auto ctrl) {
+        const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), decltype(ctrl)::value, 0xf, 0xf, false));
+        return (o < v) ? o : v;
+    };
+    if (G >= 2) best = dpp_min(best, std::integral_constant<int, 0xB1>());     // quad_perm [1,0,3,2]
+    if (G >= 4) best = dpp_min(best, std::integral_constant<int, 0x4E>());     // quad_perm [2,3,0,1]
+    if (G >= 8) best = dpp_min(best, std::integral_constant<int, 0x141>());    // row_half_mirror
+    if (G >= 16) best = dpp_min(best, std::integral_constant<int, 0x140>());   // row_mirror
+    return best;
 }
 
 __device__ __forceinline__ float de_cornell_box_table(v3 pos, const float *__restrict__ tab, int prune, int &hint, const unsigned *grid = nullptr)

@@ -12,6 +12,7 @@
              that the full-size digests below do not depend on the libm of the box that checks them).
 * --digests  tests/golden/full_size_digests.json: sha256 of the oracle's rgba8 / steps / iters planes of BASELINE
              configs 2 and 3 at full size (1280x720 @128 Cornell, 1920x1080 @256 Mandelbulb), from those cube maps.
+* --digest4  adds BASELINE config 4 (7680x4320 rays @256 -> box-resolved 3840x2160) to that file (~4 min on 8 cores).
 * --renders  tests/golden/render_<scene>_<w>x<h>_t<time>.npz : oracle float RGBA / RGBA8 / steps / iters.
 * --env      tests/golden/env_*.npz : cube faces for the procedural test env map, pixelAtBilinear probes,
              a 32x16 prefilter case.
@@ -60,10 +61,10 @@ def render_name(scene, w, h, t, ms):
 
 def main():
     ap = argparse.ArgumentParser()
-    for f in ("caches", "renders", "env", "fractals", "cubes", "digests"):
+    for f in ("caches", "renders", "env", "fractals", "cubes", "digests", "digest4"):
         ap.add_argument("--" + f, action="store_true")
     a = ap.parse_args()
-    if not (a.caches or a.renders or a.env or a.fractals or a.cubes or a.digests):
+    if not (a.caches or a.renders or a.env or a.fractals or a.cubes or a.digests or a.digest4):
         a.caches = a.renders = a.env = a.fractals = a.cubes = a.digests = True
 
     if a.caches:
@@ -96,6 +97,27 @@ def main():
                          "counters": r["counters"]}
             print(name, out[name])
         json.dump(out, open(os.path.join(GOLD, "full_size_digests.json"), "w"), indent=1, sort_keys=True)
+
+    if a.digest4:
+        # BASELINE config 4 on every pixel: 7680x4320 rays @256 (frame-buffer scale 2, App.hs:105-106,131-133), one mip level of the
+        # RGBA8 frame (FrameBuffer.hs:153-154,187-195) -> 3840x2160.  ~4 minutes on 8 cores; added to the existing digest file.
+        import hashlib
+        import json
+        z = np.load(os.path.join(GOLD, "env_cubes_uffizi.npz"))
+        env = orc.EnvSet(z["refl"], z["cos1"], z["cos8"])
+        r = orc.render(orc.SCENE_MB_POWER8, 7680, 4320, 0.0, 256, env, want_f32=False)
+        res = orc.resolve_box2(r["rgba8"])
+        assert res.shape == (2160, 3840)
+        fn = os.path.join(GOLD, "full_size_digests.json")
+        out = json.load(open(fn))
+        sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+        out["config4_mandelbulb8_3840x2160_x4rays_m256"] = {
+            "scene": orc.SCENE_MB_POWER8, "w": 3840, "h": 2160, "supersample_levels": 1, "time": 0.0, "max_steps": 256,
+            "sha256": {"rgba8_resolved_3840x2160": sha(res), "rgba8_rays_7680x4320": sha(r["rgba8"]),
+                       "steps_rays_7680x4320": sha(r["steps"]), "iters_rays_7680x4320": sha(r["iters"])},
+            "counters": r["counters"]}
+        print(out["config4_mandelbulb8_3840x2160_x4rays_m256"])
+        json.dump(out, open(fn, "w"), indent=1, sort_keys=True)
 
     if a.renders:
         env = load_env()

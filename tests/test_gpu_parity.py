@@ -732,6 +732,41 @@ def test_full_size_frames_match_the_committed_oracle_digests(rmdf, name):
         r.close()
 
 
+def test_config4_every_pixel_against_the_oracle_digest(rmdf):
+    """BASELINE config 4 on EVERY pixel: 7680x4320 rays @256 box-resolved to 3840x2160 (make_fixtures.py --digest4: the oracle's
+    render + resolve from the committed cube maps).  The product's supersampled frame in its single-launch form
+    (rmdf_render_supersampled) and in the 8-GPU form (tiles dealt to 8 ranks by probed cost, every shard resolved on its GPU before
+    the exchange, assembled) both hash to the oracle's digest; so do the 33 M-ray RGBA8 / steps / iteration planes."""
+    import hashlib
+    import json
+    import torch
+    d = json.load(open(os.path.join(GOLD, "full_size_digests.json")))["config4_mandelbulb8_3840x2160_x4rays_m256"]
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    W, H, ms, n = d["w"], d["h"], d["max_steps"], 8
+    r = _committed_cube_renderer(rmdf)
+    try:
+        assert sha(r.render_supersampled(2, W, H, 1, 0.0, max_steps=ms)) == d["sha256"]["rgba8_resolved_3840x2160"]
+        dev = torch.device("cuda", 0)
+        r.set_shard_costs(r.probe_tile_costs(2, 2 * W, 2 * H, 0.0, ms))
+        slots = rmdf.shard_slots(n)
+        gathered = dev_zeros((n, slots, H // 8, W // 8), dtype=torch.int32, device=dev)
+        big = dev_zeros((slots, 2 * H // 8, 2 * W // 8), dtype=torch.int32, device=dev)
+        for rank in range(n):
+            r.render_shard_device(2, 2 * W, 2 * H, 0.0, ms, rank, n, big.data_ptr())
+            r.resolve_box2_device(big.data_ptr(), 2 * W // 8, slots * 2 * H // 8, gathered[rank].data_ptr())
+        frame = dev_zeros((H, W), dtype=torch.int32, device=dev)
+        r.assemble_shards_device(W, H, n, gathered.data_ptr(), frame.data_ptr())
+        r.synchronize()
+        assert sha(frame.cpu().numpy().view(np.uint32)) == d["sha256"]["rgba8_resolved_3840x2160"]
+        del gathered, big, frame
+        got = r.render(2, 2 * W, 2 * H, 0.0, max_steps=ms, want_f32=False)
+        for k in ("rgba8", "steps", "iters"):
+            assert sha(got[k]) == d["sha256"]["%s_rays_7680x4320" % k], k
+        assert int((got["steps"] >> 15).astype(np.int64).sum()) == d["counters"]["hit_pixels"]
+    finally:
+        r.close()
+
+
 def test_extra_planes_are_allocated_on_demand_and_tiles_accumulate(rmdf, orc, env_oracle, env_faces):
     """rmdf_render_tile keeps only the RGBA8 frame; the float / steps / iteration planes appear with the first
     rmdf_render_tile_ex call and accumulate over the tiles rendered through it (zero elsewhere)."""

@@ -1,19 +1,19 @@
 #!/usr/bin/env python3
 """Wave timeline of the nested-loop kernel (all waves of the headline frame): measurement aid.
-usage: nested_timeline.py [flags]   (flags = rmdf_config.reserved[0], e.g. 4 = raster order, 16 = no pooling)"""
+usage: nested_timeline.py [flags [scene w h max_steps]]   (flags = rmdf_config.reserved[0], e.g. 4 = raster order, 16 = no pooling)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rmdf_amd
-w, h, ms = 1920, 1080, 256
 flags = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+scene, w, h, ms = (int(x) for x in sys.argv[2:6]) if len(sys.argv) > 5 else (2, 1920, 1080, 256)
 sr = rmdf_amd.ShaderRenderer(0, flags=flags, xcheck=True)
 sr.load_env_hdr(rmdf_amd.DEFAULT_ENV_HDR)
 fb = np.empty(w * h, np.uint32)
-sr.draw_shader_tile(2, None, w, h, 0.0, fb, max_steps=ms)
-sr.draw_shader_tile(2, None, w, h, 0.0, fb, max_steps=ms)
+sr.draw_shader_tile(scene, None, w, h, 0.0, fb, max_steps=ms)
+sr.draw_shader_tile(scene, None, w, h, 0.0, fb, max_steps=ms)
 sr.debug_march_stats(True)
-sr.draw_shader_tile(2, None, w, h, 0.0, fb, max_steps=ms)
+sr.draw_shader_tile(scene, None, w, h, 0.0, fb, max_steps=ms)
 st = sr.debug_march_stats(True, 32768).astype(np.float64).reshape(-1, 8)
 st = st[st[:, 7] > 0]
 t0 = st[:, 6].min()
@@ -32,4 +32,9 @@ for q in range(25, int(e.max()) + 25, 25):
     print("  resident at t=%d us: %d waves" % (q, ((b <= q) & (e > q)).sum()))
 idx = np.argsort(d)[-5:]
 for i in idx:
-    print("  long wave: start %.1f dur %.1f lane0 steps %d" % (b[i], d[i], st[i, 0]))
+    print("  long wave: start %.1f dur %.1f lane0 steps %d; wave-uniform march steps %d, march ended after %.1f us; lane-parallel from %.1f us with %d rays" %
+          (b[i], d[i], st[i, 0], st[i, 1], st[i, 2] / 100.0, (int(st[i, 3]) & 0xffffffff) / 100.0, int(st[i, 3]) >> 32))
+if scene == 0:
+    ns, tm = st[:, 1], st[:, 2] / 100.0
+    print("Cornell: wave-uniform steps per wave mean %.1f p90 %.0f max %.0f; march phase per wave: mean %.1f us p99 %.1f max %.1f; after-march (normal, AO, shade) mean %.1f us p99 %.1f max %.1f" %
+          (ns.mean(), np.percentile(ns, 90), ns.max(), tm.mean(), np.percentile(tm, 99), tm.max(), (d - tm).mean(), np.percentile(d - tm, 99), (d - tm).max()))

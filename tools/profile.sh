@@ -15,7 +15,9 @@ cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 args="--steps 100 --warmup 10 --no-cpu-baseline"
 export RMDF_BENCH_MARK=1     # marker dispatches around the timed blocks (tools/pmc_summary.py cuts the trace there)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_s1" -- python3 bench.py $args --streams 1 > "$out/bench_s1.json" 2> "$out/trace_s1.log"
+# (--no-secondary --no-animated: k_render<2, true, 0> is then launched for the headline frame only, so its row of the stats file IS the
+#  headline kernel's average; Cornell, the prefilter and the animated block are in the default run's files)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_s1" -- python3 bench.py $args --streams 1 --no-secondary --no-animated > "$out/bench_s1.json" 2> "$out/trace_s1.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_default" -- python3 bench.py $args > "$out/bench_default.json" 2> "$out/trace_default.log"
 export RMDF_BENCH_MIN_WARM=0
 unset RMDF_BENCH_MARK
