@@ -832,6 +832,44 @@ __device__ __forceinline__ float cornell_group_dist2(v3 pos, const float *lds_ta
     return best;
 }
 
+// The per-lane form of the pruned estimate (round 3).  Every lane works from ITS OWN cell mask and hint, on rows of an LDS copy of the
+// table: the triangle that was nearest last time first, then one pass of bound tests over the lane's remaining candidates (the
+// k-th candidate of every lane in pass k, whichever triangle that is), then the survivors, again one per lane and pass.  No scalar
+// loads, no wave-uniform branches but the loop conditions: the wave-uniform loop below spends 7.6 cycles per instruction when a wave
+// has the SIMD to itself (chains of scalar load -> wait -> test -> branch), straight-line vector code about 2.  min() is exact
+// and order-independent and the bounds only drop provable losers: same bits.
+__device__ __forceinline__ float de_cornell_box_lanes(v3 pos, const float *rows, const unsigned *grid, int &hint)
+{
+    unsigned m = cornell_cell_mask(pos, grid);
+    if (m == 0u) m = 0xffffffffu;                              // cannot happen with a well-formed grid
+    int g = hint & 31;
+    if (!((m >> g) & 1u)) g = (int)__builtin_ctz(m);
+    float best = cornell_tri_dist2(pos, rows + g * CORNELL_STRIDE);
+    const float dmax = __builtin_amdgcn_sqrtf(best) * 1.001f + 1e-5f;
+    unsigned my = m & ~(1u << g), surv = 0u;
+    while (__ballot(my != 0u) != 0ull) {
+        if (my != 0u) {
+            const int i = (int)__builtin_ctz(my);
+            my &= my - 1u;
+            const float *b = rows + i * CORNELL_STRIDE + 26;
+            const float pd = fabsf(((b[0] * pos.x + b[1] * pos.y) + b[2] * pos.z) - b[3]);
+            const v3 dc = mk3(pos.x - b[4], pos.y - b[5], pos.z - b[6]);
+            const float rs = b[7] + dmax;
+            if (!((pd > dmax) || (dot3(dc, dc) > rs * rs))) surv |= 1u << i;
+        }
+    }
+    while (__ballot(surv != 0u) != 0ull) {
+        if (surv != 0u) {
+            const int i = (int)__builtin_ctz(surv);
+            surv &= surv - 1u;
+            const float x = cornell_tri_dist2(pos, rows + i * CORNELL_STRIDE);
+            if (x < best) { best = x; g = i; }
+        }
+    }
+    hint = g;
+    return sqrt_rn(best);
+}
+
 __device__ __forceinline__ float de_cornell_box_table(v3 pos, const float *__restrict__ tab, int prune, int &hint, const unsigned *grid = nullptr)
 {
     float dist2 = 998001.0f;                                   // 999^2

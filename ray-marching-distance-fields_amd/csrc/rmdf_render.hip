@@ -46,8 +46,11 @@ __device__ __forceinline__ float fold_min_of(const FrameParams &p)
 
 template <int SCENE>
 // hint: Cornell only -- the triangle that was nearest in this lane's previous estimate (evaluation order, not a result)
-__device__ __forceinline__ float distance_estimator(v3 pos, const FrameParams &p, unsigned &iters, int &hint, const unsigned *cgrid = nullptr)
+__device__ __forceinline__ float distance_estimator(v3 pos, const FrameParams &p, unsigned &iters, int &hint, const unsigned *cgrid = nullptr, const float *lds_rows = nullptr)
 {
+    // Cornell box inside k_render: the per-lane form on the LDS copy of the table; the wave-uniform form (de_cornell_box_table) stays
+    // the estimate of the cross-check schedules and of RMDF_FLAG_NO_PRUNE
+    if (SCENE == 0 && cgrid && lds_rows) return de_cornell_box_lanes(pos, lds_rows, cgrid, hint);
     if (SCENE == 2)      return de_mandelbulb8(pos, iters, fold_min_of(p));
     else if (SCENE == 3) return de_mandelbulb_general(pos, p.power, iters);
     else if (SCENE == 1) return de_test_scene(pos);
@@ -143,7 +146,10 @@ __device__ __forceinline__ PixelGeom pixel_geom(const FrameParams &p, unsigned l
 // per ray (2, then 4, then 8 as rays finish), every lane of a group carries a copy of the ray's state, an estimate is
 // cornell_group_dist2 (one to a few triangle evaluations deep, no scalar loads), and a finished ray's result goes to its owner
 // lane through LDS.  Same arithmetic per ray, same bits.
+#ifndef CORNELL_STRAGGLER_T
 #define CORNELL_STRAGGLER_T 32
+#endif
+#define RMDF_CORNELL_WAVES 6            // 80 VGPRs, 24 KB of LDS per workgroup: seven do not fit (LDS), the scalar registers allow six
 struct CornellRay { float dx, dy, dz, tt, tmx; int st, owner; };
 // `leaders` = the lanes that hold a live ray; afterwards lanes [G k, G k + G) all hold the k-th of them
 template <int G>
@@ -268,9 +274,6 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
     // Which strip this workgroup renders: raster order over (slot, row, column), or most expensive first
     // (block_order, a permutation of the launch's linear workgroup ids -- it spans all tiles of a shard launch)
     unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-#ifdef RMDF_AB_PRIO
-    if (SCENE == 0 && p.block_order && lin < (gridDim.x * gridDim.y * gridDim.z) / RMDF_AB_PRIO) __builtin_amdgcn_s_setprio(3);
-#endif
     if (p.block_order) lin = p.block_order[lin];
     const PixelGeom g = pixel_geom(p, lin, threadIdx.x);
 #ifdef RMDF_XCHECK
@@ -309,7 +312,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
 #endif
             if (act) {
                 const v3 pos = mk3(origin.x + t * g.dir.x, origin.y + t * g.dir.y, origin.z + t * g.dir.z);
-                const float dist = distance_estimator<SCENE>(pos, p, iters, tri_hint, cgrid);
+                const float dist = distance_estimator<SCENE>(pos, p, iters, tri_hint, cgrid, s_ctab);
                 t += dist;
                 if (t > tmax) act = false;
                 else if (dist < 0.001f) { hit = true; act = false; }
@@ -480,7 +483,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
             const float dlk = k == 4 ? 0.1f : (k == 5 ? 0.2f : (k == 6 ? 0.4f : 0.5f)), wtk = k == 4 ? 0.1f : (k == 5 ? 0.2f : (k == 6 ? 0.125f : 0.0625f));
             const v3 pos = k < 4 ? mk3(np.x - (k == 1 ? eps : 0.0f), np.y - (k == 2 ? eps : 0.0f), np.z - (k == 3 ? eps : 0.0f))
                                  : mk3(isec.x + n.x * dlk, isec.y + n.y * dlk, isec.z + n.z * dlk);
-            const float d = distance_estimator<SCENE>(pos, p, iters, tri_hint, cgrid);
+            const float d = distance_estimator<SCENE>(pos, p, iters, tri_hint, cgrid, s_ctab);
             if (k == 0) d0 = d;
             else if (k == 1) ddx = d0 - d;
             else if (k == 2) ddy = d0 - d;
@@ -665,7 +668,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
 // 96 through amdgpu_num_sgpr instead was measured: the hardware then runs 7 waves); what does not fit lives in lanes of a spare
 // VGPR (v_writelane, prologue and epilogue only).  No scratch: `make resources`.
 template <int SCENE, bool MERGE, int OUT>
-__global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : ((SCENE == 0 && OUT != OUT_PLANES) ? 6 : 1)) void k_render(const FrameParams p) { render_body<SCENE, MERGE, OUT>(p); }
+__global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : ((SCENE == 0 && OUT != OUT_PLANES) ? RMDF_CORNELL_WAVES : 1)) void k_render(const FrameParams p) { render_body<SCENE, MERGE, OUT>(p); }
 
 static void render_grid(const FrameParams &p, dim3 &grid)
 {
