@@ -840,8 +840,9 @@ def secondary_workloads(sr, torch, dev, stream, cus):
     out["config5_lobe_prefilter_256x128"] = {"per_power": per, "four_powers_concurrent_host_in_out_ms": round(four * 1e3, 3),
                                              "pair_terms_per_power": pair_terms,
                                              "note": "one lane per destination texel, source summed serially in the reference's order "
-                                                     "(bit-exact); one power = 512 waves = half the SIMDs at this size, the four powers "
-                                                     "run concurrently (the reference's mapConcurrently)"}
+                                                     "(bit-exact); one power = 512 waves = half the SIMDs at this size, each wave issuing a vector "
+                                                     "instruction in ~70 % of its slots (profiles/r03_prefilter_pmc.txt); the four powers run "
+                                                     "concurrently (the reference's mapConcurrently)"}
     return out
 
 

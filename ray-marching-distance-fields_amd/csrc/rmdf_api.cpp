@@ -69,6 +69,10 @@ struct rmdf_ctx {
     CubeSlot     env[RMDF_ENV_SLOTS];
     std::vector<UvTable>   uv_tables;
     std::vector<LobeTable> lobe_tables;
+    // device scratch of the host-buffer env entry points (rmdf_prefilter_env_powers: source + one map per power), grow-only: a
+    // hipMalloc / hipFree pair per call cost more than the kernels of a 256x128 map
+    struct Scratch { void *p = nullptr; size_t bytes = 0; };
+    Scratch      env_scratch[17];
     // frame latched on the first tile (ShaderRendering.hs:162-176)
     int          w = 0, h = 0, max_steps = 128;
     float        time = 0.0f;
@@ -998,6 +1002,7 @@ void rmdf_destroy(rmdf_ctx *ctx)
     for (auto &s : ctx->env) if (s.d_texels) (void)hipFree(s.d_texels);
     for (auto &t : ctx->uv_tables) (void)hipFree(t.d_uv);
     for (auto &t : ctx->lobe_tables) { (void)hipFree(t.d_lutT); (void)hipFree(t.d_tcs); }
+    for (auto &sc : ctx->env_scratch) if (sc.p) (void)hipFree(sc.p);
     if (ctx->d_cornell) (void)hipFree(ctx->d_cornell);
     if (ctx->d_cornell_tab) (void)hipFree(ctx->d_cornell_tab);
     if (ctx->d_cornell_grid) (void)hipFree(ctx->d_cornell_grid);
@@ -1122,12 +1127,18 @@ int rmdf_prefilter_env_powers(rmdf_ctx *ctx, const float *rgb, int w, int h, con
         return fail(ctx, RMDF_E_INVALID, "rmdf_prefilter_env_powers: bad argument (2 <= w <= 8192, 2 <= h <= 4096, 1 <= npowers <= 16)");
     RMDF_GUARD_BEGIN
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf src;
-    std::vector<DevBuf> dst((size_t)npowers);
     std::vector<float *> d_out((size_t)npowers);
     const size_t b = (size_t)w * h * 12;
-    HIP_TRY(ctx, hipMalloc(&src.p, b));
-    for (int i = 0; i < npowers; i++) { HIP_TRY(ctx, hipMalloc(&dst[i].p, b)); d_out[i] = (float *)dst[i].p; }
+    for (int i = 0; i <= npowers; i++) {                   // slot 0 = the source, 1 + i = power i
+        rmdf_ctx::Scratch &sc = ctx->env_scratch[i];
+        if (sc.bytes < b) {
+            if (sc.p) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(sc.p); sc.p = nullptr; sc.bytes = 0; }
+            HIP_TRY(ctx, hipMalloc(&sc.p, b));
+            sc.bytes = b;
+        }
+        if (i > 0) d_out[i - 1] = (float *)sc.p;
+    }
+    struct { void *p; } src = { ctx->env_scratch[0].p };
     HIP_TRY(ctx, hipMemcpyAsync(src.p, rgb, b, hipMemcpyHostToDevice, ctx->stream));
     int rc = prefilter_powers_device(ctx, (const float *)src.p, w, h, powers, npowers, d_out.data());
     if (rc != RMDF_OK) { (void)hipDeviceSynchronize(); return rc; }

@@ -203,44 +203,69 @@ hipError_t launch_resize_latlong(const float *d_src, int sw, int sh, int dstw, i
 // ------------------------------------------------------------------------------------
 #define PREFILTER_WAVES 4            // destination rows (waves) per workgroup; they share the staged cosine table
 
+// Round 3.  What bounds this kernel is not arithmetic: at the reference's 256x128 one power is 512 waves on 1024 SIMDs, a wave issues
+// one vector instruction per ~6 cycles, and four powers side by side (2 waves per SIMD) took TWICE as long each as alone -- the
+// waves were waiting for the source row, which every wave of the machine read for itself, texel by texel: with scalar loads
+// (round 2; they return out of order, so every use waits for all that are in flight, the prefetch included) or with vector loads
+// of a wave-uniform address (16 cycles of the CU's address unit per instruction, for 8 waves).  Now the workgroup stages the
+// source row in LDS once, cooperatively (row y + 1 is loaded while row y is summed: two buffers, one barrier per row), and the lanes
+// read it by broadcast ds_read_b128; with the cosine table that makes the inner loop LDS-only, LDS returns in order, and the
+// loads of the next sixteen texels are in flight while sixteen compute.  Same operations in the same order per destination
+// texel: bit-equal (tests/test_gpu_env.py).
+// Measured and dropped: one lane per (destination texel, channel) -- r, g, b are independent sums, so the split is exact and gives
+// three times the waves -- 0.87 ms for p = 1 either way and slower for the other powers (every lane repeats the binary64 chain).
 template <int LOG2P, bool LUT_IN_LDS>
 __global__ __launch_bounds__(64 * PREFILTER_WAVES) void k_prefilter(const float *__restrict__ src, int w, int h, float power,
                                                   const float *__restrict__ lutT, const float2 *__restrict__ tcs,
                                                   float *__restrict__ out)
 {
-    extern __shared__ float lds_lut[];                  // [w][64] when LUT_IN_LDS
+    extern __shared__ float lds_dyn[];                  // [2][row_stride] source rows, then [w][64] cosine table when LUT_IN_LDS
+    const int row_stride = (w * 3 + 3) & ~3;            // floats per staged row, a multiple of 4 (ds_read_b128)
+    float *lds_row = lds_dyn, *lds_lut = lds_dyn + 2 * row_stride;
     // the wave index is wave-uniform, but the compiler cannot know that of threadIdx.x >> 6: say so, or every address
-    // derived from it is treated as divergent and read with per-lane vector loads
+    // derived from it is treated as divergent
     const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int blk = blockIdx.x, dy = blockIdx.y * PREFILTER_WAVES + g;
+    const int blk = blockIdx.x, dy_raw = blockIdx.y * PREFILTER_WAVES + g;
+    const int dy = dy_raw < h ? dy_raw : h - 1;         // waves past the last row keep the barriers company and store nothing
     const int dx = blk * 64 + lane;
     const float *glut = lutT + (size_t)blk * w * 64;
-    if (LUT_IN_LDS) {
+    if (LUT_IN_LDS)
         for (int i = threadIdx.x; i < w * 64; i += 64 * PREFILTER_WAVES) lds_lut[i] = glut[i];
-        __syncthreads();
-    }
-    if (dy >= h) return;
+    // stage source row 0
+    const int nrow = w * 3;
+    for (int i = threadIdx.x; i < nrow; i += 64 * PREFILTER_WAVES) lds_row[i] = src[i];
+    __syncthreads();
     typedef const float __attribute__((address_space(4))) cfloat;      // wave-uniform, read-only: scalar loads
     const float lc = ((cfloat *)tcs)[2 * dy], ls = ((cfloat *)tcs)[2 * dy + 1];
-    // A lone wave issues one instruction every ~5 cycles whatever it is, so the inner loop is written for few instructions:
+    // The inner loop is written for few instructions:
     //   * the branch `if cosAngle > 0` becomes a clamp: c0 = max(cosAngle, 0) makes cos^p, the factor and the three products
     //     +-0, and x + (+-0) == x -- the same bits as skipping the texel (finite texels: Radiance RGBE cannot encode others);
     //   * (r, g) accumulate as one packed pair (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per instruction);
-    //   * the sample count n is an integer add-with-carry on the compare's mask (the reference counts in Float: exact below
-    //     2^24, where a Float counter stops growing -- restored at the end).
+    //   * the sample count n is an integer (the reference counts in Float: exact below 2^24, where a Float counter stops growing
+    //     -- restored at the end): cos_angle > 0 <=> clamp(bits as int32, 0, 1) == 1, one v_med3_i32, and two of them go into the
+    //     count with one v_add3_u32 (inline asm: written in C the compiler turns it back into compare + select + add-with-carry).
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 arg = { 0.0f, 0.0f };
     float ab = 0.0f;
     unsigned ni = 0u;
+    constexpr int NPF = 3;                               // floats of the next row a thread carries: 64 * 4 * 3 >= 768 = 256 texels; wider rows loop
     for (int y = 0; y < h; y++) {
         const float pc = ((cfloat *)tcs)[2 * y], ps = ((cfloat *)tcs)[2 * y + 1];
         const float lcpc = lc * pc, lsps = ls * ps;
-        cfloat *row = (cfloat *)(src + (size_t)y * w * 3);
+        const float *row = lds_row + (y & 1) * row_stride;
+        // the next source row: loaded into registers now, written to the other buffer after this row's sums
+        const bool more = y + 1 < h;
+        const float *nsrc = src + (size_t)(more ? y + 1 : y) * nrow;
+        float pf[NPF];
+#pragma unroll
+        for (int k = 0; k < NPF; k++) { const int i = threadIdx.x + k * 64 * PREFILTER_WAVES; pf[k] = i < nrow ? nsrc[i] : 0.0f; }
         if (LOG2P >= 0) {
             // one texel: the reference's arithmetic, operation for operation
             auto texel = [&](float l, float r, float g, float b) {
                 const float cos_angle = lcpc + lsps * l;
-                ni += (cos_angle > 0.0f) ? 1u : 0u;
+                unsigned ind;
+                asm("v_med3_i32 %0, %1, 0, 1" : "=v"(ind) : "v"(__float_as_int(cos_angle)));
+                ni += ind;
                 const float c0 = __builtin_fmaxf(cos_angle, 0.0f);
                 float cp = c0;
                 if (LOG2P > 0) {
@@ -255,35 +280,34 @@ __global__ __launch_bounds__(64 * PREFILTER_WAVES) void k_prefilter(const float 
                 arg = arg + rg * fac2;
                 ab = ab + b * fac;
             };
-            // Eight texels per trip, software-pipelined: the scalar loads of the source row and the cosine-table reads of
-            // trip i + 1 are issued before trip i computes, so a lone wave does not sit through their latency every trip
-            // (scalar loads of the next ROW's first chunk are harmless: the last row is followed by w * 3 floats of padding
-            // only when another row exists, so the prefetch is skipped on the last trip of the last row).
-            const int w8 = w & ~7;
-            float rn[24], ln[8];
-            if (w8 > 0) {
+            // Sixteen texels per block over TWO register sets (A, B) that alternate without being copied: the LDS reads of block
+            // i + 1 are in flight while block i computes (LDS returns in order: the compiler waits with lgkmcnt(n) for exactly the
+            // older block).
+            constexpr int PB = 16;
+            const int wb = w - w % PB;
+            float ra[3 * PB], la[PB], rb[3 * PB], lb[PB];
+            auto load_block = [&](float (&r)[3 * PB], float (&l)[PB], int x) {
+                const float4 *q = (const float4 *)(row + x * 3);           // 16-byte aligned: 192 bytes per block, row_stride % 4 == 0
 #pragma unroll
-                for (int k = 0; k < 24; k++) rn[k] = row[k];
+                for (int k = 0; k < 3 * PB / 4; k++) { const float4 v = q[k]; r[4 * k] = v.x; r[4 * k + 1] = v.y; r[4 * k + 2] = v.z; r[4 * k + 3] = v.w; }
 #pragma unroll
-                for (int k = 0; k < 8; k++) ln[k] = LUT_IN_LDS ? lds_lut[k * 64 + lane] : glut[k * 64 + lane];
+                for (int k = 0; k < PB; k++) l[k] = LUT_IN_LDS ? lds_lut[(x + k) * 64 + lane] : glut[(x + k) * 64 + lane];
+            };
+            auto compute_block = [&](const float (&r)[3 * PB], const float (&l)[PB]) {
+#pragma unroll
+                for (int k = 0; k < PB; k++) texel(l[k], r[3 * k], r[3 * k + 1], r[3 * k + 2]);
+            };
+            if (wb > 0) load_block(ra, la, 0);
+            int x = 0;
+            for (; x + 2 * PB <= wb; x += 2 * PB) {
+                load_block(rb, lb, x + PB);
+                compute_block(ra, la);
+                load_block(ra, la, (x + 2 * PB < wb) ? x + 2 * PB : 0);      // past the last block: block 0 again (valid, unused) -- no branch, no copies
+                compute_block(rb, lb);
             }
-            for (int x = 0; x < w8; x += 8) {
-                float rc[24], lc8[8];
-#pragma unroll
-                for (int k = 0; k < 24; k++) rc[k] = rn[k];
-#pragma unroll
-                for (int k = 0; k < 8; k++) lc8[k] = ln[k];
-                if (x + 8 < w8) {
-#pragma unroll
-                    for (int k = 0; k < 24; k++) rn[k] = row[(x + 8) * 3 + k];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) ln[k] = LUT_IN_LDS ? lds_lut[(x + 8 + k) * 64 + lane] : glut[(x + 8 + k) * 64 + lane];
-                }
-#pragma unroll
-                for (int k = 0; k < 8; k++) texel(lc8[k], rc[3 * k], rc[3 * k + 1], rc[3 * k + 2]);
-            }
-            for (int x = w8; x < w; x++)
-                texel(LUT_IN_LDS ? lds_lut[x * 64 + lane] : glut[x * 64 + lane], row[x * 3], row[x * 3 + 1], row[x * 3 + 2]);
+            if (x < wb) compute_block(ra, la);                  // an odd number of blocks: the last one is loaded already
+            for (int xt = wb; xt < w; xt++)
+                texel(LUT_IN_LDS ? lds_lut[xt * 64 + lane] : glut[xt * 64 + lane], row[xt * 3], row[xt * 3 + 1], row[xt * 3 + 2]);
         } else {
             for (int x = 0; x < w; x++) {
                 const float l = LUT_IN_LDS ? lds_lut[x * 64 + lane] : glut[x * 64 + lane];
@@ -295,10 +319,18 @@ __global__ __launch_bounds__(64 * PREFILTER_WAVES) void k_prefilter(const float 
                 }
             }
         }
+        // hand the next row over (its buffer was last read for row y - 1: every wave is past the barrier that ended that row)
+        if (more) {
+            float *nrowbuf = lds_row + ((y + 1) & 1) * row_stride;
+#pragma unroll
+            for (int k = 0; k < NPF; k++) { const int i = threadIdx.x + k * 64 * PREFILTER_WAVES; if (i < nrow) nrowbuf[i] = pf[k]; }
+            for (int i = threadIdx.x + NPF * 64 * PREFILTER_WAVES; i < nrow; i += 64 * PREFILTER_WAVES) nrowbuf[i] = nsrc[i];      // rows wider than 256 texels
+        }
+        __syncthreads();
     }
     const float ar = arg.x, ag = arg.y;
     const float n = (float)(ni < 16777216u ? ni : 16777216u);       // a Float counter: n + 1 == n from 2^24 on
-    if (dx < w) {
+    if (dx < w && dy_raw < h) {
         float *o = out + ((size_t)dx + (size_t)dy * w) * 3;
         o[0] = ar / n; o[1] = ag / n; o[2] = ab / n;
     }
@@ -318,13 +350,17 @@ static hipError_t launch_prefilter_t(const float *d_src, int w, int h, float pow
                                      float *d_out, hipStream_t stream)
 {
     const dim3 grid((w + 63) / 64, (h + PREFILTER_WAVES - 1) / PREFILTER_WAVES), block(64 * PREFILTER_WAVES);
-    const size_t lds = (size_t)w * 64 * sizeof(float);
-    if (lds <= 64 * 1024) {          // two workgroups per CU keep their slice in LDS; wider maps read it through L2
-        hipError_t e = hipFuncSetAttribute((const void *)k_prefilter<LOG2P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t rows = 2 * (size_t)((w * 3 + 3) & ~3) * sizeof(float);          // two staged source rows
+    const size_t lut = (size_t)w * 64 * sizeof(float);
+    if (rows + lut <= 72 * 1024) {   // two workgroups per CU keep table and rows in LDS (w <= 256: 70 KB each); wider maps read the table through L2
+        hipError_t e = hipFuncSetAttribute((const void *)k_prefilter<LOG2P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(rows + lut));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_prefilter<LOG2P, true>), grid, block, lds, stream, d_src, w, h, power, d_lutT, d_tcs, d_out);
+        hipLaunchKernelGGL((k_prefilter<LOG2P, true>), grid, block, rows + lut, stream, d_src, w, h, power, d_lutT, d_tcs, d_out);
     } else {
-        hipLaunchKernelGGL((k_prefilter<LOG2P, false>), grid, block, 0, stream, d_src, w, h, power, d_lutT, d_tcs, d_out);
+        if (rows > 160 * 1024) return hipErrorInvalidValue;
+        hipError_t e = hipFuncSetAttribute((const void *)k_prefilter<LOG2P, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_prefilter<LOG2P, false>), grid, block, rows, stream, d_src, w, h, power, d_lutT, d_tcs, d_out);
     }
     return hipGetLastError();
 }

@@ -1,0 +1,27 @@
+#!/bin/bash
+# PMC counters of k_prefilter (256x128, the four reference powers through rmdf_prefilter_env_powers = four kernels side by side).
+# One rocprofv3 --pmc pass per group.   usage: tools/pmc_prefilter.sh
+export TMPDIR=/tmp
+out=gpurun_out/pmc_prefilter; rm -rf $out; mkdir -p $out
+i=0
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" \
+           "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --output-format csv -d $out/p$i -- python3 tools/prefilter_trace.py > /dev/null 2> $out/p$i.log || tail -3 $out/p$i.log
+done
+python3 - $out <<'PY'
+import csv, glob, statistics, sys
+c = {}
+for f in glob.glob(sys.argv[1] + "/p*/**/*_counter_collection.csv", recursive=True):
+    per = {}
+    for r in csv.DictReader(open(f)):
+        if "k_prefilter" in r["Kernel_Name"]:
+            key = r["Kernel_Name"][18:28]
+            per.setdefault((key, r["Counter_Name"]), {}).setdefault(r["Dispatch_Id"], 0.0)
+            per[(key, r["Counter_Name"])][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    for k, v in per.items():
+        c[k] = statistics.median(v.values())
+for k in sorted(c):
+    print("%-12s %-26s %16.0f" % (k[0], k[1], c[k]))
+PY
