@@ -703,7 +703,7 @@ def main():
                                   "note": "operation counters are only known for the headline workload (or after the "
                                           "cpu_baseline leg counted them)"}
         if not a.no_secondary and world == 1 and not sharded and L == 0:
-            result["secondary"] = secondary_workloads(sr, torch, dev, stream, cus)
+            result["secondary"] = secondary_workloads(sr, torch, dev, stream, cus, streams)
         if ref is not None:
             from oracle import orc
             # the reference's own CPU paths (BASELINE.json north_star: "timed on the same box's host cores ... as the
@@ -743,7 +743,7 @@ def main():
     return result
 
 
-def secondary_workloads(sr, torch, dev, stream, cus):
+def secondary_workloads(sr, torch, dev, stream, cus, streams=()):
     """The other configurations SURVEY.md 8(d) lists, timed after the headline run (device-resident unless said otherwise): config 2
     (Cornell box 1280x720 @128), config 5 (lobe prefilter 256x128, the four powers), config 4 on one GPU (3840x2160 output from
     7680x4320 rays, box-resolved on the GPU), the reference's 64-tile mode through the boundary call (rmdf_render_tile into a host
@@ -761,18 +761,33 @@ def secondary_workloads(sr, torch, dev, stream, cus):
         torch.cuda.synchronize(dev)
         return float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
     cornell = lambda: sr.render_rect_device(0, 1280, 720, 0.0, 128, (0, 0, 1280, 720), d_rgba8=fb.data_ptr(), stream=sp)
-    for _ in range(20):
-        cornell()
+
+    def warm(fn, seconds=0.25):
+        """keep launching until `seconds` have passed: the shader clock needs ~20 ms of continuous load to reach its steady 2.4 GHz
+        (a run of a few milliseconds after a pause sees 2.06-2.1 GHz), and the headline figure is measured warm too"""
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize(dev)
+    warm(cornell)
     t = ev(cornell, 50)
     # the same with two frames in flight on two streams (what the headline figure does): the launch is 14 400 waves = 1.76
     # fillings of the machine, so the thin end of one frame overlaps the start of the next
     fb2 = torch.empty((720, 1280), dtype=torch.int32, device=dev)
-    st2 = torch.cuda.Stream(dev)
+    # the second frame stream: one of the headline run's frame streams when there is one (they are known to sit on hardware queues of
+    # their own; a stream created this late can end up sharing a queue with `stream`: 0.18 instead of 0.14 ms per frame, the
+    # "bimodal" figure of round 2)
+    st2 = streams[1] if len(streams) > 1 else torch.cuda.Stream(dev)
     torch.cuda.synchronize(dev)
     bufs, sps = (fb, fb2), (sp, st2.cuda_stream)
     n2 = 200
-    for i in range(20):
+    ctr = [0]
+
+    def two():
+        i = ctr[0]; ctr[0] += 1
         sr.render_rect_device(0, 1280, 720, 0.0, 128, (0, 0, 1280, 720), d_rgba8=bufs[i & 1].data_ptr(), stream=sps[i & 1])
+    warm(two)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(n2):
