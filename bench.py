@@ -327,12 +327,19 @@ def main():
                 return int(flag.item()) == 1
             uid = torch.zeros(rmdf_amd.COMM_ID_BYTES, dtype=torch.uint8, device=cdev)
             try:
+                # The exchange's own calls against this rank itself, BEFORE it joins the job's communicator: the ctx has none yet,
+                # so the library runs its grouped ncclRecv + ncclSend of one shard's size on a private one-rank communicator --
+                # nothing a peer could hold up -- and compares the bytes (the lines that move the tiles have no other coverage on
+                # a single GPU).  A failure makes all ranks fall back to the torch.distributed gather together.
+                dog.arm("rmdf_comm_selftest_loopback (private one-rank communicator)")
+                sr.comm_selftest_loopback(slots * (h // 8) * (w // 8) * 4, stream=streams[0].cuda_stream)
+                dog.disarm()
                 my_id = rmdf_amd.comm_get_unique_id()          # on every rank: proves librccl loads here (only rank 0's is used)
                 if rank == 0:
                     uid.copy_(torch.frombuffer(bytearray(my_id), dtype=torch.uint8))
                 ok = True
             except Exception as e:                              # noqa: BLE001
-                print("rank %d: rmdf_comm_get_unique_id failed (%s)" % (rank, e), file=sys.stderr)
+                print("rank %d: rmdf_comm_selftest_loopback / rmdf_comm_get_unique_id failed (%s)" % (rank, e), file=sys.stderr)
                 ok = False
             use_abi_comm = all_ok(ok)
             if use_abi_comm:
@@ -351,21 +358,6 @@ def main():
             if not use_abi_comm:
                 print("rank %d: falling back to the torch.distributed gather" % rank, file=sys.stderr)
         dog.disarm()
-        if use_abi_comm:
-            # the exchange's own calls against this rank itself before any peer is involved: a grouped ncclRecv + ncclSend of one
-            # shard's size on a frame stream (the lines that move the tiles have no other single-GPU coverage)
-            dog.arm("rmdf_comm_selftest_loopback")
-            try:
-                sr.comm_selftest_loopback(slots * (h // 8) * (w // 8) * 4, stream=streams[0].cuda_stream)
-                ok = True
-            except Exception as e:                              # noqa: BLE001
-                print("rank %d: rmdf_comm_selftest_loopback failed (%s)" % (rank, e), file=sys.stderr)
-                ok = False
-            dog.disarm()
-            use_abi_comm = all_ok(ok)
-            if not use_abi_comm:
-                sr.comm_destroy()
-                print("rank %d: falling back to the torch.distributed gather" % rank, file=sys.stderr)
         if use_abi_comm:
             rccl_ranks = sr.comm_info()[1]
             exchange = "librmdf: rmdf_render_frame_sharded_device (grouped ncclSend/ncclRecv fan-in to rank 0), RCCL communicator of %d ranks" % rccl_ranks

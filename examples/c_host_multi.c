@@ -52,9 +52,10 @@ static int run_rank(int rank, int nranks, const char *hdr, const char *png, int 
         while (!sh->ready) usleep(1000);
         __sync_synchronize();
     }
-    TRY(ctx, rmdf_comm_init(ctx, sh->id, rank, nranks));
     const size_t slots = (size_t)((64 + nranks - 1) / nranks), tile = (size_t)(w / 8) * (h / 8) * 4;
-    TRY(ctx, rmdf_comm_selftest_loopback(ctx, slots * tile, NULL, NULL));      /* the exchange's send / receive against this rank itself */
+    /* the exchange's send / receive calls against this rank itself, on a private one-rank communicator (the ctx has none yet) */
+    TRY(ctx, rmdf_comm_selftest_loopback(ctx, slots * tile, NULL, NULL));
+    TRY(ctx, rmdf_comm_init(ctx, sh->id, rank, nranks));
     void *d_shard = NULL, *d_gathered = NULL, *d_frame = NULL;
     if (rank == 0) {
         TRY(ctx, rmdf_device_malloc(ctx, (size_t)nranks * slots * tile, &d_gathered));
