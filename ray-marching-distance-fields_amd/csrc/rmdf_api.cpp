@@ -1487,7 +1487,7 @@ int rmdf_comm_selftest_loopback(rmdf_ctx *ctx, size_t bytes, void *stream, uint6
     int me = ctx->comm_rank;
     struct TmpComm {
         ncclComm_t c = nullptr;
-        ~TmpComm() { if (c) g_rccl.CommDestroy(c); }
+        ~TmpComm() { if (c) { (void)hipDeviceSynchronize(); g_rccl.CommDestroy(c); } }     // an error path may leave its operations in flight
     } tmp;
     if (!comm) {
         ncclUniqueId uid;
