@@ -217,11 +217,13 @@ hipError_t launch_resize_latlong(const float *d_src, int sw, int sh, int dstw, i
 template <int LOG2P, bool LUT_IN_LDS>
 __global__ __launch_bounds__(64 * PREFILTER_WAVES) void k_prefilter(const float *__restrict__ src, int w, int h, float power,
                                                   const float *__restrict__ lutT, const float2 *__restrict__ tcs,
-                                                  float *__restrict__ out)
+                                                  float *__restrict__ out, int nbuf)
 {
-    extern __shared__ float lds_dyn[];                  // [2][row_stride] source rows, then [w][64] cosine table when LUT_IN_LDS
+    extern __shared__ float lds_dyn[];                  // [nbuf][row_stride] source rows, then [w][64] cosine table when LUT_IN_LDS
+    // nbuf = 2: the next row is written while this one is still being read by slower waves; nbuf = 1 (rows too wide for two
+    // buffers in 160 KB: w > 6800): one more barrier per row separates the two
     const int row_stride = (w * 3 + 3) & ~3;            // floats per staged row, a multiple of 4 (ds_read_b128)
-    float *lds_row = lds_dyn, *lds_lut = lds_dyn + 2 * row_stride;
+    float *lds_row = lds_dyn, *lds_lut = lds_dyn + nbuf * row_stride;
     // the wave index is wave-uniform, but the compiler cannot know that of threadIdx.x >> 6: say so, or every address
     // derived from it is treated as divergent
     const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(64 * PREFILTER_WAVES) void k_prefilter(const float 
     for (int y = 0; y < h; y++) {
         const float pc = ((cfloat *)tcs)[2 * y], ps = ((cfloat *)tcs)[2 * y + 1];
         const float lcpc = lc * pc, lsps = ls * ps;
-        const float *row = lds_row + (y & 1) * row_stride;
+        const float *row = lds_row + (nbuf == 2 ? (y & 1) : 0) * row_stride;
         // the next source row: loaded into registers now, written to the other buffer after this row's sums
         const bool more = y + 1 < h;
         const float *nsrc = src + (size_t)(more ? y + 1 : y) * nrow;
@@ -320,8 +322,9 @@ __global__ __launch_bounds__(64 * PREFILTER_WAVES) void k_prefilter(const float 
             }
         }
         // hand the next row over (its buffer was last read for row y - 1: every wave is past the barrier that ended that row)
+        if (nbuf == 1) __syncthreads();
         if (more) {
-            float *nrowbuf = lds_row + ((y + 1) & 1) * row_stride;
+            float *nrowbuf = lds_row + (nbuf == 2 ? ((y + 1) & 1) : 0) * row_stride;
 #pragma unroll
             for (int k = 0; k < NPF; k++) { const int i = threadIdx.x + k * 64 * PREFILTER_WAVES; if (i < nrow) nrowbuf[i] = pf[k]; }
             for (int i = threadIdx.x + NPF * 64 * PREFILTER_WAVES; i < nrow; i += 64 * PREFILTER_WAVES) nrowbuf[i] = nsrc[i];      // rows wider than 256 texels
@@ -350,17 +353,18 @@ static hipError_t launch_prefilter_t(const float *d_src, int w, int h, float pow
                                      float *d_out, hipStream_t stream)
 {
     const dim3 grid((w + 63) / 64, (h + PREFILTER_WAVES - 1) / PREFILTER_WAVES), block(64 * PREFILTER_WAVES);
-    const size_t rows = 2 * (size_t)((w * 3 + 3) & ~3) * sizeof(float);          // two staged source rows
+    const size_t row = (size_t)((w * 3 + 3) & ~3) * sizeof(float);             // one staged source row
     const size_t lut = (size_t)w * 64 * sizeof(float);
-    if (rows + lut <= 72 * 1024) {   // two workgroups per CU keep table and rows in LDS (w <= 256: 70 KB each); wider maps read the table through L2
-        hipError_t e = hipFuncSetAttribute((const void *)k_prefilter<LOG2P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(rows + lut));
+    if (2 * row + lut <= 72 * 1024) {   // two workgroups per CU keep table and rows in LDS (w <= 256: 70 KB each); wider maps read the table through L2
+        hipError_t e = hipFuncSetAttribute((const void *)k_prefilter<LOG2P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * row + lut));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_prefilter<LOG2P, true>), grid, block, rows + lut, stream, d_src, w, h, power, d_lutT, d_tcs, d_out);
+        hipLaunchKernelGGL((k_prefilter<LOG2P, true>), grid, block, 2 * row + lut, stream, d_src, w, h, power, d_lutT, d_tcs, d_out, 2);
     } else {
-        if (rows > 160 * 1024) return hipErrorInvalidValue;
-        hipError_t e = hipFuncSetAttribute((const void *)k_prefilter<LOG2P, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows);
+        const int nbuf = 2 * row <= 80 * 1024 ? 2 : 1;              // w <= 3413: two buffers and still two workgroups per CU
+        if ((size_t)nbuf * row > 160 * 1024) return hipErrorInvalidValue;
+        hipError_t e = hipFuncSetAttribute((const void *)k_prefilter<LOG2P, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(nbuf * row));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_prefilter<LOG2P, false>), grid, block, rows, stream, d_src, w, h, power, d_lutT, d_tcs, d_out);
+        hipLaunchKernelGGL((k_prefilter<LOG2P, false>), grid, block, (size_t)nbuf * row, stream, d_src, w, h, power, d_lutT, d_tcs, d_out, nbuf);
     }
     return hipGetLastError();
 }

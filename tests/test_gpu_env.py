@@ -82,7 +82,9 @@ def test_lobe_prefilter_wide_maps_and_device_entry(sr, orc):
     """Maps wider than 256 texels read their cosine table through L2 instead of LDS (w = 640 > the old 600 limit, w = 1030
     ragged); and the device-resident entry (rmdf_prefilter_env_device) gives the same bits as the host-pointer one."""
     import torch
-    for (w, h, p) in ((640, 12, 8.0), (1030, 6, 1.0), (512, 24, 512.0)):
+    # ... and the source row is staged in LDS by the workgroup: two buffers up to w = 3413, ONE (and a second barrier per row) for
+    # rows that would not fit twice (w = 7000), tail blocks of every residue mod 16
+    for (w, h, p) in ((640, 12, 8.0), (1030, 6, 1.0), (512, 24, 512.0), (3500, 3, 8.0), (7000, 2, 1.0), (263, 9, 64.0), (40, 20, 8.0)):
         src = synthetic_latlong(w, h, w)
         ref = orc.cosine_convolve(src, p, pow_mode=1)
         got = sr.prefilter_env(src, p)
