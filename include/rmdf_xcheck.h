@@ -30,6 +30,11 @@ extern "C" {
  * passes, sum of waiting lanes over march tails, begin / end timestamps (100 MHz s_memrealtime ticks). */
 int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_waves);
 
+/* Host-only check aid: the Cornell box's candidate grid of n^3 cells (n = 16, 32, 64, 128; rmdf_device.hpp: the set of triangles
+ * that can be nearest somewhere in a cell), built with every triangle measured in every cell (brute_force != 0) or by halving
+ * cells from the 16^3 grid the way rmdf_create builds its 64^3 one.  out: n^3 uint32 masks. */
+int rmdf_debug_cornell_masks(int n, int brute_force, uint32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

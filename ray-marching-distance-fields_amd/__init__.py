@@ -56,7 +56,7 @@ ABI_SYMBOLS = (
     "rmdf_gather_shards_device", "rmdf_render_frame_sharded_device", "rmdf_device_malloc", "rmdf_device_free",
     "rmdf_copy_to_host", "rmdf_probe_shader_clock", "rmdf_comm_selftest_loopback",
 )
-XCHECK_SYMBOLS = ("rmdf_debug_march_stats",)      # include/rmdf_xcheck.h
+XCHECK_SYMBOLS = ("rmdf_debug_march_stats", "rmdf_debug_cornell_masks")      # include/rmdf_xcheck.h
 
 
 class RmdfError(RuntimeError):
@@ -191,6 +191,7 @@ def load_library(xcheck=False):
     L.rmdf_device_info.argtypes = [vp, C.c_char_p, C.c_int, ip]
     if xcheck:
         L.rmdf_debug_march_stats.argtypes = [vp, C.c_int, vp, C.c_int]
+        L.rmdf_debug_cornell_masks.argtypes = [C.c_int, C.c_int, vp]
     L.rmdf_selftest_exact_math.argtypes = [vp, vp]
     L.rmdf_selftest_pinned_math.argtypes = [vp, vp]
     L.rmdf_resolve_box2_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]

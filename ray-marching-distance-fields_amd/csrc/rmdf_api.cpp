@@ -292,23 +292,52 @@ static double point_triangle_distance(const double p[3], const double a[3], cons
     return sqrt(s2);
 }
 
-void cornell_grid(const float tri[96 * 3], uint32_t masks[CORNELL_GRID_N * CORNELL_GRID_N * CORNELL_GRID_N])
+// masks[cell] = the triangles that can be the nearest one for SOME point of the cell: d(centre, t) <= min_s d(centre, s) + 2 rho,
+// rho = the cell's half diagonal + 1e-4 (float rounding of the cell index at cell borders and of the shader's formulas).  Double
+// arithmetic.  `parent` (a grid of N / 2 cells per axis, or null): a child's candidates are a subset of its parent's (the centres
+// are half a child diagonal apart and 2 rho_parent = 4 half-diagonals + 2e-4), and the triangle nearest to the child's centre is one
+// of them, so only the parent's candidates are measured -- the 64^3 grid costs 0.1 s instead of a second.
+void cornell_grid(const float tri[96 * 3], int N, uint32_t *masks /* N^3 */, const uint32_t *parent = nullptr)
 {
-    const int N = CORNELL_GRID_N;
     const double H = (double)CORNELL_GRID_H, cell = 2.0 * H / N, rho = 0.5 * cell * sqrt(3.0) + 1e-4;
+    double v[32][3][3];
+    for (int t = 0; t < 32; t++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) v[t][j][k] = (double)tri[t * 9 + j * 3 + k];
     for (int iz = 0; iz < N; iz++) for (int iy = 0; iy < N; iy++) for (int ix = 0; ix < N; ix++) {
         const double c[3] = { -H + (ix + 0.5) * cell, -H + (iy + 0.5) * cell, -H + (iz + 0.5) * cell };
+        const uint32_t pm = parent ? parent[((iz / 2) * (N / 2) + iy / 2) * (N / 2) + ix / 2] : 0xffffffffu;
         double d[32], dmin = 1e30;
         for (int t = 0; t < 32; t++) {
-            double v[3][3];
-            for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) v[j][k] = (double)tri[t * 9 + j * 3 + k];
-            d[t] = point_triangle_distance(c, v[0], v[1], v[2]);
+            if (!((pm >> t) & 1u)) continue;
+            d[t] = point_triangle_distance(c, v[t][0], v[t][1], v[t][2]);
             if (d[t] < dmin) dmin = d[t];
         }
         uint32_t m = 0u;
-        for (int t = 0; t < 32; t++) if (d[t] <= dmin + 2.0 * rho) m |= 1u << t;
+        for (int t = 0; t < 32; t++) if (((pm >> t) & 1u) && d[t] <= dmin + 2.0 * rho) m |= 1u << t;
         masks[(iz * N + iy) * N + ix] = m;
     }
+}
+
+// the coarse grid (CORNELL_GRID_N^3, staged in LDS by the kernel) followed by the fine one (CORNELL_FINE_N^3, read from global
+// memory); the geometry is a constant, so the pair is built once per process
+const std::vector<uint32_t> &cornell_grids(const float tri[96 * 3])
+{
+    static std::vector<uint32_t> grids;
+    static std::once_flag once;
+    std::call_once(once, [&] {
+        static_assert(CORNELL_FINE_N % CORNELL_GRID_N == 0 && ((CORNELL_FINE_N / CORNELL_GRID_N) & (CORNELL_FINE_N / CORNELL_GRID_N - 1)) == 0,
+                      "the fine grid is reached from the coarse one by halving cells");
+        const size_t nc = (size_t)CORNELL_GRID_N * CORNELL_GRID_N * CORNELL_GRID_N, nf = (size_t)CORNELL_FINE_N * CORNELL_FINE_N * CORNELL_FINE_N;
+        grids.resize(nc + nf);
+        cornell_grid(tri, CORNELL_GRID_N, grids.data());
+        std::vector<uint32_t> cur(grids.begin(), grids.begin() + nc), next;
+        for (int n = CORNELL_GRID_N * 2; n <= CORNELL_FINE_N; n *= 2) {
+            next.resize((size_t)n * n * n);
+            cornell_grid(tri, n, next.data(), cur.data());
+            cur.swap(next);
+        }
+        memcpy(grids.data() + nc, cur.data(), nf * 4);
+    });
+    return grids;
 }
 
 int ensure_frame(rmdf_ctx *ctx, int w, int h, bool planes)
@@ -970,8 +999,7 @@ int rmdf_create(rmdf_ctx **out, const rmdf_config *cfg)
     cornell_triangles(tri);
     float tab[CORNELL_TAB_FLOATS];
     cornell_table(tri, tab);
-    std::vector<uint32_t> cgrid((size_t)CORNELL_GRID_N * CORNELL_GRID_N * CORNELL_GRID_N);
-    cornell_grid(tri, cgrid.data());
+    const std::vector<uint32_t> &cgrid = cornell_grids(tri);
     if ((e = hipSetDevice(dev)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc((void **)&ctx->d_cornell, sizeof tri)) != hipSuccess ||
@@ -1628,6 +1656,21 @@ int rmdf_selftest_pinned_math(rmdf_ctx *ctx, uint64_t mismatches[7])
 
 
 #ifdef RMDF_XCHECK
+int rmdf_debug_cornell_masks(int n, int brute_force, uint32_t *out)
+{
+    // host-only (no ctx, no device): the candidate grid of n^3 cells, built directly (brute_force != 0: every triangle measured in
+    // every cell) or by halving cells from the 16^3 grid as rmdf_create does (tests compare the two)
+    if (!out || n < CORNELL_GRID_N || n > 128 || n % CORNELL_GRID_N || ((n / CORNELL_GRID_N) & (n / CORNELL_GRID_N - 1))) return RMDF_E_INVALID;
+    float tri[96 * 3];
+    cornell_triangles(tri);
+    if (brute_force) { cornell_grid(tri, n, out); return RMDF_OK; }
+    std::vector<uint32_t> cur((size_t)CORNELL_GRID_N * CORNELL_GRID_N * CORNELL_GRID_N), next;
+    cornell_grid(tri, CORNELL_GRID_N, cur.data());
+    for (int m = CORNELL_GRID_N * 2; m <= n; m *= 2) { next.resize((size_t)m * m * m); cornell_grid(tri, m, next.data(), cur.data()); cur.swap(next); }
+    memcpy(out, cur.data(), cur.size() * 4);
+    return RMDF_OK;
+}
+
 int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_waves)
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");

@@ -779,13 +779,20 @@ __device__ __forceinline__ float cornell_tri_dist2(v3 pos, PTR t)
 // losing triangles are left out.  Points outside the grid (and the NO_PRUNE loop) take every triangle.
 #define CORNELL_GRID_N 16
 #define CORNELL_GRID_H 1.1f
-__device__ __forceinline__ unsigned cornell_cell_mask(v3 p, const unsigned *grid)
+// Round 3: a second, finer grid of the same kind (CORNELL_FINE_N^3 cells, 1 MB: it stays in global memory, L2-resident) behind the
+// coarse one in the same allocation.  The per-lane estimate (de_cornell_box_lanes) reads it -- one dword per estimate, needed only
+// after the hinted triangle has been evaluated, so its latency hides -- and finds fewer candidates per cell (sweep: 24^3 0.198 ms per frame, 32^3 0.184, 48^3 0.172, 64^3 0.164, 96^3 0.164, 128^3 0.162; 16^3 0.229); the
+// lane-parallel paths, which need the mask at once, keep the coarse grid in LDS.
+#define CORNELL_FINE_N 64
+template <int N>
+__device__ __forceinline__ unsigned cornell_cell_mask_n(v3 p, const unsigned *grid)
 {
-    const float s = (float)CORNELL_GRID_N / (2.0f * CORNELL_GRID_H);
+    const float s = (float)N / (2.0f * CORNELL_GRID_H);
     const int ix = (int)floorf((p.x + CORNELL_GRID_H) * s), iy = (int)floorf((p.y + CORNELL_GRID_H) * s), iz = (int)floorf((p.z + CORNELL_GRID_H) * s);
-    if ((unsigned)ix >= (unsigned)CORNELL_GRID_N || (unsigned)iy >= (unsigned)CORNELL_GRID_N || (unsigned)iz >= (unsigned)CORNELL_GRID_N) return 0xffffffffu;
-    return grid[(iz * CORNELL_GRID_N + iy) * CORNELL_GRID_N + ix];
+    if ((unsigned)ix >= (unsigned)N || (unsigned)iy >= (unsigned)N || (unsigned)iz >= (unsigned)N) return 0xffffffffu;
+    return grid[(iz * N + iy) * N + ix];
 }
+__device__ __forceinline__ unsigned cornell_cell_mask(v3 p, const unsigned *grid) { return cornell_cell_mask_n<CORNELL_GRID_N>(p, grid); }
 // OR of `m` over the active lanes of the wave (exec-safe: reads only lanes that are active, one per distinct missing bit set)
 __device__ __forceinline__ unsigned wave_or_active(unsigned m)
 {
@@ -838,12 +845,16 @@ __device__ __forceinline__ float cornell_group_dist2(v3 pos, const float *lds_ta
 // loads, no wave-uniform branches but the loop conditions: the wave-uniform loop below spends 7.6 cycles per instruction when a wave
 // has the SIMD to itself (chains of scalar load -> wait -> test -> branch), straight-line vector code about 2.  min() is exact
 // and order-independent and the bounds only drop provable losers: same bits.
-__device__ __forceinline__ float de_cornell_box_lanes(v3 pos, const float *rows, const unsigned *grid, int &hint)
+// `fine` != nullptr: the candidates come from the fine grid in global memory; the hinted triangle is then evaluated whether or not it is
+// a candidate of the cell (min over a superset of the candidates is the same min), so that the mask is not needed before.
+__device__ __forceinline__ float de_cornell_box_lanes(v3 pos, const float *rows, const unsigned *grid, const unsigned *fine, int &hint)
 {
-    unsigned m = cornell_cell_mask(pos, grid);
-    if (m == 0u) m = 0xffffffffu;                              // cannot happen with a well-formed grid
+    unsigned m = fine ? cornell_cell_mask_n<CORNELL_FINE_N>(pos, fine) : cornell_cell_mask(pos, grid);
     int g = hint & 31;
-    if (!((m >> g) & 1u)) g = (int)__builtin_ctz(m);
+    if (!fine) {
+        if (m == 0u) m = 0xffffffffu;                          // cannot happen with a well-formed grid
+        if (!((m >> g) & 1u)) g = (int)__builtin_ctz(m);
+    }
     float best = cornell_tri_dist2(pos, rows + g * CORNELL_STRIDE);
     const float dmax = __builtin_amdgcn_sqrtf(best) * 1.001f + 1e-5f;
     unsigned my = m & ~(1u << g), surv = 0u;

@@ -50,7 +50,11 @@ __device__ __forceinline__ float distance_estimator(v3 pos, const FrameParams &p
 {
     // Cornell box inside k_render: the per-lane form on the LDS copy of the table; the wave-uniform form (de_cornell_box_table) stays
     // the estimate of the cross-check schedules and of RMDF_FLAG_NO_PRUNE
-    if (SCENE == 0 && cgrid && lds_rows) return de_cornell_box_lanes(pos, lds_rows, cgrid, hint);
+#ifdef RMDF_AB_CORNELL_COARSE
+    if (SCENE == 0 && cgrid && lds_rows) return de_cornell_box_lanes(pos, lds_rows, cgrid, nullptr, hint);
+#else
+    if (SCENE == 0 && cgrid && lds_rows) return de_cornell_box_lanes(pos, lds_rows, cgrid, p.cornell_grid + CORNELL_GRID_N * CORNELL_GRID_N * CORNELL_GRID_N, hint);
+#endif
     if (SCENE == 2)      return de_mandelbulb8(pos, iters, fold_min_of(p));
     else if (SCENE == 3) return de_mandelbulb_general(pos, p.power, iters);
     else if (SCENE == 1) return de_test_scene(pos);

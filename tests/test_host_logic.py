@@ -175,3 +175,26 @@ def test_two_rank_gather_reassembles_the_frame():
         assert p.exitcode == 0
     results = [q.get(timeout=10) for _ in range(3)]     # static-deal frame, cost-aware-deal frame (+ agreement protocol), timing reduce
     assert results == [True, True, True]
+
+
+def test_cornell_candidate_grid_built_by_halving_equals_brute_force():
+    """rmdf_create builds the Cornell box's 64^3 candidate grid (rmdf_device.hpp: CORNELL_FINE_N) from the 16^3 one by halving cells,
+    measuring in a child cell only the parent's candidate triangles.  Host arithmetic, no GPU: the result equals the grid in which
+    every triangle is measured in every cell, every cell has a candidate, and a child's candidates are a subset of its parent's."""
+    import ctypes as C
+    import rmdf_amd
+    L = rmdf_amd.load_library(xcheck=True)
+    grids = {}
+    for n in (16, 32, 64):
+        a, b = np.zeros(n ** 3, np.uint32), np.zeros(n ** 3, np.uint32)
+        assert L.rmdf_debug_cornell_masks(n, 0, a.ctypes.data) == 0 and L.rmdf_debug_cornell_masks(n, 1, b.ctypes.data) == 0
+        assert np.array_equal(a, b), n
+        assert (a != 0).all()
+        grids[n] = a.reshape(n, n, n)
+    for n in (32, 64):
+        parent = np.repeat(np.repeat(np.repeat(grids[n // 2], 2, 0), 2, 1), 2, 2)
+        assert ((grids[n] & ~parent) == 0).all(), n
+    counts = {n: float(np.mean([bin(int(m)).count("1") for m in g.ravel()[::7]])) for n, g in grids.items()}
+    assert counts[64] < counts[32] < counts[16], counts        # what the finer grid buys: fewer candidates per cell
+    assert L.rmdf_debug_cornell_masks(48, 0, grids[16].ctypes.data) != 0     # only powers of two times 16
+
