@@ -317,8 +317,8 @@ void cornell_grid(const float tri[96 * 3], int N, uint32_t *masks /* N^3 */, con
     }
 }
 
-// the coarse grid (CORNELL_GRID_N^3, staged in LDS by the kernel) followed by the fine one (CORNELL_FINE_N^3, read from global
-// memory); the geometry is a constant, so the pair is built once per process
+// the grid k_render reads from global memory (CORNELL_FINE_N^3 masks), reached from the CORNELL_GRID_N^3 one by halving cells; the
+// geometry is a constant, so it is built once per process
 const std::vector<uint32_t> &cornell_grids(const float tri[96 * 3])
 {
     static std::vector<uint32_t> grids;
@@ -327,15 +327,14 @@ const std::vector<uint32_t> &cornell_grids(const float tri[96 * 3])
         static_assert(CORNELL_FINE_N % CORNELL_GRID_N == 0 && ((CORNELL_FINE_N / CORNELL_GRID_N) & (CORNELL_FINE_N / CORNELL_GRID_N - 1)) == 0,
                       "the fine grid is reached from the coarse one by halving cells");
         const size_t nc = (size_t)CORNELL_GRID_N * CORNELL_GRID_N * CORNELL_GRID_N, nf = (size_t)CORNELL_FINE_N * CORNELL_FINE_N * CORNELL_FINE_N;
-        grids.resize(nc + nf);
-        cornell_grid(tri, CORNELL_GRID_N, grids.data());
-        std::vector<uint32_t> cur(grids.begin(), grids.begin() + nc), next;
+        std::vector<uint32_t> cur(nc), next;
+        cornell_grid(tri, CORNELL_GRID_N, cur.data());
         for (int n = CORNELL_GRID_N * 2; n <= CORNELL_FINE_N; n *= 2) {
             next.resize((size_t)n * n * n);
             cornell_grid(tri, n, next.data(), cur.data());
             cur.swap(next);
         }
-        memcpy(grids.data() + nc, cur.data(), nf * 4);
+        grids.assign(cur.begin(), cur.begin() + nf);
     });
     return grids;
 }

@@ -12,7 +12,6 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
-#include <type_traits>
 
 namespace rmdf {
 
@@ -779,10 +778,10 @@ __device__ __forceinline__ float cornell_tri_dist2(v3 pos, PTR t)
 // losing triangles are left out.  Points outside the grid (and the NO_PRUNE loop) take every triangle.
 #define CORNELL_GRID_N 16
 #define CORNELL_GRID_H 1.1f
-// Round 3: a second, finer grid of the same kind (CORNELL_FINE_N^3 cells, 1 MB: it stays in global memory, L2-resident) behind the
-// coarse one in the same allocation.  The per-lane estimate (de_cornell_box_lanes) reads it -- one dword per estimate, needed only
-// after the hinted triangle has been evaluated, so its latency hides -- and finds fewer candidates per cell (sweep: 24^3 0.198 ms per frame, 32^3 0.184, 48^3 0.172, 64^3 0.164, 96^3 0.164, 128^3 0.162; 16^3 0.229); the
-// lane-parallel paths, which need the mask at once, keep the coarse grid in LDS.
+// Round 3: the grid k_render uses has CORNELL_FINE_N^3 cells (1 MB: it stays in global memory, L2-resident; built from the
+// CORNELL_GRID_N^3 one by halving cells, rmdf_api.cpp).  The per-lane estimate (de_cornell_box_lanes) reads one dword of it per
+// estimate, needed only after the hinted triangle has been evaluated, so its latency hides -- and the finer the cells the fewer
+// candidates (one frame at a time: 16^3 in LDS 0.229 ms, 24^3 0.198, 32^3 0.184, 48^3 0.172, 64^3 0.164, 96^3 0.164, 128^3 0.162).
 #define CORNELL_FINE_N 64
 template <int N>
 __device__ __forceinline__ unsigned cornell_cell_mask_n(v3 p, const unsigned *grid)
@@ -805,56 +804,19 @@ __device__ __forceinline__ unsigned wave_or_active(unsigned m)
     return acc;
 }
 
-// Lane-parallel form for the LAST rays of a wave (rmdf_render.hip: cornell_straggler_march): the wave's lanes are split into groups
-// of G, a group works on ONE ray, lane `sub` of the group evaluates the candidates i == sub (mod G) of the ray's own cell mask -- each
-// from its own row of an LDS copy of the table -- and the group takes the minimum (min is exact and order-independent, and the cell's
-// candidates contain the nearest triangle: same bits as the loop below).  One estimate is then ONE triangle evaluation deep
-// instead of a chain of scalar loads, bound tests and evaluations: what a wave's last, long rays need is latency, not throughput.
-template <int G>
-__device__ __forceinline__ float cornell_group_dist2(v3 pos, const float *lds_tab, const unsigned *grid, int sub)
-{
-    static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "group size");
-    const unsigned residue = (G == 1 ? 0xffffffffu : (G == 2 ? 0x55555555u : (G == 4 ? 0x11111111u : (G == 8 ? 0x01010101u : 0x00010001u)))) << sub;
-    unsigned my = cornell_cell_mask(pos, grid) & residue;
-    float best = 998001.0f;                                    // 999^2
-    while (__ballot(my != 0u) != 0ull) {
-        if (my != 0u) {
-            const int i = (int)__builtin_ctz(my);
-            my &= my - 1u;
-            const float x = cornell_tri_dist2(pos, lds_tab + i * CORNELL_STRIDE);
-            best = (x < best) ? x : best;
-        }
-    }
-    // minimum over the group's G consecutive lanes by DPP (no LDS round trip as __shfl_xor would take): quad_perm for the lanes
-    // 1 and 2 apart, then -- the quads being uniform by now -- row_half_mirror (lane i <-> 7 - i) and row_mirror (i <-> 15 - i)
-    // swap the quads of a group of 8 and the halves of a group of 16 (a disabled source lane leaves the lane's own value: `old` = v)
-    auto dpp_min = [](float v, auto ctrl) {
-        const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), decltype(ctrl)::value, 0xf, 0xf, false));
-        return (o < v) ? o : v;
-    };
-    if (G >= 2) best = dpp_min(best, std::integral_constant<int, 0xB1>());     // quad_perm [1,0,3,2]
-    if (G >= 4) best = dpp_min(best, std::integral_constant<int, 0x4E>());     // quad_perm [2,3,0,1]
-    if (G >= 8) best = dpp_min(best, std::integral_constant<int, 0x141>());    // row_half_mirror
-    if (G >= 16) best = dpp_min(best, std::integral_constant<int, 0x140>());   // row_mirror
-    return best;
-}
-
 // The per-lane form of the pruned estimate (round 3).  Every lane works from ITS OWN cell mask and hint, on rows of an LDS copy of the
 // table: the triangle that was nearest last time first, then one pass of bound tests over the lane's remaining candidates (the
 // k-th candidate of every lane in pass k, whichever triangle that is), then the survivors, again one per lane and pass.  No scalar
 // loads, no wave-uniform branches but the loop conditions: the wave-uniform loop below spends 7.6 cycles per instruction when a wave
 // has the SIMD to itself (chains of scalar load -> wait -> test -> branch), straight-line vector code about 2.  min() is exact
 // and order-independent and the bounds only drop provable losers: same bits.
-// `fine` != nullptr: the candidates come from the fine grid in global memory; the hinted triangle is then evaluated whether or not it is
-// a candidate of the cell (min over a superset of the candidates is the same min), so that the mask is not needed before.
-__device__ __forceinline__ float de_cornell_box_lanes(v3 pos, const float *rows, const unsigned *grid, const unsigned *fine, int &hint)
+// The candidates come from the fine grid in global memory (`fine`, CORNELL_FINE_N^3 masks); the hinted triangle is evaluated whether or
+// not it is a candidate of the cell -- the minimum over a superset of the candidates is the same minimum -- so the mask is not
+// needed before ~140 instructions have run, and its latency hides.
+__device__ __forceinline__ float de_cornell_box_lanes(v3 pos, const float *rows, const unsigned *fine, int &hint)
 {
-    unsigned m = fine ? cornell_cell_mask_n<CORNELL_FINE_N>(pos, fine) : cornell_cell_mask(pos, grid);
+    const unsigned m = cornell_cell_mask_n<CORNELL_FINE_N>(pos, fine);
     int g = hint & 31;
-    if (!fine) {
-        if (m == 0u) m = 0xffffffffu;                          // cannot happen with a well-formed grid
-        if (!((m >> g) & 1u)) g = (int)__builtin_ctz(m);
-    }
     float best = cornell_tri_dist2(pos, rows + g * CORNELL_STRIDE);
     const float dmax = __builtin_amdgcn_sqrtf(best) * 1.001f + 1e-5f;
     unsigned my = m & ~(1u << g), surv = 0u;

@@ -30,7 +30,7 @@ struct FrameParams {
     CubeDev env_refl, env_cos1, env_cos8;
     const float *cornell;     // 96 vertices
     const float *cornell_tab; // 32 x CORNELL_STRIDE per-triangle constants (rmdf_device.hpp: de_cornell_box_table)
-    const unsigned *cornell_grid;   // CORNELL_GRID_N^3 candidate masks (rmdf_device.hpp: cornell_cell_mask); null = none
+    const unsigned *cornell_grid;   // CORNELL_FINE_N^3 candidate masks in global memory (rmdf_device.hpp: de_cornell_box_lanes); null = none
     int   cornell_prune;      // skip triangles that provably cannot undercut the running minimum (bit-identical result)
     uint32_t *rgba8;
     uint32_t *rgba8_mirror;   // optional second destination of the RGBA8 frame: a registered (GPU-mapped) host buffer, written

@@ -48,13 +48,9 @@ template <int SCENE>
 // hint: Cornell only -- the triangle that was nearest in this lane's previous estimate (evaluation order, not a result)
 __device__ __forceinline__ float distance_estimator(v3 pos, const FrameParams &p, unsigned &iters, int &hint, const unsigned *cgrid = nullptr, const float *lds_rows = nullptr)
 {
-    // Cornell box inside k_render: the per-lane form on the LDS copy of the table; the wave-uniform form (de_cornell_box_table) stays
-    // the estimate of the cross-check schedules and of RMDF_FLAG_NO_PRUNE
-#ifdef RMDF_AB_CORNELL_COARSE
-    if (SCENE == 0 && cgrid && lds_rows) return de_cornell_box_lanes(pos, lds_rows, cgrid, nullptr, hint);
-#else
-    if (SCENE == 0 && cgrid && lds_rows) return de_cornell_box_lanes(pos, lds_rows, cgrid, p.cornell_grid + CORNELL_GRID_N * CORNELL_GRID_N * CORNELL_GRID_N, hint);
-#endif
+    // Cornell box inside k_render: the per-lane form on the LDS copy of the table, candidates from the fine grid (cgrid = its global
+    // address); the wave-uniform form (de_cornell_box_table) stays the estimate of the cross-check schedules and of RMDF_FLAG_NO_PRUNE
+    if (SCENE == 0 && cgrid && lds_rows) return de_cornell_box_lanes(pos, lds_rows, cgrid, hint);
     if (SCENE == 2)      return de_mandelbulb8(pos, iters, fold_min_of(p));
     else if (SCENE == 3) return de_mandelbulb_general(pos, p.power, iters);
     else if (SCENE == 1) return de_test_scene(pos);
@@ -142,135 +138,18 @@ __device__ __forceinline__ PixelGeom pixel_geom(const FrameParams &p, unsigned l
     return g;
 }
 
-// Cornell box: the last rays of a wave.  The launch cannot end before its longest ray has: 128 steps of one estimate after the
-// other, and in the wave-uniform loop (de_cornell_box_table) an estimate is a chain of a cell lookup, the hinted triangle's row by
-// scalar load, ~130 dependent instructions, then per chunk of candidates another scalar load, the bound tests, a row load and
-// another evaluation -- 2.1 us per step for a wave that has the SIMD to itself (wave timeline, round 3: the longest waves lived the
-// whole 272 us of the launch while the mean wave took 58).  Once a wave is down to CORNELL_STRAGGLER_T rays it regroups: G lanes
-// per ray (2, then 4, then 8 as rays finish), every lane of a group carries a copy of the ray's state, an estimate is
-// cornell_group_dist2 (one to a few triangle evaluations deep, no scalar loads), and a finished ray's result goes to its owner
-// lane through LDS.  Same arithmetic per ray, same bits.
-#ifndef CORNELL_STRAGGLER_T
-#define CORNELL_STRAGGLER_T 32
-#endif
-#define RMDF_CORNELL_WAVES 6            // 80 VGPRs, 24 KB of LDS per workgroup: seven do not fit (LDS), the scalar registers allow six
-struct CornellRay { float dx, dy, dz, tt, tmx; int st, owner; };
-// `leaders` = the lanes that hold a live ray; afterwards lanes [G k, G k + G) all hold the k-th of them
-template <int G>
-__device__ __forceinline__ void cornell_regroup(unsigned long long leaders, int lane, CornellRay &r, bool &ract)
-{
-    const int grp = lane / G;
-    // src = the grp-th set bit of `leaders` (per lane; a regroup happens at most three times per wave)
-    unsigned long long m = leaders;
-#pragma unroll 1
-    for (int k = 0; k < grp; k++) m &= m - 1ull;
-    const int src = m ? (int)__builtin_ctzll(m) : 0;
-    r.dx = __shfl(r.dx, src, 64); r.dy = __shfl(r.dy, src, 64); r.dz = __shfl(r.dz, src, 64);
-    r.tt = __shfl(r.tt, src, 64); r.tmx = __shfl(r.tmx, src, 64);
-    r.st = __shfl(r.st, src, 64); r.owner = __shfl(r.owner, src, 64);
-    ract = grp < __popcll(leaders);
-}
-// march until at most `stop_at` rays are left (0 = to the end); returns the leaders (lane 0 of every live group)
-template <int G>
-__device__ __forceinline__ unsigned long long cornell_group_march(const FrameParams &p, v3 origin, const unsigned *cgrid, const float *lds_tab, float2 *res,
-                                                                  int lane, CornellRay &r, bool &ract, int stop_at)
-{
-    const int sub = lane % G;
-    for (;;) {
-        const unsigned long long live = __ballot(ract && sub == 0);
-        if (live == 0ull || __popcll(live) <= stop_at) return live;
-        if (ract) {
-            const v3 pos = mk3(origin.x + r.tt * r.dx, origin.y + r.tt * r.dy, origin.z + r.tt * r.dz);
-            const float dist = sqrt_rn(cornell_group_dist2<G>(pos, lds_tab, cgrid, sub));
-            r.tt += dist;
-            bool h2 = false;
-            if (r.tt > r.tmx) ract = false;
-            else if (dist < 0.001f) { h2 = true; ract = false; }
-            else { r.st++; ract = r.st < p.max_steps; }
-            if (!ract && sub == 0) res[r.owner] = make_float2(r.tt, __int_as_float(r.st | (h2 ? 0x8000 : 0)));
-        }
-    }
-}
-__device__ __forceinline__ void cornell_straggler_march(const FrameParams &p, v3 origin, const unsigned *cgrid, const float *lds_tab, float2 *res,
-                                                        unsigned long long am, int lane, bool act, v3 dir, float &t, float tmax, int &steps, bool &hit)
-{
-    CornellRay r = { dir.x, dir.y, dir.z, t, tmax, steps, lane };
-    bool ract = act;
-    unsigned long long leaders = am;
-    if (__popcll(leaders) > 16) { cornell_regroup<2>(leaders, lane, r, ract); leaders = cornell_group_march<2>(p, origin, cgrid, lds_tab, res, lane, r, ract, 16); }
-    if (__popcll(leaders) > 8)  { cornell_regroup<4>(leaders, lane, r, ract); leaders = cornell_group_march<4>(p, origin, cgrid, lds_tab, res, lane, r, ract, 8); }
-    if (leaders != 0ull)        { cornell_regroup<8>(leaders, lane, r, ract); (void)cornell_group_march<8>(p, origin, cgrid, lds_tab, res, lane, r, ract, 0); }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (act) {
-        const float2 o = res[lane];
-        t = o.x;
-        const int sb = __float_as_int(o.y);
-        steps = sb & 0x7fff;
-        hit = (sb >> 15) != 0;
-    }
-}
-
-// Cornell box, after the march: a hit pixel needs the four estimates of its normal and then the four taps of its distance AO
-// (fragment.shd:463-470, 568-589).  When at most 16 lanes of the wave hit, the 4 x 16 estimates of a phase run side by side, one
-// per lane (lane 4 r + k = point k of the r-th hit ray, each lane over the candidates of its own cell: cornell_group_dist2<1>), and
-// the owner collects its four distances by shuffle.  Two passes of a few triangle evaluations deep instead of eight wave-uniform
-// estimates one after the other (~6 us each for a lone wave: the sample points far off the surface see many candidates).
-// Same distances (min over a cell's candidates = min over all triangles), combined by the owner in the written order.
-__device__ __forceinline__ void cornell_hit_estimates_lp(const unsigned *cgrid, const float *lds_tab, unsigned long long hitmask, int lane, bool hit,
-                                                         v3 np, v3 isec, v3 &n, float &ao)
-{
-    const int task_r = lane >> 2, task_k = lane & 3;
-    const bool valid = task_r < __popcll(hitmask);
-    unsigned long long m = hitmask;
-#pragma unroll 1
-    for (int k = 0; k < task_r; k++) m &= m - 1ull;
-    const int src = m ? (int)__builtin_ctzll(m) : 0;                                 // the task_r-th hit lane
-    const int my_rank = __builtin_amdgcn_mbcnt_hi((unsigned)(hitmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hitmask, 0));
-    const float eps = 0.00001f;
-    const float dl[4] = { 0.1f, 0.2f, 0.4f, 0.5f }, wt[4] = { 0.1f, 0.2f, 0.125f, 0.0625f };
-    const float my_dl = task_k == 0 ? dl[0] : (task_k == 1 ? dl[1] : (task_k == 2 ? dl[2] : dl[3]));
-    float d4[4];
-#pragma unroll 1
-    for (int phase = 0; phase < 2; phase++) {
-        // phase 0: the normal's points np, np - eps x, np - eps y, np - eps z; phase 1: the AO taps isec + n * dl[k]
-        const v3 a = phase == 0 ? np : isec;
-        const v3 b = mk3(__shfl(a.x, src, 64), __shfl(a.y, src, 64), __shfl(a.z, src, 64));
-        const v3 nn = mk3(__shfl(n.x, src, 64), __shfl(n.y, src, 64), __shfl(n.z, src, 64));
-        v3 pos;
-        if (phase == 0) pos = mk3(b.x - (task_k == 1 ? eps : 0.0f), b.y - (task_k == 2 ? eps : 0.0f), b.z - (task_k == 3 ? eps : 0.0f));
-        else            pos = mk3(b.x + nn.x * my_dl, b.y + nn.y * my_dl, b.z + nn.z * my_dl);
-        float d = 0.0f;
-        if (valid) d = sqrt_rn(cornell_group_dist2<1>(pos, lds_tab, cgrid, 0));
-#pragma unroll
-        for (int k = 0; k < 4; k++) d4[k] = __shfl(d, 4 * my_rank + k, 64);
-        if (phase == 0) {
-            if (hit) n = normalize3(mk3(d4[0] - d4[1], d4[0] - d4[2], d4[0] - d4[3]));
-        } else if (hit) {
-            float occl = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 4; k++) occl += wt[k] * gclamp(1.0f - d4[k] / dl[k], 0.0f, 1.0f);
-            ao = 1.0f - occl;
-        }
-    }
-}
-
 template <int SCENE, bool MERGE, int OUT>
 __device__ __forceinline__ void render_body(const FrameParams &p)
 {
     constexpr bool AO_POOL = (SCENE == 2) && MERGE;
-    // Cornell box: the candidate grid (rmdf_device.hpp) lives in LDS for the whole launch
-    __shared__ unsigned s_cgrid[SCENE == 0 ? CORNELL_GRID_N * CORNELL_GRID_N * CORNELL_GRID_N : 1];
-    const unsigned *cgrid = nullptr;
-    // ... and so does a copy of the triangle rows, for the lane-parallel march of a wave's last rays (cornell_straggler_march)
+    // Cornell box: a copy of the triangle rows lives in LDS for the whole launch (every lane reads the rows of ITS candidates:
+    // de_cornell_box_lanes); the candidate grid itself stays in global memory (cgrid, 1 MB, L2-resident)
     __shared__ float  s_ctab[SCENE == 0 ? 32 * CORNELL_STRIDE : 1];
-    __shared__ float2 s_cres[SCENE == 0 ? WPB * 64 : 1];        // its results: t, steps | hit << 15, per lane of a wave
+    const unsigned *cgrid = nullptr;
     if (SCENE == 0 && p.cornell_prune && p.cornell_grid) {
-        for (int i = threadIdx.x; i < CORNELL_GRID_N * CORNELL_GRID_N * CORNELL_GRID_N; i += WPB * 64) s_cgrid[i] = p.cornell_grid[i];
         for (int i = threadIdx.x; i < 32 * CORNELL_STRIDE; i += WPB * 64) s_ctab[i] = p.cornell_tab[i];
         __syncthreads();
-        cgrid = s_cgrid;
+        cgrid = p.cornell_grid;
     }
     __shared__ unsigned s_ao_cnt;
     __shared__ float4   s_ao_q[AO_POOL ? AO_CAP : 1][2];      // w.xyz, dr | pos.xyz, r
@@ -286,7 +165,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
 #endif
     const v3 origin = mk3(p.cam[9], p.cam[10], p.cam[11]);
 #ifdef RMDF_XCHECK
-    unsigned dbg_normal_steps = 0u, dbg_t_march = 0u, dbg_t_switch = 0u, dbg_n_switch = 0u;            // Cornell: wave-steps of the wave-uniform loop; cycles until the march ended
+    unsigned dbg_t_march = 0u;          // when this wave's march ended (100 MHz ticks since its start): tools/nested_timeline.py
 #endif
 
     // ray_march (fragment.shd:618-676)
@@ -296,47 +175,20 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
     int tri_hint = 0;               // Cornell: evaluation-order hint of the distance estimate (never a result)
     float t = 0.0f;
     float tmin, tmax;
-    if (!MERGE && SCENE == 0) {
-        // Cornell box: the same loop with the wave's trip count explicit, so that the wave can hand its last rays to the
-        // lane-parallel march (cgrid != nullptr: pruning on)
-        bool act = g.active && ray_sphere(origin, g.dir, bsphere_r<SCENE>(), tmin, tmax) && p.max_steps > 0;
-        if (act) t = gmax(0.0f, tmin);
-        for (;;) {
-            const unsigned long long am = __ballot(act);
-            if (am == 0ull) break;
-            if (cgrid && __popcll(am) <= CORNELL_STRAGGLER_T) {
-#ifdef RMDF_XCHECK
-                dbg_t_switch = p.dbg ? (unsigned)((__builtin_amdgcn_s_memrealtime() - dbg_t0)) : 0u; dbg_n_switch = (unsigned)__popcll(am);
-#endif
-                cornell_straggler_march(p, origin, cgrid, s_ctab, s_cres + (threadIdx.x & ~63), am, g.lane, act, g.dir, t, tmax, steps, hit);
-                break;
-            }
-#ifdef RMDF_XCHECK
-            dbg_normal_steps++;
-#endif
-            if (act) {
-                const v3 pos = mk3(origin.x + t * g.dir.x, origin.y + t * g.dir.y, origin.z + t * g.dir.z);
-                const float dist = distance_estimator<SCENE>(pos, p, iters, tri_hint, cgrid, s_ctab);
-                t += dist;
-                if (t > tmax) act = false;
-                else if (dist < 0.001f) { hit = true; act = false; }
-                else { steps++; act = steps < p.max_steps; }
-            }
-        }
-#ifdef RMDF_XCHECK
-        dbg_t_march = p.dbg ? (unsigned)((__builtin_amdgcn_s_memrealtime() - dbg_t0)) : 0u;
-#endif
-    } else if (!MERGE) {
+    if (!MERGE) {
         if (g.active && ray_sphere(origin, g.dir, bsphere_r<SCENE>(), tmin, tmax)) {
             t = gmax(0.0f, tmin);
             for (steps = 0; steps < p.max_steps; steps++) {
                 v3 pos = mk3(origin.x + t * g.dir.x, origin.y + t * g.dir.y, origin.z + t * g.dir.z);
-                float dist = distance_estimator<SCENE>(pos, p, iters, tri_hint, cgrid);
+                float dist = distance_estimator<SCENE>(pos, p, iters, tri_hint, cgrid, s_ctab);
                 t += dist;
                 if (t > tmax) break;
                 if (dist < 0.001f) { hit = true; break; }
             }
         }
+#ifdef RMDF_XCHECK
+        dbg_t_march = p.dbg ? (unsigned)((__builtin_amdgcn_s_memrealtime() - dbg_t0)) : 0u;
+#endif
     } else {
         __shared__ int    s_host, s_nreported;
         __shared__ int    s_mb_n[WPB], s_mb_ready[WPB];
@@ -460,21 +312,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
     v3 n = mk3(0.0f, 0.0f, 0.0f), refl = mk3(0.0f, 0.0f, 0.0f);
     float ao = 0.0f, fresnel = 0.0f;
     v3 isec = mk3(0.0f, 0.0f, 0.0f);
-    // Cornell box with at most 16 hit lanes in the wave: normal and AO estimates side by side (cornell_hit_estimates_lp)
-    bool cornell_lp_done = false;
-    if (SCENE == 0 && !MERGE && cgrid) {
-        const unsigned long long hm = __ballot(hit);
-        if (hm != 0ull && __popcll(hm) <= 16) {
-            v3 np = mk3(0.0f, 0.0f, 0.0f);
-            if (hit) {
-                isec = mk3(origin.x + dir.x * t, origin.y + dir.y * t, origin.z + dir.z * t);
-                np = mk3(isec.x - dir.x * 0.00001f, isec.y - dir.y * 0.00001f, isec.z - dir.z * 0.00001f);
-            }
-            cornell_hit_estimates_lp(cgrid, s_ctab, hm, lane, hit, np, isec, n, ao);
-            cornell_lp_done = true;
-        }
-    }
-    if (SCENE == 0 && hit && !cornell_lp_done) {
+    if (SCENE == 0 && hit) {
         // Cornell box: the normal's four estimates and the four AO taps as ONE loop around one copy of the estimate (inlined nine
         // times the kernel was 130 KB of code, twice the instruction cache)
         isec = mk3(origin.x + dir.x * t, origin.y + dir.y * t, origin.z + dir.z * t);
@@ -495,7 +333,6 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
             else occl += wtk * gclamp(1.0f - d / dlk, 0.0f, 1.0f);
         }
         ao = 1.0f - occl;
-        cornell_lp_done = true;                                  // normal and AO are done: skip the generic code below
     }
     if (SCENE != 0 && hit) {
         isec = mk3(origin.x + dir.x * t, origin.y + dir.y * t, origin.z + dir.z * t);
@@ -589,7 +426,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
             occl *= 3.5f;
             occl *= occl;
             ao = gclamp(occl, 0.0f, 1.0f);
-        }   // Cornell box: the four taps (fragment.shd:568-589) ran above, in the loop with the normal or side by side
+        }   // Cornell box: the four taps (fragment.shd:568-589) ran above, in the loop with the normal
         fresnel = fresnel_conductor(dot3(mk3(-dir.x, -dir.y, -dir.z), n), 0.4f, 0.8f);
         refl = reflect3(dir, n);
     }
@@ -663,7 +500,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
 #ifdef RMDF_XCHECK
     if (p.dbg && lane == 0) {
         const unsigned wid = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
-        if (wid < 32768u * 2u) { p.dbg[wid * 8 + 4] = dbg_c0; p.dbg[wid * 8 + 5] = __builtin_amdgcn_s_memtime(); p.dbg[wid * 8 + 6] = dbg_t0; p.dbg[wid * 8 + 7] = __builtin_amdgcn_s_memrealtime(); p.dbg[wid * 8] = (unsigned long long)steps; p.dbg[wid * 8 + 1] = dbg_normal_steps; p.dbg[wid * 8 + 2] = dbg_t_march; p.dbg[wid * 8 + 3] = ((unsigned long long)dbg_n_switch << 32) | dbg_t_switch; }
+        if (wid < 32768u * 2u) { p.dbg[wid * 8 + 4] = dbg_c0; p.dbg[wid * 8 + 5] = __builtin_amdgcn_s_memtime(); p.dbg[wid * 8 + 6] = dbg_t0; p.dbg[wid * 8 + 7] = __builtin_amdgcn_s_memrealtime(); p.dbg[wid * 8] = (unsigned long long)steps; p.dbg[wid * 8 + 2] = dbg_t_march; }
     }
 #endif
 }
@@ -671,8 +508,9 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
 // wave is worth 3 %).  The same bound caps the SGPRs at 80 (8 x (80 + the 16 of the trap handler) <= the 800 of a SIMD -- stating
 // 96 through amdgpu_num_sgpr instead was measured: the hardware then runs 7 waves); what does not fit lives in lanes of a spare
 // VGPR (v_writelane, prologue and epilogue only).  No scratch: `make resources`.
+// The Cornell box's product variants are bound to 6 waves per SIMD (80 VGPRs; 7 and 8 spill and were measured slower).
 template <int SCENE, bool MERGE, int OUT>
-__global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : ((SCENE == 0 && OUT != OUT_PLANES) ? RMDF_CORNELL_WAVES : 1)) void k_render(const FrameParams p) { render_body<SCENE, MERGE, OUT>(p); }
+__global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : ((SCENE == 0 && OUT != OUT_PLANES) ? 6 : 1)) void k_render(const FrameParams p) { render_body<SCENE, MERGE, OUT>(p); }
 
 static void render_grid(const FrameParams &p, dim3 &grid)
 {

@@ -32,9 +32,8 @@ for q in range(25, int(e.max()) + 25, 25):
     print("  resident at t=%d us: %d waves" % (q, ((b <= q) & (e > q)).sum()))
 idx = np.argsort(d)[-5:]
 for i in idx:
-    print("  long wave: start %.1f dur %.1f lane0 steps %d; wave-uniform march steps %d, march ended after %.1f us; lane-parallel from %.1f us with %d rays" %
-          (b[i], d[i], st[i, 0], st[i, 1], st[i, 2] / 100.0, (int(st[i, 3]) & 0xffffffff) / 100.0, int(st[i, 3]) >> 32))
+    print("  long wave: start %.1f dur %.1f lane0 steps %d; march ended after %.1f us" % (b[i], d[i], st[i, 0], st[i, 2] / 100.0))
 if scene == 0:
-    ns, tm = st[:, 1], st[:, 2] / 100.0
-    print("Cornell: wave-uniform steps per wave mean %.1f p90 %.0f max %.0f; march phase per wave: mean %.1f us p99 %.1f max %.1f; after-march (normal, AO, shade) mean %.1f us p99 %.1f max %.1f" %
-          (ns.mean(), np.percentile(ns, 90), ns.max(), tm.mean(), np.percentile(tm, 99), tm.max(), (d - tm).mean(), np.percentile(d - tm, 99), (d - tm).max()))
+    tm = st[:, 2] / 100.0
+    print("Cornell: march phase per wave: mean %.1f us p99 %.1f max %.1f; after-march (normal, AO, shade) mean %.1f us p99 %.1f max %.1f" %
+          (tm.mean(), np.percentile(tm, 99), tm.max(), (d - tm).mean(), np.percentile(d - tm, 99), (d - tm).max()))
