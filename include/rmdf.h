@@ -261,6 +261,13 @@ int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[10]);
  * atan(y,x) and pow(x,y): 2^32 operand pairs) against the branchy fdlibm-style forms they restate.
  * mismatches[0..6] = exp, acos, atan, sin, cos, atan2, pow.  All must be 0. */
 int rmdf_selftest_pinned_math(rmdf_ctx *ctx, uint64_t mismatches[7]);
+/* Self-test of the short quotients of the shading tail (generate_ray's pixel-centre divisions, the ambient-occlusion terms,
+ * fresnel_conductor, the cube-map texture coordinates: Markstein quotients on a correctly rounded reciprocal instead of the
+ * compiler's IEEE expansion) against the compiler's division: mismatches[0] = the quotient itself on 2^33 operand pairs inside its
+ * range, [1] = clamp(1 - d / e) for every distance d (inf and NaN included) and each tap offset e, [2] = fresnel_conductor for every cosine
+ * in [-2, 2], inf and NaN, [3] = whole cube-map lookups on 2^30 (direction, neighbour, neighbour) triples of the kind normalize() can
+ * produce, degenerate ones included.  All must be 0.  A few seconds on an MI355X. */
+int rmdf_selftest_shading_math(rmdf_ctx *ctx, uint64_t mismatches[4]);
 
 /* The clock the shader engines run at right now: one wave (issuing vector instructions) stamps the shader-cycle counter against the
  * 100 MHz real-time counter over `spin_us` microseconds, on a highest-priority stream of the library's own -- launched while the

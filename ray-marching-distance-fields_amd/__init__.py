@@ -51,7 +51,7 @@ ABI_SYMBOLS = (
     "rmdf_device_info", "rmdf_resolve_box2_device", "rmdf_render_supersampled",
     "rmdf_selftest_exact_math", "rmdf_shard_tiles", "rmdf_probe_tile_costs", "rmdf_set_shard_costs",
     "rmdf_get_shard_tiles", "rmdf_save_png", "rmdf_register_host_buffer", "rmdf_unregister_host_buffer",
-    "rmdf_selftest_pinned_math", "rmdf_set_shard_root_handicap", "rmdf_create_ex", "rmdf_prefilter_env_powers",
+    "rmdf_selftest_pinned_math", "rmdf_selftest_shading_math", "rmdf_set_shard_root_handicap", "rmdf_create_ex", "rmdf_prefilter_env_powers",
     "rmdf_prefilter_env_device", "rmdf_comm_get_unique_id", "rmdf_comm_init", "rmdf_comm_destroy", "rmdf_comm_info",
     "rmdf_gather_shards_device", "rmdf_render_frame_sharded_device", "rmdf_device_malloc", "rmdf_device_free",
     "rmdf_copy_to_host", "rmdf_probe_shader_clock", "rmdf_comm_selftest_loopback",
@@ -194,6 +194,7 @@ def load_library(xcheck=False):
         L.rmdf_debug_cornell_masks.argtypes = [C.c_int, C.c_int, vp]
     L.rmdf_selftest_exact_math.argtypes = [vp, vp]
     L.rmdf_selftest_pinned_math.argtypes = [vp, vp]
+    L.rmdf_selftest_shading_math.argtypes = [vp, vp]
     L.rmdf_resolve_box2_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     L.rmdf_render_supersampled.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]
     _libs[xcheck] = L
@@ -426,6 +427,12 @@ class ShaderRenderer:
         """Mismatch counts (exp, acos, atan, sin, cos, atan2, pow) of the straight-line device forms vs the branchy ones."""
         out = np.zeros(7, np.uint64)
         self._check(self._lib.rmdf_selftest_pinned_math(self._ctx, out.ctypes.data))
+        return out
+
+    def selftest_shading_math(self):
+        """Mismatch counts (quotient, AO term, fresnel, cube-map lookup) of the shading tail's short quotients vs the compiler's division."""
+        out = np.zeros(4, np.uint64)
+        self._check(self._lib.rmdf_selftest_shading_math(self._ctx, out.ctypes.data))
         return out
 
     def debug_march_stats(self, enable=True, read_waves=0):

@@ -1653,6 +1653,22 @@ int rmdf_selftest_pinned_math(rmdf_ctx *ctx, uint64_t mismatches[7])
     return RMDF_OK;
 }
 
+int rmdf_selftest_shading_math(rmdf_ctx *ctx, uint64_t mismatches[4])
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!mismatches) return fail(ctx, RMDF_E_INVALID, "null output");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int face_w = 64;                                  // a cube map of its own: 6 faces of 64 x 64 texels plus the seam padding
+    DevBuf d, t;
+    HIP_TRY(ctx, hipMalloc(&d.p, 4 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMalloc(&t.p, (size_t)6 * (face_w + 2) * (face_w + 2) * 8));
+    HIP_TRY(ctx, hipMemsetAsync(d.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, launch_selftest_shading_math((unsigned long long *)d.p, t.p, face_w, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(mismatches, d.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RMDF_OK;
+}
+
 
 #ifdef RMDF_XCHECK
 int rmdf_debug_cornell_masks(int n, int brute_force, uint32_t *out)

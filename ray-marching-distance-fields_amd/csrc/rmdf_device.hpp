@@ -91,6 +91,29 @@ __device__ __forceinline__ float div_known_range(float a, float b)
     return __builtin_fmaf(r0, y, q0);
 }
 
+// the same quotient with y = RN(1/b) supplied by the caller (several numerators over one divisor; a constant divisor)
+__device__ __forceinline__ float div_with_rcp(float a, float b, float y)
+{
+    const float q0 = a * y;
+    const float r0 = __builtin_fmaf(-b, q0, a);
+    return __builtin_fmaf(r0, y, q0);
+}
+// One term of the distance-field ambient occlusion, clamp(1 - d / e, 0, 1) (fragment.shd:542-591), e a compile-time tap offset and
+// y = RN(1 / e) folded by the compiler.  d is a distance estimate: usually within a few units, but +inf and NaN do occur (a sample
+// point next to the Mandelbulb's pole overflows its triplex power), so an infinite first quotient is returned as it is (the
+// remainder step would turn it into NaN, where the division gives inf and the term clamps to 0).  |d| below 2^-102 leaves a quotient
+// the "1 -" absorbs in either form.  rmdf_selftest_shading_math: every d bit pattern x every tap offset.
+template <bool FAST>
+__device__ __forceinline__ float ao_term(float d, float e, float y)
+{
+    if (!FAST) return gclamp(1.0f - d / e, 0.0f, 1.0f);
+    const float q0 = d * y;
+    const float r0 = __builtin_fmaf(-e, q0, d);
+    float q = __builtin_fmaf(r0, y, q0);
+    q = (fabsf(q0) == __builtin_inff()) ? q0 : q;
+    return gclamp(1.0f - q, 0.0f, 1.0f);
+}
+
 __device__ __forceinline__ float length3(v3 a) { return sqrt_rn(dot3(a, a)); }
 // inversesqrt := 1/sqrt, two roundings.  If x is in the core range so is sqrt(x) (2^-50 .. 2^50): one range test.
 __device__ __forceinline__ float rsqrt_ieee(float x)
@@ -156,8 +179,20 @@ __device__ __forceinline__ float log_pinned(float x)
     return r;
 }
 
+// Round 3: the divisions inside the straight-line pinned functions (exp, acos, atan) have operands of known range, so they take the
+// 5-instruction Markstein quotient (div_known_range) instead of the compiler's ~10-instruction IEEE expansion; the branchy *_full
+// forms keep the compiler's division, and rmdf_selftest_pinned_math compares the two for ALL 2^32 inputs of each function (zero
+// mismatches is the proof that the quotients agree wherever these functions evaluate them).  RMDF_AB_IEEE_DIV restores the old form.
+#ifdef RMDF_AB_IEEE_DIV
+#define RMDF_FAST_DIV(a, b) ((a) / (b))
+#define RMDF_SHADE_FAST false
+#else
+#define RMDF_FAST_DIV(a, b) div_known_range((a), (b))
+#define RMDF_SHADE_FAST true
+#endif
 // exp(x), fixed operation order; x < -87 -> 0, x > 88.5 -> inf.  exp_core: -87 <= x <= 88.5.
-__device__ __forceinline__ float exp_core(float x)
+template <bool FAST_DIV>
+__device__ __forceinline__ float exp_core_t(float x)
 {
     const float ln2_hi = 6.9314575195e-01f, ln2_lo = 1.4286067653e-06f, invln2 = 1.4426950216e+00f;
     const float P1 = 1.6666625440e-1f, P2 = -2.7667332906e-3f;
@@ -169,19 +204,21 @@ __device__ __forceinline__ float exp_core(float x)
     float r = hi - lo;
     float tt = r * r;
     float c = r - tt * (P1 + tt * P2);
-    float y = 1.0f - ((lo - (r * c) / (2.0f - c)) - hi);
+    const float num = r * c, den = 2.0f - c;                              // den in [1.6, 2.4], |num| <= 0.13 or 0
+    float y = 1.0f - ((lo - (FAST_DIV ? RMDF_FAST_DIV(num, den) : num / den)) - hi);
     int32_t k1 = k / 2, k2 = k - k1;
     y = y * __int_as_float((k1 + 127) << 23);
     y = y * __int_as_float((k2 + 127) << 23);
     return y;
 }
-// the branchy form (reference of the device self-test)
+__device__ __forceinline__ float exp_core(float x) { return exp_core_t<true>(x); }
+// the branchy form (reference of the device self-test; the compiler's division)
 __device__ __noinline__ float exp_full(float x)
 {
     if (x != x) return x;
     if (x > 88.5f) return __builtin_inff();
     if (x < -87.0f) return 0.0f;
-    return exp_core(x);
+    return exp_core_t<false>(x);
 }
 // Straight-line core for every lane; NaN / overflow / underflow lanes are patched on a wave-uniform branch.
 __device__ __forceinline__ float exp_pinned(float x)
@@ -487,13 +524,13 @@ __device__ __forceinline__ float acos_pinned(float x)
     const float z = small ? x * x : (1.0f - ax) * 0.5f;
     const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
     const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-    const float r = p / q;
+    const float r = RMDF_FAST_DIV(p, q);                     // z in [0, 0.5]: q in [0.3, 1], p in [0, 0.1]
     const float s = sqrt_rn(z);
     const float r_small = pio2_hi - (x - (pio2_lo - x * r));
     const float wn = r * s - pio2_lo;
     const float r_neg = pi - 2.0f * (s + wn);
     const float df = __uint_as_float(__float_as_uint(s) & 0xfffff000u);
-    const float c = (z - df * df) / (s + df);
+    const float c = RMDF_FAST_DIV(z - df * df, s + df);
     const float wp = r * s + c;
     const float r_pos = 2.0f * (df + wp);
     float res = small ? r_small : ((x < 0.0f) ? r_neg : r_pos);
@@ -551,7 +588,7 @@ __device__ __forceinline__ float atan_pinned(float x)
     const float den = r1 ? (2.0f + ax) : (r2 ? (ax + 1.0f) : (r3 ? (1.0f + 1.5f * ax) : ax));
     const float hi = r1 ? 4.6364760399e-01f : (r2 ? 7.8539812565e-01f : (r3 ? 9.8279368877e-01f : 1.5707962513e+00f));
     const float lo = r1 ? 5.0121582440e-09f : (r2 ? 3.7748947079e-08f : (r3 ? 3.4473217170e-08f : 7.5497894159e-08f));
-    const float quo = num / den;
+    const float quo = RMDF_FAST_DIV(num, den);               // |num| <= 1, den in [1.4, 2^26]
     const float t = small ? x : quo;
     const float z = t * t;
     const float w = z * z;
@@ -582,7 +619,9 @@ __device__ __noinline__ float atan2_full(float y, float x)
     return (m == 0) ? z : (m == 1) ? -z : (m == 2) ? pi - (z - pi_lo) : (z - pi_lo) - pi;
 }
 
-// GLSL atan(y, x): finite non-zero operands take the straight-line path; zeros, infinities and NaN go through atan2_full
+// GLSL atan(y, x): finite non-zero operands take the straight-line path; zeros, infinities and NaN go through atan2_full.
+// (Its division has operands of any magnitude; widening the range test to [2^-40, 2^40) so that it could take the short quotient
+// too was measured: 1.915 -> 1.922 ms for the general-power frame, not adopted.)
 __device__ __forceinline__ float atan2_pinned(float y, float x)
 {
     const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
@@ -897,13 +936,18 @@ __device__ __forceinline__ float de_cornell_box_table(v3 pos, const float *__res
     return sqrt_rn(dist2);
 }
 
-// fragment.shd:694-719
+// fragment.shd:694-719.  FAST: the two quotients as div_known_range -- for the shader's eta = 0.4, k = 0.8 and |cosi| <= 1 (a dot
+// product of two unit vectors) every numerator and denominator lies in [0.64, 2.6]; rmdf_selftest_shading_math compares the two
+// forms for every cosi in [-2, 2] and NaN.  The alternative schedules of librmdf_xcheck keep the compiler's division.
+template <bool FAST = RMDF_SHADE_FAST>
 __device__ __forceinline__ float fresnel_conductor(float cosi, float eta, float k)
 {
     float tmp = (eta * eta + k * k) * cosi * cosi;
-    float r_parallel_2 = (tmp - (2.0f * eta * cosi) + 1.0f) / (tmp + (2.0f * eta * cosi) + 1.0f);
+    const float pn = tmp - (2.0f * eta * cosi) + 1.0f, pd = tmp + (2.0f * eta * cosi) + 1.0f;
+    float r_parallel_2 = FAST ? RMDF_FAST_DIV(pn, pd) : pn / pd;
     float tmp_f = eta * eta + k * k;
-    float r_perpend_2 = (tmp_f - (2.0f * eta * cosi) + cosi * cosi) / (tmp_f + (2.0f * eta * cosi) + cosi * cosi);
+    const float qn = tmp_f - (2.0f * eta * cosi) + cosi * cosi, qd = tmp_f + (2.0f * eta * cosi) + cosi * cosi;
+    float r_perpend_2 = FAST ? RMDF_FAST_DIV(qn, qd) : qn / qd;
     return (r_parallel_2 + r_perpend_2) / 2.0f;
 }
 
@@ -956,6 +1000,12 @@ __device__ __forceinline__ void cube_project(int face, v3 q, float &sc, float &t
 }
 
 __device__ __forceinline__ float cube_texcoord(float c, float ama, float W) { return (0.5f * (c / ama + 1.0f)) * W; }
+// The same with y = rcp_core(ama) (two coordinates share one major axis).  The quotient is the IEEE one whenever ama is in
+// [2^-40, 2^40] and |c| >= 2^-102 (no underflow in the remainder); a smaller |c| gives a quotient below 2^-60 either way, which
+// the "+ 1" absorbs.  The lane's own direction is a unit vector (ama in [0.57, 1]) or NaN.  A NEIGHBOUR's direction projected
+// on this lane's face can have any major-axis component > 0: below 2^-40 one of the two quotients is beyond 2^38 (or inf / NaN
+// from the reciprocal), its texel distance fails "<= 1" in both forms, and the quotients feed nothing else (cube_texture).
+__device__ __forceinline__ float cube_texcoord_rcp(float c, float ama, float y, float W) { return (0.5f * (div_with_rcp(c, ama, y) + 1.0f)) * W; }
 
 // RMDF_AB_NO_TEXEL_FETCH (tools/abtest only, never defined in the product build): every texel read is replaced by a value
 // made from its address -- no memory access at all.  The frame is wrong, of course; the build exists to measure an UPPER
@@ -1009,12 +1059,15 @@ __device__ __forceinline__ v3 cube_fetch_linear(const CubeDev &c, int face, floa
 
 // texture(samplerCube, r) inside a 2x2 quad; rh / rv = the same expression in the
 // horizontal / vertical quad neighbour, valid_* = that neighbour evaluated it.
+template <bool FAST = RMDF_SHADE_FAST>
 __device__ __forceinline__ v3 cube_texture(const CubeDev &c, v3 r, bool valid_h, v3 rh, bool valid_v, v3 rv)
 {
     int face; float sc, tc, ma;
     cube_coords(r, face, sc, tc, ma);
     float W = (float)c.W, ama = fabsf(ma);
-    float u = cube_texcoord(sc, ama, W), v = cube_texcoord(tc, ama, W);
+    float u, v;
+    if (FAST) { const float y = rcp_core(ama); u = cube_texcoord_rcp(sc, ama, y, W); v = cube_texcoord_rcp(tc, ama, y, W); }
+    else { u = cube_texcoord(sc, ama, W); v = cube_texcoord(tc, ama, W); }
     bool linear = false;
     if (valid_h && valid_v) {
         float sh, th, mh, sv, tv, mv;
@@ -1025,8 +1078,15 @@ __device__ __forceinline__ v3 cube_texture(const CubeDev &c, v3 r, bool valid_h,
         bool okv = pos ? (mv > 0.0f) : (mv < 0.0f);
         if (okh && okv) {
             float amh = fabsf(mh), amv = fabsf(mv);
-            float dux = cube_texcoord(sh, amh, W) - u, dvx = cube_texcoord(th, amh, W) - v;
-            float duy = cube_texcoord(sv, amv, W) - u, dvy = cube_texcoord(tv, amv, W) - v;
+            float dux, dvx, duy, dvy;
+            if (FAST) {
+                const float yh = rcp_core(amh), yv = rcp_core(amv);
+                dux = cube_texcoord_rcp(sh, amh, yh, W) - u; dvx = cube_texcoord_rcp(th, amh, yh, W) - v;
+                duy = cube_texcoord_rcp(sv, amv, yv, W) - u; dvy = cube_texcoord_rcp(tv, amv, yv, W) - v;
+            } else {
+                dux = cube_texcoord(sh, amh, W) - u; dvx = cube_texcoord(th, amh, W) - v;
+                duy = cube_texcoord(sv, amv, W) - u; dvy = cube_texcoord(tv, amv, W) - v;
+            }
             float rx = dux * dux + dvx * dvx;
             float ry = duy * duy + dvy * dvy;
             linear = (rx <= 1.0f) && (ry <= 1.0f);

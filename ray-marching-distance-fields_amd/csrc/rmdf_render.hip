@@ -101,9 +101,11 @@ struct PixelGeom {
 __device__ __forceinline__ v3 primary_dir(const FrameParams &p, int px, int py)
 {
     // generate_ray, perspective branch (fragment.shd:840-871)
-    const float ndcx = ((float)px + 0.5f) / p.wf * 2.0f - 1.0f;
-    const float ndcy = ((float)py + 0.5f) / p.hf * 2.0f - 1.0f;
-    const v3 dcam = normalize3(mk3(ndcx * p.fov_xs, ndcy * p.fov_xs / p.aspect, -1.0f));
+    // frame sizes are 1 .. 32768 per side, times at most 8 rays (rmdf_api.cpp), so pixel centres, sizes and the aspect ratio are all inside div_known_range's
+    // range; ndcy * fov_xs is 0 or at least 2^-24 in magnitude
+    const float ndcx = RMDF_FAST_DIV((float)px + 0.5f, p.wf) * 2.0f - 1.0f;
+    const float ndcy = RMDF_FAST_DIV((float)py + 0.5f, p.hf) * 2.0f - 1.0f;
+    const v3 dcam = normalize3(mk3(ndcx * p.fov_xs, RMDF_FAST_DIV(ndcy * p.fov_xs, p.aspect), -1.0f));
     return mk3(p.cam[0] * dcam.x + p.cam[3] * dcam.y + p.cam[6] * dcam.z,
                p.cam[1] * dcam.x + p.cam[4] * dcam.y + p.cam[7] * dcam.z,
                p.cam[2] * dcam.x + p.cam[5] * dcam.y + p.cam[8] * dcam.z);
@@ -330,7 +332,10 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
             else if (k == 1) ddx = d0 - d;
             else if (k == 2) ddy = d0 - d;
             else if (k == 3) ddz = d0 - d;
-            else occl += wtk * gclamp(1.0f - d / dlk, 0.0f, 1.0f);
+            else {
+                const float ylk = k == 4 ? 1.0f / 0.1f : (k == 5 ? 1.0f / 0.2f : (k == 6 ? 1.0f / 0.4f : 1.0f / 0.5f));
+                occl += wtk * ao_term<RMDF_SHADE_FAST>(d, dlk, ylk);
+            }
         }
         ao = 1.0f - occl;
     }
@@ -419,8 +424,8 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
                 ao_dist[0] = distance_estimator<SCENE>(mk3(isec.x + n.x * e0, isec.y + n.y * e0, isec.z + n.z * e0), p, iters, tri_hint, cgrid);
                 ao_dist[1] = distance_estimator<SCENE>(mk3(isec.x + n.x * e1, isec.y + n.y * e1, isec.z + n.z * e1), p, iters, tri_hint, cgrid);
             }
-            occl += w0 * gclamp(1.0f - ao_dist[0] / e0, 0.0f, 1.0f);
-            occl += w1 * gclamp(1.0f - ao_dist[1] / e1, 0.0f, 1.0f);
+            occl += w0 * ao_term<RMDF_SHADE_FAST>(ao_dist[0], e0, 1.0f / e0);      // rmdf_device.hpp: the quotient by a constant offset
+            occl += w1 * ao_term<RMDF_SHADE_FAST>(ao_dist[1], e1, 1.0f / e1);
             occl = 1.0f - occl;
             occl -= 0.29f;
             occl *= 3.5f;

@@ -151,7 +151,12 @@ __global__ void k_selftest_pinned_math(unsigned long long *counts)
         uint32_t h = (uint32_t)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
         // every fourth pair uses a "shader-like" second operand (finite, moderate) so that the main path is exercised densely
         const float y = (i & 3) ? __uint_as_float(h) : (float)((int)(h >> 8) - 8388608) * (1.0f / 1048576.0f);
-        c[5] += differ(atan2_pinned(x, y), atan2_full(x, y));
+        // another fourth: both operands forced into [2^-40, 2^40), the range in which atan2_pinned divides the short way (every
+        // mantissa and sign of the first operand against a hashed second)
+        const bool both_in = (i & 3) == 1;
+        const float xa = both_in ? __uint_as_float(((uint32_t)i & 0x807fffffu) | ((87u + (((uint32_t)i >> 23) & 0xffu) % 80u) << 23)) : x;
+        const float ya = both_in ? __uint_as_float((h & 0x807fffffu) | ((87u + ((h >> 23) & 0xffu) % 80u) << 23)) : y;
+        c[5] += differ(atan2_pinned(xa, ya), atan2_full(xa, ya));
         const float pw = 2.0f + (float)(h & 1023u) * (4.5f / 1023.0f);         // the animated power range 2 .. 6.5
         const float pr = !(x > 0.0f) ? 0.0f : exp_full(pw * log_ref_division(x));
         c[6] += differ(pow_pinned(x, pw), pr);
@@ -162,6 +167,114 @@ __global__ void k_selftest_pinned_math(unsigned long long *counts)
 hipError_t launch_selftest_pinned_math(unsigned long long *d_counts, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_selftest_pinned_math, dim3(8192), dim3(256), 0, stream, d_counts);
+    return hipGetLastError();
+}
+
+// Self-test of the short quotients of the shading tail (round 3) against the compiler's division.
+//   counts[0]: div_known_range itself, 2^33 operand pairs inside its stated range: every bit pattern as the numerator (exponent
+//              folded into 2^-40 .. 2^40, and zero) over a hashed divisor, and every bit pattern as the divisor under a hashed numerator;
+//   counts[1]: the ambient-occlusion term clamp(1 - d / e) for EVERY d (infinities and NaN included) and each of the six tap offsets e;
+//   counts[2]: fresnel_conductor (eta 0.4, k 0.8) for every cosi in [-2, 2], +-inf and every NaN;
+//   counts[3]: cube_texture on 2^30 hashed (direction, horizontal neighbour, vertical neighbour) triples of what the shader can hand
+//              it -- normalize()'s results: unit vectors (neighbours near and far, components down to 2^-149 and zero, a neighbour whose
+//              component along this lane's major axis is tiny or of the other sign) and the inf / NaN vectors a vanishing gradient
+//              normalises to; the whole result (three floats of the fetched texel) must agree.
+__device__ __forceinline__ uint32_t hash32(uint32_t h) { h *= 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16; return h; }
+__device__ __forceinline__ float fold_exponent(uint32_t bits) { return __uint_as_float((bits & 0x807fffffu) | ((87u + ((bits >> 23) & 0xffu) % 80u) << 23)); }
+__device__ __forceinline__ bool same_bits(float a, float b) { return (__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b); }
+
+__device__ v3 selftest_vector(uint32_t h, uint32_t mode, v3 near)
+{
+    const uint32_t h1 = hash32(h ^ 0x68bc21ebu), h2 = hash32(h ^ 0x02e5be93u), h3 = hash32(h + 0x7f4a7c15u);
+    v3 a = mk3((float)(h1 >> 8) * (1.0f / 8388608.0f) - 1.0f, (float)(h2 >> 8) * (1.0f / 8388608.0f) - 1.0f, (float)(h3 >> 8) * (1.0f / 8388608.0f) - 1.0f);
+    switch (mode & 7u) {
+    case 0: case 1: return normalize3(a);                                                    // any unit vector
+    case 2: case 3: {                                                                        // a close neighbour (2^-3 .. 2^-18 away)
+        const float sc = __builtin_ldexpf(1.0f, -3 - (int)(h1 & 15u));
+        return normalize3(mk3(near.x + a.x * sc, near.y + a.y * sc, near.z + a.z * sc));
+    }
+    case 4: {                                                                                // unit vector with one or two tiny components
+        const float sc = __builtin_ldexpf(1.0f, -(int)(h1 % 150u));
+        float c[3] = { a.x, a.y, a.z };
+        c[h2 % 3u] *= sc;
+        if (h3 & 1u) c[(h2 + 1u) % 3u] *= __builtin_ldexpf(1.0f, -(int)(h3 % 150u));
+        if (h3 & 2u) c[h2 % 3u] = (h3 & 4u) ? 0.0f : -0.0f;
+        return normalize3(mk3(c[0], c[1], c[2]));
+    }
+    case 5: {                                                                                // `near` with ONE component tiny, zero or flipped, normalised
+        float c[3] = { near.x, near.y, near.z };
+        const float tiny = __builtin_ldexpf((h3 & 8u) ? -1.0f : 1.0f, -(int)(h1 % 150u));
+        c[h2 % 3u] = (h3 & 3u) == 0u ? 0.0f : ((h3 & 3u) == 1u ? -c[h2 % 3u] : tiny);
+        return normalize3(mk3(c[0], c[1], c[2]));                                            // (0, 0, 2^-100) -> components inf / NaN, as in the shader
+    }
+    case 6: {                                                                                // what normalize() makes of a vanishing gradient: inf / NaN components
+        const float inf = __builtin_inff(), nan = __builtin_nanf("");
+        return mk3((h1 & 1u) ? nan : ((h1 & 2u) ? inf : -inf), (h2 & 1u) ? nan : ((h2 & 2u) ? inf : -inf), (h3 & 1u) ? nan : ((h3 & 2u) ? inf : -inf));
+    }
+    default:                                                                                 // a NaN component now and then, else a unit vector
+        if ((h1 & 63u) == 0u) return mk3(__builtin_nanf(""), a.y, a.z);
+        return normalize3(a);
+    }
+}
+
+__global__ void k_selftest_shading_math(unsigned long long *counts, CubeDev cube)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (uint64_t i = tid; i < (1ull << 32); i += stride) {
+        const uint32_t bits = (uint32_t)i, h = hash32(bits);
+        const float x = __uint_as_float(bits);
+        {
+            // (a numerator of -0 comes back as +0: every call site adds a non-zero constant to the quotient or squares it)
+            const float a = (bits & 0x7fffffffu) == 0u ? 0.0f : fold_exponent(bits), b = fold_exponent(h);
+            c0 += !same_bits(div_known_range(a, b), a / b);
+            const float a2 = (h & 0xffu) == 0u ? 0.0f : fold_exponent(hash32(h)), b2 = fold_exponent(bits);
+            c0 += !same_bits(div_known_range(a2, b2), a2 / b2);
+            c0 += !same_bits(div_with_rcp(a, b, rcp_core(b)), a / b);
+        }
+        {
+            const float e[6] = { 0.016f, 0.081f, 0.1f, 0.2f, 0.4f, 0.5f };
+            const float y[6] = { 1.0f / 0.016f, 1.0f / 0.081f, 1.0f / 0.1f, 1.0f / 0.2f, 1.0f / 0.4f, 1.0f / 0.5f };
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                c1 += !same_bits(ao_term<true>(x, e[k], y[k]), ao_term<false>(x, e[k], y[k]));
+        }
+        if (!(fabsf(x) > 2.0f) || fabsf(x) == __builtin_inff()) c2 += !same_bits(fresnel_conductor<true>(x, 0.4f, 0.8f), fresnel_conductor<false>(x, 0.4f, 0.8f));
+        if ((bits >> 30) == 0u) {
+            const v3 r = selftest_vector(h, h >> 29, normalize3(mk3((float)(h & 3u), (float)((h >> 2) & 3u), 1.0f)));
+            const uint32_t g = hash32(h ^ 0x5bd1e995u);
+            const v3 rh = selftest_vector(g, g >> 29, r), rv = selftest_vector(~g, g >> 26, r);
+            const bool vh = (g & 3u) != 0u, vv = (g & 12u) != 0u;
+            const v3 ta = cube_texture<true>(cube, r, vh, rh, vv, rv), tb = cube_texture<false>(cube, r, vh, rh, vv, rv);
+            c3 += !(same_bits(ta.x, tb.x) && same_bits(ta.y, tb.y) && same_bits(ta.z, tb.z));
+        }
+    }
+    if (c0) atomicAdd(&counts[0], c0);
+    if (c1) atomicAdd(&counts[1], c1);
+    if (c2) atomicAdd(&counts[2], c2);
+    if (c3) atomicAdd(&counts[3], c3);
+}
+
+// texels of the self-test's cube map: every texel a different colour, so that two forms that pick different texels (or different
+// bilinear weights) cannot agree by accident
+__global__ void k_selftest_fill_cube(uint2 *texels, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t h = hash32((uint32_t)i + 12345u);
+    const __half2 rg = __floats2half2_rn((float)(h & 1023u) * (1.0f / 64.0f), (float)((h >> 10) & 1023u) * (1.0f / 64.0f));
+    const __half2 b0 = __floats2half2_rn((float)((h >> 20) & 1023u) * (1.0f / 64.0f), 0.0f);
+    texels[i] = make_uint2(*reinterpret_cast<const uint32_t *>(&rg), *reinterpret_cast<const uint32_t *>(&b0));
+}
+
+hipError_t launch_selftest_shading_math(unsigned long long *d_counts, void *d_texels, int face_w, hipStream_t stream)
+{
+    const int n = 6 * (face_w + 2) * (face_w + 2);
+    hipLaunchKernelGGL(k_selftest_fill_cube, dim3((n + 255) / 256), dim3(256), 0, stream, (uint2 *)d_texels, n);
+    CubeDev cube;
+    cube.texels = (const uint2 *)d_texels;
+    cube.W = face_w;
+    hipLaunchKernelGGL(k_selftest_shading_math, dim3(8192), dim3(256), 0, stream, d_counts, cube);
     return hipGetLastError();
 }
 

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void k_shade(const FrameParams p)
     float fresnel = 0.0f;
     v3 refl = mk3(0.0f, 0.0f, 0.0f);
     if (hit) {
-        fresnel = fresnel_conductor(dot3(mk3(-dir.x, -dir.y, -dir.z), n), 0.4f, 0.8f);
+        fresnel = fresnel_conductor<false>(dot3(mk3(-dir.x, -dir.y, -dir.z), n), 0.4f, 0.8f);
         refl = reflect3(dir, n);
     }
     // quad neighbours: lane^1 horizontal, lane^2 vertical
@@ -376,15 +376,15 @@ __global__ __launch_bounds__(256) void k_shade(const FrameParams p)
     v3 color;
     if (hit) {
         const float ao = nao.w;
-        const v3 t1 = cube_texture(p.env_cos1, n, hit_h, n_h, hit_v, n_v);
-        const v3 t8 = cube_texture(p.env_cos8, refl, hit_h, refl_h, hit_v, refl_v);
-        const v3 tr = cube_texture(p.env_refl, refl, hit_h, refl_h, hit_v, refl_v);
+        const v3 t1 = cube_texture<false>(p.env_cos1, n, hit_h, n_h, hit_v, n_v);
+        const v3 t8 = cube_texture<false>(p.env_cos8, refl, hit_h, refl_h, hit_v, refl_v);
+        const v3 tr = cube_texture<false>(p.env_refl, refl, hit_h, refl_h, hit_v, refl_v);
         const float diff_weight = 0.5f, spec_weight = 1.0f - 0.5f, npl = (8.0f + 2.0f) / 2.0f;
         color.x = (t1.x * 1.0f * diff_weight + t8.x * 0.8f * npl * fresnel * spec_weight + tr.x * spec_weight * fresnel * 0.1f) * 3.0f * ao;
         color.y = (t1.y * 0.8f * diff_weight + t8.y * 0.8f * npl * fresnel * spec_weight + tr.y * spec_weight * fresnel * 0.1f) * 3.0f * ao;
         color.z = (t1.z * 0.8f * diff_weight + t8.z * 1.0f * npl * fresnel * spec_weight + tr.z * spec_weight * fresnel * 0.1f) * 3.0f * ao;
     } else {
-        color = cube_texture(p.env_refl, dir, !hit_h, dir_h, !hit_v, dir_v);   // neighbours in the hit branch: undefined derivative -> minified
+        color = cube_texture<false>(p.env_refl, dir, !hit_h, dir_h, !hit_v, dir_v);   // neighbours in the hit branch: undefined derivative -> minified
     }
     const float inv_gamma = 1.0f / 2.2f;
     const float gr = pow_pinned(color.x, inv_gamma), gg = pow_pinned(color.y, inv_gamma), gb = pow_pinned(color.z, inv_gamma);

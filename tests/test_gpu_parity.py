@@ -627,6 +627,16 @@ def test_pinned_math_exhaustive(sr):
     assert mism.tolist() == [0] * 7, mism
 
 
+def test_shading_math_exhaustive(sr):
+    """Round 3: the divisions of the shading tail (pixel centres, AO terms, fresnel_conductor, cube-map texture coordinates) are
+    Markstein quotients on a correctly rounded reciprocal.  Checked on the device against the compiler's IEEE division: the
+    quotient on 2^33 operand pairs of its range, the AO term for every distance, fresnel for every cosine, and whole cube-map
+    lookups on 2^30 direction triples including the degenerate ones (rmdf_util.hip: k_selftest_shading_math).  The frames of the
+    alternative schedules (librmdf_xcheck) keep the compiler's division, so test_both_mandelbulb_schedules_agree and test_pipeline_schedule_agrees compare the two forms on real frames too."""
+    mism = sr.selftest_shading_math()
+    assert mism.tolist() == [0] * 4, mism
+
+
 @pytest.mark.parametrize("scene", [0, 1, 2, 3])
 def test_degenerate_frame_sizes(sr, orc, env_oracle, scene):
     """1x1, 2x2, single rows and columns: lone pixels have no quad neighbours inside the frame (helper invocations only)."""
