@@ -846,10 +846,11 @@ def secondary_workloads(sr, torch, dev, stream, cus, streams=()):
     out["headline_scene_other_views_1920x1080_m256"] = views
     out["config5_lobe_prefilter_256x128"] = {"per_power": per, "four_powers_concurrent_host_in_out_ms": round(four * 1e3, 3),
                                              "pair_terms_per_power": pair_terms,
-                                             "note": "one lane per destination texel, source summed serially in the reference's order "
-                                                     "(bit-exact); one power = 512 waves = half the SIMDs at this size, each wave issuing a vector "
-                                                     "instruction in ~70 % of its slots (profiles/r03_prefilter_pmc.txt); the four powers run "
-                                                     "concurrently (the reference's mapConcurrently)"}
+                                             "note": "one lane per destination texel sums the source serially in the reference's order "
+                                                     "(bit-exact).  A power alone: the factor sin*cos^p of every (destination, source) pair is "
+                                                     "computed by producer waves and handed to the summing wave through LDS (2048 waves instead "
+                                                     "of 512; k_prefilter_split).  Four powers at once (the reference's mapConcurrently): the "
+                                                     "one-wave kernel, whose four launches overlap (k_prefilter)"}
     return out
 
 

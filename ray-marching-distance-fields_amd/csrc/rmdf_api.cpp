@@ -824,7 +824,7 @@ int prefilter_powers_device(rmdf_ctx *ctx, const float *d_src, int w, int h, con
     const int ns = n < 4 ? n : 4;
     for (int k = 0; k < ns; k++) HIP_TRY(ctx, hipStreamWaitEvent(ctx->pstream[k], ctx->ev_fork, 0));
     for (int i = 0; i < n; i++)
-        HIP_TRY(ctx, launch_prefilter(d_src, w, h, powers[i], d_lutT, d_tcs, d_out[i], ctx->pstream[i % 4]));
+        HIP_TRY(ctx, launch_prefilter(d_src, w, h, powers[i], d_lutT, d_tcs, d_out[i], ctx->pstream[i % 4], n <= 3));
     for (int k = 0; k < ns; k++) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_join[k], ctx->pstream[k]));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[k], 0));
@@ -1194,7 +1194,7 @@ int rmdf_prefilter_env_device(rmdf_ctx *ctx, const void *d_rgb, int w, int h, fl
     const float *d_lutT = nullptr; const float2 *d_tcs = nullptr;
     int rc = get_lobe_tables(ctx, w, h, &d_lutT, &d_tcs);
     if (rc != RMDF_OK) return rc;
-    HIP_TRY(ctx, launch_prefilter((const float *)d_rgb, w, h, power, d_lutT, d_tcs, (float *)d_out, stream ? (hipStream_t)stream : ctx->stream));
+    HIP_TRY(ctx, launch_prefilter((const float *)d_rgb, w, h, power, d_lutT, d_tcs, (float *)d_out, stream ? (hipStream_t)stream : ctx->stream, true));
     return RMDF_OK;
     RMDF_GUARD_END(ctx)
 }

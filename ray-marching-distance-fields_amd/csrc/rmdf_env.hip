@@ -339,6 +339,186 @@ __global__ __launch_bounds__(64 * PREFILTER_WAVES) void k_prefilter(const float 
     }
 }
 
+// Round 3, second form (w <= 256, w % 4 == 0, the reference's powers): the per-destination chain is split between waves WITHOUT
+// touching the order of a single addition.  One lane per destination texel is all the parallelism the sums allow, and at 256x128
+// that is 512 waves, each issuing one vector instruction per ~5 cycles for 32768 x ~12 instructions.  But of those twelve only four
+// belong to the chain (r, g, b: one packed multiply-add pair and one scalar pair per source texel); the rest computes the factor
+// sin(theta) * cos^p, which depends on nothing the lane has summed.  So every CONSUMER wave (64 destination texels of one row, as
+// before) gets SPLIT_PROD PRODUCER waves on the other SIMDs of its CU: they evaluate the factors of alternating groups of four source
+// texels for the same 64 destination lanes and hand them over through LDS, 64 source texels (one chunk) at a time, double-buffered,
+// one workgroup barrier per chunk; the consumer reads factor and texel and does the reference's four operations in the reference's
+// order.  The sample count n is an integer (see k_prefilter), so the producers count.  Same bits (tests/test_gpu_env.py compares
+// both kernels with the oracle), 2048 waves instead of 512.
+#define SPLIT_CONS 2                  // consumer waves (destination rows) per workgroup; they share the staged cosine table
+#define SPLIT_PROD 3                  // producer waves per consumer
+#define SPLIT_CHUNK 64                // source texels per hand-over
+#define SPLIT_STRIDE 68               // floats per destination lane in a chunk buffer: 16-byte aligned, 4 banks apart
+template <int LOG2P>
+__global__ __launch_bounds__(64 * SPLIT_CONS * (1 + SPLIT_PROD)) void k_prefilter_split(const float *__restrict__ src, int w, int h,
+                                                  const float *__restrict__ lutT, const float2 *__restrict__ tcs, float *__restrict__ out)
+{
+    extern __shared__ float lds_dyn[];
+    const int nch = (w + SPLIT_CHUNK - 1) / SPLIT_CHUNK;                 // chunks per source row
+    const int row_stride = nch * SPLIT_CHUNK * 3;                        // floats per staged row, zero beyond w * 3
+    float *lds_lut = lds_dyn;                                            // [w][64]
+    float *lds_row = lds_lut + w * 64;                                   // [2][row_stride]
+    float *lds_ring = lds_row + 2 * row_stride;                          // [SPLIT_CONS][2][64][SPLIT_STRIDE]
+    unsigned *lds_cnt = (unsigned *)(lds_ring + SPLIT_CONS * 2 * 64 * SPLIT_STRIDE);     // [SPLIT_CONS][SPLIT_PROD][64]
+    const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool consumer = g < SPLIT_CONS;
+    const int cidx = consumer ? g : (g - SPLIT_CONS) / SPLIT_PROD, pidx = consumer ? 0 : (g - SPLIT_CONS) % SPLIT_PROD;
+    const int blk = blockIdx.x, dy_raw = blockIdx.y * SPLIT_CONS + cidx;
+    const int dy = dy_raw < h ? dy_raw : h - 1;
+    const int dx = blk * 64 + lane;
+    const float *glut = lutT + (size_t)blk * w * 64;
+    constexpr int NT = 64 * SPLIT_CONS * (1 + SPLIT_PROD);
+    for (int i = threadIdx.x; i < w * 64; i += NT) lds_lut[i] = glut[i];
+    for (int i = threadIdx.x; i < 2 * row_stride; i += NT) lds_row[i] = 0.0f;
+    // the producers stage the source rows: row y + 1 travels in registers while the last chunk of row y is produced
+    constexpr int NP = 64 * SPLIT_CONS * SPLIT_PROD, NPF = 2;            // 384 threads x 2 floats = 768 = 256 texels
+    const int ptid = (int)threadIdx.x - 64 * SPLIT_CONS;
+    const int nrow = w * 3;
+    float pf[NPF] = { 0.0f, 0.0f };
+    if (!consumer) {
+#pragma unroll
+        for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; pf[k] = i < nrow ? src[i] : 0.0f; }
+    }
+    typedef const float __attribute__((address_space(4))) cfloat;
+    const float lc = ((cfloat *)tcs)[2 * dy], ls = ((cfloat *)tcs)[2 * dy + 1];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 arg = { 0.0f, 0.0f };
+    float ab = 0.0f;
+    unsigned ni = 0u;
+    float *ring = lds_ring + cidx * 2 * 64 * SPLIT_STRIDE + lane * SPLIT_STRIDE;
+    const int total = h * nch;
+    __syncthreads();
+    // staged rows are swizzled for the consumer: four texels = three 16-byte pieces (r0 g0 r1 g1 | r2 g2 r3 g3 | b0 b1 b2 b3), so that
+    // every (r, g) pair the packed instructions take sits in an even-aligned register pair
+    auto row_slot = [](int i) { const int t = i / 3, ch = i - 3 * t, q = t >> 2, k = t & 3; return q * 12 + (ch < 2 ? 2 * k + ch : 8 + k); };
+    constexpr int GPP = (SPLIT_CHUNK / 4 + SPLIT_PROD - 1) / SPLIT_PROD;      // groups of four texels per producer and chunk, at most
+    for (int s = 0; s <= total; s++) {
+        if (!consumer) {
+            const int y = s / nch, j = s - y * nch;                      // (for s == total: nothing left to produce)
+            if (j == 0 && s < total) {
+                float *rb = lds_row + (y & 1) * row_stride;
+#pragma unroll
+                for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; if (i < nrow) rb[row_slot(i)] = pf[k]; }
+            }
+            if (j == nch - 1 && y + 1 < h) {
+                const float *nsrc = src + (size_t)(y + 1) * nrow;
+#pragma unroll
+                for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; pf[k] = i < nrow ? nsrc[i] : 0.0f; }
+            }
+            if (s < total) {
+                const float pc = ((cfloat *)tcs)[2 * y], ps = ((cfloat *)tcs)[2 * y + 1];
+                const float lcpc = lc * pc, lsps = ls * ps;
+                const int x0 = j * SPLIT_CHUNK;
+                const int ng = ((w - x0 < SPLIT_CHUNK ? w - x0 : SPLIT_CHUNK) + 3) >> 2;
+                float *dst = ring + (s & 1) * 64 * SPLIT_STRIDE;
+                // one group of four source texels for this wave's 64 destination lanes
+                auto factors4 = [&](const float (&l)[4], int gi) {
+                    float fac[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const float cos_angle = lcpc + lsps * l[t];
+                        unsigned ind;
+                        asm("v_med3_i32 %0, %1, 0, 1" : "=v"(ind) : "v"(__float_as_int(cos_angle)));
+                        ni += ind;
+                        const float c0 = __builtin_fmaxf(cos_angle, 0.0f);
+                        float cp = c0;
+                        if (LOG2P > 0) {
+                            double cd = (double)c0;
+#pragma unroll
+                            for (int q = 0; q < LOG2P; q++) cd = cd * cd;
+                            cp = (float)cd;
+                        }
+                        fac[t] = ps * cp;
+                    }
+                    *(float4 *)(dst + 4 * gi) = make_float4(fac[0], fac[1], fac[2], fac[3]);
+                };
+                if (ng == SPLIT_CHUNK / 4) {
+                    // a full chunk: every producer has GPP - 1 groups for certain -- one basic block, all their cosines read first, twenty
+                    // independent chains for the scheduler to interleave -- and the first few producers one more
+                    float l[GPP][4];
+#pragma unroll
+                    for (int k = 0; k < GPP; k++) {
+                        const int gi = pidx + k * SPLIT_PROD, gic = gi < ng ? gi : pidx;
+#pragma unroll
+                        for (int t = 0; t < 4; t++) l[k][t] = lds_lut[(x0 + 4 * gic + t) * 64 + lane];
+                    }
+#pragma unroll
+                    for (int k = 0; k < GPP - 1; k++) factors4(l[k], pidx + k * SPLIT_PROD);
+                    if (pidx + (GPP - 1) * SPLIT_PROD < ng) factors4(l[GPP - 1], pidx + (GPP - 1) * SPLIT_PROD);
+                } else {
+                    for (int gi = pidx; gi < ng; gi += SPLIT_PROD) {
+                        float l[4];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) l[t] = lds_lut[(x0 + 4 * gi + t) * 64 + lane];
+                        factors4(l, gi);
+                    }
+                }
+            }
+        } else if (s > 0) {
+            const int sc = s - 1, y = sc / nch, j = sc - y * nch;
+            const int x0 = j * SPLIT_CHUNK;
+            const int ng = ((w - x0 < SPLIT_CHUNK ? w - x0 : SPLIT_CHUNK) + 3) >> 2;
+            const float *fsrc = ring + (sc & 1) * 64 * SPLIT_STRIDE;
+            const float4 *rq = (const float4 *)(lds_row + (y & 1) * row_stride + x0 * 3);
+            // one group of four source texels: the reference's four operations per texel, in its order
+            auto sum4 = [&](const float4 &f, const float4 &a, const float4 &b, const float4 &c) {
+                { const f2 rg = { a.x, a.y }, ff = { f.x, f.x }; arg = arg + rg * ff; ab = ab + c.x * f.x; }
+                { const f2 rg = { a.z, a.w }, ff = { f.y, f.y }; arg = arg + rg * ff; ab = ab + c.y * f.y; }
+                { const f2 rg = { b.x, b.y }, ff = { f.z, f.z }; arg = arg + rg * ff; ab = ab + c.z * f.z; }
+                { const f2 rg = { b.z, b.w }, ff = { f.w, f.w }; arg = arg + rg * ff; ab = ab + c.w * f.w; }
+            };
+            if (ng == SPLIT_CHUNK / 4) {
+                // a full chunk: four blocks of four groups over two register sets, the next block's LDS reads in flight while one sums
+                constexpr int GB = 4;
+                float4 fa[GB], ra[3 * GB], fb[GB], rb[3 * GB];
+                auto load_block = [&](float4 (&f)[GB], float4 (&r)[3 * GB], int g0) {
+#pragma unroll
+                    for (int k = 0; k < GB; k++) f[k] = *(const float4 *)(fsrc + 4 * (g0 + k));
+#pragma unroll
+                    for (int k = 0; k < 3 * GB; k++) r[k] = rq[3 * g0 + k];
+                };
+                auto sum_block = [&](const float4 (&f)[GB], const float4 (&r)[3 * GB]) {
+#pragma unroll
+                    for (int k = 0; k < GB; k++) sum4(f[k], r[3 * k], r[3 * k + 1], r[3 * k + 2]);
+                };
+                load_block(fa, ra, 0);
+                load_block(fb, rb, GB);
+                sum_block(fa, ra);
+                load_block(fa, ra, 2 * GB);
+                sum_block(fb, rb);
+                load_block(fb, rb, 3 * GB);
+                sum_block(fa, ra);
+                sum_block(fb, rb);
+            } else {
+                for (int gi = 0; gi < ng; gi++) sum4(*(const float4 *)(fsrc + 4 * gi), rq[3 * gi], rq[3 * gi + 1], rq[3 * gi + 2]);
+            }
+        }
+        __syncthreads();
+    }
+    if (!consumer) lds_cnt[(cidx * SPLIT_PROD + pidx) * 64 + lane] = ni;
+    __syncthreads();
+    if (consumer) {
+        unsigned nt = 0u;
+#pragma unroll
+        for (int k = 0; k < SPLIT_PROD; k++) nt += lds_cnt[(cidx * SPLIT_PROD + k) * 64 + lane];
+        const float n = (float)(nt < 16777216u ? nt : 16777216u);        // a Float counter: n + 1 == n from 2^24 on
+        if (dx < w && dy_raw < h) {
+            float *o = out + ((size_t)dx + (size_t)dy * w) * 3;
+            o[0] = arg.x / n; o[1] = arg.y / n; o[2] = ab / n;
+        }
+    }
+}
+
+static size_t prefilter_split_lds(int w)
+{
+    const int nch = (w + SPLIT_CHUNK - 1) / SPLIT_CHUNK;
+    return ((size_t)w * 64 + 2 * (size_t)nch * SPLIT_CHUNK * 3 + (size_t)SPLIT_CONS * 2 * 64 * SPLIT_STRIDE + (size_t)SPLIT_CONS * SPLIT_PROD * 64) * sizeof(float);
+}
+
 int prefilter_log2p(float power)
 {
     if (power == 1.0f) return 0;
@@ -350,8 +530,17 @@ int prefilter_log2p(float power)
 
 template <int LOG2P>
 static hipError_t launch_prefilter_t(const float *d_src, int w, int h, float power, const float *d_lutT, const float2 *d_tcs,
-                                     float *d_out, hipStream_t stream)
+                                     float *d_out, hipStream_t stream, bool split_ok)
 {
+    static const bool one_wave = getenv("RMDF_PREFILTER_ONE_WAVE") != nullptr;          // A/B switch (tools/, tests): the one-wave kernel at every size
+    if (LOG2P >= 0 && w <= 256 && w % 4 == 0 && split_ok && !one_wave) {       // the reference's size: factor and sum on different waves
+        const dim3 grid((w + 63) / 64, (h + SPLIT_CONS - 1) / SPLIT_CONS), block(64 * SPLIT_CONS * (1 + SPLIT_PROD));
+        const size_t lds = prefilter_split_lds(w);
+        hipError_t e = hipFuncSetAttribute((const void *)k_prefilter_split<(LOG2P >= 0 ? LOG2P : 0)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_prefilter_split<(LOG2P >= 0 ? LOG2P : 0)>), grid, block, lds, stream, d_src, w, h, d_lutT, d_tcs, d_out);
+        return hipGetLastError();
+    }
     const dim3 grid((w + 63) / 64, (h + PREFILTER_WAVES - 1) / PREFILTER_WAVES), block(64 * PREFILTER_WAVES);
     const size_t row = (size_t)((w * 3 + 3) & ~3) * sizeof(float);             // one staged source row
     const size_t lut = (size_t)w * 64 * sizeof(float);
@@ -369,16 +558,20 @@ static hipError_t launch_prefilter_t(const float *d_src, int w, int h, float pow
     return hipGetLastError();
 }
 
+// split_ok: the caller runs at most three powers side by side.  The split kernel fills the machine by itself (2048 waves, one
+// workgroup per CU) and is 1.7 - 1.9 times as fast per power as the one-wave kernel (0.54 / 0.62 / 0.72 / 0.81 against 0.92 / 1.17 / 1.33 /
+// 1.54 ms for p = 1, 8, 64, 512 at 256x128); four powers at once are the one case where the one-wave kernel's launches, which overlap,
+// finish sooner together (2.75 against 3.27 ms), so rmdf_prefilter_env_powers keeps it for four or more.
 hipError_t launch_prefilter(const float *d_src, int w, int h, float power, const float *d_lutT, const float2 *d_tcs,
-                            float *d_out, hipStream_t stream)
+                            float *d_out, hipStream_t stream, bool split_ok)
 {
     if (w < 2 || h < 2) return hipErrorInvalidValue;
     switch (prefilter_log2p(power)) {
-    case 0:  return launch_prefilter_t<0>(d_src, w, h, power, d_lutT, d_tcs, d_out, stream);
-    case 3:  return launch_prefilter_t<3>(d_src, w, h, power, d_lutT, d_tcs, d_out, stream);
-    case 6:  return launch_prefilter_t<6>(d_src, w, h, power, d_lutT, d_tcs, d_out, stream);
-    case 9:  return launch_prefilter_t<9>(d_src, w, h, power, d_lutT, d_tcs, d_out, stream);
-    default: return launch_prefilter_t<-1>(d_src, w, h, power, d_lutT, d_tcs, d_out, stream);
+    case 0:  return launch_prefilter_t<0>(d_src, w, h, power, d_lutT, d_tcs, d_out, stream, split_ok);
+    case 3:  return launch_prefilter_t<3>(d_src, w, h, power, d_lutT, d_tcs, d_out, stream, split_ok);
+    case 6:  return launch_prefilter_t<6>(d_src, w, h, power, d_lutT, d_tcs, d_out, stream, split_ok);
+    case 9:  return launch_prefilter_t<9>(d_src, w, h, power, d_lutT, d_tcs, d_out, stream, split_ok);
+    default: return launch_prefilter_t<-1>(d_src, w, h, power, d_lutT, d_tcs, d_out, stream, split_ok);
     }
 }
 

@@ -129,7 +129,7 @@ hipError_t launch_cube_upload(const float *d_faces_f32, int W, uint2 *d_padded, 
 hipError_t launch_latlong_to_cube(const float *d_latlong, int w, int h, const float2 *d_uv, float *d_faces_f32, hipStream_t stream);
 hipError_t launch_resize_latlong(const float *d_src, int sw, int sh, int dstw, int dsth, float *d_out, hipStream_t stream);
 hipError_t launch_prefilter(const float *d_src, int w, int h, float power, const float *d_lutT, const float2 *d_tcs,
-                            float *d_out, hipStream_t stream);
+                            float *d_out, hipStream_t stream, bool split_ok);
 #ifdef RMDF_XCHECK
 hipError_t launch_march_stats(const FrameParams &p, hipStream_t stream);                               // xcheck/rmdf_stats.hip
 hipError_t launch_render_mb8(const FrameParams &p, hipStream_t stream, int num_cus);                   // xcheck/rmdf_march.hip

@@ -32,3 +32,9 @@ t0 = time.perf_counter()
 for _ in range(5):
     sr.prefilter_env_powers(src, P)
 print("rmdf_prefilter_env_powers (host in/out): %.3f ms" % ((time.perf_counter() - t0) / 5 * 1e3))
+for PP in ((1.0, 8.0), (1.0, 8.0, 64.0)):
+    sr.prefilter_env_powers(src, PP)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        sr.prefilter_env_powers(src, PP)
+    print("rmdf_prefilter_env_powers %r (host in/out): %.3f ms" % (PP, (time.perf_counter() - t0) / 5 * 1e3))
