@@ -952,6 +952,7 @@ __device__ __forceinline__ float fresnel_conductor(float cosi, float eta, float 
 }
 
 // fragment.shd:595-616, spherePos = 0
+template <bool FAST = RMDF_SHADE_FAST>
 __device__ __forceinline__ bool ray_sphere(v3 origin, v3 dir, float R, float &tmin, float &tmax)
 {
     v3 rs = mk3(0.0f - origin.x, 0.0f - origin.y, 0.0f - origin.z);
@@ -959,7 +960,7 @@ __device__ __forceinline__ bool ray_sphere(v3 origin, v3 dir, float R, float &tm
     float a = dot3(rs, rs) - t * t;
     float r2 = R * R;
     if (a > r2) return false;
-    float h = sqrtf(r2 - a);
+    float h = FAST ? sqrt_rn(r2 - a) : sqrtf(r2 - a);        // sqrt_rn: the same bits for every input (rmdf_selftest_exact_math)
     tmin = t - h;
     tmax = t + h;
     return true;

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_march_mb8(const FrameParams p)
                         dirz = p.cam[2] * dc.x + p.cam[5] * dc.y + p.cam[8] * dc.z;
                         float tmin;
                         steps = 0; iters = 0;
-                        if (ray_sphere(origin, mk3(dirx, diry, dirz), 1.15f, tmin, tmax) && max_steps > 0) {
+                        if (ray_sphere<false>(origin, mk3(dirx, diry, dirz), 1.15f, tmin, tmax) && max_steps > 0) {
                             t = gmax(0.0f, tmin);
                             phase = PH_MARCH;
                             START_DE(origin.x + t * dirx, origin.y + t * diry, origin.z + t * dirz, ST_WAIT_M);

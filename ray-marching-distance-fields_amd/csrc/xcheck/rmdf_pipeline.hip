@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_march_refill(const FrameParams p)
                         dirx = d.x; diry = d.y; dirz = d.z;
                         float tmin;
                         steps = 0; iters = 0;
-                        if (ray_sphere(origin, d, pl_bsphere<SCENE>(), tmin, tmax) && max_steps > 0) {
+                        if (ray_sphere<false>(origin, d, pl_bsphere<SCENE>(), tmin, tmax) && max_steps > 0) {
                             t = gmax(0.0f, tmin);
                             active = true;
                         } else {

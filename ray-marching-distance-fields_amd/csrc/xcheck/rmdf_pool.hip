@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void k_march_pool(const FrameParams p)
                         const float ddy = p.cam[1] * dc.x + p.cam[4] * dc.y + p.cam[7] * dc.z;
                         const float ddz = p.cam[2] * dc.x + p.cam[5] * dc.y + p.cam[8] * dc.z;
                         float tmin, tmx;
-                        if (ray_sphere(origin, mk3(ddx, ddy, ddz), 1.15f, tmin, tmx) && max_steps > 0) {
+                        if (ray_sphere<false>(origin, mk3(ddx, ddy, ddz), 1.15f, tmin, tmx) && max_steps > 0) {
                             const float tt = gmax(0.0f, tmin);
                             L.t[s] = tt; L.tmax[s] = tmx; L.dx[s] = ddx; L.dy[s] = ddy; L.dz[s] = ddz;
                             L.pix[s] = pixi; L.steps[s] = 0u; L.iters[s] = 0u; L.phase[s] = PH_MARCH;

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_march_stats(const FrameParams p)
     float t = 0.0f, tmin, tmax;
     int steps = 0;
     bool hit = false;
-    if (active && ray_sphere(origin, dir, 1.15f, tmin, tmax)) {
+    if (active && ray_sphere<false>(origin, dir, 1.15f, tmin, tmax)) {
         t = gmax(0.0f, tmin);
         for (steps = 0; steps < p.max_steps; steps++) {
             wsteps++;

@@ -11,17 +11,18 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES GRBM
   rocprofv3 --pmc $grp --output-format csv -d $out/p$i -- python3 tools/prefilter_trace.py > /dev/null 2> $out/p$i.log || tail -3 $out/p$i.log
 done
 python3 - $out <<'PY'
-import csv, glob, statistics, sys
+import csv, glob, re, statistics, sys
 c = {}
 for f in glob.glob(sys.argv[1] + "/p*/**/*_counter_collection.csv", recursive=True):
     per = {}
     for r in csv.DictReader(open(f)):
         if "k_prefilter" in r["Kernel_Name"]:
-            key = r["Kernel_Name"][18:28]
+            m = re.search(r"k_prefilter(_split)?<(-?\d+)", r["Kernel_Name"])
+            key = ("split" if m.group(1) else "one-wave") + " p=2^" + m.group(2)
             per.setdefault((key, r["Counter_Name"]), {}).setdefault(r["Dispatch_Id"], 0.0)
             per[(key, r["Counter_Name"])][r["Dispatch_Id"]] += float(r["Counter_Value"])
     for k, v in per.items():
         c[k] = statistics.median(v.values())
 for k in sorted(c):
-    print("%-12s %-26s %16.0f" % (k[0], k[1], c[k]))
+    print("%-16s %-26s %16.0f" % (k[0], k[1], c[k]))
 PY
