@@ -820,6 +820,21 @@ int prefilter_powers_device(rmdf_ctx *ctx, const float *d_src, int w, int h, con
     const float *d_lutT = nullptr; const float2 *d_tcs = nullptr;
     int rc = get_lobe_tables(ctx, w, h, &d_lutT, &d_tcs);
     if (rc != RMDF_OK) return rc;
+    // the reference's own job -- powers 1, 8, 64 and 512 of one map -- is one launch (rmdf_env.hip: k_prefilter_fused4)
+    static const bool no_fused = getenv("RMDF_PREFILTER_NO_FUSED") != nullptr;       // A/B switch (tools/)
+    if (n == 4 && w <= 256 && w % 4 == 0 && !no_fused) {
+        float *by_k[4] = { nullptr, nullptr, nullptr, nullptr };
+        bool ok = true;
+        for (int i = 0; i < 4; i++) {
+            const int l2 = prefilter_log2p(powers[i]);
+            if (l2 < 0 || by_k[l2 / 3]) { ok = false; break; }
+            by_k[l2 / 3] = d_out[i];
+        }
+        if (ok) {
+            HIP_TRY(ctx, launch_prefilter_fused4(d_src, w, h, d_lutT, d_tcs, by_k, ctx->stream));
+            return RMDF_OK;
+        }
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     const int ns = n < 4 ? n : 4;
     for (int k = 0; k < ns; k++) HIP_TRY(ctx, hipStreamWaitEvent(ctx->pstream[k], ctx->ev_fork, 0));

@@ -519,6 +519,182 @@ static size_t prefilter_split_lds(int w)
     return ((size_t)w * 64 + 2 * (size_t)nch * SPLIT_CHUNK * 3 + (size_t)SPLIT_CONS * 2 * 64 * SPLIT_STRIDE + (size_t)SPLIT_CONS * SPLIT_PROD * 64) * sizeof(float);
 }
 
+// Round 3, third form: the reference's FOUR powers (1, 8, 64, 512: buildPreConvolvedHDREnvMapCache, ShaderRendering.hs:131-149) in one
+// launch.  The four maps differ only in the exponent, and the binary64 squaring chains nest: c^8 is three squarings, c^64 three more
+// ON THE SAME VALUE, c^512 three more -- nine multiplications where four separate launches do eighteen, one cosine, one table read,
+// one sample count.  A workgroup is four summing waves (one per power, one per SIMD) fed by eight producer waves through four LDS rings,
+// 32 source texels per barrier.  With four summing waves per CU the LDS return path becomes the scarce unit, and three quarters of what
+// k_prefilter_split moves through it is the SOURCE ROW, broadcast to 64 lanes by ds_read_b128 (1 KB per instruction for 16 distinct
+// bytes).  Here a summing wave reads sixteen consecutive floats of the row ONCE into the sixteen lanes of each row of the wave
+// (ds_read_b32, 256 bytes) and multiplies straight out of that register with v_mul_f32_dpp row_newbcast:k -- the DPP operand fetch
+// does the broadcast, no LDS traffic, no extra instruction; the products and sums are the reference's, in its order.
+#define F4_PROD 8                     // producer waves: one group of four source texels each per chunk
+#define F4_CHUNK 32                   // source texels per hand-over
+#define F4_STRIDE 36                  // floats per destination lane in a chunk buffer: 16-byte aligned, 4 banks apart
+template <int K>
+__device__ __forceinline__ float mul_row_bcast(float row16, float f)       // (lane K of each 16-lane row of row16) * f
+{
+    float r;
+    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(row16), "v"(f), "n"(K));
+    return r;
+}
+// texel T of a chunk (static): its three floats sit at 3T .. 3T+2 of the chunk's 96 = six registers of sixteen
+template <int T>
+__device__ __forceinline__ void f4_sum_texel(const float (&rr)[F4_CHUNK * 3 / 16], float f, float &ar, float &ag, float &ab)
+{
+    ar = ar + mul_row_bcast<(3 * T) % 16>(rr[(3 * T) / 16], f);
+    ag = ag + mul_row_bcast<(3 * T + 1) % 16>(rr[(3 * T + 1) / 16], f);
+    ab = ab + mul_row_bcast<(3 * T + 2) % 16>(rr[(3 * T + 2) / 16], f);
+}
+template <int G>
+__device__ __forceinline__ void f4_sum_group(const float (&rr)[F4_CHUNK * 3 / 16], const float4 &f, float &ar, float &ag, float &ab)
+{
+    f4_sum_texel<4 * G>(rr, f.x, ar, ag, ab);
+    f4_sum_texel<4 * G + 1>(rr, f.y, ar, ag, ab);
+    f4_sum_texel<4 * G + 2>(rr, f.z, ar, ag, ab);
+    f4_sum_texel<4 * G + 3>(rr, f.w, ar, ag, ab);
+}
+
+__global__ __launch_bounds__(64 * (4 + F4_PROD)) void k_prefilter_fused4(const float *__restrict__ src, int w, int h,
+        const float *__restrict__ lutT, const float2 *__restrict__ tcs, float *__restrict__ out0, float *__restrict__ out1,
+        float *__restrict__ out2, float *__restrict__ out3)
+{
+    extern __shared__ float lds_dyn[];
+    const int nch = (w + F4_CHUNK - 1) / F4_CHUNK;                      // chunks per source row
+    const int row_stride = nch * F4_CHUNK * 3;                           // floats per staged row, zero beyond w * 3
+    float *lds_lut = lds_dyn;                                            // [w][64]
+    float *lds_row = lds_lut + w * 64;                                   // [2][row_stride]
+    float *lds_ring = lds_row + 2 * row_stride;                          // [4 powers][2][64][F4_STRIDE]
+    unsigned *lds_cnt = (unsigned *)(lds_ring + 4 * 2 * 64 * F4_STRIDE); // [F4_PROD][64]
+    const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool consumer = g < 4;
+    const int pidx = consumer ? 0 : g - 4;
+    const int blk = blockIdx.x, dy = blockIdx.y;
+    const int dx = blk * 64 + lane;
+    const float *glut = lutT + (size_t)blk * w * 64;
+    constexpr int NT = 64 * (4 + F4_PROD), NP = 64 * F4_PROD, NPF = 2;  // 512 producer threads x 2 floats >= 768 = 256 texels
+    for (int i = threadIdx.x; i < w * 64; i += NT) lds_lut[i] = glut[i];
+    for (int i = threadIdx.x; i < 2 * row_stride; i += NT) lds_row[i] = 0.0f;
+    const int ptid = (int)threadIdx.x - 64 * 4;
+    const int nrow = w * 3;
+    float pf[NPF] = { 0.0f, 0.0f };
+    if (!consumer) {
+#pragma unroll
+        for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; pf[k] = i < nrow ? src[i] : 0.0f; }
+    }
+    typedef const float __attribute__((address_space(4))) cfloat;
+    const float lc = ((cfloat *)tcs)[2 * dy], ls = ((cfloat *)tcs)[2 * dy + 1];
+    float ar = 0.0f, ag = 0.0f, ab = 0.0f;
+    unsigned ni = 0u;
+    float *ring_c = lds_ring + g * 2 * 64 * F4_STRIDE + lane * F4_STRIDE;      // (consumers: their power's ring)
+    float *ring_p = lds_ring + lane * F4_STRIDE;
+    const int total = h * nch;
+    __syncthreads();
+    int y = 0, j = 0;                                                    // the chunk the producers fill at step s: source row y, chunk j
+    float lcpc = 0.0f, lsps = 0.0f, ps = 0.0f;                           // of source row y (producers): loaded once per row
+    for (int s = 0; s <= total; s++) {
+        if (!consumer) {
+            if (s < total) {
+                if (j == 0) {
+                    const float pc = ((cfloat *)tcs)[2 * y];
+                    ps = ((cfloat *)tcs)[2 * y + 1];
+                    lcpc = lc * pc; lsps = ls * ps;
+                    float *rb = lds_row + (y & 1) * row_stride;
+#pragma unroll
+                    for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; if (i < nrow) rb[i] = pf[k]; }
+                }
+                if (j == nch - 1 && y + 1 < h) {
+                    const float *nsrc = src + (size_t)(y + 1) * nrow;
+#pragma unroll
+                    for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; pf[k] = i < nrow ? nsrc[i] : 0.0f; }
+                }
+                const int x0 = j * F4_CHUNK;
+                const int ng = ((w - x0 < F4_CHUNK ? w - x0 : F4_CHUNK) + 3) >> 2;
+                if (pidx < ng) {
+                    float l[4], f1[4], f8[4], f64[4], f512[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) l[t] = lds_lut[(x0 + 4 * pidx + t) * 64 + lane];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const float cos_angle = lcpc + lsps * l[t];
+                        unsigned ind;
+                        asm("v_med3_i32 %0, %1, 0, 1" : "=v"(ind) : "v"(__float_as_int(cos_angle)));
+                        ni += ind;
+                        const float c0 = __builtin_fmaxf(cos_angle, 0.0f);
+                        double cd = (double)c0;
+                        cd = cd * cd; cd = cd * cd; cd = cd * cd;
+                        const float c8 = (float)cd;
+                        cd = cd * cd; cd = cd * cd; cd = cd * cd;
+                        const float c64 = (float)cd;
+                        cd = cd * cd; cd = cd * cd; cd = cd * cd;
+                        const float c512 = (float)cd;
+                        f1[t] = ps * c0; f8[t] = ps * c8; f64[t] = ps * c64; f512[t] = ps * c512;
+                    }
+                    float *dst = ring_p + (s & 1) * 64 * F4_STRIDE + 4 * pidx;
+                    *(float4 *)(dst) = make_float4(f1[0], f1[1], f1[2], f1[3]);
+                    *(float4 *)(dst + 1 * 2 * 64 * F4_STRIDE) = make_float4(f8[0], f8[1], f8[2], f8[3]);
+                    *(float4 *)(dst + 2 * 2 * 64 * F4_STRIDE) = make_float4(f64[0], f64[1], f64[2], f64[3]);
+                    *(float4 *)(dst + 3 * 2 * 64 * F4_STRIDE) = make_float4(f512[0], f512[1], f512[2], f512[3]);
+                }
+            }
+        } else if (s > 0) {
+            const int sc = s - 1, yc = j == 0 ? y - 1 : y, jc = j == 0 ? nch - 1 : j - 1;      // the chunk filled in the step before
+            const int x0 = jc * F4_CHUNK;
+            const int ng = ((w - x0 < F4_CHUNK ? w - x0 : F4_CHUNK) + 3) >> 2;
+            const float *fsrc = ring_c + (sc & 1) * 64 * F4_STRIDE;
+            const float *rrow = lds_row + (yc & 1) * row_stride + x0 * 3 + (lane & 15);
+            float rr[F4_CHUNK * 3 / 16];
+            float4 f[F4_CHUNK / 4];
+#pragma unroll
+            for (int m = 0; m < F4_CHUNK * 3 / 16; m++) rr[m] = rrow[16 * m];
+#pragma unroll
+            for (int k = 0; k < F4_CHUNK / 4; k++) f[k] = *(const float4 *)(fsrc + 4 * k);        // (groups past ng: stale, unused)
+            if (ng == F4_CHUNK / 4) {
+                f4_sum_group<0>(rr, f[0], ar, ag, ab); f4_sum_group<1>(rr, f[1], ar, ag, ab);
+                f4_sum_group<2>(rr, f[2], ar, ag, ab); f4_sum_group<3>(rr, f[3], ar, ag, ab);
+                f4_sum_group<4>(rr, f[4], ar, ag, ab); f4_sum_group<5>(rr, f[5], ar, ag, ab);
+                f4_sum_group<6>(rr, f[6], ar, ag, ab); f4_sum_group<7>(rr, f[7], ar, ag, ab);
+            } else {
+                if (0 < ng) f4_sum_group<0>(rr, f[0], ar, ag, ab);
+                if (1 < ng) f4_sum_group<1>(rr, f[1], ar, ag, ab);
+                if (2 < ng) f4_sum_group<2>(rr, f[2], ar, ag, ab);
+                if (3 < ng) f4_sum_group<3>(rr, f[3], ar, ag, ab);
+                if (4 < ng) f4_sum_group<4>(rr, f[4], ar, ag, ab);
+                if (5 < ng) f4_sum_group<5>(rr, f[5], ar, ag, ab);
+                if (6 < ng) f4_sum_group<6>(rr, f[6], ar, ag, ab);
+            }
+        }
+        __syncthreads();
+        if (++j == nch) { j = 0; y++; }
+    }
+    if (!consumer) lds_cnt[pidx * 64 + lane] = ni;
+    __syncthreads();
+    if (consumer) {
+        unsigned nt = 0u;
+#pragma unroll
+        for (int k = 0; k < F4_PROD; k++) nt += lds_cnt[k * 64 + lane];
+        const float n = (float)(nt < 16777216u ? nt : 16777216u);        // a Float counter: n + 1 == n from 2^24 on
+        if (dx < w) {
+            float *o = (g == 0 ? out0 : g == 1 ? out1 : g == 2 ? out2 : out3) + ((size_t)dx + (size_t)dy * w) * 3;
+            o[0] = ar / n; o[1] = ag / n; o[2] = ab / n;
+        }
+    }
+}
+
+// d_out[k] = the map of power 8^k (1, 8, 64, 512)
+hipError_t launch_prefilter_fused4(const float *d_src, int w, int h, const float *d_lutT, const float2 *d_tcs, float *const d_out[4],
+                                   hipStream_t stream)
+{
+    if (w < 2 || h < 2 || w > 256 || w % 4) return hipErrorInvalidValue;
+    const int nch = (w + F4_CHUNK - 1) / F4_CHUNK;
+    const size_t lds = ((size_t)w * 64 + 2 * (size_t)nch * F4_CHUNK * 3 + (size_t)4 * 2 * 64 * F4_STRIDE + (size_t)F4_PROD * 64) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void *)k_prefilter_fused4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_prefilter_fused4, dim3((w + 63) / 64, h), dim3(64 * (4 + F4_PROD)), lds, stream, d_src, w, h, d_lutT, d_tcs,
+                       d_out[0], d_out[1], d_out[2], d_out[3]);
+    return hipGetLastError();
+}
+
 int prefilter_log2p(float power)
 {
     if (power == 1.0f) return 0;

@@ -128,6 +128,9 @@ hipError_t launch_clock_probe(unsigned long long *d_out, unsigned long long tick
 hipError_t launch_cube_upload(const float *d_faces_f32, int W, uint2 *d_padded, hipStream_t stream);
 hipError_t launch_latlong_to_cube(const float *d_latlong, int w, int h, const float2 *d_uv, float *d_faces_f32, hipStream_t stream);
 hipError_t launch_resize_latlong(const float *d_src, int sw, int sh, int dstw, int dsth, float *d_out, hipStream_t stream);
+hipError_t launch_prefilter_fused4(const float *d_src, int w, int h, const float *d_lutT, const float2 *d_tcs, float *const d_out[4],
+                                   hipStream_t stream);
+int prefilter_log2p(float power);
 hipError_t launch_prefilter(const float *d_src, int w, int h, float power, const float *d_lutT, const float2 *d_tcs,
                             float *d_out, hipStream_t stream, bool split_ok);
 #ifdef RMDF_XCHECK
