@@ -849,8 +849,9 @@ def secondary_workloads(sr, torch, dev, stream, cus, streams=()):
                                              "note": "one lane per destination texel sums the source serially in the reference's order "
                                                      "(bit-exact).  A power alone: the factor sin*cos^p of every (destination, source) pair is "
                                                      "computed by producer waves and handed to the summing wave through LDS (2048 waves instead "
-                                                     "of 512; k_prefilter_split).  Four powers at once (the reference's mapConcurrently): the "
-                                                     "one-wave kernel, whose four launches overlap (k_prefilter)"}
+                                                     "of 512; k_prefilter_split).  The reference's four powers at once (mapConcurrently): ONE launch "
+                                                     "-- the squaring chains nest, so producers compute all four factors from one cosine and feed "
+                                                     "four summing waves (k_prefilter_fused4)"}
     return out
 
 

@@ -555,17 +555,20 @@ __device__ __forceinline__ void f4_sum_group(const float (&rr)[F4_CHUNK * 3 / 16
     f4_sum_texel<4 * G + 3>(rr, f.w, ar, ag, ab);
 }
 
-__global__ __launch_bounds__(64 * (4 + F4_PROD)) void k_prefilter_fused4(const float *__restrict__ src, int w, int h,
+#define F4_MAXCH 8                     // chunks per source row at most (w <= 256)
+__global__ __launch_bounds__(64 * (4 + F4_PROD), 6) void k_prefilter_fused4(const float *__restrict__ src, int w, int h,
         const float *__restrict__ lutT, const float2 *__restrict__ tcs, float *__restrict__ out0, float *__restrict__ out1,
         float *__restrict__ out2, float *__restrict__ out3)
 {
+    // LDS: the four rings and two staged source rows, 78 KB -- two workgroups per CU.  The cosine table stays out of it: a producer
+    // meets the same 32 entries (its group of each of the row's <= 8 chunks, for its lane's destination column) in every source row
+    // and keeps them in registers; the chunk loop is unrolled so that every index into them is static.
     extern __shared__ float lds_dyn[];
     const int nch = (w + F4_CHUNK - 1) / F4_CHUNK;                      // chunks per source row
     const int row_stride = nch * F4_CHUNK * 3;                           // floats per staged row, zero beyond w * 3
-    float *lds_lut = lds_dyn;                                            // [w][64]
-    float *lds_row = lds_lut + w * 64;                                   // [2][row_stride]
+    float *lds_row = lds_dyn;                                            // [2][row_stride]
     float *lds_ring = lds_row + 2 * row_stride;                          // [4 powers][2][64][F4_STRIDE]
-    unsigned *lds_cnt = (unsigned *)(lds_ring + 4 * 2 * 64 * F4_STRIDE); // [F4_PROD][64]
+    unsigned *lds_cnt = (unsigned *)lds_ring;                            // [F4_PROD][64], after the last chunk has been summed
     const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool consumer = g < 4;
     const int pidx = consumer ? 0 : g - 4;
@@ -573,14 +576,18 @@ __global__ __launch_bounds__(64 * (4 + F4_PROD)) void k_prefilter_fused4(const f
     const int dx = blk * 64 + lane;
     const float *glut = lutT + (size_t)blk * w * 64;
     constexpr int NT = 64 * (4 + F4_PROD), NP = 64 * F4_PROD, NPF = 2;  // 512 producer threads x 2 floats >= 768 = 256 texels
-    for (int i = threadIdx.x; i < w * 64; i += NT) lds_lut[i] = glut[i];
     for (int i = threadIdx.x; i < 2 * row_stride; i += NT) lds_row[i] = 0.0f;
     const int ptid = (int)threadIdx.x - 64 * 4;
     const int nrow = w * 3;
     float pf[NPF] = { 0.0f, 0.0f };
+    float lutreg[F4_MAXCH][4];
     if (!consumer) {
 #pragma unroll
         for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; pf[k] = i < nrow ? src[i] : 0.0f; }
+#pragma unroll
+        for (int j = 0; j < F4_MAXCH; j++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) { const int x = j * F4_CHUNK + 4 * pidx + t; lutreg[j][t] = x < w ? glut[x * 64 + lane] : 0.0f; }
     }
     typedef const float __attribute__((address_space(4))) cfloat;
     const float lc = ((cfloat *)tcs)[2 * dy], ls = ((cfloat *)tcs)[2 * dy + 1];
@@ -588,86 +595,91 @@ __global__ __launch_bounds__(64 * (4 + F4_PROD)) void k_prefilter_fused4(const f
     unsigned ni = 0u;
     float *ring_c = lds_ring + g * 2 * 64 * F4_STRIDE + lane * F4_STRIDE;      // (consumers: their power's ring)
     float *ring_p = lds_ring + lane * F4_STRIDE;
-    const int total = h * nch;
     __syncthreads();
-    int y = 0, j = 0;                                                    // the chunk the producers fill at step s: source row y, chunk j
-    float lcpc = 0.0f, lsps = 0.0f, ps = 0.0f;                           // of source row y (producers): loaded once per row
-    for (int s = 0; s <= total; s++) {
-        if (!consumer) {
-            if (s < total) {
-                if (j == 0) {
-                    const float pc = ((cfloat *)tcs)[2 * y];
-                    ps = ((cfloat *)tcs)[2 * y + 1];
-                    lcpc = lc * pc; lsps = ls * ps;
-                    float *rb = lds_row + (y & 1) * row_stride;
-#pragma unroll
-                    for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; if (i < nrow) rb[i] = pf[k]; }
-                }
-                if (j == nch - 1 && y + 1 < h) {
-                    const float *nsrc = src + (size_t)(y + 1) * nrow;
-#pragma unroll
-                    for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; pf[k] = i < nrow ? nsrc[i] : 0.0f; }
-                }
-                const int x0 = j * F4_CHUNK;
-                const int ng = ((w - x0 < F4_CHUNK ? w - x0 : F4_CHUNK) + 3) >> 2;
-                if (pidx < ng) {
-                    float l[4], f1[4], f8[4], f64[4], f512[4];
-#pragma unroll
-                    for (int t = 0; t < 4; t++) l[t] = lds_lut[(x0 + 4 * pidx + t) * 64 + lane];
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const float cos_angle = lcpc + lsps * l[t];
-                        unsigned ind;
-                        asm("v_med3_i32 %0, %1, 0, 1" : "=v"(ind) : "v"(__float_as_int(cos_angle)));
-                        ni += ind;
-                        const float c0 = __builtin_fmaxf(cos_angle, 0.0f);
-                        double cd = (double)c0;
-                        cd = cd * cd; cd = cd * cd; cd = cd * cd;
-                        const float c8 = (float)cd;
-                        cd = cd * cd; cd = cd * cd; cd = cd * cd;
-                        const float c64 = (float)cd;
-                        cd = cd * cd; cd = cd * cd; cd = cd * cd;
-                        const float c512 = (float)cd;
-                        f1[t] = ps * c0; f8[t] = ps * c8; f64[t] = ps * c64; f512[t] = ps * c512;
-                    }
-                    float *dst = ring_p + (s & 1) * 64 * F4_STRIDE + 4 * pidx;
-                    *(float4 *)(dst) = make_float4(f1[0], f1[1], f1[2], f1[3]);
-                    *(float4 *)(dst + 1 * 2 * 64 * F4_STRIDE) = make_float4(f8[0], f8[1], f8[2], f8[3]);
-                    *(float4 *)(dst + 2 * 2 * 64 * F4_STRIDE) = make_float4(f64[0], f64[1], f64[2], f64[3]);
-                    *(float4 *)(dst + 3 * 2 * 64 * F4_STRIDE) = make_float4(f512[0], f512[1], f512[2], f512[3]);
-                }
-            }
-        } else if (s > 0) {
-            const int sc = s - 1, yc = j == 0 ? y - 1 : y, jc = j == 0 ? nch - 1 : j - 1;      // the chunk filled in the step before
-            const int x0 = jc * F4_CHUNK;
-            const int ng = ((w - x0 < F4_CHUNK ? w - x0 : F4_CHUNK) + 3) >> 2;
-            const float *fsrc = ring_c + (sc & 1) * 64 * F4_STRIDE;
-            const float *rrow = lds_row + (yc & 1) * row_stride + x0 * 3 + (lane & 15);
-            float rr[F4_CHUNK * 3 / 16];
-            float4 f[F4_CHUNK / 4];
-#pragma unroll
-            for (int m = 0; m < F4_CHUNK * 3 / 16; m++) rr[m] = rrow[16 * m];
-#pragma unroll
-            for (int k = 0; k < F4_CHUNK / 4; k++) f[k] = *(const float4 *)(fsrc + 4 * k);        // (groups past ng: stale, unused)
-            if (ng == F4_CHUNK / 4) {
-                f4_sum_group<0>(rr, f[0], ar, ag, ab); f4_sum_group<1>(rr, f[1], ar, ag, ab);
-                f4_sum_group<2>(rr, f[2], ar, ag, ab); f4_sum_group<3>(rr, f[3], ar, ag, ab);
-                f4_sum_group<4>(rr, f[4], ar, ag, ab); f4_sum_group<5>(rr, f[5], ar, ag, ab);
-                f4_sum_group<6>(rr, f[6], ar, ag, ab); f4_sum_group<7>(rr, f[7], ar, ag, ab);
-            } else {
-                if (0 < ng) f4_sum_group<0>(rr, f[0], ar, ag, ab);
-                if (1 < ng) f4_sum_group<1>(rr, f[1], ar, ag, ab);
-                if (2 < ng) f4_sum_group<2>(rr, f[2], ar, ag, ab);
-                if (3 < ng) f4_sum_group<3>(rr, f[3], ar, ag, ab);
-                if (4 < ng) f4_sum_group<4>(rr, f[4], ar, ag, ab);
-                if (5 < ng) f4_sum_group<5>(rr, f[5], ar, ag, ab);
-                if (6 < ng) f4_sum_group<6>(rr, f[6], ar, ag, ab);
-            }
+    // Step s: the producers fill chunk s (source row y, chunk j of the row) into ring buffer s & 1 while the summing waves take chunk
+    // s - 1 out of the other one; one barrier per step; h * nch + 1 steps.
+    int s = 0;
+    for (int y = 0; y <= h; y++) {
+        float lcpc = 0.0f, lsps = 0.0f, ps = 0.0f;
+        if (!consumer && y < h) {
+            const float pc = ((cfloat *)tcs)[2 * y];
+            ps = ((cfloat *)tcs)[2 * y + 1];
+            lcpc = lc * pc; lsps = ls * ps;
         }
-        __syncthreads();
-        if (++j == nch) { j = 0; y++; }
+#pragma unroll
+        for (int j = 0; j < F4_MAXCH; j++) {
+            if (j >= nch || (y == h && j > 0)) continue;                // (y == h: the one step that only sums the last chunk)
+            if (!consumer) {
+                if (y < h) {
+                    if (j == 0) {
+                        float *rb = lds_row + (y & 1) * row_stride;
+#pragma unroll
+                        for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; if (i < nrow) rb[i] = pf[k]; }
+                    }
+                    if (j == nch - 1 && y + 1 < h) {
+                        const float *nsrc = src + (size_t)(y + 1) * nrow;
+#pragma unroll
+                        for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; pf[k] = i < nrow ? nsrc[i] : 0.0f; }
+                    }
+                    const int x0 = j * F4_CHUNK;
+                    const int ng = ((w - x0 < F4_CHUNK ? w - x0 : F4_CHUNK) + 3) >> 2;
+                    if (pidx < ng) {
+                        float f1[4], f8[4], f64[4], f512[4];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const float cos_angle = lcpc + lsps * lutreg[j][t];
+                            unsigned ind;
+                            asm("v_med3_i32 %0, %1, 0, 1" : "=v"(ind) : "v"(__float_as_int(cos_angle)));
+                            ni += ind;
+                            const float c0 = __builtin_fmaxf(cos_angle, 0.0f);
+                            double cd = (double)c0;
+                            cd = cd * cd; cd = cd * cd; cd = cd * cd;
+                            const float c8 = (float)cd;
+                            cd = cd * cd; cd = cd * cd; cd = cd * cd;
+                            const float c64 = (float)cd;
+                            cd = cd * cd; cd = cd * cd; cd = cd * cd;
+                            const float c512 = (float)cd;
+                            f1[t] = ps * c0; f8[t] = ps * c8; f64[t] = ps * c64; f512[t] = ps * c512;
+                        }
+                        float *dst = ring_p + (s & 1) * 64 * F4_STRIDE + 4 * pidx;
+                        *(float4 *)(dst) = make_float4(f1[0], f1[1], f1[2], f1[3]);
+                        *(float4 *)(dst + 1 * 2 * 64 * F4_STRIDE) = make_float4(f8[0], f8[1], f8[2], f8[3]);
+                        *(float4 *)(dst + 2 * 2 * 64 * F4_STRIDE) = make_float4(f64[0], f64[1], f64[2], f64[3]);
+                        *(float4 *)(dst + 3 * 2 * 64 * F4_STRIDE) = make_float4(f512[0], f512[1], f512[2], f512[3]);
+                    }
+                }
+            } else if (s > 0) {
+                const int sc = s - 1, yc = j == 0 ? y - 1 : y, jc = j == 0 ? nch - 1 : j - 1;      // the chunk filled in the step before
+                const int x0 = jc * F4_CHUNK;
+                const int ng = ((w - x0 < F4_CHUNK ? w - x0 : F4_CHUNK) + 3) >> 2;
+                const float *fsrc = ring_c + (sc & 1) * 64 * F4_STRIDE;
+                const float *rrow = lds_row + (yc & 1) * row_stride + x0 * 3 + (lane & 15);
+                float rr[F4_CHUNK * 3 / 16];
+                float4 f[F4_CHUNK / 4];
+#pragma unroll
+                for (int m = 0; m < F4_CHUNK * 3 / 16; m++) rr[m] = rrow[16 * m];
+#pragma unroll
+                for (int k = 0; k < F4_CHUNK / 4; k++) f[k] = *(const float4 *)(fsrc + 4 * k);        // (groups past ng: stale, unused)
+                if (ng == F4_CHUNK / 4) {
+                    f4_sum_group<0>(rr, f[0], ar, ag, ab); f4_sum_group<1>(rr, f[1], ar, ag, ab);
+                    f4_sum_group<2>(rr, f[2], ar, ag, ab); f4_sum_group<3>(rr, f[3], ar, ag, ab);
+                    f4_sum_group<4>(rr, f[4], ar, ag, ab); f4_sum_group<5>(rr, f[5], ar, ag, ab);
+                    f4_sum_group<6>(rr, f[6], ar, ag, ab); f4_sum_group<7>(rr, f[7], ar, ag, ab);
+                } else {
+                    if (0 < ng) f4_sum_group<0>(rr, f[0], ar, ag, ab);
+                    if (1 < ng) f4_sum_group<1>(rr, f[1], ar, ag, ab);
+                    if (2 < ng) f4_sum_group<2>(rr, f[2], ar, ag, ab);
+                    if (3 < ng) f4_sum_group<3>(rr, f[3], ar, ag, ab);
+                    if (4 < ng) f4_sum_group<4>(rr, f[4], ar, ag, ab);
+                    if (5 < ng) f4_sum_group<5>(rr, f[5], ar, ag, ab);
+                    if (6 < ng) f4_sum_group<6>(rr, f[6], ar, ag, ab);
+                }
+            }
+            __syncthreads();
+            s++;
+        }
     }
-    if (!consumer) lds_cnt[pidx * 64 + lane] = ni;
+    if (!consumer) lds_cnt[pidx * 64 + lane] = ni;                       // (the rings are free: the barrier above ended the last sum)
     __syncthreads();
     if (consumer) {
         unsigned nt = 0u;
@@ -687,7 +699,7 @@ hipError_t launch_prefilter_fused4(const float *d_src, int w, int h, const float
 {
     if (w < 2 || h < 2 || w > 256 || w % 4) return hipErrorInvalidValue;
     const int nch = (w + F4_CHUNK - 1) / F4_CHUNK;
-    const size_t lds = ((size_t)w * 64 + 2 * (size_t)nch * F4_CHUNK * 3 + (size_t)4 * 2 * 64 * F4_STRIDE + (size_t)F4_PROD * 64) * sizeof(float);
+    const size_t lds = (2 * (size_t)nch * F4_CHUNK * 3 + (size_t)4 * 2 * 64 * F4_STRIDE) * sizeof(float);
     hipError_t e = hipFuncSetAttribute((const void *)k_prefilter_fused4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_prefilter_fused4, dim3((w + 63) / 64, h), dim3(64 * (4 + F4_PROD)), lds, stream, d_src, w, h, d_lutT, d_tcs,
@@ -736,8 +748,9 @@ static hipError_t launch_prefilter_t(const float *d_src, int w, int h, float pow
 
 // split_ok: the caller runs at most three powers side by side.  The split kernel fills the machine by itself (2048 waves, one
 // workgroup per CU) and is 1.7 - 1.9 times as fast per power as the one-wave kernel (0.54 / 0.62 / 0.72 / 0.81 against 0.92 / 1.17 / 1.33 /
-// 1.54 ms for p = 1, 8, 64, 512 at 256x128); four powers at once are the one case where the one-wave kernel's launches, which overlap,
-// finish sooner together (2.75 against 3.27 ms), so rmdf_prefilter_env_powers keeps it for four or more.
+// 1.54 ms for p = 1, 8, 64, 512 at 256x128); with four or more launches side by side the one-wave kernel's, which overlap, finish
+// sooner together (2.75 against 3.27 ms), so rmdf_prefilter_env_powers keeps it there -- except for the reference's own set
+// 1, 8, 64, 512, which is ONE launch of k_prefilter_fused4 (1.1 ms).
 hipError_t launch_prefilter(const float *d_src, int w, int h, float power, const float *d_lutT, const float2 *d_tcs,
                             float *d_out, hipStream_t stream, bool split_ok)
 {
