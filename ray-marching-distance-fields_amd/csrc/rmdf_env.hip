@@ -686,14 +686,15 @@ __global__ __launch_bounds__(64 * (4 + F4_PROD), 6) void k_prefilter_fused4(cons
 #pragma unroll
         for (int k = 0; k < F4_PROD; k++) nt += lds_cnt[k * 64 + lane];
         const float n = (float)(nt < 16777216u ? nt : 16777216u);        // a Float counter: n + 1 == n from 2^24 on
-        if (dx < w) {
-            float *o = (g == 0 ? out0 : g == 1 ? out1 : g == 2 ? out2 : out3) + ((size_t)dx + (size_t)dy * w) * 3;
+        float *ob = g == 0 ? out0 : g == 1 ? out1 : g == 2 ? out2 : out3;      // null: a power the caller did not ask for
+        if (dx < w && ob) {
+            float *o = ob + ((size_t)dx + (size_t)dy * w) * 3;
             o[0] = ar / n; o[1] = ag / n; o[2] = ab / n;
         }
     }
 }
 
-// d_out[k] = the map of power 8^k (1, 8, 64, 512)
+// d_out[k] = the map of power 8^k (1, 8, 64, 512), or null
 hipError_t launch_prefilter_fused4(const float *d_src, int w, int h, const float *d_lutT, const float2 *d_tcs, float *const d_out[4],
                                    hipStream_t stream)
 {

@@ -18,11 +18,11 @@ for f in glob.glob(sys.argv[1] + "/p*/**/*_counter_collection.csv", recursive=Tr
     for r in csv.DictReader(open(f)):
         if "k_prefilter" in r["Kernel_Name"]:
             m = re.search(r"k_prefilter(_split)?<(-?\d+)", r["Kernel_Name"])
-            key = ("split" if m.group(1) else "one-wave") + " p=2^" + m.group(2)
+            key = "fused 1,8,64,512" if "k_prefilter_fused4" in r["Kernel_Name"] else ("split" if m.group(1) else "one-wave") + " p=2^" + m.group(2)
             per.setdefault((key, r["Counter_Name"]), {}).setdefault(r["Dispatch_Id"], 0.0)
             per[(key, r["Counter_Name"])][r["Dispatch_Id"]] += float(r["Counter_Value"])
     for k, v in per.items():
         c[k] = statistics.median(v.values())
 for k in sorted(c):
-    print("%-16s %-26s %16.0f" % (k[0], k[1], c[k]))
+    print("%-18s %-26s %16.0f" % (k[0], k[1], c[k]))
 PY
