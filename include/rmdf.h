@@ -132,8 +132,9 @@ int rmdf_resize_latlong(rmdf_ctx *ctx, const float *rgb, int w, int h, int dstw,
  * reference's order (source rows outer, columns inner); sin / cos come from host-built tables (the libm the reference calls);
  * cos^power for the reference's powers 1, 8, 64, 512 = 2^k is k squarings in binary64 rounded once (DESIGN.md "spec pins"),
  * other powers use the device powf.  2 <= w <= 8192, 2 <= h <= 4096.
- * rmdf_prefilter_env_powers: `npowers` powers of one map, concurrently like the reference's mapConcurrently
- * (ShaderRendering.hs:142); out = npowers * w*h*3 floats.
+ * rmdf_prefilter_env_powers: `npowers` powers of one map, the job of the reference's mapConcurrently (ShaderRendering.hs:142);
+ * out = npowers * w*h*3 floats.  The reference's own set 1, 8, 64, 512 (or three of it) of a map up to 256 texels wide is ONE
+ * kernel launch whose squaring chains share their prefix; other sets run their powers side by side on four streams.
  * rmdf_prefilter_env_device: one power, device-resident source and destination, asynchronous on `stream`. */
 int rmdf_prefilter_env(rmdf_ctx *ctx, const float *rgb, int w, int h, float power, float *out);
 int rmdf_prefilter_env_powers(rmdf_ctx *ctx, const float *rgb, int w, int h, const float *powers, int npowers, float *out);
