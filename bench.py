@@ -675,6 +675,10 @@ def main():
                 result["roofline"]["issue"] = {"valu_instructions_per_launch": valu_instr, "source": pmc_src, "simds": simds,
                                                "achieved": round(rate, 3), "peak": VALU_ISSUE_PEAK, "frac": round(rate / VALU_ISSUE_PEAK, 3),
                                                "unit": "G wave-instructions/s/SIMD",
+                                               "achieved_frames_in_flight": round(valu_instr / simds / (ms_per_step * 1e-3) / 1e9, 3),
+                                               "frames_in_flight_note": "the same instruction count over ms_per_step (the schedule `value` is measured "
+                                                                        "on): with frames in flight the vector pipes issue at this rate; `peak` is what a "
+                                                                        "pure v_mul_f32 stream sustains (tools/ubench/valu_rates)",
                                                "lane_utilisation": (pmc.get("valu") or {}).get("lane_utilisation")}
         elif ctr is not None and sharded and L == 0:
             # N GPUs: the frame's as-written operations against the job's N vector-ALU roofs, at the whole-job rate the timed region
