@@ -339,6 +339,34 @@ __global__ __launch_bounds__(64 * PREFILTER_WAVES) void k_prefilter(const float 
     }
 }
 
+// Source texels for a summing wave without broadcast LDS reads: the wave reads sixteen consecutive floats of the staged row ONCE into the
+// sixteen lanes of each of its four rows (ds_read_b32, 256 bytes returned, where a broadcast ds_read_b128 returns 1 KB for 16 distinct
+// bytes) and multiplies straight out of that register with v_mul_f32_dpp row_newbcast:k -- the DPP operand fetch does the broadcast:
+// no LDS traffic, no extra instruction (hipcc does not fold update_dpp into the multiply, hence the inline asm); same IEEE product.
+template <int K>
+__device__ __forceinline__ float mul_row_bcast(float row16, float f)       // (lane K of each 16-lane row of row16) * f
+{
+    float r;
+    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(row16), "v"(f), "n"(K));
+    return r;
+}
+// texel T of a chunk (static): its three floats sit at 3T .. 3T+2 of the chunk's floats, held sixteen per register
+template <int T, int NR>
+__device__ __forceinline__ void f4_sum_texel(const float (&rr)[NR], float f, float &ar, float &ag, float &ab)
+{
+    ar = ar + mul_row_bcast<(3 * T) % 16>(rr[(3 * T) / 16], f);
+    ag = ag + mul_row_bcast<(3 * T + 1) % 16>(rr[(3 * T + 1) / 16], f);
+    ab = ab + mul_row_bcast<(3 * T + 2) % 16>(rr[(3 * T + 2) / 16], f);
+}
+template <int G, int NR>
+__device__ __forceinline__ void f4_sum_group(const float (&rr)[NR], const float4 &f, float &ar, float &ag, float &ab)
+{
+    f4_sum_texel<4 * G, NR>(rr, f.x, ar, ag, ab);
+    f4_sum_texel<4 * G + 1, NR>(rr, f.y, ar, ag, ab);
+    f4_sum_texel<4 * G + 2, NR>(rr, f.z, ar, ag, ab);
+    f4_sum_texel<4 * G + 3, NR>(rr, f.w, ar, ag, ab);
+}
+
 // Round 3, second form (w <= 256, w % 4 == 0, the reference's powers): the per-destination chain is split between waves WITHOUT
 // touching the order of a single addition.  One lane per destination texel is all the parallelism the sums allow, and at 256x128
 // that is 512 waves, each issuing one vector instruction per ~5 cycles for 32768 x ~12 instructions.  But of those twelve only four
@@ -385,16 +413,11 @@ __global__ __launch_bounds__(64 * SPLIT_CONS * (1 + SPLIT_PROD)) void k_prefilte
     }
     typedef const float __attribute__((address_space(4))) cfloat;
     const float lc = ((cfloat *)tcs)[2 * dy], ls = ((cfloat *)tcs)[2 * dy + 1];
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 arg = { 0.0f, 0.0f };
-    float ab = 0.0f;
+    float ar = 0.0f, ag = 0.0f, ab = 0.0f;
     unsigned ni = 0u;
     float *ring = lds_ring + cidx * 2 * 64 * SPLIT_STRIDE + lane * SPLIT_STRIDE;
     const int total = h * nch;
     __syncthreads();
-    // staged rows are swizzled for the consumer: four texels = three 16-byte pieces (r0 g0 r1 g1 | r2 g2 r3 g3 | b0 b1 b2 b3), so that
-    // every (r, g) pair the packed instructions take sits in an even-aligned register pair
-    auto row_slot = [](int i) { const int t = i / 3, ch = i - 3 * t, q = t >> 2, k = t & 3; return q * 12 + (ch < 2 ? 2 * k + ch : 8 + k); };
     constexpr int GPP = (SPLIT_CHUNK / 4 + SPLIT_PROD - 1) / SPLIT_PROD;      // groups of four texels per producer and chunk, at most
     for (int s = 0; s <= total; s++) {
         if (!consumer) {
@@ -402,7 +425,7 @@ __global__ __launch_bounds__(64 * SPLIT_CONS * (1 + SPLIT_PROD)) void k_prefilte
             if (j == 0 && s < total) {
                 float *rb = lds_row + (y & 1) * row_stride;
 #pragma unroll
-                for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; if (i < nrow) rb[row_slot(i)] = pf[k]; }
+                for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; if (i < nrow) rb[i] = pf[k]; }
             }
             if (j == nch - 1 && y + 1 < h) {
                 const float *nsrc = src + (size_t)(y + 1) * nrow;
@@ -463,39 +486,28 @@ __global__ __launch_bounds__(64 * SPLIT_CONS * (1 + SPLIT_PROD)) void k_prefilte
             const int x0 = j * SPLIT_CHUNK;
             const int ng = ((w - x0 < SPLIT_CHUNK ? w - x0 : SPLIT_CHUNK) + 3) >> 2;
             const float *fsrc = ring + (sc & 1) * 64 * SPLIT_STRIDE;
-            const float4 *rq = (const float4 *)(lds_row + (y & 1) * row_stride + x0 * 3);
-            // one group of four source texels: the reference's four operations per texel, in its order
-            auto sum4 = [&](const float4 &f, const float4 &a, const float4 &b, const float4 &c) {
-                { const f2 rg = { a.x, a.y }, ff = { f.x, f.x }; arg = arg + rg * ff; ab = ab + c.x * f.x; }
-                { const f2 rg = { a.z, a.w }, ff = { f.y, f.y }; arg = arg + rg * ff; ab = ab + c.y * f.y; }
-                { const f2 rg = { b.x, b.y }, ff = { f.z, f.z }; arg = arg + rg * ff; ab = ab + c.z * f.z; }
-                { const f2 rg = { b.z, b.w }, ff = { f.w, f.w }; arg = arg + rg * ff; ab = ab + c.w * f.w; }
-            };
+            // the chunk's 192 row floats, sixteen per register (each lane of a 16-lane row holds one); the factors of its 16 groups
+            const float *rrow = lds_row + (y & 1) * row_stride + x0 * 3 + (lane & 15);
+            float rr[SPLIT_CHUNK * 3 / 16];
+            float4 f[SPLIT_CHUNK / 4];
+#pragma unroll
+            for (int m = 0; m < SPLIT_CHUNK * 3 / 16; m++) rr[m] = rrow[16 * m];
+#pragma unroll
+            for (int k = 0; k < SPLIT_CHUNK / 4; k++) f[k] = *(const float4 *)(fsrc + 4 * k);            // (groups past ng: stale, unused)
+            // one group of four source texels: the reference's operations per texel, in its order (f4_sum_group: v_mul_f32_dpp + v_add_f32)
+#define SPLIT_G(G) if (G < ng) f4_sum_group<G>(rr, f[G], ar, ag, ab);
             if (ng == SPLIT_CHUNK / 4) {
-                // a full chunk: four blocks of four groups over two register sets, the next block's LDS reads in flight while one sums
-                constexpr int GB = 4;
-                float4 fa[GB], ra[3 * GB], fb[GB], rb[3 * GB];
-                auto load_block = [&](float4 (&f)[GB], float4 (&r)[3 * GB], int g0) {
-#pragma unroll
-                    for (int k = 0; k < GB; k++) f[k] = *(const float4 *)(fsrc + 4 * (g0 + k));
-#pragma unroll
-                    for (int k = 0; k < 3 * GB; k++) r[k] = rq[3 * g0 + k];
-                };
-                auto sum_block = [&](const float4 (&f)[GB], const float4 (&r)[3 * GB]) {
-#pragma unroll
-                    for (int k = 0; k < GB; k++) sum4(f[k], r[3 * k], r[3 * k + 1], r[3 * k + 2]);
-                };
-                load_block(fa, ra, 0);
-                load_block(fb, rb, GB);
-                sum_block(fa, ra);
-                load_block(fa, ra, 2 * GB);
-                sum_block(fb, rb);
-                load_block(fb, rb, 3 * GB);
-                sum_block(fa, ra);
-                sum_block(fb, rb);
+                f4_sum_group<0>(rr, f[0], ar, ag, ab);   f4_sum_group<1>(rr, f[1], ar, ag, ab);   f4_sum_group<2>(rr, f[2], ar, ag, ab);
+                f4_sum_group<3>(rr, f[3], ar, ag, ab);   f4_sum_group<4>(rr, f[4], ar, ag, ab);   f4_sum_group<5>(rr, f[5], ar, ag, ab);
+                f4_sum_group<6>(rr, f[6], ar, ag, ab);   f4_sum_group<7>(rr, f[7], ar, ag, ab);   f4_sum_group<8>(rr, f[8], ar, ag, ab);
+                f4_sum_group<9>(rr, f[9], ar, ag, ab);   f4_sum_group<10>(rr, f[10], ar, ag, ab); f4_sum_group<11>(rr, f[11], ar, ag, ab);
+                f4_sum_group<12>(rr, f[12], ar, ag, ab); f4_sum_group<13>(rr, f[13], ar, ag, ab); f4_sum_group<14>(rr, f[14], ar, ag, ab);
+                f4_sum_group<15>(rr, f[15], ar, ag, ab);
             } else {
-                for (int gi = 0; gi < ng; gi++) sum4(*(const float4 *)(fsrc + 4 * gi), rq[3 * gi], rq[3 * gi + 1], rq[3 * gi + 2]);
+                SPLIT_G(0) SPLIT_G(1) SPLIT_G(2) SPLIT_G(3) SPLIT_G(4) SPLIT_G(5) SPLIT_G(6) SPLIT_G(7)
+                SPLIT_G(8) SPLIT_G(9) SPLIT_G(10) SPLIT_G(11) SPLIT_G(12) SPLIT_G(13) SPLIT_G(14)
             }
+#undef SPLIT_G
         }
         __syncthreads();
     }
@@ -508,7 +520,7 @@ __global__ __launch_bounds__(64 * SPLIT_CONS * (1 + SPLIT_PROD)) void k_prefilte
         const float n = (float)(nt < 16777216u ? nt : 16777216u);        // a Float counter: n + 1 == n from 2^24 on
         if (dx < w && dy_raw < h) {
             float *o = out + ((size_t)dx + (size_t)dy * w) * 3;
-            o[0] = arg.x / n; o[1] = arg.y / n; o[2] = ab / n;
+            o[0] = ar / n; o[1] = ag / n; o[2] = ab / n;
         }
     }
 }
@@ -531,30 +543,6 @@ static size_t prefilter_split_lds(int w)
 #define F4_PROD 8                     // producer waves: one group of four source texels each per chunk
 #define F4_CHUNK 32                   // source texels per hand-over
 #define F4_STRIDE 36                  // floats per destination lane in a chunk buffer: 16-byte aligned, 4 banks apart
-template <int K>
-__device__ __forceinline__ float mul_row_bcast(float row16, float f)       // (lane K of each 16-lane row of row16) * f
-{
-    float r;
-    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(row16), "v"(f), "n"(K));
-    return r;
-}
-// texel T of a chunk (static): its three floats sit at 3T .. 3T+2 of the chunk's 96 = six registers of sixteen
-template <int T>
-__device__ __forceinline__ void f4_sum_texel(const float (&rr)[F4_CHUNK * 3 / 16], float f, float &ar, float &ag, float &ab)
-{
-    ar = ar + mul_row_bcast<(3 * T) % 16>(rr[(3 * T) / 16], f);
-    ag = ag + mul_row_bcast<(3 * T + 1) % 16>(rr[(3 * T + 1) / 16], f);
-    ab = ab + mul_row_bcast<(3 * T + 2) % 16>(rr[(3 * T + 2) / 16], f);
-}
-template <int G>
-__device__ __forceinline__ void f4_sum_group(const float (&rr)[F4_CHUNK * 3 / 16], const float4 &f, float &ar, float &ag, float &ab)
-{
-    f4_sum_texel<4 * G>(rr, f.x, ar, ag, ab);
-    f4_sum_texel<4 * G + 1>(rr, f.y, ar, ag, ab);
-    f4_sum_texel<4 * G + 2>(rr, f.z, ar, ag, ab);
-    f4_sum_texel<4 * G + 3>(rr, f.w, ar, ag, ab);
-}
-
 #define F4_MAXCH 8                     // chunks per source row at most (w <= 256)
 __global__ __launch_bounds__(64 * (4 + F4_PROD), 6) void k_prefilter_fused4(const float *__restrict__ src, int w, int h,
         const float *__restrict__ lutT, const float2 *__restrict__ tcs, float *__restrict__ out0, float *__restrict__ out1,
