@@ -343,6 +343,8 @@ __global__ __launch_bounds__(64 * PREFILTER_WAVES) void k_prefilter(const float 
 // sixteen lanes of each of its four rows (ds_read_b32, 256 bytes returned, where a broadcast ds_read_b128 returns 1 KB for 16 distinct
 // bytes) and multiplies straight out of that register with v_mul_f32_dpp row_newbcast:k -- the DPP operand fetch does the broadcast:
 // no LDS traffic, no extra instruction (hipcc does not fold update_dpp into the multiply, hence the inline asm); same IEEE product.
+// The DPP operand must not have been written by a vector instruction in the two slots before (a gfx9 hazard the compiler does not see
+// inside inline asm): here it always comes from an LDS read; tests/test_host_logic.py checks the generated assembly for it.
 template <int K>
 __device__ __forceinline__ float mul_row_bcast(float row16, float f)       // (lane K of each 16-lane row of row16) * f
 {

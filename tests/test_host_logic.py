@@ -198,3 +198,41 @@ def test_cornell_candidate_grid_built_by_halving_equals_brute_force():
     assert counts[64] < counts[32] < counts[16], counts        # what the finer grid buys: fewer candidates per cell
     assert L.rmdf_debug_cornell_masks(48, 0, grids[16].ctypes.data) != 0     # only powers of two times 16
 
+
+
+def test_dpp_products_of_the_prefilter_have_no_read_after_write_hazard(tmp_path):
+    """k_prefilter_split / k_prefilter_fused4 multiply source texels through `v_mul_f32_dpp ... row_newbcast` written as inline asm
+    (hipcc does not fold update_dpp into the multiply).  The compiler's hazard recogniser does not look inside inline asm, and gfx9
+    requires two wait states between a VALU write of a VGPR and a DPP read of it.  The DPP operand is always a register loaded from
+    LDS (a waitcnt, not a VALU write, precedes its use); this test compiles rmdf_env.hip to assembly with the product's flags and
+    checks that it stays that way: no vector instruction writes a DPP source in the two slots before the multiply."""
+    import re
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "ray-marching-distance-fields_amd", "csrc")
+    out = str(tmp_path / "env.s")
+    flags = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fno-gpu-flush-denormals-to-zero".split()
+    subprocess.run([hipcc] + flags + ["-Wno-unused-function", "--cuda-device-only", "-S", os.path.join(csrc, "rmdf_env.hip"), "-o", out],
+                   check=True, capture_output=True, timeout=600)
+    ins = []
+    for l in open(out):
+        t = l.split(";")[0].strip()
+        if t and not t.startswith((".", "//")) and not t.endswith(":"):
+            ins.append(t)
+    n_dpp = 0
+    for i, t in enumerate(ins):
+        m = re.match(r"v_mul_f32_dpp\s+v\d+,\s*v(\d+),", t)
+        if not m:
+            continue
+        n_dpp += 1
+        src0 = int(m.group(1))
+        for back in (1, 2):
+            d = re.match(r"v_\w+\s+v(?:\[(\d+):(\d+)\]|(\d+))", ins[i - back])
+            if d:
+                lo, hi = (int(d.group(1)), int(d.group(2))) if d.group(1) else (int(d.group(3)), int(d.group(3)))
+                assert not (lo <= src0 <= hi), (ins[i - back], t)
+    assert n_dpp > 1000                                      # both kernels are there, fully unrolled
