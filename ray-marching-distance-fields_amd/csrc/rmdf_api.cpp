@@ -822,8 +822,9 @@ int prefilter_powers_device(rmdf_ctx *ctx, const float *d_src, int w, int h, con
     if (rc != RMDF_OK) return rc;
     // the reference's own job -- powers 1, 8, 64 and 512 of one map -- is one launch (rmdf_env.hip: k_prefilter_fused4)
     static const bool no_fused = getenv("RMDF_PREFILTER_NO_FUSED") != nullptr;       // A/B switch (tools/)
-    // (three of the four too: 1.1 ms for the launch against 2.0 for three split launches; the fourth sum is computed and dropped)
-    if ((n == 4 || n == 3) && w <= 256 && w % 4 == 0 && !no_fused) {
+    // (two or three of the four too: 0.9 ms for the launch against 1.1 / 1.8 for two / three split launches; the other sums are computed
+    // and dropped)
+    if (n >= 2 && n <= 4 && w <= 256 && w % 4 == 0 && !no_fused) {
         float *by_k[4] = { nullptr, nullptr, nullptr, nullptr };
         bool ok = true;
         for (int i = 0; i < n; i++) {

@@ -559,6 +559,7 @@ __global__ __launch_bounds__(64 * (4 + F4_PROD), 6) void k_prefilter_fused4(cons
     float *lds_row = lds_dyn;                                            // [2][row_stride]
     float *lds_ring = lds_row + 2 * row_stride;                          // [4 powers][2][64][F4_STRIDE]
     unsigned *lds_cnt = (unsigned *)lds_ring;                            // [F4_PROD][64], after the last chunk has been summed
+    unsigned *lds_flag = (unsigned *)(lds_ring + 4 * 2 * 64 * F4_STRIDE); // [2][F4_PROD]: does any lane have a positive cosine in this group?
     const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool consumer = g < 4;
     const int pidx = consumer ? 0 : g - 4;
@@ -614,28 +615,39 @@ __global__ __launch_bounds__(64 * (4 + F4_PROD), 6) void k_prefilter_fused4(cons
                     const int x0 = j * F4_CHUNK;
                     const int ng = ((w - x0 < F4_CHUNK ? w - x0 : F4_CHUNK) + 3) >> 2;
                     if (pidx < ng) {
-                        float f1[4], f8[4], f64[4], f512[4];
+                        // A group of four source texels that lies behind ALL 64 destination texels of this workgroup (every cosine <= 0:
+                        // a quarter to a half of the sphere, depending on the row) contributes +-0 to every sum, and x + (+-0) == x: the
+                        // producers skip its squaring chains and say so, the summing waves skip its twelve products and sums.
+                        float c0[4];
 #pragma unroll
                         for (int t = 0; t < 4; t++) {
                             const float cos_angle = lcpc + lsps * lutreg[j][t];
                             unsigned ind;
                             asm("v_med3_i32 %0, %1, 0, 1" : "=v"(ind) : "v"(__float_as_int(cos_angle)));
                             ni += ind;
-                            const float c0 = __builtin_fmaxf(cos_angle, 0.0f);
-                            double cd = (double)c0;
+                            c0[t] = __builtin_fmaxf(cos_angle, 0.0f);
+                        }
+                        const bool live = __ballot(__builtin_fmaxf(__builtin_fmaxf(c0[0], c0[1]), __builtin_fmaxf(c0[2], c0[3])) > 0.0f) != 0ull;
+                        if (lane == 0) lds_flag[(s & 1) * F4_PROD + pidx] = live ? 1u : 0u;
+                        if (live) {
+                        float f1[4], f8[4], f64[4], f512[4];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            double cd = (double)c0[t];
                             cd = cd * cd; cd = cd * cd; cd = cd * cd;
                             const float c8 = (float)cd;
                             cd = cd * cd; cd = cd * cd; cd = cd * cd;
                             const float c64 = (float)cd;
                             cd = cd * cd; cd = cd * cd; cd = cd * cd;
                             const float c512 = (float)cd;
-                            f1[t] = ps * c0; f8[t] = ps * c8; f64[t] = ps * c64; f512[t] = ps * c512;
+                            f1[t] = ps * c0[t]; f8[t] = ps * c8; f64[t] = ps * c64; f512[t] = ps * c512;
                         }
                         float *dst = ring_p + (s & 1) * 64 * F4_STRIDE + 4 * pidx;
                         *(float4 *)(dst) = make_float4(f1[0], f1[1], f1[2], f1[3]);
                         *(float4 *)(dst + 1 * 2 * 64 * F4_STRIDE) = make_float4(f8[0], f8[1], f8[2], f8[3]);
                         *(float4 *)(dst + 2 * 2 * 64 * F4_STRIDE) = make_float4(f64[0], f64[1], f64[2], f64[3]);
                         *(float4 *)(dst + 3 * 2 * 64 * F4_STRIDE) = make_float4(f512[0], f512[1], f512[2], f512[3]);
+                        }
                     }
                 }
             } else if (s > 0) {
@@ -650,20 +662,17 @@ __global__ __launch_bounds__(64 * (4 + F4_PROD), 6) void k_prefilter_fused4(cons
                 for (int m = 0; m < F4_CHUNK * 3 / 16; m++) rr[m] = rrow[16 * m];
 #pragma unroll
                 for (int k = 0; k < F4_CHUNK / 4; k++) f[k] = *(const float4 *)(fsrc + 4 * k);        // (groups past ng: stale, unused)
-                if (ng == F4_CHUNK / 4) {
-                    f4_sum_group<0>(rr, f[0], ar, ag, ab); f4_sum_group<1>(rr, f[1], ar, ag, ab);
-                    f4_sum_group<2>(rr, f[2], ar, ag, ab); f4_sum_group<3>(rr, f[3], ar, ag, ab);
-                    f4_sum_group<4>(rr, f[4], ar, ag, ab); f4_sum_group<5>(rr, f[5], ar, ag, ab);
-                    f4_sum_group<6>(rr, f[6], ar, ag, ab); f4_sum_group<7>(rr, f[7], ar, ag, ab);
-                } else {
-                    if (0 < ng) f4_sum_group<0>(rr, f[0], ar, ag, ab);
-                    if (1 < ng) f4_sum_group<1>(rr, f[1], ar, ag, ab);
-                    if (2 < ng) f4_sum_group<2>(rr, f[2], ar, ag, ab);
-                    if (3 < ng) f4_sum_group<3>(rr, f[3], ar, ag, ab);
-                    if (4 < ng) f4_sum_group<4>(rr, f[4], ar, ag, ab);
-                    if (5 < ng) f4_sum_group<5>(rr, f[5], ar, ag, ab);
-                    if (6 < ng) f4_sum_group<6>(rr, f[6], ar, ag, ab);
-                }
+                // groups the producers declared dead (and groups past the row's end) are skipped: their ring slots hold stale factors
+                const unsigned fl = lds_flag[(sc & 1) * F4_PROD + (lane & (F4_PROD - 1))];
+                const unsigned live = (unsigned)__ballot(fl != 0u) & ((ng >= F4_CHUNK / 4) ? 0xffu : ((1u << ng) - 1u));
+                if (live & 1u)   f4_sum_group<0>(rr, f[0], ar, ag, ab);
+                if (live & 2u)   f4_sum_group<1>(rr, f[1], ar, ag, ab);
+                if (live & 4u)   f4_sum_group<2>(rr, f[2], ar, ag, ab);
+                if (live & 8u)   f4_sum_group<3>(rr, f[3], ar, ag, ab);
+                if (live & 16u)  f4_sum_group<4>(rr, f[4], ar, ag, ab);
+                if (live & 32u)  f4_sum_group<5>(rr, f[5], ar, ag, ab);
+                if (live & 64u)  f4_sum_group<6>(rr, f[6], ar, ag, ab);
+                if (live & 128u) f4_sum_group<7>(rr, f[7], ar, ag, ab);
             }
             __syncthreads();
             s++;
@@ -690,7 +699,7 @@ hipError_t launch_prefilter_fused4(const float *d_src, int w, int h, const float
 {
     if (w < 2 || h < 2 || w > 256 || w % 4) return hipErrorInvalidValue;
     const int nch = (w + F4_CHUNK - 1) / F4_CHUNK;
-    const size_t lds = (2 * (size_t)nch * F4_CHUNK * 3 + (size_t)4 * 2 * 64 * F4_STRIDE) * sizeof(float);
+    const size_t lds = (2 * (size_t)nch * F4_CHUNK * 3 + (size_t)4 * 2 * 64 * F4_STRIDE + 2 * F4_PROD) * sizeof(float);
     hipError_t e = hipFuncSetAttribute((const void *)k_prefilter_fused4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_prefilter_fused4, dim3((w + 63) / 64, h), dim3(64 * (4 + F4_PROD)), lds, stream, d_src, w, h, d_lutT, d_tcs,

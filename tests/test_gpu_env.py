@@ -72,7 +72,7 @@ def test_lobe_prefilter_is_bit_exact(sr, orc, env_latlongs, w, h):
         ref = orc.cosine_convolve(src, p, pow_mode=1)
         assert np.array_equal(got[i].view(np.uint32), ref.view(np.uint32)), (p, rel_err(got[i], ref).max())
         assert np.array_equal(sr.prefilter_env(src, p).view(np.uint32), ref.view(np.uint32))        # single-power entry
-    # three of the four powers, out of order: the fused launch with one sum dropped; two: split launches side by side
+    # three or two of the four powers, out of order: the fused launch with the other sums dropped
     sub = sr.prefilter_env_powers(src, (512.0, 1.0, 64.0))
     for q, p in zip(sub, (512.0, 1.0, 64.0)):
         assert np.array_equal(q.view(np.uint32), got[POWERS.index(p)].view(np.uint32)), p
