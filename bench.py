@@ -255,7 +255,8 @@ def main():
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dog.arm("torch.distributed.init_process_group")
+        # (the rendezvous also waits for ranks that are still importing torch on a cold box: minutes, not a hang)
+        dog.arm("torch.distributed.init_process_group", seconds=max(dog.seconds, 600.0))
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -852,8 +853,8 @@ def secondary_workloads(sr, torch, dev, stream, cus, streams=()):
                                              "pair_terms_per_power": pair_terms,
                                              "note": "one lane per destination texel sums the source serially in the reference's order "
                                                      "(bit-exact).  A power alone: the factor sin*cos^p of every (destination, source) pair is "
-                                                     "computed by producer waves and handed to the summing wave through LDS (2048 waves instead "
-                                                     "of 512; k_prefilter_split).  The reference's four powers at once (mapConcurrently): ONE launch "
+                                                     "computed by producer waves and handed through LDS to three summing waves, one per colour channel "
+                                                     "(5632 waves instead of 512; k_prefilter_chan).  The reference's four powers at once (mapConcurrently): ONE launch "
                                                      "-- the squaring chains nest, so producers compute all four factors from one cosine and feed "
                                                      "four summing waves (k_prefilter_fused4)"}
     return out

@@ -371,174 +371,22 @@ __device__ __forceinline__ void f4_sum_group(const float (&rr)[NR], const float4
 
 // Round 3, second form (w <= 256, w % 4 == 0, the reference's powers): the per-destination chain is split between waves WITHOUT
 // touching the order of a single addition.  One lane per destination texel is all the parallelism the sums allow, and at 256x128
-// that is 512 waves, each issuing one vector instruction per ~5 cycles for 32768 x ~12 instructions.  But of those twelve only four
-// belong to the chain (r, g, b: one packed multiply-add pair and one scalar pair per source texel); the rest computes the factor
-// sin(theta) * cos^p, which depends on nothing the lane has summed.  So every CONSUMER wave (64 destination texels of one row, as
-// before) gets SPLIT_PROD PRODUCER waves on the other SIMDs of its CU: they evaluate the factors of alternating groups of four source
-// texels for the same 64 destination lanes and hand them over through LDS, 64 source texels (one chunk) at a time, double-buffered,
-// one workgroup barrier per chunk; the consumer reads factor and texel and does the reference's four operations in the reference's
-// order.  The sample count n is an integer (see k_prefilter), so the producers count.  Same bits (tests/test_gpu_env.py compares
-// both kernels with the oracle), 2048 waves instead of 512.
-#define SPLIT_CONS 2                  // consumer waves (destination rows) per workgroup; they share the staged cosine table
-#define SPLIT_PROD 3                  // producer waves per consumer
-#define SPLIT_CHUNK 64                // source texels per hand-over
-#define SPLIT_STRIDE 68               // floats per destination lane in a chunk buffer: 16-byte aligned, 4 banks apart
-template <int LOG2P>
-__global__ __launch_bounds__(64 * SPLIT_CONS * (1 + SPLIT_PROD)) void k_prefilter_split(const float *__restrict__ src, int w, int h,
-                                                  const float *__restrict__ lutT, const float2 *__restrict__ tcs, float *__restrict__ out)
-{
-    extern __shared__ float lds_dyn[];
-    const int nch = (w + SPLIT_CHUNK - 1) / SPLIT_CHUNK;                 // chunks per source row
-    const int row_stride = nch * SPLIT_CHUNK * 3;                        // floats per staged row, zero beyond w * 3
-    float *lds_lut = lds_dyn;                                            // [w][64]
-    float *lds_row = lds_lut + w * 64;                                   // [2][row_stride]
-    float *lds_ring = lds_row + 2 * row_stride;                          // [SPLIT_CONS][2][64][SPLIT_STRIDE]
-    unsigned *lds_cnt = (unsigned *)(lds_ring + SPLIT_CONS * 2 * 64 * SPLIT_STRIDE);     // [SPLIT_CONS][SPLIT_PROD][64]
-    const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool consumer = g < SPLIT_CONS;
-    const int cidx = consumer ? g : (g - SPLIT_CONS) / SPLIT_PROD, pidx = consumer ? 0 : (g - SPLIT_CONS) % SPLIT_PROD;
-    const int blk = blockIdx.x, dy_raw = blockIdx.y * SPLIT_CONS + cidx;
-    const int dy = dy_raw < h ? dy_raw : h - 1;
-    const int dx = blk * 64 + lane;
-    const float *glut = lutT + (size_t)blk * w * 64;
-    constexpr int NT = 64 * SPLIT_CONS * (1 + SPLIT_PROD);
-    for (int i = threadIdx.x; i < w * 64; i += NT) lds_lut[i] = glut[i];
-    for (int i = threadIdx.x; i < 2 * row_stride; i += NT) lds_row[i] = 0.0f;
-    // the producers stage the source rows: row y + 1 travels in registers while the last chunk of row y is produced
-    constexpr int NP = 64 * SPLIT_CONS * SPLIT_PROD, NPF = 2;            // 384 threads x 2 floats = 768 = 256 texels
-    const int ptid = (int)threadIdx.x - 64 * SPLIT_CONS;
-    const int nrow = w * 3;
-    float pf[NPF] = { 0.0f, 0.0f };
-    if (!consumer) {
-#pragma unroll
-        for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; pf[k] = i < nrow ? src[i] : 0.0f; }
-    }
-    typedef const float __attribute__((address_space(4))) cfloat;
-    const float lc = ((cfloat *)tcs)[2 * dy], ls = ((cfloat *)tcs)[2 * dy + 1];
-    float ar = 0.0f, ag = 0.0f, ab = 0.0f;
-    unsigned ni = 0u;
-    float *ring = lds_ring + cidx * 2 * 64 * SPLIT_STRIDE + lane * SPLIT_STRIDE;
-    const int total = h * nch;
-    __syncthreads();
-    constexpr int GPP = (SPLIT_CHUNK / 4 + SPLIT_PROD - 1) / SPLIT_PROD;      // groups of four texels per producer and chunk, at most
-    for (int s = 0; s <= total; s++) {
-        if (!consumer) {
-            const int y = s / nch, j = s - y * nch;                      // (for s == total: nothing left to produce)
-            if (j == 0 && s < total) {
-                float *rb = lds_row + (y & 1) * row_stride;
-#pragma unroll
-                for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; if (i < nrow) rb[i] = pf[k]; }
-            }
-            if (j == nch - 1 && y + 1 < h) {
-                const float *nsrc = src + (size_t)(y + 1) * nrow;
-#pragma unroll
-                for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; pf[k] = i < nrow ? nsrc[i] : 0.0f; }
-            }
-            if (s < total) {
-                const float pc = ((cfloat *)tcs)[2 * y], ps = ((cfloat *)tcs)[2 * y + 1];
-                const float lcpc = lc * pc, lsps = ls * ps;
-                const int x0 = j * SPLIT_CHUNK;
-                const int ng = ((w - x0 < SPLIT_CHUNK ? w - x0 : SPLIT_CHUNK) + 3) >> 2;
-                float *dst = ring + (s & 1) * 64 * SPLIT_STRIDE;
-                // one group of four source texels for this wave's 64 destination lanes
-                auto factors4 = [&](const float (&l)[4], int gi) {
-                    float fac[4];
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const float cos_angle = lcpc + lsps * l[t];
-                        unsigned ind;
-                        asm("v_med3_i32 %0, %1, 0, 1" : "=v"(ind) : "v"(__float_as_int(cos_angle)));
-                        ni += ind;
-                        const float c0 = __builtin_fmaxf(cos_angle, 0.0f);
-                        float cp = c0;
-                        if (LOG2P > 0) {
-                            double cd = (double)c0;
-#pragma unroll
-                            for (int q = 0; q < LOG2P; q++) cd = cd * cd;
-                            cp = (float)cd;
-                        }
-                        fac[t] = ps * cp;
-                    }
-                    *(float4 *)(dst + 4 * gi) = make_float4(fac[0], fac[1], fac[2], fac[3]);
-                };
-                if (ng == SPLIT_CHUNK / 4) {
-                    // a full chunk: every producer has GPP - 1 groups for certain -- one basic block, all their cosines read first, twenty
-                    // independent chains for the scheduler to interleave -- and the first few producers one more
-                    float l[GPP][4];
-#pragma unroll
-                    for (int k = 0; k < GPP; k++) {
-                        const int gi = pidx + k * SPLIT_PROD, gic = gi < ng ? gi : pidx;
-#pragma unroll
-                        for (int t = 0; t < 4; t++) l[k][t] = lds_lut[(x0 + 4 * gic + t) * 64 + lane];
-                    }
-#pragma unroll
-                    for (int k = 0; k < GPP - 1; k++) factors4(l[k], pidx + k * SPLIT_PROD);
-                    if (pidx + (GPP - 1) * SPLIT_PROD < ng) factors4(l[GPP - 1], pidx + (GPP - 1) * SPLIT_PROD);
-                } else {
-                    for (int gi = pidx; gi < ng; gi += SPLIT_PROD) {
-                        float l[4];
-#pragma unroll
-                        for (int t = 0; t < 4; t++) l[t] = lds_lut[(x0 + 4 * gi + t) * 64 + lane];
-                        factors4(l, gi);
-                    }
-                }
-            }
-        } else if (s > 0) {
-            const int sc = s - 1, y = sc / nch, j = sc - y * nch;
-            const int x0 = j * SPLIT_CHUNK;
-            const int ng = ((w - x0 < SPLIT_CHUNK ? w - x0 : SPLIT_CHUNK) + 3) >> 2;
-            const float *fsrc = ring + (sc & 1) * 64 * SPLIT_STRIDE;
-            // the chunk's 192 row floats, sixteen per register (each lane of a 16-lane row holds one); the factors of its 16 groups
-            const float *rrow = lds_row + (y & 1) * row_stride + x0 * 3 + (lane & 15);
-            float rr[SPLIT_CHUNK * 3 / 16];
-            float4 f[SPLIT_CHUNK / 4];
-#pragma unroll
-            for (int m = 0; m < SPLIT_CHUNK * 3 / 16; m++) rr[m] = rrow[16 * m];
-#pragma unroll
-            for (int k = 0; k < SPLIT_CHUNK / 4; k++) f[k] = *(const float4 *)(fsrc + 4 * k);            // (groups past ng: stale, unused)
-            // one group of four source texels: the reference's operations per texel, in its order (f4_sum_group: v_mul_f32_dpp + v_add_f32)
-#define SPLIT_G(G) if (G < ng) f4_sum_group<G>(rr, f[G], ar, ag, ab);
-            if (ng == SPLIT_CHUNK / 4) {
-                f4_sum_group<0>(rr, f[0], ar, ag, ab);   f4_sum_group<1>(rr, f[1], ar, ag, ab);   f4_sum_group<2>(rr, f[2], ar, ag, ab);
-                f4_sum_group<3>(rr, f[3], ar, ag, ab);   f4_sum_group<4>(rr, f[4], ar, ag, ab);   f4_sum_group<5>(rr, f[5], ar, ag, ab);
-                f4_sum_group<6>(rr, f[6], ar, ag, ab);   f4_sum_group<7>(rr, f[7], ar, ag, ab);   f4_sum_group<8>(rr, f[8], ar, ag, ab);
-                f4_sum_group<9>(rr, f[9], ar, ag, ab);   f4_sum_group<10>(rr, f[10], ar, ag, ab); f4_sum_group<11>(rr, f[11], ar, ag, ab);
-                f4_sum_group<12>(rr, f[12], ar, ag, ab); f4_sum_group<13>(rr, f[13], ar, ag, ab); f4_sum_group<14>(rr, f[14], ar, ag, ab);
-                f4_sum_group<15>(rr, f[15], ar, ag, ab);
-            } else {
-                SPLIT_G(0) SPLIT_G(1) SPLIT_G(2) SPLIT_G(3) SPLIT_G(4) SPLIT_G(5) SPLIT_G(6) SPLIT_G(7)
-                SPLIT_G(8) SPLIT_G(9) SPLIT_G(10) SPLIT_G(11) SPLIT_G(12) SPLIT_G(13) SPLIT_G(14)
-            }
-#undef SPLIT_G
-        }
-        __syncthreads();
-    }
-    if (!consumer) lds_cnt[(cidx * SPLIT_PROD + pidx) * 64 + lane] = ni;
-    __syncthreads();
-    if (consumer) {
-        unsigned nt = 0u;
-#pragma unroll
-        for (int k = 0; k < SPLIT_PROD; k++) nt += lds_cnt[(cidx * SPLIT_PROD + k) * 64 + lane];
-        const float n = (float)(nt < 16777216u ? nt : 16777216u);        // a Float counter: n + 1 == n from 2^24 on
-        if (dx < w && dy_raw < h) {
-            float *o = out + ((size_t)dx + (size_t)dy * w) * 3;
-            o[0] = ar / n; o[1] = ag / n; o[2] = ab / n;
-        }
-    }
-}
-
-static size_t prefilter_split_lds(int w)
-{
-    const int nch = (w + SPLIT_CHUNK - 1) / SPLIT_CHUNK;
-    return ((size_t)w * 64 + 2 * (size_t)nch * SPLIT_CHUNK * 3 + (size_t)SPLIT_CONS * 2 * 64 * SPLIT_STRIDE + (size_t)SPLIT_CONS * SPLIT_PROD * 64) * sizeof(float);
-}
+// that is 512 waves, each issuing one vector instruction per ~5 cycles for 32768 x ~12 instructions.  But of those twelve only the
+// multiply-adds of r, g and b belong to the chain; the rest computes the factor sin(theta) * cos^p, which depends on nothing the lane
+// has summed.  So SUMMING waves (64 destination texels of one row, as before) get PRODUCER waves on the other SIMDs of their CU: these
+// evaluate the factors of groups of four source texels for the same 64 destination lanes and hand them over through an LDS ring, one
+// chunk of source texels per workgroup barrier, double-buffered; the summing waves read factor and texel and do the reference's
+// operations in the reference's order.  The sample count n is an integer (see k_prefilter), so the producers count.  Two kernels are
+// built this way: k_prefilter_fused4 (the reference's four powers at once) and k_prefilter_chan (one power).  The first kernel of
+// the kind (k_prefilter_split: two summing waves + six producers per workgroup, cosine table in LDS, packed (r, g) sums on broadcast
+// row reads: 0.54 / 0.62 / 0.72 / 0.82 ms per power) is in the history of this file; DESIGN.md 4.3 has its measurements.
 
 // Round 3, third form: the reference's FOUR powers (1, 8, 64, 512: buildPreConvolvedHDREnvMapCache, ShaderRendering.hs:131-149) in one
 // launch.  The four maps differ only in the exponent, and the binary64 squaring chains nest: c^8 is three squarings, c^64 three more
 // ON THE SAME VALUE, c^512 three more -- nine multiplications where four separate launches do eighteen, one cosine, one table read,
 // one sample count.  A workgroup is four summing waves (one per power, one per SIMD) fed by eight producer waves through four LDS rings,
 // 32 source texels per barrier.  With four summing waves per CU the LDS return path becomes the scarce unit, and three quarters of what
-// k_prefilter_split moves through it is the SOURCE ROW, broadcast to 64 lanes by ds_read_b128 (1 KB per instruction for 16 distinct
+// the first kernel of this kind moved through it was the SOURCE ROW, broadcast to 64 lanes by ds_read_b128 (1 KB per instruction for 16 distinct
 // bytes).  Here a summing wave reads sixteen consecutive floats of the row ONCE into the sixteen lanes of each row of the wave
 // (ds_read_b32, 256 bytes) and multiplies straight out of that register with v_mul_f32_dpp row_newbcast:k -- the DPP operand fetch
 // does the broadcast, no LDS traffic, no extra instruction; the products and sums are the reference's, in its order.
@@ -693,6 +541,188 @@ __global__ __launch_bounds__(64 * (4 + F4_PROD), 6) void k_prefilter_fused4(cons
     }
 }
 
+// Round 3, fourth form: ONE power with the fused kernel's machinery and the sum split by CHANNEL.  r, g and b are three independent
+// chains (the channel split of k_prefilter lost because every lane repeated the weight; here the weight comes from the producers,
+// once): three summing waves -- one per channel, two instructions per source texel each (v_mul_f32_dpp + v_add_f32) -- share one ring
+// of factors written by eight producer waves.  Same ring, row registers, table in registers, dead-group skipping and barrier scheme as
+// k_prefilter_fused4, with 64-texel chunks (one power's ring is small): 41 KB of LDS, two workgroups of eleven waves per CU.
+#define CH_PROD 8                     // producer waves: two groups of four source texels each per chunk
+#define CH_CHUNK 64                   // source texels per hand-over (one power's ring is small: half as many barriers as the fused kernel)
+#define CH_STRIDE 68                  // floats per destination lane in a chunk buffer
+#define CH_MAXCH 4                    // chunks per source row at most (w <= 256)
+#define CH_GPP (CH_CHUNK / 4 / CH_PROD)
+template <int G, int CH, int NR>
+__device__ __forceinline__ void ch_sum_group(const float (&rr)[NR], const float4 &f, float &a)
+{
+    // the four products first (independent), then the chain of sums: a sum never waits for a product issued just before it
+    const float p0 = mul_row_bcast<(12 * G + CH) % 16>(rr[(12 * G + CH) / 16], f.x);
+    const float p1 = mul_row_bcast<(12 * G + 3 + CH) % 16>(rr[(12 * G + 3 + CH) / 16], f.y);
+    const float p2 = mul_row_bcast<(12 * G + 6 + CH) % 16>(rr[(12 * G + 6 + CH) / 16], f.z);
+    const float p3 = mul_row_bcast<(12 * G + 9 + CH) % 16>(rr[(12 * G + 9 + CH) / 16], f.w);
+    a = a + p0; a = a + p1; a = a + p2; a = a + p3;
+}
+// eight groups (half a chunk) starting at group G0; `live` holds their flags in its low eight bits
+template <int G0, int CH, int NR>
+__device__ __forceinline__ void ch_sum_half(const float (&rr)[NR], const float4 (&f)[CH_CHUNK / 4], unsigned live, float &a)
+{
+    if (live & 1u)   ch_sum_group<G0 + 0, CH>(rr, f[G0 + 0], a);
+    if (live & 2u)   ch_sum_group<G0 + 1, CH>(rr, f[G0 + 1], a);
+    if (live & 4u)   ch_sum_group<G0 + 2, CH>(rr, f[G0 + 2], a);
+    if (live & 8u)   ch_sum_group<G0 + 3, CH>(rr, f[G0 + 3], a);
+    if (live & 16u)  ch_sum_group<G0 + 4, CH>(rr, f[G0 + 4], a);
+    if (live & 32u)  ch_sum_group<G0 + 5, CH>(rr, f[G0 + 5], a);
+    if (live & 64u)  ch_sum_group<G0 + 6, CH>(rr, f[G0 + 6], a);
+    if (live & 128u) ch_sum_group<G0 + 7, CH>(rr, f[G0 + 7], a);
+}
+
+template <int LOG2P>
+__global__ __launch_bounds__(64 * (3 + CH_PROD), 6) void k_prefilter_chan(const float *__restrict__ src, int w, int h,
+        const float *__restrict__ lutT, const float2 *__restrict__ tcs, float *__restrict__ out)
+{
+    extern __shared__ float lds_dyn[];
+    const int nch = (w + CH_CHUNK - 1) / CH_CHUNK;                      // chunks per source row
+    const int row_stride = nch * CH_CHUNK * 3;                           // floats per staged row, zero beyond w * 3
+    float *lds_row = lds_dyn;                                            // [2][row_stride]
+    float *lds_ring = lds_row + 2 * row_stride;                          // [2][64][CH_STRIDE]
+    unsigned *lds_cnt = (unsigned *)lds_ring;                            // [CH_PROD][64], after the last chunk has been summed
+    unsigned *lds_flag = (unsigned *)(lds_ring + 2 * 64 * CH_STRIDE);    // [2][CH_CHUNK / 4]
+    const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool consumer = g < 3;                                         // summing wave g = channel g
+    const int pidx = consumer ? 0 : g - 3;
+    const int blk = blockIdx.x, dy = blockIdx.y;
+    const int dx = blk * 64 + lane;
+    const float *glut = lutT + (size_t)blk * w * 64;
+    constexpr int NT = 64 * (3 + CH_PROD), NP = 64 * CH_PROD, NPF = 2;  // 512 producer threads x 2 floats >= 768 = 256 texels
+    for (int i = threadIdx.x; i < 2 * row_stride; i += NT) lds_row[i] = 0.0f;
+    const int ptid = (int)threadIdx.x - 64 * 3;
+    const int nrow = w * 3;
+    float pf[NPF] = { 0.0f, 0.0f };
+    float lutreg[CH_MAXCH][CH_GPP][4];
+    if (!consumer) {
+#pragma unroll
+        for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; pf[k] = i < nrow ? src[i] : 0.0f; }
+#pragma unroll
+        for (int j = 0; j < CH_MAXCH; j++)
+#pragma unroll
+            for (int k = 0; k < CH_GPP; k++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) { const int x = j * CH_CHUNK + 4 * (pidx + k * CH_PROD) + t; lutreg[j][k][t] = x < w ? glut[x * 64 + lane] : 0.0f; }
+    }
+    typedef const float __attribute__((address_space(4))) cfloat;
+    const float lc = ((cfloat *)tcs)[2 * dy], ls = ((cfloat *)tcs)[2 * dy + 1];
+    float acc = 0.0f;
+    unsigned ni = 0u;
+    float *ring = lds_ring + lane * CH_STRIDE;
+    __syncthreads();
+    int s = 0;
+    float pcn = ((cfloat *)tcs)[0], psn = ((cfloat *)tcs)[1];           // (cos, sin) of the NEXT source row: loaded a row ahead
+    for (int y = 0; y <= h; y++) {
+        const float pc = pcn, ps = psn;
+        const float lcpc = lc * pc, lsps = ls * ps;
+        if (y + 1 < h) { pcn = ((cfloat *)tcs)[2 * (y + 1)]; psn = ((cfloat *)tcs)[2 * (y + 1) + 1]; }
+#pragma unroll
+        for (int j = 0; j < CH_MAXCH; j++) {
+            if (j >= nch || (y == h && j > 0)) continue;                // (y == h: the one step that only sums the last chunk)
+            if (!consumer) {
+                if (y < h) {
+                    if (j == 0) {
+                        // hand row y to the summing waves, then fetch row y + 1 at once: it has the row's remaining steps to arrive
+                        float *rb = lds_row + (y & 1) * row_stride;
+#pragma unroll
+                        for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; if (i < nrow) rb[i] = pf[k]; }
+                        if (y + 1 < h) {
+                            const float *nsrc = src + (size_t)(y + 1) * nrow;
+#pragma unroll
+                            for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; pf[k] = i < nrow ? nsrc[i] : 0.0f; }
+                        }
+                    }
+                    const int x0 = j * CH_CHUNK;
+                    const int ng = ((w - x0 < CH_CHUNK ? w - x0 : CH_CHUNK) + 3) >> 2;
+#pragma unroll
+                    for (int k = 0; k < CH_GPP; k++) {
+                        const int gi = pidx + k * CH_PROD;
+                        if (gi < ng) {
+                            float c0[4];
+#pragma unroll
+                            for (int t = 0; t < 4; t++) {
+                                const float cos_angle = lcpc + lsps * lutreg[j][k][t];
+                                unsigned ind;
+                                asm("v_med3_i32 %0, %1, 0, 1" : "=v"(ind) : "v"(__float_as_int(cos_angle)));
+                                ni += ind;
+                                c0[t] = __builtin_fmaxf(cos_angle, 0.0f);
+                            }
+                            const bool live = __ballot(__builtin_fmaxf(__builtin_fmaxf(c0[0], c0[1]), __builtin_fmaxf(c0[2], c0[3])) > 0.0f) != 0ull;
+                            if (lane == 0) lds_flag[(s & 1) * (CH_CHUNK / 4) + gi] = live ? 1u : 0u;
+                            if (live) {
+                                float fac[4];
+#pragma unroll
+                                for (int t = 0; t < 4; t++) {
+                                    float cp = c0[t];
+                                    if (LOG2P > 0) {
+                                        double cd = (double)c0[t];
+#pragma unroll
+                                        for (int q = 0; q < LOG2P; q++) cd = cd * cd;
+                                        cp = (float)cd;
+                                    }
+                                    fac[t] = ps * cp;
+                                }
+                                *(float4 *)(ring + (s & 1) * 64 * CH_STRIDE + 4 * gi) = make_float4(fac[0], fac[1], fac[2], fac[3]);
+                            }
+                        }
+                    }
+                }
+            } else if (s > 0) {
+                const int sc = s - 1, yc = j == 0 ? y - 1 : y, jc = j == 0 ? nch - 1 : j - 1;      // the chunk filled in the step before
+                const int x0 = jc * CH_CHUNK;
+                const int ng = ((w - x0 < CH_CHUNK ? w - x0 : CH_CHUNK) + 3) >> 2;
+                const float *fsrc = ring + (sc & 1) * 64 * CH_STRIDE;
+                const float *rrow = lds_row + (yc & 1) * row_stride + x0 * 3 + (lane & 15);
+                float rr[CH_CHUNK * 3 / 16];
+                float4 f[CH_CHUNK / 4];
+                const unsigned fl = lds_flag[(sc & 1) * (CH_CHUNK / 4) + (lane & (CH_CHUNK / 4 - 1))];
+                const unsigned live = (unsigned)__ballot(fl != 0u) & ((ng >= CH_CHUNK / 4) ? 0xffffu : ((1u << ng) - 1u));
+                // two halves of eight groups (32 texels = six row registers): the second half's LDS reads are issued after the first half's sums
+#pragma unroll
+                for (int m = 0; m < 6; m++) rr[m] = rrow[16 * m];
+#pragma unroll
+                for (int k = 0; k < 8; k++) f[k] = *(const float4 *)(fsrc + 4 * k);                   // (dead groups: stale, unused)
+                if (g == 0)      ch_sum_half<0, 0>(rr, f, live & 0xffu, acc);
+                else if (g == 1) ch_sum_half<0, 1>(rr, f, live & 0xffu, acc);
+                else             ch_sum_half<0, 2>(rr, f, live & 0xffu, acc);
+                if (live >> 8) {
+#pragma unroll
+                    for (int m = 6; m < 12; m++) rr[m] = rrow[16 * m];
+#pragma unroll
+                    for (int k = 8; k < 16; k++) f[k] = *(const float4 *)(fsrc + 4 * k);
+                    if (g == 0)      ch_sum_half<8, 0>(rr, f, live >> 8, acc);
+                    else if (g == 1) ch_sum_half<8, 1>(rr, f, live >> 8, acc);
+                    else             ch_sum_half<8, 2>(rr, f, live >> 8, acc);
+                }
+            }
+            __syncthreads();
+            s++;
+        }
+    }
+    if (!consumer) lds_cnt[pidx * 64 + lane] = ni;                       // (the ring is free: the barrier above ended the last sum)
+    __syncthreads();
+    if (consumer) {
+        unsigned nt = 0u;
+#pragma unroll
+        for (int k = 0; k < CH_PROD; k++) nt += lds_cnt[k * 64 + lane];
+        const float n = (float)(nt < 16777216u ? nt : 16777216u);        // a Float counter: n + 1 == n from 2^24 on
+        if (dx < w) out[((size_t)dx + (size_t)dy * w) * 3 + g] = acc / n;
+    }
+}
+
+template <int LOG2P>
+static hipError_t launch_prefilter_chan_t(const float *d_src, int w, int h, const float *d_lutT, const float2 *d_tcs, float *d_out, hipStream_t stream)
+{
+    const int nch = (w + CH_CHUNK - 1) / CH_CHUNK;
+    const size_t lds = (2 * (size_t)nch * CH_CHUNK * 3 + (size_t)2 * 64 * CH_STRIDE + 2 * (CH_CHUNK / 4)) * sizeof(float);
+    hipLaunchKernelGGL((k_prefilter_chan<LOG2P>), dim3((w + 63) / 64, h), dim3(64 * (3 + CH_PROD)), lds, stream, d_src, w, h, d_lutT, d_tcs, d_out);
+    return hipGetLastError();
+}
+
 // d_out[k] = the map of power 8^k (1, 8, 64, 512), or null
 hipError_t launch_prefilter_fused4(const float *d_src, int w, int h, const float *d_lutT, const float2 *d_tcs, float *const d_out[4],
                                    hipStream_t stream)
@@ -721,14 +751,8 @@ static hipError_t launch_prefilter_t(const float *d_src, int w, int h, float pow
                                      float *d_out, hipStream_t stream, bool split_ok)
 {
     static const bool one_wave = getenv("RMDF_PREFILTER_ONE_WAVE") != nullptr;          // A/B switch (tools/, tests): the one-wave kernel at every size
-    if (LOG2P >= 0 && w <= 256 && w % 4 == 0 && split_ok && !one_wave) {       // the reference's size: factor and sum on different waves
-        const dim3 grid((w + 63) / 64, (h + SPLIT_CONS - 1) / SPLIT_CONS), block(64 * SPLIT_CONS * (1 + SPLIT_PROD));
-        const size_t lds = prefilter_split_lds(w);
-        hipError_t e = hipFuncSetAttribute((const void *)k_prefilter_split<(LOG2P >= 0 ? LOG2P : 0)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_prefilter_split<(LOG2P >= 0 ? LOG2P : 0)>), grid, block, lds, stream, d_src, w, h, d_lutT, d_tcs, d_out);
-        return hipGetLastError();
-    }
+    if (LOG2P >= 0 && w <= 256 && w % 4 == 0 && split_ok && !one_wave)                  // the reference's size: factor and sum on different waves
+        return launch_prefilter_chan_t<(LOG2P >= 0 ? LOG2P : 0)>(d_src, w, h, d_lutT, d_tcs, d_out, stream);
     const dim3 grid((w + 63) / 64, (h + PREFILTER_WAVES - 1) / PREFILTER_WAVES), block(64 * PREFILTER_WAVES);
     const size_t row = (size_t)((w * 3 + 3) & ~3) * sizeof(float);             // one staged source row
     const size_t lut = (size_t)w * 64 * sizeof(float);
@@ -746,11 +770,11 @@ static hipError_t launch_prefilter_t(const float *d_src, int w, int h, float pow
     return hipGetLastError();
 }
 
-// split_ok: the caller runs at most three powers side by side.  The split kernel fills the machine by itself (2048 waves, one
-// workgroup per CU) and is 1.7 - 1.9 times as fast per power as the one-wave kernel (0.54 / 0.62 / 0.72 / 0.81 against 0.92 / 1.17 / 1.33 /
-// 1.54 ms for p = 1, 8, 64, 512 at 256x128); with four or more launches side by side the one-wave kernel's, which overlap, finish
-// sooner together (2.75 against 3.27 ms), so rmdf_prefilter_env_powers keeps it there -- except for the reference's own set
-// 1, 8, 64, 512, which is ONE launch of k_prefilter_fused4 (1.1 ms).
+// split_ok: the caller runs this power alone (or beside one or two others).  k_prefilter_chan fills the machine by itself (5632 waves,
+// two workgroups per CU): 0.52 / 0.60 / 0.62 / 0.65 ms for p = 1, 8, 64, 512 at 256x128 against the one-wave kernel's 0.92 / 1.17 / 1.33 /
+// 1.54; with four or more launches side by side the one-wave kernel's, which overlap, finish sooner together, so
+// rmdf_prefilter_env_powers keeps it for power sets that are not the reference's (whose two to four powers are ONE launch of
+// k_prefilter_fused4).
 hipError_t launch_prefilter(const float *d_src, int w, int h, float power, const float *d_lutT, const float2 *d_tcs,
                             float *d_out, hipStream_t stream, bool split_ok)
 {

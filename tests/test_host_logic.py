@@ -201,7 +201,7 @@ def test_cornell_candidate_grid_built_by_halving_equals_brute_force():
 
 
 def test_dpp_products_of_the_prefilter_have_no_read_after_write_hazard(tmp_path):
-    """k_prefilter_split / k_prefilter_fused4 multiply source texels through `v_mul_f32_dpp ... row_newbcast` written as inline asm
+    """k_prefilter_chan / k_prefilter_fused4 multiply source texels through `v_mul_f32_dpp ... row_newbcast` written as inline asm
     (hipcc does not fold update_dpp into the multiply).  The compiler's hazard recogniser does not look inside inline asm, and gfx9
     requires two wait states between a VALU write of a VGPR and a DPP read of it.  The DPP operand is always a register loaded from
     LDS (a waitcnt, not a VALU write, precedes its use); this test compiles rmdf_env.hip to assembly with the product's flags and

@@ -17,8 +17,8 @@ for f in glob.glob(sys.argv[1] + "/p*/**/*_counter_collection.csv", recursive=Tr
     per = {}
     for r in csv.DictReader(open(f)):
         if "k_prefilter" in r["Kernel_Name"]:
-            m = re.search(r"k_prefilter(_split)?<(-?\d+)", r["Kernel_Name"])
-            key = "fused 1,8,64,512" if "k_prefilter_fused4" in r["Kernel_Name"] else ("split" if m.group(1) else "one-wave") + " p=2^" + m.group(2)
+            m = re.search(r"k_prefilter(_chan)?<(-?\d+)", r["Kernel_Name"])
+            key = "fused 1,8,64,512" if "k_prefilter_fused4" in r["Kernel_Name"] else ("chan" if m.group(1) else "one-wave") + " p=2^" + m.group(2)
             per.setdefault((key, r["Counter_Name"]), {}).setdefault(r["Dispatch_Id"], 0.0)
             per[(key, r["Counter_Name"])][r["Dispatch_Id"]] += float(r["Counter_Value"])
     for k, v in per.items():

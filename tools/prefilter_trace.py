@@ -12,5 +12,5 @@ if os.environ.get("RMDF_PREFILTER_NO_FUSED"):
     pass                                                         # (with that switch: the one-wave kernel, four launches side by side)
 for _ in range(3):
     for p in (1.0, 8.0, 64.0, 512.0):
-        sr.prefilter_env(src, p)                                 # a power alone: k_prefilter_split
+        sr.prefilter_env(src, p)                                 # a power alone: k_prefilter_chan
 sr.close()
