@@ -48,6 +48,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_TLANEOPS = 78.6       # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (157.3 TFLOPS only if every op were an FMA)
 VALU_ISSUE_PEAK = 1.0           # G wave-instructions/s/SIMD a pure v_mul stream sustains after the clock has ramped (tools/ubench/valu_rates,
                                 # "sustained": 0.98-1.03 at 2.3-2.4 GHz = one per 2.2-2.4 cycles; 0.93-0.97 in a 1 ms launch from idle at ~2.0 GHz)
+VALU_ISSUE_SPEC = 1.2           # the guide's figure: one wave64 instruction per SIMD-32 every 2 cycles, at 2.4 GHz (MI355X_MICROARCH.md)
 MIN_WARM_SECONDS = float(os.environ.get("RMDF_BENCH_MIN_WARM", "0.3"))   # profiling runs shorten it
 
 # as-written operation counters of the headline frame (scene 2, 1920x1080, in_time 0, 256 steps), counted by the
@@ -196,6 +197,46 @@ def pmc_record(lib_path, workload):
 
 # ---- the benchmark ----------------------------------------------------------------------------------
 
+def self_launch(n_gpus, json_fd):
+    """Start the N ranks of this benchmark as child processes (python -m torch.distributed.run --nproc-per-node N bench.py <same
+    arguments>) and relay the one JSON line rank 0 prints.  Returns the exit code: the launcher's, or 1 if no JSON line came back."""
+    import socket
+    import subprocess
+    import torch                                            # device_count() does not initialise the GPU on this image
+    have = torch.cuda.device_count()
+    if have < n_gpus and os.environ.get("RMDF_BENCH_SHARE_GPU") != "1":
+        sys.stderr.write("bench.py --gpus %d: this node shows %d GPU(s)\n" % (n_gpus, have))
+        return 2
+    with socket.socket() as sk:                             # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.pop("RMDF_BENCH_SELF_LAUNCH", None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: the only kind this pool's host driver supports
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: no launcher in the environment -- starting %d rank(s): %s\n" % (n_gpus, " ".join(cmd)))
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for raw in child.stdout:
+        txt = raw.decode("utf-8", "replace")
+        if txt.lstrip().startswith("{") and line is None:
+            try:
+                json.loads(txt)
+                line = txt
+                continue
+            except ValueError:
+                pass
+        sys.stderr.write(txt)                               # anything else a rank wrote to fd 1
+    rc = child.wait()
+    if line is not None and rc == 0:
+        os.write(json_fd, line.encode())
+        return 0
+    sys.stderr.write("bench.py: the %d-rank run ended with exit code %d%s\n" % (n_gpus, rc, "" if line is not None else " and printed no JSON line"))
+    return rc if rc != 0 else 1
+
+
 def main():
     # stdout carries exactly ONE line, the JSON result: everything else that writes to fd 1 (RCCL's version banner,
     # library chatter) is sent to stderr for the duration of the run
@@ -226,6 +267,12 @@ def main():
     ap.add_argument("--check", action="store_true", help="also compare the frame with the oracle (slow)")
     a = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It starts `python -m torch.distributed.run`
+    # with one rank per GPU as a CHILD (nothing here has touched the GPU, and nothing is exec'ed), relays rank 0's JSON line and
+    # exits with the child's code.  RMDF_BENCH_SELF_LAUNCH=1 forces that path for --gpus 1 too (GPU-tier test on a 1-GPU box).
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("RMDF_BENCH_SELF_LAUNCH") == "1"):
+        raise SystemExit(self_launch(a.gpus, json_fd))
+
     import torch
     import torch.distributed as dist
     import rmdf_amd
@@ -234,8 +281,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
@@ -459,29 +504,93 @@ def main():
         handicap = float(os.environ.get("RMDF_ROOT_HANDICAP", measured))
         sr.set_shard_root_handicap(handicap)
         agree = ranks_agree_on_deal([sr.shard_tiles(r, world) for r in range(world)], dist, cdev)
+        verified = False
+        if agree and use_abi_comm:
+            # the library's own collective check (rmdf_comm_verify_deal: fingerprints to rank 0, verdict back): only then does the
+            # exchange put exact tile counts on the wire; the verdict is the same on every rank
+            dog.arm("rmdf_comm_verify_deal")
+            try:
+                sr.comm_verify_deal(stream=streams[0].cuda_stream)
+                verified = True
+            except Exception as e:                              # noqa: BLE001
+                print("rank %d: %s" % (rank, e), file=sys.stderr)
+                agree = False
+            dog.disarm()
         if agree:
-            deal = "cost-aware (probe frame, LPT, rank 0 handicap %.3f = measured exchange+assemble %.4f ms / mean shard render %.4f ms%s)" % (
-                handicap, root_exchange, mean_render, ", overridden by RMDF_ROOT_HANDICAP" if "RMDF_ROOT_HANDICAP" in os.environ else "")
+            deal = "cost-aware (probe frame, LPT, rank 0 handicap %.3f = measured exchange+assemble %.4f ms / mean shard render %.4f ms%s)%s" % (
+                handicap, root_exchange, mean_render, ", overridden by RMDF_ROOT_HANDICAP" if "RMDF_ROOT_HANDICAP" in os.environ else "",
+                ", deal verified by the library (rmdf_comm_verify_deal): exact tile counts on the wire" if verified else "")
         else:
             sr.set_shard_costs(None)
             sr.set_shard_root_handicap(0.0)
             deal = "static (ranks disagreed on the probed costs)"
 
-    # warm-up: W steps, then keep stepping until MIN_WARM_SECONDS have passed (all ranks decide together)
+    # N > 1: before anything is timed, the frames the exchange assembles are compared with the committed digest of this very frame
+    # (tests/golden/full_size_digests.json: sha256 of the oracle's RGBA8 plane) -- first one frame at a time, then with all S frame
+    # streams in flight on the one communicator.  Frames that differ with S in flight but not alone drop the run to ONE frame in
+    # flight (one stream on the communicator) and the JSON line says so; frames that differ even alone end the run: a wrong frame
+    # is not timed.
+    frames_verified = None
     if sharded:
-        dog.arm("warm-up and timed blocks", seconds=max(dog.seconds, 600.0))
+        want = None
+        if [scene, w, h, ms, L] == [2, 1920, 1080, 256, 0] and a.time == 0.0 and a.animate == 0.0:
+            try:
+                want = json.load(open(os.path.join(ROOT, "tests", "golden", "full_size_digests.json")))["config3_mandelbulb8_1920x1080_m256"]["sha256"]["rgba8"]
+            except Exception as e:                              # noqa: BLE001
+                print("no committed digest for the exchanged frame: %s" % e, file=sys.stderr)
+
+        def frames_ok(ks):
+            ok = 1
+            if rank == 0 and want is not None:
+                for k in ks:
+                    got = hashlib.sha256(frames[k].cpu().numpy().tobytes()).hexdigest()
+                    if got != want:
+                        print("exchanged frame of stream %d differs from the committed digest (%s... != %s...)" % (k, got[:12], want[:12]), file=sys.stderr)
+                        ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+        if want is not None:
+            dog.arm("verification of the exchanged frames against the committed digest")
+            for k in range(S):
+                frames[k].zero_() if rank == 0 else None
+            torch.cuda.synchronize(dev)
+            step(0)
+            barrier()
+            alone_ok = frames_ok([0])
+            if not alone_ok:
+                raise SystemExit("bench.py: the frame assembled from %d shard(s) differs from the committed digest -- not timing wrong frames" % world)
+            for i in range(2 * S):
+                step(i)
+            barrier()
+            if frames_ok(range(S)):
+                frames_verified = "%d exchanged frame(s) in flight == committed sha256 of the frame" % S
+            else:
+                S = 1
+                frames_verified = "frames differed with several in flight on one communicator: dropped to ONE frame in flight (alone == committed sha256)"
+                print("rank %d: %s" % (rank, frames_verified), file=sys.stderr)
+            dog.disarm()
+
+    # warm-up: W steps, then keep stepping until MIN_WARM_SECONDS have passed (all ranks decide together)
+    def dog_block(what, n_steps):
+        # re-armed per block, scaled with its size: a long block is not a hung collective (10 ms per step is 25x the slowest step measured)
+        if sharded:
+            dog.arm(what, seconds=max(dog.seconds, 60.0 + 0.01 * n_steps))
+    dog_block("warm-up", a.warmup)
     for i in range(a.warmup):
         step(i)
     barrier()
     t_w0 = time.perf_counter()
     extra_warm = 0
     while True:
+        dog_block("warm-up", max(a.warmup, 10))
         for i in range(max(a.warmup, 10)):
             step(i)
         extra_warm += max(a.warmup, 10)
         barrier()
         if max_over_ranks(time.perf_counter() - t_w0, dist, cdev) >= MIN_WARM_SECONDS or extra_warm >= 100000:
             break
+    dog.disarm()
     # RMDF_BENCH_MARK=1 (tools/profile.sh): a one-thread marker kernel (k_resolve_box2 on a 2x2 image, used by nothing else in this
     # run) is launched BEFORE the opening barrier of every timed block and after the closing barrier of the last one, so that a
     # rocprofv3 kernel trace of this command can be cut into the timed blocks (tools/pmc_summary.py: first dispatch start -> last
@@ -497,6 +606,7 @@ def main():
         this rank spent issuing; device span in ms: first stream-start event -> last stream-end event of the block)."""
         if mark:
             mark()
+        dog_block("a timed block of %d steps" % n_steps, n_steps)
         ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
         ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
         barrier()
@@ -510,6 +620,7 @@ def main():
             ev1[k].record(streams[k])
         barrier()
         wall = max_over_ranks(time.perf_counter() - t0, dist, cdev)
+        dog.disarm()
         span = max(e0.elapsed_time(e1) for e0 in ev0 for e1 in ev1)
         return wall, t_issue, span
 
@@ -600,7 +711,9 @@ def main():
             "metric": "Mpixels/s, Mandelbulb power-8 1920x1080 @256 steps; 1/2/4/8 GPU",
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "no input data beyond the scene: the Mandelbulb is procedural; environment = the reference's own light probe "
+                    "uffizi_512.hdr (shipped, sha256 ef959a2b...), prefiltered and converted by the product's pipeline",
             "config": {"workload": "FragmentShader %d (2 = FSMBPower8Shader) %dx%d%s, max_steps %d, in_time %.1f, uffizi_512.hdr env "
                                    "(cube maps built by the product's own env pipeline), full frame -> RGBA8 resident in HBM" %
                                    (scene, w, h, (" x %d rays/px, box-resolved on the GPU" % (4 ** L)) if L else "", ms, a.time),
@@ -613,7 +726,7 @@ def main():
                        "exchange": exchange, "rccl_ranks": rccl_ranks,
                        "exchange_ms": None if shard_split is None else shard_split["exchange_plus_assemble_ms_rank0"],
                        "shard_render_ms": None if shard_split is None else shard_split["shard_render_ms_mean_over_ranks"],
-                       "frames_in_flight": S, "tile_deal": deal, "animate_dt": a.animate,
+                       "frames_in_flight": S, "exchanged_frames_verified": frames_verified, "tile_deal": deal, "animate_dt": a.animate,
                        "device": dev_name, "compute_units": cus},
             "repeats": len(blocks), "ms_per_step_blocks": [round(b / a.steps * 1e3, 4) for b in blocks],
             "ms_per_step_min": round(min(blocks) / a.steps * 1e3, 4),
@@ -675,6 +788,11 @@ def main():
                 rate = valu_instr / simds / (kern_ms * 1e-3) / 1e9
                 result["roofline"]["issue"] = {"valu_instructions_per_launch": valu_instr, "source": pmc_src, "simds": simds,
                                                "achieved": round(rate, 3), "peak": VALU_ISSUE_PEAK, "frac": round(rate / VALU_ISSUE_PEAK, 3),
+                                               "peak_spec_2_cycles_at_2p4_ghz": VALU_ISSUE_SPEC, "frac_of_spec_peak": round(rate / VALU_ISSUE_SPEC, 3),
+                                               "frac_of_spec_peak_at_measured_clock": None if clock_mhz is None else round(rate / (clock_mhz / 2000.0), 3),
+                                               "peak_note": "`peak` = what a pure v_mul_f32 stream was MEASURED to sustain on this chip (one per 2.2-2.4 "
+                                                            "cycles); `peak_spec_2_cycles_at_2p4_ghz` = the documented one wave64 instruction per 2 cycles; "
+                                                            "the gap between the two is not explained by this project",
                                                "unit": "G wave-instructions/s/SIMD",
                                                "achieved_frames_in_flight": round(valu_instr / simds / (ms_per_step * 1e-3) / 1e9, 3),
                                                "frames_in_flight_note": "the same instruction count over ms_per_step (the schedule `value` is measured "
@@ -738,6 +856,15 @@ def main():
         dist.destroy_process_group()
     sr.close()
     return result
+
+
+def scene_pmc(name):
+    """VALU instruction count of a secondary scene from the committed counter pass (profiles/scene_pmc.json, written by tools/prof_scene.sh),
+    or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "scene_pmc.json"))).get(name, {}).get("SQ_INSTS_VALU_per_launch")
+    except Exception:                                           # noqa: BLE001
+        return None
 
 
 def secondary_workloads(sr, torch, dev, stream, cus, streams=()):
@@ -839,6 +966,13 @@ def secondary_workloads(sr, torch, dev, stream, cus, streams=()):
                                            "mpixels_s": round(2.0736 / (64 * t_tile * 1e-3), 1),
                                            "note": "rmdf_render_tile with tile_idx 0..63, host buffer handed back whole on every call "
                                                    "(FrameBuffer.hs:129,207-213), wall clock, PCIe included"}
+    # the other two FragmentShader values (ShaderRendering.hs:46-47,119-122) at the size and view of their committed digests
+    for name, sc, tv in (("scene1_detest_1280x720_m128", 1, 2.5), ("scene3_mbgeneral_1280x720_m128", 3, 3.0)):
+        fs = lambda sc=sc, tv=tv: sr.render_rect_device(sc, 1280, 720, tv, 128, (0, 0, 1280, 720), d_rgba8=fb.data_ptr(), stream=sp)
+        warm(fs, 0.1)
+        tt = ev(fs, 20)
+        out[name] = {"kernel_ms_avg": round(tt, 4), "mpixels_s": round(0.9216 / (tt * 1e-3), 1), "in_time": tv,
+                     "valu_instructions_per_launch": scene_pmc(name), "note": "one frame at a time, HIP events; instruction count from profiles/ (rocprofv3 --pmc of this scene) when present"}
     # the headline scene from the SURVEY's other camera times
     fbv = torch.empty((1080, 1920), dtype=torch.int32, device=dev)
     views = {}

@@ -56,6 +56,12 @@ static int run_rank(int rank, int nranks, const char *hdr, const char *png, int 
     /* the exchange's send / receive calls against this rank itself, on a private one-rank communicator (the ctx has none yet) */
     TRY(ctx, rmdf_comm_selftest_loopback(ctx, slots * tile, NULL, NULL));
     TRY(ctx, rmdf_comm_init(ctx, sh->id, rank, nranks));
+    /* collective: every rank probed its costs by itself (the kernels are bit-reproducible); compare the resulting deals once.  On a
+     * mismatch fall back to the static deal on this rank -- the verdict is the same on every rank, so all of them do. */
+    if (rmdf_comm_verify_deal(ctx, NULL) != RMDF_OK) {
+        fprintf(stderr, "rank %d: %s -- using the static deal\n", rank, rmdf_last_error(ctx));
+        TRY(ctx, rmdf_set_shard_costs(ctx, NULL));
+    }
     void *d_shard = NULL, *d_gathered = NULL, *d_frame = NULL;
     if (rank == 0) {
         TRY(ctx, rmdf_device_malloc(ctx, (size_t)nranks * slots * tile, &d_gathered));

@@ -229,10 +229,16 @@ int rmdf_render_supersampled(rmdf_ctx *ctx, int scene, int w, int h, int levels,
  *   per frame:   rmdf_render_frame_sharded_device(...)            -- = rmdf_render_shard_device + rmdf_gather_shards_device
  *                                                                    + (rank 0) rmdf_assemble_shards_device, all on `stream`
  * rmdf_gather_shards_device: every rank's packed shard (ceil(64/nranks) tile slots of (w/8)*(h/8) uint32) lands in
- * d_gathered[rank] on rank 0 (grouped ncclRecv fan-in; the other ranks ncclSend).  Only the tiles a rank owns under the deal in
- * effect travel (the root derives every peer's count from the same deal: ALL ranks must have set the same costs / handicap, or
- * none -- rmdf_set_shard_costs).  Rank 0 may pass d_shard == d_gathered (it rendered straight into its own slot).  d_gathered is
+ * d_gathered[rank] on rank 0 (grouped ncclRecv fan-in; the other ranks ncclSend).  ALL ranks must have set the same costs /
+ * handicap, or none (rmdf_set_shard_costs).  With the static deal, or once rmdf_comm_verify_deal has found every rank holding the
+ * same cost-aware deal, only the tiles a rank owns travel (the root derives every peer's count from the common deal); before that
+ * every rank sends its whole fixed-size region, so that a rank with different costs mis-assembles a frame instead of hanging the
+ * job on mismatched sizes.  Rank 0 may pass d_shard == d_gathered (it rendered straight into its own slot).  d_gathered is
  * ignored on the other ranks.
+ * rmdf_comm_verify_deal: COLLECTIVE over the ctx's communicator (every rank calls it, after its last rmdf_set_shard_costs /
+ * rmdf_set_shard_root_handicap): the peers send a fingerprint of the deal they hold to rank 0 (8 bytes), rank 0 compares and
+ * answers; RMDF_OK on every rank iff all deals are equal, RMDF_E_COMM on every rank otherwise.  Blocks until `stream` (NULL = ctx
+ * stream) has drained.  Any later change of costs or handicap on a rank drops the verification on that rank.
  * rmdf_comm_selftest_loopback: the exchange's own calls against this rank itself -- a grouped ncclRecv from self + ncclSend to
  * self of `bytes` bytes on `stream` (NULL = ctx stream), compared word for word; on the ctx's communicator, or on a private
  * one-rank communicator when the ctx has none (a single-GPU box can run it).  *mismatches (may be NULL) = differing words. */
@@ -243,6 +249,7 @@ int rmdf_comm_destroy(rmdf_ctx *ctx);
 /* *nranks = 0 when the ctx has no communicator */
 int rmdf_comm_info(rmdf_ctx *ctx, int *rank, int *nranks);
 int rmdf_gather_shards_device(rmdf_ctx *ctx, int w, int h, const void *d_shard, void *d_gathered, void *stream);
+int rmdf_comm_verify_deal(rmdf_ctx *ctx, void *stream);
 int rmdf_comm_selftest_loopback(rmdf_ctx *ctx, size_t bytes, void *stream, uint64_t *mismatches);
 int rmdf_render_frame_sharded_device(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps,
                                      void *d_shard, void *d_gathered, void *d_frame_rgba8, void *stream);

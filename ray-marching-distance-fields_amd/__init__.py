@@ -53,7 +53,7 @@ ABI_SYMBOLS = (
     "rmdf_get_shard_tiles", "rmdf_save_png", "rmdf_register_host_buffer", "rmdf_unregister_host_buffer",
     "rmdf_selftest_pinned_math", "rmdf_selftest_shading_math", "rmdf_set_shard_root_handicap", "rmdf_create_ex", "rmdf_prefilter_env_powers",
     "rmdf_prefilter_env_device", "rmdf_comm_get_unique_id", "rmdf_comm_init", "rmdf_comm_destroy", "rmdf_comm_info",
-    "rmdf_gather_shards_device", "rmdf_render_frame_sharded_device", "rmdf_device_malloc", "rmdf_device_free",
+    "rmdf_gather_shards_device", "rmdf_comm_verify_deal", "rmdf_render_frame_sharded_device", "rmdf_device_malloc", "rmdf_device_free",
     "rmdf_copy_to_host", "rmdf_probe_shader_clock", "rmdf_comm_selftest_loopback",
 )
 XCHECK_SYMBOLS = ("rmdf_debug_march_stats", "rmdf_debug_cornell_masks")      # include/rmdf_xcheck.h
@@ -124,7 +124,7 @@ def build(force=False, verbose=False):
                 out = None if verbose else subprocess.DEVNULL
                 # the digest is the authority, not make's file times: a tree restored with its mtimes (cp -p, rsync) would make a
                 # plain `make` a no-op and the new digest would then bless stale libraries
-                subprocess.check_call(["make", "-B", "-C", CSRC], stdout=out)
+                subprocess.check_call(["make", "-B", "-j4", "-C", CSRC], stdout=out)
                 with open(stamp + ".tmp", "w") as f:
                     f.write(_source_digest() + "\n")
                 os.replace(stamp + ".tmp", stamp)
@@ -166,6 +166,7 @@ def load_library(xcheck=False):
     L.rmdf_comm_destroy.argtypes = [vp]
     L.rmdf_comm_info.argtypes = [vp, ip, ip]
     L.rmdf_gather_shards_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+    L.rmdf_comm_verify_deal.argtypes = [vp, vp]
     L.rmdf_comm_selftest_loopback.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_uint64)]
     L.rmdf_render_frame_sharded_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp]
     L.rmdf_is_tile_idx_first_tile.argtypes = [C.c_int]
@@ -322,6 +323,11 @@ class ShaderRenderer:
         bad = C.c_uint64(0)
         self._check(self._lib.rmdf_comm_selftest_loopback(self._ctx, int(nbytes), stream or None, C.byref(bad)))
         return bad.value
+
+    def comm_verify_deal(self, stream=0):
+        """COLLECTIVE: every rank of the communicator calls it after its last set_shard_costs / set_shard_root_handicap; raises on
+        every rank if the ranks hold different deals (the exchange then keeps whole fixed-size slots)."""
+        self._check(self._lib.rmdf_comm_verify_deal(self._ctx, stream or None))
 
     def gather_shards_device(self, w, h, d_shard, d_gathered=0, stream=0):
         self._check(self._lib.rmdf_gather_shards_device(self._ctx, w, h, d_shard, d_gathered or None, stream or None))

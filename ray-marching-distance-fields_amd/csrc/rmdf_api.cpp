@@ -94,6 +94,10 @@ struct rmdf_ctx {
     // the deal of the last (nranks, cost generation) asked for: per-frame calls must not redo the sort
     int          deal_nranks = 0;
     unsigned     deal_gen = ~0u;
+    // the (cost set, handicap) generation and rank count for which rmdf_comm_verify_deal found every rank holding the same deal; the
+    // exchange sends exact tile counts only then (otherwise whole fixed-size slots: sizes on the wire cannot disagree)
+    unsigned     deal_verified_gen = 0;
+    int          deal_verified_nranks = 0;
     unsigned char deal_tiles[64][64];
     int          deal_count[64];
     ShardWhere   deal_where;
@@ -476,6 +480,14 @@ void ensure_deal(rmdf_ctx *ctx, int nranks)
         for (int s = 0; s < ctx->deal_count[r]; s++) ctx->deal_where.v[ctx->deal_tiles[r][s]] = (unsigned short)((r << 8) | s);
     }
     ctx->deal_nranks = nranks; ctx->deal_gen = ctx->shard_cost_gen;
+}
+
+// is the deal in effect known to be the same on every rank of the communicator?  The static deal depends on the rank count alone;
+// a deal steered by costs or a root handicap only after rmdf_comm_verify_deal compared it (and nothing changed since).
+bool deal_is_common(const rmdf_ctx *ctx, int nranks)
+{
+    if (!ctx->shard_cost_set && ctx->shard_root_handicap == 0.0f) return true;
+    return ctx->deal_verified_nranks == nranks && ctx->deal_verified_gen == ctx->shard_cost_gen;
 }
 
 
@@ -891,6 +903,17 @@ int load_rccl(rmdf_ctx *ctx)
         ncclResult_t r_ = (expr);                                                                         \
         if (r_ != ncclSuccess)                                                                            \
             return fail(ctx, RMDF_E_COMM, std::string(#expr) + ": " + g_rccl.GetErrorString(r_));         \
+    } while (0)
+
+// between ncclGroupStart and ncclGroupEnd: a failing call still closes the group before the error is returned (an open group would
+// swallow every later call on this thread)
+#define RCCL_GROUP_TRY(ctx, expr)                                                                         \
+    do {                                                                                                  \
+        ncclResult_t r_ = (expr);                                                                         \
+        if (r_ != ncclSuccess) {                                                                          \
+            (void)g_rccl.GroupEnd();                                                                      \
+            return fail(ctx, RMDF_E_COMM, std::string(#expr) + ": " + g_rccl.GetErrorString(r_));         \
+        }                                                                                                 \
     } while (0)
 
 int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double time, int max_steps,
@@ -1495,23 +1518,85 @@ int rmdf_gather_shards_device(rmdf_ctx *ctx, int w, int h, const void *d_shard, 
     const size_t slots = (size_t)((64 + n - 1) / n);
     const size_t tile_bytes = (size_t)(w / 8) * (size_t)(h / 8) * 4;
     const size_t bytes = slots * tile_bytes;                                       // the stride of a rank's region in d_gathered
-    // A rank sends the tiles it OWNS under the deal in effect (ensure_deal: static, or by the costs every rank has set alike -- the
-    // deal is a pure function of them, so the root knows every peer's count without asking); unused slots stay where they are.
+    // A rank sends the tiles it OWNS under the deal in effect -- when every rank is known to hold that deal: the static deal is a pure
+    // function of the rank count, a cost-aware one counts once rmdf_comm_verify_deal has compared it across the ranks.  Until then
+    // every rank sends its whole fixed-size region, so that a rank whose costs differ mis-assembles a frame instead of leaving the
+    // root waiting for bytes that never come.  Unused slots stay where they are.
     ensure_deal(ctx, n);
+    const bool exact = deal_is_common(ctx, n);
+    auto count_of = [&](int r) -> size_t { return exact ? (size_t)ctx->deal_count[r] * tile_bytes : bytes; };
     if (rank == 0) {
         // fan-in: one receive per peer, grouped so that they progress together over the seven xGMI links of the root
         if (n > 1) {
             RCCL_TRY(ctx, g_rccl.GroupStart());
             for (int r = 1; r < n; r++)
-                if (ctx->deal_count[r] > 0)
-                    RCCL_TRY(ctx, g_rccl.Recv((char *)d_gathered + (size_t)r * bytes, (size_t)ctx->deal_count[r] * tile_bytes, ncclChar, r, ctx->comm, st));
+                if (count_of(r) > 0)
+                    RCCL_GROUP_TRY(ctx, g_rccl.Recv((char *)d_gathered + (size_t)r * bytes, count_of(r), ncclChar, r, ctx->comm, st));
             RCCL_TRY(ctx, g_rccl.GroupEnd());
         }
         if ((const char *)d_shard != (const char *)d_gathered)     // the root may render straight into its own slot
             HIP_TRY(ctx, hipMemcpyAsync(d_gathered, d_shard, (size_t)ctx->deal_count[0] * tile_bytes, hipMemcpyDeviceToDevice, st));
-    } else if (ctx->deal_count[rank] > 0) {
-        RCCL_TRY(ctx, g_rccl.Send(d_shard, (size_t)ctx->deal_count[rank] * tile_bytes, ncclChar, 0, ctx->comm, st));
+    } else if (count_of(rank) > 0) {
+        RCCL_TRY(ctx, g_rccl.Send(d_shard, count_of(rank), ncclChar, 0, ctx->comm, st));
     }
+    return RMDF_OK;
+    RMDF_GUARD_END(ctx)
+}
+
+// FNV-1a over everything the deal is a function of
+static uint64_t deal_fingerprint(rmdf_ctx *ctx, int n)
+{
+    ensure_deal(ctx, n);
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t len) { for (size_t i = 0; i < len; i++) { h ^= ((const unsigned char *)p)[i]; h *= 1099511628211ull; } };
+    mix(&n, sizeof n);
+    for (int r = 0; r < n; r++) { mix(&ctx->deal_count[r], sizeof(int)); mix(ctx->deal_tiles[r], (size_t)ctx->deal_count[r]); }
+    return h;
+}
+
+int rmdf_comm_verify_deal(rmdf_ctx *ctx, void *stream)
+{
+    if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
+    if (!ctx->comm) return fail(ctx, RMDF_E_COMM, "rmdf_comm_verify_deal: no communicator (rmdf_comm_init)");
+    RMDF_GUARD_BEGIN
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    const int n = ctx->comm_nranks, rank = ctx->comm_rank;
+    const uint64_t mine = deal_fingerprint(ctx, n);
+    const unsigned gen = ctx->shard_cost_gen;
+    ctx->deal_verified_nranks = 0;
+    uint32_t verdict = 1;
+    if (n > 1) {
+        // peers -> root: 8 bytes each; root -> peers: the verdict.  Fixed sizes: nothing here depends on the deal.
+        DevBuf buf;
+        HIP_TRY(ctx, hipMalloc(&buf.p, (size_t)n * 8 + 8));
+        uint64_t *d_fp = (uint64_t *)buf.p;
+        uint32_t *d_verdict = (uint32_t *)(d_fp + n);
+        HIP_TRY(ctx, hipMemcpyAsync(d_fp + rank, &mine, 8, hipMemcpyHostToDevice, st));
+        if (rank == 0) {
+            RCCL_TRY(ctx, g_rccl.GroupStart());
+            for (int r = 1; r < n; r++) RCCL_GROUP_TRY(ctx, g_rccl.Recv(d_fp + r, 8, ncclChar, r, ctx->comm, st));
+            RCCL_TRY(ctx, g_rccl.GroupEnd());
+            std::vector<uint64_t> all((size_t)n);
+            HIP_TRY(ctx, hipMemcpyAsync(all.data(), d_fp, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            for (int r = 1; r < n; r++) if (all[(size_t)r] != mine) verdict = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(d_verdict, &verdict, 4, hipMemcpyHostToDevice, st));
+            RCCL_TRY(ctx, g_rccl.GroupStart());
+            for (int r = 1; r < n; r++) RCCL_GROUP_TRY(ctx, g_rccl.Send(d_verdict, 4, ncclChar, r, ctx->comm, st));
+            RCCL_TRY(ctx, g_rccl.GroupEnd());
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+        } else {
+            RCCL_TRY(ctx, g_rccl.Send(d_fp + rank, 8, ncclChar, 0, ctx->comm, st));
+            RCCL_TRY(ctx, g_rccl.Recv(d_verdict, 4, ncclChar, 0, ctx->comm, st));
+            HIP_TRY(ctx, hipMemcpyAsync(&verdict, d_verdict, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+        }
+    }
+    if (!verdict)
+        return fail(ctx, RMDF_E_COMM, "rmdf_comm_verify_deal: the ranks hold different tile deals (rmdf_set_shard_costs / rmdf_set_shard_root_handicap "
+                                      "must be called with the same values on every rank); the exchange keeps whole fixed-size slots");
+    ctx->deal_verified_gen = gen; ctx->deal_verified_nranks = n;
     return RMDF_OK;
     RMDF_GUARD_END(ctx)
 }
@@ -1549,8 +1634,8 @@ int rmdf_comm_selftest_loopback(rmdf_ctx *ctx, size_t bytes, void *stream, uint6
     HIP_TRY(ctx, hipMemsetAsync(dst.p, 0, bytes, st));
     // exactly the calls of the exchange step: a grouped receive (the root's side) and a send (a peer's side), on the caller's stream
     RCCL_TRY(ctx, g_rccl.GroupStart());
-    RCCL_TRY(ctx, g_rccl.Recv(dst.p, bytes, ncclChar, me, comm, st));
-    RCCL_TRY(ctx, g_rccl.Send(src.p, bytes, ncclChar, me, comm, st));
+    RCCL_GROUP_TRY(ctx, g_rccl.Recv(dst.p, bytes, ncclChar, me, comm, st));
+    RCCL_GROUP_TRY(ctx, g_rccl.Send(src.p, bytes, ncclChar, me, comm, st));
     RCCL_TRY(ctx, g_rccl.GroupEnd());
     HIP_TRY(ctx, hipMemcpyAsync(back.data(), dst.p, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));

@@ -124,6 +124,8 @@ foreign import ccall safe "rmdf_comm_get_unique_id"
     c_rmdf_comm_get_unique_id :: Ptr Word8 -> IO CInt
 foreign import ccall safe "rmdf_comm_init"
     c_rmdf_comm_init :: Ptr RmdfCtx -> Ptr Word8 -> CInt -> CInt -> IO CInt
+foreign import ccall safe "rmdf_comm_verify_deal"
+    c_rmdf_comm_verify_deal :: Ptr RmdfCtx -> Ptr () -> IO CInt
 foreign import ccall safe "rmdf_probe_tile_costs"
     c_rmdf_probe_tile_costs :: Ptr RmdfCtx -> CInt -> CInt -> CInt -> CDouble -> CInt -> Ptr Float -> IO CInt
 foreign import ccall safe "rmdf_set_shard_costs"
@@ -163,6 +165,10 @@ withHipRendererOnRank reflMapFn commId rank nranks shd0 w h time0 maxSteps f =
             c_rmdf_set_shard_costs ctx cost >>= check "rmdf_set_shard_costs"
         BU.unsafeUseAsCString commId $ \p ->
             c_rmdf_comm_init ctx (castPtr p) (fromIntegral rank) (fromIntegral nranks) >>= check "rmdf_comm_init"
+        -- collective: do all ranks hold the deal this rank computed from its own probe?  The verdict is the same on every rank; on a
+        -- mismatch all of them drop to the static deal (a function of the rank count alone)
+        agreed <- c_rmdf_comm_verify_deal ctx nullPtr
+        when (agreed /= 0) $ c_rmdf_set_shard_costs ctx nullPtr >>= check "rmdf_set_shard_costs"
         let dmalloc n = alloca $ \pp -> c_rmdf_device_malloc ctx (fromIntegral n) pp >>= check "rmdf_device_malloc" >> peek pp
             dfree p   = when (p /= nullPtr) $ void $ c_rmdf_device_free ctx p
         -- rmdf_device_malloc is a bare device allocation: rmdf_destroy does not own it, so the bracket releases it

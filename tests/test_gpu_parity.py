@@ -531,6 +531,35 @@ def test_bench_sharded_path_over_rccl_with_one_rank():
     assert d["roofline"]["frac"] is not None and 0.0 < d["roofline"]["frac"] < 1.0
     assert d["roofline"]["exchange"]["exchange_plus_assemble_ms_rank0"] == d["config"]["exchange_ms"]
     assert "falling back" not in err
+    # the assembled frames were compared with the committed digest before the timed region, with all frame streams in flight
+    assert d["config"]["exchanged_frames_verified"].startswith("8 exchanged frame(s) in flight == committed sha256"), d["config"]
+    assert "deal verified by the library" in d["config"]["tile_deal"]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` WITHOUT torch.distributed.run around it (how the driver starts the N = 1 line; if its N > 1 command is
+    not wrapped either, bench.py must still produce a number): the process becomes the launcher before anything touches the GPU, starts
+    its ranks as children, relays rank 0's one JSON line and its exit code.  Here with one rank (RMDF_BENCH_SELF_LAUNCH=1 takes the
+    launcher path for --gpus 1, RMDF_BENCH_FORCE_DIST=1 the sharded path): RCCL communicator of one rank, frames equal to the oracle's."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, RMDF_BENCH_SELF_LAUNCH="1", RMDF_BENCH_FORCE_DIST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "9", "--warmup", "3", "--check"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout       # stdout = the JSON line and nothing else
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["rccl_ranks"] == 1 and d["check_rgba8_equal"] is True, d["config"]
+    assert "starting 1 rank(s)" in r.stderr
+    # a failing child is reported as a failure: no JSON line, non-zero exit code
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--scene", "9"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    assert bad.returncode != 0 and not bad.stdout.strip(), (bad.returncode, bad.stdout)
 
 
 def test_comm_selftest_loopback(rmdf, sr):
@@ -565,6 +594,16 @@ def test_two_gpus_if_present():
     assert d["n_gpus"] == 2 and d["check_rgba8_equal"] is True
     assert d["config"]["rccl_ranks"] == 2 and d["config"]["exchange"].startswith("librmdf"), (d["config"], err[-2000:])
     assert d["roofline"]["frac"] is not None
+    assert "deal verified by the library" in d["config"]["tile_deal"], d["config"]["tile_deal"]
+    # the same without a launcher around it
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4", "--check"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d2 = json.loads(r.stdout)
+    assert d2["n_gpus"] == 2 and d2["check_rgba8_equal"] is True and d2["config"]["rccl_ranks"] == 2
     import rmdf_amd
     exe = os.path.join(ROOT, "gpurun_out", "c_host_multi_test")
     os.makedirs(os.path.dirname(exe), exist_ok=True)

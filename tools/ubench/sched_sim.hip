@@ -15,6 +15,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include <vector>
 #include "rmdf_device.hpp"
@@ -107,7 +108,118 @@ static double run_wave(std::vector<Ray> &rays, int T, double A, double B, double
     return cost;
 }
 
-int main()
+
+// Round 4: lockstep regrouping inside a workgroup.  The NW packets of a strip share a ray pool in LDS; at every march-step boundary
+// the live rays are (optionally) sorted by a key and dealt 64 at a time to ceil(live / 64) waves, so dead lanes vanish and -- with a
+// key that predicts the next estimate's escape iteration -- a wave's lanes need similar k.  Cost per wave-step: A * max k + B + Q
+// (Q = what writing and reading a ray's state through LDS and the sort cost per wave-step).  key: 0 = pool order (compaction only),
+// 1 = k of the ray's previous estimate (what a kernel knows), 2 = k of the estimate to come (oracle: the bound of any predictor),
+// 3 = previous k, but only rays are exchanged when the step index is a multiple of `every` (regroup every few steps)
+static void regroup_sims(const std::vector<unsigned short> &n)
+{
+    const double A = 87.0, B = 100.0;
+    const int PX = (W + 7) / 8, PY = (H + 7) / 8;
+    auto packet = [&](int bx, int by, std::vector<Ray> &rays) {
+        for (int ly = 0; ly < 8; ly++) for (int lx = 0; lx < 8; lx++) {
+            const int x = bx * 8 + lx, y = by * 8 + ly;
+            if (x < W && y < H && n[(size_t)y * W + x] > 0) rays.push_back(Ray{ y * W + x, 0 });
+        }
+    };
+    // reference points with the same A, B: nested packets, and ideal
+    double lane_work = 0.0, c_nested = 0.0;
+    { std::vector<Ray> r; for (int by = 0; by < PY; by++) for (int bx = 0; bx < PX; bx++) { r.clear(); packet(bx, by, r); c_nested += run_wave(r, 0, A, B, &lane_work); } }
+    const double ideal = lane_work / 64.0;
+    printf("A = %.0f, B = %.0f: ideal %.1f M, nested %.1f M (lane utilisation %.3f)\n", A, B, ideal / 1e6, c_nested / 1e6, ideal / c_nested);
+    // idle lane-slot causes of the nested schedule: (a) lanes whose ray has ended (or never started) while the packet marches on,
+    // (b) live lanes waiting for the packet's largest k inside an estimate
+    {
+        double slots = 0, dead = 0, kwait = 0, useful = 0;
+        std::vector<Ray> r;
+        for (int by = 0; by < PY; by++) for (int bx = 0; bx < PX; bx++) {
+            r.clear(); packet(bx, by, r);
+            for (;;) {
+                int act = 0, mk = 0, sumk = 0;
+                for (auto &x : r) if (x.step < g_n[x.pix]) { act++; const int k = kof(x.pix, x.step); sumk += k; if (k > mk) mk = k; }
+                if (!act) break;
+                slots += 64.0 * (A * mk + B);
+                useful += A * sumk + B * act;
+                kwait += A * ((double)mk * act - sumk);
+                dead += (64.0 - act) * (A * mk + B);
+                for (auto &x : r) if (x.step < g_n[x.pix]) x.step++;
+            }
+        }
+        printf("nested packets, lane-slots of the march: useful %.3f, live lanes waiting for the packet's largest k %.3f, lanes whose ray has ended %.3f\n",
+               useful / slots, kwait / slots, dead / slots);
+    }
+    for (int NW : { 4, 8 }) for (int key : { 0, 1, 2 }) for (double Q : { 0.0, 40.0 }) {
+        double c = 0.0, steps = 0.0;
+        for (int by = 0; by < PY; by++) for (int sx = 0; sx < (PX + NW - 1) / NW; sx++) {
+            std::vector<Ray> pool;
+            for (int q = 0; q < NW; q++) { const int bx = sx * NW + q; if (bx >= PX) break; packet(bx, by, pool); }
+            std::vector<int> prevk(pool.size(), 0), idx;
+            for (;;) {
+                idx.clear();
+                for (size_t i = 0; i < pool.size(); i++) if (pool[i].step < g_n[pool[i].pix]) idx.push_back((int)i);
+                if (idx.empty()) break;
+                if (key == 1) std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return prevk[a] < prevk[b]; });
+                if (key == 2) std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return kof(pool[a].pix, pool[a].step) < kof(pool[b].pix, pool[b].step); });
+                for (size_t j = 0; j < idx.size(); j += 64) {
+                    int mk = 0;
+                    for (size_t jj = j; jj < std::min(idx.size(), j + 64); jj++) { const int k = kof(pool[idx[jj]].pix, pool[idx[jj]].step); if (k > mk) mk = k; }
+                    c += A * mk + B + Q; steps += 1.0;
+                }
+                for (int i : idx) { prevk[i] = kof(pool[i].pix, pool[i].step); pool[i].step++; }
+            }
+        }
+        printf("lockstep regroup, %d waves per workgroup, key %-22s Q = %2.0f: %8.1f M wave-instr (x%.3f of nested) lane utilisation %.3f, %.2f M wave-steps\n",
+               NW, key == 0 ? "none (compaction)" : key == 1 ? "previous k" : "next k (oracle)", Q, c / 1e6, c / c_nested, ideal / c, steps / 1e6);
+    }
+    // the product's schedule with the same A, B for comparison: event-driven host pooling, T = 32
+    {
+        const int T = 32;
+        double c = 0.0, by_live[5] = { 0, 0, 0, 0, 0 }, longest = 0.0;
+        for (int by = 0; by < PY; by++) for (int sx = 0; sx < (PX + 3) / 4; sx++) {
+            std::vector<Ray> wv[4], mail;
+            double clk[4] = { 0, 0, 0, 0 };
+            bool alive[4] = { false, false, false, false };
+            int host = -1, nalive = 0;
+            for (int q = 0; q < 4; q++) { const int bx = sx * 4 + q; if (bx >= PX) break; packet(bx, by, wv[q]); alive[q] = !wv[q].empty(); nalive += alive[q]; }
+            while (nalive > 0) {
+                int w = -1;
+                for (int q = 0; q < 4; q++) if (alive[q] && (w < 0 || clk[q] < clk[w])) w = q;
+                std::vector<Ray> &r = wv[w];
+                if ((int)r.size() <= T && host < 0) host = w;
+                if (w == host) { while (r.size() < 64 && !mail.empty()) { r.push_back(mail.back()); mail.pop_back(); } }
+                else if ((int)r.size() <= T && host >= 0) { mail.insert(mail.end(), r.begin(), r.end()); r.clear(); }
+                if (r.empty()) {
+                    if (w == host && nalive > 1) { double nxt = 1e300; for (int q = 0; q < 4; q++) if (alive[q] && q != w && clk[q] < nxt) nxt = clk[q]; clk[w] = nxt + 1e-9; continue; }
+                    alive[w] = false; nalive--; continue;
+                }
+                int mk = 0;
+                for (auto &x : r) { const int k = kof(x.pix, x.step); if (k > mk) mk = k; }
+                const double cost = A * mk + B;
+                c += cost; clk[w] += cost;
+                const int live = (int)r.size();
+                by_live[live <= 4 ? 0 : live <= 8 ? 1 : live <= 16 ? 2 : live <= 32 ? 3 : 4] += cost;
+                std::vector<Ray> nr;
+                for (auto &x : r) { x.step++; if (x.step < g_n[x.pix]) nr.push_back(x); }
+                r.swap(nr);
+            }
+            for (int q = 0; q < 4; q++) if (clk[q] > longest) longest = clk[q];
+        }
+        printf("product schedule (host pooling, T = 32) %8.1f M wave-instr (x%.3f of nested) lane utilisation %.3f\n", c / 1e6, c / c_nested, ideal / c);
+        printf("  of which wave-steps with <= 4 / 5-8 / 9-16 / 17-32 / > 32 live rays: %.1f / %.1f / %.1f / %.1f / %.1f M; longest wave: %.0f instructions\n",
+               by_live[0] / 1e6, by_live[1] / 1e6, by_live[2] / 1e6, by_live[3] / 1e6, by_live[4] / 1e6, longest);
+        // the same schedule with G lanes per ray once a wave is down to 64 / G rays (the lanes of a group evaluate one ray's iteration
+        // together: a pass costs A / speedup(G), the tail B / speedup_tail(G))
+        for (double sp4 : { 2.0, 2.5 }) for (double sp2 : { 1.0, 1.5 }) {
+            const double tot = by_live[0] / sp4 + by_live[1] / sp4 + by_live[2] / sp4 + by_live[3] / sp2 + by_live[4];
+            printf("  lane groups: <= 16 live rays x%.1f faster, 17-32 x%.1f: %8.1f M wave-instr (x%.3f of the product schedule)\n", sp4, sp2, tot / 1e6, tot / c);
+        }
+    }
+}
+
+int main(int argc, char **argv)
 {
     Cam cam;
     host_camera(cam.c, &cam.fov_xs);
@@ -135,6 +247,7 @@ int main()
         hipLaunchKernelGGL(k_trace, dim3((W + 63) / 64, H), dim3(64), 0, 0, cam2, d_trace, d_n, d_kn);
         hipMemcpy(n_prev10.data(), d_n, npx * 2, hipMemcpyDeviceToHost);
     }
+    if (argc > 1 && !strcmp(argv[1], "regroup")) { regroup_sims(n); return 0; }
     double evals = 0, iters = 0; int maxn = 0;
     for (size_t i = 0; i < npx; i++) { evals += n[i]; if (n[i] > maxn) maxn = n[i]; for (int s = 0; s < n[i]; s++) iters += kof((int)i, s); }
     printf("rays with estimates: march estimates %.4e  escape iterations %.4e  mean k %.2f  longest ray %d estimates\n", evals, iters, iters / evals, maxn);

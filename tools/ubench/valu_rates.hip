@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 #define REPS 32768
@@ -152,7 +153,7 @@ static void run(const char *name, F launch, int ops_per_instr, double instr_scal
     hipMalloc(&out, (size_t)cus * 32 * 64 * 4 * 2);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    printf("%-14s", name);
+    printf("%-26s", name);
     for (int wps : { 1, 2, 4 }) {               // waves per SIMD
         const int blocks = cus * wps, threads = 256; // 4 waves per block -> one per SIMD
         launch(blocks, threads, out);
@@ -170,6 +171,42 @@ static void run(const char *name, F launch, int ops_per_instr, double instr_scal
     }
     printf("\n");
     hipFree(out);
+}
+
+
+// Round 4: does a wave64 instruction skip a 32-lane pass whose EXEC half is zero?  (wave64 issues on the SIMD-32 in two passes.)  The
+// loop runs under a per-lane condition taken from a run-time mask, so the compiler narrows EXEC with s_and_saveexec; the instruction
+// count per wave is the same for every mask.
+__global__ void k_execmask(float *out, float c, unsigned long long mask)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    if ((mask >> (threadIdx.x & 63u)) & 1ull) {
+        for (int i = 0; i < REPS; i++) { CHAIN8("v_mul_f32") }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+__global__ void k_execmask_trans(float *out, float c, unsigned long long mask)
+{
+    float a0 = threadIdx.x + 1.0f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    if ((mask >> (threadIdx.x & 63u)) & 1ull) {
+        for (int i = 0; i < REPS; i++) { UN8("v_rsq_f32") }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + c;
+}
+static void exec_halves()
+{
+    const struct { const char *name; unsigned long long m; } masks[] = {
+        { "all 64 lanes", ~0ull }, { "lanes 0-31", 0xffffffffull }, { "lanes 32-63", 0xffffffff00000000ull },
+        { "lanes 0-15", 0xffffull }, { "lane 0", 1ull }, { "even lanes", 0x5555555555555555ull },
+        { "lanes 0-15 + 32-47", 0x0000ffff0000ffffull }, { "lanes 16-31", 0xffff0000ull }, { "lane 0 + lane 63", 0x8000000000000001ull } };
+    for (int trans = 0; trans < 2; trans++)
+        for (const auto &mk : masks) {
+            const unsigned long long m = mk.m;
+            char name[64];
+            snprintf(name, sizeof name, "%s %s", trans ? "rsq" : "mul", mk.name);
+            if (trans) run(name, [m](int b, int t, float *o) { hipLaunchKernelGGL(k_execmask_trans, dim3(b), dim3(t), 0, 0, o, 1.0001f, m); }, 1);
+            else       run(name, [m](int b, int t, float *o) { hipLaunchKernelGGL(k_execmask, dim3(b), dim3(t), 0, 0, o, 1.0001f, m); }, 1);
+        }
 }
 
 static void clock_under_load()
@@ -226,8 +263,9 @@ static void sustained()
     }
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 1 && !strcmp(argv[1], "exec")) { exec_halves(); return 0; }
     clock_under_load();
     sustained();
 #define S(K, NAME) run(NAME, [](int b, int t, float *o) { hipLaunchKernelGGL(k_scalar<K>, dim3(b), dim3(t), 0, 0, o, 1.0001f); }, 1)
