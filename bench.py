@@ -334,10 +334,10 @@ def main():
     # finished a ~0.45 ms serial chain -- with the bulk of the next; on N GPUs it also overlaps the gather of frame i
     # with the render of frame i+1.  --streams 1 = strictly one frame at a time.
     S = a.streams if a.streams > 0 else (3 if not sharded else 8)
-    if int(os.environ.get("RMDF_FLAGS", "0")) & (rmdf_amd.FLAG_FLAT_MARCH | rmdf_amd.FLAG_PIPELINE):
-        # the alternative schedules of librmdf_xcheck.so keep one scratch set per ctx and render on the ctx stream only
-        raise SystemExit("RMDF_FLAGS selects an alternative schedule (librmdf_xcheck.so): those support neither frames in flight nor "
-                         "caller streams; time them with tools/bench_configs.py / the cross-check tests, not with bench.py")
+    if int(os.environ.get("RMDF_FLAGS", "0")) & rmdf_amd.FLAG_FLAT_MARCH:
+        # the alternative schedule of librmdf_xcheck.so keeps one scratch set per ctx and renders on the ctx stream only
+        raise SystemExit("RMDF_FLAGS selects the alternative schedule (librmdf_xcheck.so): it supports neither frames in flight nor "
+                         "caller streams; time it with tools/bench_configs.py / the cross-check tests, not with bench.py")
     streams = [torch.cuda.Stream(dev) for _ in range(S)]
     stream = streams[0]
     torch.cuda.set_stream(stream)

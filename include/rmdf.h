@@ -254,6 +254,15 @@ int rmdf_comm_selftest_loopback(rmdf_ctx *ctx, size_t bytes, void *stream, uint6
 int rmdf_render_frame_sharded_device(rmdf_ctx *ctx, int scene, int w, int h, double time, int max_steps,
                                      void *d_shard, void *d_gathered, void *d_frame_rgba8, void *stream);
 
+/* The constant tables the kernels are built from, for checking against the reference (host-only: no ctx, no device).
+ * rmdf_get_cornell_vertices: the 96 triangle vertices mkCornellBoxVerticesTex uploads (CornellBox.hs:21-46,48-129), 96*3 floats.
+ * rmdf_get_shader_constants: the named constants of fragment.shd the kernels use (bailout, MIN_DIST, the distance-AO taps, the
+ * shading weights, ...: csrc/rmdf_device.hpp RMDF_SHADER_CONSTANTS); fills up to `cap` entries of names[] (static strings) and
+ * values[] (either may be NULL) and returns how many there are.  tests/test_reference_pins.py compares both with values a script
+ * extracted from the reference (tests/golden/reference_pins.json). */
+int rmdf_get_cornell_vertices(float out[96 * 3]);
+int rmdf_get_shader_constants(const char **names, float *values, int cap);
+
 /* Self-test of the kernels' short correctly-rounded sequences (sqrt, reciprocal, 1/sqrt, and the known-range
  * division inside log) against the compiler's IEEE expansions for ALL 2^32 float inputs on the device.
  * mismatches[0..3] = sqrt, reciprocal, log, 1/sqrt; mismatches[4] = the table-driven division of the Cornell

@@ -1,12 +1,14 @@
 /*
  * rmdf_xcheck.h -- additions of librmdf_xcheck.so, the cross-check / measurement build of the renderer.
  *
- * librmdf_xcheck.so is built from the same sources as librmdf.so (make -C .../csrc xcheck) plus three alternative
- * schedules of the same per-ray arithmetic (csrc/xcheck/): they are slower than the product kernel and exist
- * so that independently scheduled implementations can be compared bit for bit in the tests, and for A/B measurements.
+ * librmdf_xcheck.so is built from the same sources as librmdf.so (make -C .../csrc xcheck) plus ONE alternative
+ * schedule of the same per-ray arithmetic (csrc/xcheck/rmdf_march.hip: both loops flattened into a per-lane state machine, shading
+ * in a second kernel behind a G-buffer, the compiler's divisions everywhere): slower than the product kernel
+ * and kept so that an independently scheduled implementation can be compared bit for bit in the tests.  (Rounds 1-3 carried two
+ * more -- a wave-local ray pool and a march-with-refill pipeline; both measured slower, removed in round 4, in the history.)
  * Nothing here is part of the drop-in boundary; the product library rejects these flag bits.
- * The alternative schedules keep ONE scratch set (G-buffer, hit list, work counters) per ctx: calls must use the ctx stream
- * (stream = NULL) -- another stream returns RMDF_E_UNSUPPORTED -- so frames in flight are not available with them.
+ * The alternative schedule keeps ONE scratch set (G-buffer, work counter) per ctx: calls must use the ctx stream
+ * (stream = NULL) -- another stream returns RMDF_E_UNSUPPORTED -- so frames in flight are not available with it.
  */
 #ifndef RMDF_XCHECK_H
 #define RMDF_XCHECK_H
@@ -19,8 +21,7 @@ extern "C" {
 
 /* rmdf_config.reserved[0] */
 #define RMDF_FLAG_NESTED_LOOPS 1   /* no-op (the default render kernel)                                                      */
-#define RMDF_FLAG_FLAT_MARCH   2   /* Mandelbulb power 8: flattened march kernel + shade kernel (xcheck/rmdf_march.hip, rmdf_pool.hip) */
-#define RMDF_FLAG_PIPELINE     8   /* all scenes: march-with-refill + normal/AO-on-hit-list + shade kernels (xcheck/rmdf_pipeline.hip) */
+#define RMDF_FLAG_FLAT_MARCH   2   /* Mandelbulb power 8: flattened march kernel + shade kernel (xcheck/rmdf_march.hip)     */
 #define RMDF_FLAG_FORCE_WRITTEN 64 /* power-8 Mandelbulb: the folded iteration passes' underflow guard always trips, so every ray, normal and
                                       AO estimate of the product kernel takes its written fall-back (tests: the frame must not change) */
 

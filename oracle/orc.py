@@ -153,6 +153,17 @@ def cornell_vertices():
     return np.array(out[:], dtype=np.float32).reshape(96, 3)
 
 
+def shader_constants():
+    """{name: value} of the fragment.shd constants the oracle uses (orc_shader_constants)."""
+    L = lib()
+    L.orc_shader_constants.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    n = L.orc_shader_constants(None, None, 0)
+    names = (C.c_char_p * n)()
+    vals = (C.c_float * n)()
+    L.orc_shader_constants(names, vals, n)
+    return {names[i].decode(): float(vals[i]) for i in range(n)}
+
+
 def make_n_segments(nseg, low, high):
     out = (C.c_int * (2 * max(nseg, 1)))()
     n = lib().orc_make_n_segments(nseg, low, high, out)

@@ -322,6 +322,44 @@ void orc_triplex_pow8(const float w[3], float out[3])
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 
+/* The constants fragment.shd states, by name (value, shader line).  The restatement below uses these names; orc_shader_constants
+ * hands the table out and tests/test_reference_pins.py compares it with the values a script extracted from the reference itself
+ * (tests/golden/reference_pins.json). */
+#define ORC_SHADER_CONSTANTS(X)                                                                                              \
+    X(mb_bailout, 4.0f) X(mb_iterations, 25.0f)                         /* fragment.shd:121-122 */                            \
+    X(march_max_steps_default, 128.0f) X(march_min_dist, 0.001f)         /* :634-635 */                                        \
+    X(bsphere_r_power8, 1.15f) X(bsphere_r_general, 1.5f) X(bsphere_r_other, 1.0f)   /* :643-648 */                            \
+    X(ao_w0, 0.5f) X(ao_d0, 0.016f) X(ao_w1, 0.25f) X(ao_d1, 0.081f) X(ao_bias, 0.29f) X(ao_gain, 3.5f)   /* :548-559 */       \
+    X(cornell_ao_w0, 0.1f) X(cornell_ao_d0, 0.1f) X(cornell_ao_w1, 0.2f) X(cornell_ao_d1, 0.2f)          /* :571-576 */       \
+    X(cornell_ao_w2, 0.125f) X(cornell_ao_d2, 0.4f) X(cornell_ao_w3, 0.0625f) X(cornell_ao_d3, 0.5f)     /* :579-584 */       \
+    X(normal_eps, 0.00001f) X(isec_step_back, 0.00001f)                  /* :466, :751 */                                      \
+    X(fresnel_eta, 0.4f) X(fresnel_k, 0.8f) X(diff_weight, 0.5f)         /* :799, :801 */                                      \
+    X(diff_r, 1.0f) X(diff_g, 0.8f) X(diff_b, 0.8f) X(spec_r, 0.8f) X(spec_g, 0.8f) X(spec_b, 1.0f)      /* :802-803 */       \
+    X(spec_weight_one_minus, 1.0f) X(phong_lobe_n, 8.0f) X(refl_weight, 0.1f) X(exposure, 3.0f)          /* :804-810 */       \
+    X(phong_lobe_plus, 2.0f) X(phong_lobe_div, 2.0f)                     /* :723 */                                            \
+    X(camera_distance, 2.414213562373095f) X(camera_cornell_radius, 0.4f) X(camera_cornell_z, -2.0f)     /* :888-897 */       \
+    X(hfov_deg_a, 45.0f) X(hfov_deg_b, 1.5f) X(gamma, 2.2f)              /* :910, :959 */
+#define ORC_X(name, value) static const float K_##name = value;
+ORC_SHADER_CONSTANTS(ORC_X)
+#undef ORC_X
+
+int orc_shader_constants(const char **names, float *values, int cap)
+{
+    static const char *const k_names[] = {
+#define ORC_X(name, value) #name,
+        ORC_SHADER_CONSTANTS(ORC_X)
+#undef ORC_X
+    };
+    const float k_values[] = {          /* the variables the code below uses, not a second copy of the literals */
+#define ORC_X(name, value) K_##name,
+        ORC_SHADER_CONSTANTS(ORC_X)
+#undef ORC_X
+    };
+    const int n = (int)(sizeof k_values / sizeof k_values[0]);
+    for (int i = 0; i < n && i < cap; i++) { if (names) names[i] = k_names[i]; if (values) values[i] = k_values[i]; }
+    return n;
+}
+
 typedef struct {
     int      scene;
     float    time;
@@ -334,8 +372,8 @@ typedef struct {
  * r2=r*r, r4=r2*r2, r7=(r4*r2)*r */
 static float de_mandelbulb8(v3 pos, de_ctx *c)
 {
-    const float bailout = 4.0f;
-    const int iterations = 25;
+    const float bailout = K_mb_bailout;
+    const int iterations = (int)K_mb_iterations;
     pos = V3(pos.z, pos.x, pos.y);          /* pos.zxy, :125 */
     v3 w = pos;
     float dr = 1.0f;
@@ -384,13 +422,13 @@ void orc_triplex_pow(const float w[3], float power, float out[3])
 /* fragment.shd:101-158 without POWER8 */
 static float de_mandelbulb_general(v3 pos, de_ctx *c)
 {
-    const float bailout = 4.0f;
+    const float bailout = K_mb_bailout;
     const float power = c->power;
     pos = V3(pos.z, pos.x, pos.y);
     v3 w = pos;
     float dr = 1.0f;
     float r = 0.0f;
-    for (int i = 0; i < 25; i++) {
+    for (int i = 0; i < (int)K_mb_iterations; i++) {
         r = rm_length(w);
         if (r > bailout) break;
         w = triplex_pow(w, power);
@@ -584,9 +622,9 @@ static float scene_bsphere(int scene)
 {
     /* fragment.shd:640-649 */
     switch (scene) {
-    case ORC_SCENE_MB_POWER8:  return 1.15f;
-    case ORC_SCENE_MB_GENERAL: return 1.5f;
-    default:                   return 1.0f;
+    case ORC_SCENE_MB_POWER8:  return K_bsphere_r_power8;
+    case ORC_SCENE_MB_GENERAL: return K_bsphere_r_general;
+    default:                   return K_bsphere_r_other;
     }
 }
 
@@ -595,7 +633,7 @@ static float scene_bsphere(int scene)
 static int ray_march(v3 origin, v3 dir, int max_steps, de_ctx *c, float *t_out, int *steps_out, int *entered,
                      uint64_t *march_steps)
 {
-    const float MIN_DIST = 0.001f;
+    const float MIN_DIST = K_march_min_dist;
     float tmin, tmax;
     *steps_out = 0;
     *entered = 0;
@@ -618,7 +656,7 @@ static int ray_march(v3 origin, v3 dir, int max_steps, de_ctx *c, float *t_out, 
 /* fragment.shd:463-470 */
 static v3 normal_backward_difference(v3 pos, de_ctx *c)
 {
-    const float eps = 0.00001f;
+    const float eps = K_normal_eps;
     float d0 = distance_estimator(pos, c);
     float dx = distance_estimator(V3(pos.x - eps, pos.y - 0.0f, pos.z - 0.0f), c);
     float dy = distance_estimator(V3(pos.x - 0.0f, pos.y - eps, pos.z - 0.0f), c);
@@ -637,19 +675,19 @@ static float distance_ao(v3 p, v3 n, de_ctx *c)
 {
     float occl_sum = 0.0f;
     if (c->scene != ORC_SCENE_CORNELL) {
-        occl_sum += 0.5f * ao_tap(p, n, 0.016f, c);
-        occl_sum += 0.25f * ao_tap(p, n, 0.081f, c);
+        occl_sum += K_ao_w0 * ao_tap(p, n, K_ao_d0, c);
+        occl_sum += K_ao_w1 * ao_tap(p, n, K_ao_d1, c);
         occl_sum = 1.0f - occl_sum;
-        occl_sum -= 0.29f;
-        occl_sum *= 3.5f;
+        occl_sum -= K_ao_bias;
+        occl_sum *= K_ao_gain;
         occl_sum *= occl_sum;
         occl_sum = rm_clamp(occl_sum, 0.0f, 1.0f);
         return occl_sum;
     } else {
-        occl_sum += 0.1f * ao_tap(p, n, 0.1f, c);
-        occl_sum += 0.2f * ao_tap(p, n, 0.2f, c);
-        occl_sum += 0.125f * ao_tap(p, n, 0.4f, c);
-        occl_sum += 0.0625f * ao_tap(p, n, 0.5f, c);
+        occl_sum += K_cornell_ao_w0 * ao_tap(p, n, K_cornell_ao_d0, c);
+        occl_sum += K_cornell_ao_w1 * ao_tap(p, n, K_cornell_ao_d1, c);
+        occl_sum += K_cornell_ao_w2 * ao_tap(p, n, K_cornell_ao_d2, c);
+        occl_sum += K_cornell_ao_w3 * ao_tap(p, n, K_cornell_ao_d3, c);
         occl_sum = 1.0f - occl_sum;
         return occl_sum;
     }
@@ -904,7 +942,7 @@ void orc_cube_pad_f16(const float *faces, int W, uint16_t *padded)
 float orc_fov_xs(void)
 {
     /* radians(45.0 * 1.5), tan(hfov / 2)  -- fragment.shd:866-867,910 */
-    float hfov = (45.0f * 1.5f) * 0.017453292519943295f;
+    float hfov = (K_hfov_deg_a * K_hfov_deg_b) * 0.017453292519943295f;
     return tanf(hfov / 2.0f);
 }
 
@@ -913,11 +951,11 @@ void orc_camera(int scene, float time, float out[12])
     v3 cam;
     if (scene == ORC_SCENE_CORNELL) {
         /* fragment.shd:888-890 */
-        cam = V3(sinf(time / 2.0f) * 0.4f, cosf(time / 2.0f) * 0.4f, -2.0f);
+        cam = V3(sinf(time / 2.0f) * K_camera_cornell_radius, cosf(time / 2.0f) * K_camera_cornell_radius, K_camera_cornell_z);
     } else {
         /* fragment.shd:892-897 */
         cam = V3(sinf(time / 3.0f), cosf(time / 4.0f), cosf(time / 3.0f));
-        cam = rm_scale(rm_normalize(cam), 2.414213562373095f);
+        cam = rm_scale(rm_normalize(cam), K_camera_distance);
     }
     /* lookat(cam, 0, (0,1,0)), fragment.shd:829-838 */
     v3 zaxis = rm_normalize(rm_sub(cam, V3(0.0f, 0.0f, 0.0f)));
@@ -978,10 +1016,10 @@ static void trace_pixel(render_job *j, int px, int py, px_state *s)
     if (s->hit) {
         /* render_ray, fragment.shd:743-799 */
         v3 isec = V3(origin.x + s->dir.x * t, origin.y + s->dir.y * t, origin.z + s->dir.z * t);
-        v3 np = V3(isec.x - s->dir.x * 0.00001f, isec.y - s->dir.y * 0.00001f, isec.z - s->dir.z * 0.00001f);
+        v3 np = V3(isec.x - s->dir.x * K_isec_step_back, isec.y - s->dir.y * K_isec_step_back, isec.z - s->dir.z * K_isec_step_back);
         s->n = normal_backward_difference(np, &c);
         s->ao = distance_ao(isec, s->n, &c);
-        s->fresnel = fresnel_conductor(rm_dot(rm_neg(s->dir), s->n), 0.4f, 0.8f);
+        s->fresnel = fresnel_conductor(rm_dot(rm_neg(s->dir), s->n), K_fresnel_eta, K_fresnel_k);
         s->refl = rm_reflect(s->dir, s->n);
     }
     s->iters = (unsigned)c.triplex_iters;
@@ -1003,12 +1041,13 @@ static void shade_pixel(const render_job *j, const px_state q[4], int k, float r
         cube_texture(&f->env_cos_1, s->n, sh->hit, sh->n, sv->hit, sv->n, t1);
         cube_texture(&f->env_cos_8, s->refl, sh->hit, sh->refl, sv->hit, sv->refl, t8);
         cube_texture(&f->env_reflection, s->refl, sh->hit, sh->refl, sv->hit, sv->refl, tr);
-        const float diff_col[3] = { 1.0f, 0.8f, 0.8f }, spec_col[3] = { 0.8f, 0.8f, 1.0f };
-        const float diff_weight = 0.5f, spec_weight = 1.0f - 0.5f, npl = (8.0f + 2.0f) / 2.0f;
+        const float diff_col[3] = { K_diff_r, K_diff_g, K_diff_b }, spec_col[3] = { K_spec_r, K_spec_g, K_spec_b };
+        const float diff_weight = K_diff_weight, spec_weight = K_spec_weight_one_minus - K_diff_weight;
+        const float npl = (K_phong_lobe_n + K_phong_lobe_plus) / K_phong_lobe_div;
         for (int c = 0; c < 3; c++)
             rgb[c] = (t1[c] * diff_col[c] * diff_weight
                       + t8[c] * spec_col[c] * npl * s->fresnel * spec_weight
-                      + tr[c] * spec_weight * s->fresnel * 0.1f) * 3.0f * s->ao;
+                      + tr[c] * spec_weight * s->fresnel * K_refl_weight) * K_exposure * s->ao;
     } else {
         /* fragment.shd:823.  The lookup sits in the miss branch: a quad neighbour that took the hit
          * branch leaves the derivative undefined (GLSL non-uniform control flow) -> pinned as minified,
@@ -1040,7 +1079,7 @@ static void *render_worker(void *arg)
                 size_t idx = (size_t)px + (size_t)py * f->w;
                 /* fragment.shd:959-960: pow(color, 1/2.2), alpha 1 */
                 float g[3];
-                for (int c = 0; c < 3; c++) g[c] = rm_powf(rgb[c], 1.0f / 2.2f);
+                for (int c = 0; c < 3; c++) g[c] = rm_powf(rgb[c], 1.0f / K_gamma);
                 if (j->rgba_f32) {
                     j->rgba_f32[idx * 4 + 0] = g[0]; j->rgba_f32[idx * 4 + 1] = g[1];
                     j->rgba_f32[idx * 4 + 2] = g[2]; j->rgba_f32[idx * 4 + 3] = 1.0f;
@@ -1079,7 +1118,7 @@ int orc_shade_gbuffer(const orc_frame *f, const float *nao /* w*h*4 */, const ui
                 if (q[k].hit) {
                     q[k].n = V3(nao[idx * 4], nao[idx * 4 + 1], nao[idx * 4 + 2]);
                     q[k].ao = nao[idx * 4 + 3];
-                    q[k].fresnel = fresnel_conductor(rm_dot(rm_neg(q[k].dir), q[k].n), 0.4f, 0.8f);
+                    q[k].fresnel = fresnel_conductor(rm_dot(rm_neg(q[k].dir), q[k].n), K_fresnel_eta, K_fresnel_k);
                     q[k].refl = rm_reflect(q[k].dir, q[k].n);
                 }
             }
@@ -1088,7 +1127,7 @@ int orc_shade_gbuffer(const orc_frame *f, const float *nao /* w*h*4 */, const ui
                 const size_t idx = (size_t)px + (size_t)py * f->w;
                 float rgb[3];
                 shade_pixel(&j, q, k, rgb);
-                for (int c = 0; c < 3; c++) rgba_f32[idx * 4 + c] = rm_powf(rgb[c], 1.0f / 2.2f);
+                for (int c = 0; c < 3; c++) rgba_f32[idx * 4 + c] = rm_powf(rgb[c], 1.0f / K_gamma);
                 rgba_f32[idx * 4 + 3] = 1.0f;
             }
         }

@@ -149,6 +149,8 @@ void orc_cosine_convolve(const float *src, int w, int h, float power, float *out
 
 /* ---- geometry (CornellBox.hs) ------------------------------------------------ */
 void orc_cornell_vertices(float out[96 * 3]);
+/* the named constants of fragment.shd this restatement uses (ORC_SHADER_CONSTANTS): fills up to cap entries, returns the count */
+int  orc_shader_constants(const char **names, float *values, int cap);
 
 /* ---- 2-D fractals (Fractal2D.hs) and segments (ConcurrentSegments.hs) -------- */
 void orc_julia_animated(int w, int h, uint32_t *fb, int smooth, double tick, int nthreads);

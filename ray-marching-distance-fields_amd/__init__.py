@@ -35,7 +35,7 @@ DEFAULT_ENV_HDR = os.path.join(DATA_DIR, "latlong_envmaps", "uffizi_512.hdr")
 TILES_X, TILES_Y, N_TILES = 8, 8, 64          # ShaderRendering.hs:49-52
 ENV_REFLECTION, ENV_COS_1, ENV_COS_8, ENV_COS_64, ENV_COS_512 = range(5)
 FLAG_RASTER_ORDER, FLAG_NO_MERGE, FLAG_NO_PRUNE = 4, 16, 32          # rmdf.h RMDF_FLAG_*
-FLAG_NESTED_LOOPS, FLAG_FLAT_MARCH, FLAG_PIPELINE = 1, 2, 8         # rmdf_xcheck.h: librmdf_xcheck.so only
+FLAG_NESTED_LOOPS, FLAG_FLAT_MARCH = 1, 2                            # rmdf_xcheck.h: librmdf_xcheck.so only
 FLAG_FORCE_WRITTEN = 64                                              # rmdf_xcheck.h: every folded Mandelbulb pass takes its written fall-back
 COMM_ID_BYTES = 128
 
@@ -54,7 +54,8 @@ ABI_SYMBOLS = (
     "rmdf_selftest_pinned_math", "rmdf_selftest_shading_math", "rmdf_set_shard_root_handicap", "rmdf_create_ex", "rmdf_prefilter_env_powers",
     "rmdf_prefilter_env_device", "rmdf_comm_get_unique_id", "rmdf_comm_init", "rmdf_comm_destroy", "rmdf_comm_info",
     "rmdf_gather_shards_device", "rmdf_comm_verify_deal", "rmdf_render_frame_sharded_device", "rmdf_device_malloc", "rmdf_device_free",
-    "rmdf_copy_to_host", "rmdf_probe_shader_clock", "rmdf_comm_selftest_loopback",
+    "rmdf_copy_to_host", "rmdf_probe_shader_clock", "rmdf_comm_selftest_loopback", "rmdf_get_cornell_vertices",
+    "rmdf_get_shader_constants",
 )
 XCHECK_SYMBOLS = ("rmdf_debug_march_stats", "rmdf_debug_cornell_masks")      # include/rmdf_xcheck.h
 
@@ -167,6 +168,8 @@ def load_library(xcheck=False):
     L.rmdf_comm_info.argtypes = [vp, ip, ip]
     L.rmdf_gather_shards_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.rmdf_comm_verify_deal.argtypes = [vp, vp]
+    L.rmdf_get_cornell_vertices.argtypes = [vp]
+    L.rmdf_get_shader_constants.argtypes = [vp, vp, C.c_int]
     L.rmdf_comm_selftest_loopback.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_uint64)]
     L.rmdf_render_frame_sharded_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp]
     L.rmdf_is_tile_idx_first_tile.argtypes = [C.c_int]
@@ -215,8 +218,8 @@ class ShaderRenderer:
     the Cornell geometry table and the accumulating frame."""
 
     def __init__(self, device=0, flags=0, xcheck=False):
-        """xcheck=True (implied by FLAG_FLAT_MARCH / FLAG_PIPELINE / FLAG_FORCE_WRITTEN): run on librmdf_xcheck.so, the cross-check build."""
-        self.xcheck = bool(xcheck or (flags & (FLAG_FLAT_MARCH | FLAG_PIPELINE | FLAG_FORCE_WRITTEN)))
+        """xcheck=True (implied by FLAG_FLAT_MARCH / FLAG_FORCE_WRITTEN): run on librmdf_xcheck.so, the cross-check build."""
+        self.xcheck = bool(xcheck or (flags & (FLAG_FLAT_MARCH | FLAG_FORCE_WRITTEN)))
         self._lib = load_library(self.xcheck)
         self._ctx = C.c_void_p()
         cfg = _Config(device=device)
@@ -475,6 +478,25 @@ def comm_get_unique_id():
     if rc != 0:
         raise RmdfError(rc, (L.rmdf_last_error(None) or b"").decode())
     return buf.raw
+
+
+def cornell_vertices():
+    """The 96 x 3 triangle vertices the kernels' Cornell box is built from (mkCornellBoxVerticesTex, CornellBox.hs:21-46).  Host only."""
+    out = np.empty((96, 3), np.float32)
+    rc = load_library().rmdf_get_cornell_vertices(out.ctypes.data)
+    if rc != 0:
+        raise RmdfError(rc, "rmdf_get_cornell_vertices")
+    return out
+
+
+def shader_constants():
+    """{name: value} of the fragment.shd constants the kernels use (rmdf_get_shader_constants).  Host only."""
+    L = load_library()
+    n = L.rmdf_get_shader_constants(None, None, 0)
+    names = (C.c_char_p * n)()
+    vals = (C.c_float * n)()
+    L.rmdf_get_shader_constants(names, vals, n)
+    return {names[i].decode(): float(vals[i]) for i in range(n)}
 
 
 class FrameBuffer:

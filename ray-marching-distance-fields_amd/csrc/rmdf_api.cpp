@@ -110,7 +110,6 @@ struct rmdf_ctx {
     float4      *d_gbuf_nao = nullptr;
     unsigned    *d_gbuf_meta = nullptr;
     int         *d_work_counter = nullptr;
-    int         *d_hit_list = nullptr;
     size_t       gbuf_cap = 0;
     unsigned long long *d_dbg = nullptr;   // per-wave march diagnostics (rmdf_debug_march_stats)
 #endif
@@ -165,11 +164,11 @@ void host_camera(int scene, float time, float cam[12])
 {
     hv3 c;
     if (scene == RMDF_FS_DE_CORNELL_BOX) {
-        c = hv3{ sinf(time / 2.0f) * 0.4f, cosf(time / 2.0f) * 0.4f, -2.0f };
+        c = hv3{ sinf(time / 2.0f) * shk::camera_cornell_radius, cosf(time / 2.0f) * shk::camera_cornell_radius, shk::camera_cornell_z };
     } else {
         c = hv3{ sinf(time / 3.0f), cosf(time / 4.0f), cosf(time / 3.0f) };
         hv3 nrm = hnormalize(c);
-        c = hv3{ nrm.x * 2.414213562373095f, nrm.y * 2.414213562373095f, nrm.z * 2.414213562373095f };
+        c = hv3{ nrm.x * shk::camera_distance, nrm.y * shk::camera_distance, nrm.z * shk::camera_distance };
     }
     hv3 zaxis = hnormalize(hv3{ c.x - 0.0f, c.y - 0.0f, c.z - 0.0f });
     hv3 xaxis = hnormalize(hcross(hv3{ 0.0f, 1.0f, 0.0f }, zaxis));
@@ -182,7 +181,7 @@ void host_camera(int scene, float time, float cam[12])
 
 float host_fov_xs()
 {
-    float hfov = (45.0f * 1.5f) * 0.017453292519943295f;   // radians(45.0 * 1.5)
+    float hfov = (shk::hfov_deg_a * shk::hfov_deg_b) * 0.017453292519943295f;   // radians(45.0 * 1.5)
     return tanf(hfov / 2.0f);
 }
 
@@ -390,11 +389,9 @@ int ensure_gbuf(rmdf_ctx *ctx, int w, int h)
     if (need <= ctx->gbuf_cap) return RMDF_OK;
     if (ctx->d_gbuf_nao) (void)hipFree(ctx->d_gbuf_nao);
     if (ctx->d_gbuf_meta) (void)hipFree(ctx->d_gbuf_meta);
-    if (ctx->d_hit_list) (void)hipFree(ctx->d_hit_list);
-    ctx->d_gbuf_nao = nullptr; ctx->d_gbuf_meta = nullptr; ctx->d_hit_list = nullptr; ctx->gbuf_cap = 0;
+    ctx->d_gbuf_nao = nullptr; ctx->d_gbuf_meta = nullptr; ctx->gbuf_cap = 0;
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_gbuf_nao, need * sizeof(float4)));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_gbuf_meta, need * sizeof(unsigned)));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_hit_list, need * sizeof(int)));
     ctx->gbuf_cap = need;
     return RMDF_OK;
 }
@@ -403,23 +400,21 @@ int ensure_gbuf(rmdf_ctx *ctx, int w, int h)
 int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t stream)
 {
 #ifdef RMDF_XCHECK
-    // librmdf_xcheck.so: the alternative schedules of the same per-ray arithmetic (cross-check tests, A/B measurements).
-    // They share ONE G-buffer / work counter / hit list per ctx, so they run on the ctx stream only.
+    // librmdf_xcheck.so: the alternative schedule of the same per-ray arithmetic (cross-check tests, A/B measurements).
+    // It keeps ONE G-buffer / work counter per ctx, so it runs on the ctx stream only.
     if (scene == RMDF_FS_MB_POWER8 && ctx->d_dbg && getenv("RMDF_NESTED_STATS")) {
         HIP_TRY(ctx, launch_march_stats(p, stream));
         return RMDF_OK;
     }
-    if ((ctx->flags & RMDF_FLAG_PIPELINE) || (scene == RMDF_FS_MB_POWER8 && (ctx->flags & RMDF_FLAG_FLAT_MARCH))) {
+    if (scene == RMDF_FS_MB_POWER8 && (ctx->flags & RMDF_FLAG_FLAT_MARCH)) {
         if (stream != ctx->stream)
             return fail(ctx, RMDF_E_UNSUPPORTED, "the alternative schedules keep one scratch set per ctx: use the ctx stream (stream = NULL)");
         FrameParams q = p;
         int rc = ensure_gbuf(ctx, p.w, p.h);
         if (rc != RMDF_OK) return rc;
         q.gbuf_nao = ctx->d_gbuf_nao; q.gbuf_meta = ctx->d_gbuf_meta; q.gw = (p.w + 1) & ~1;
-        q.work_counter = ctx->d_work_counter; q.hit_count = ctx->d_work_counter + 1; q.hit_list = ctx->d_hit_list;
-        q.tile_order = nullptr;
-        if (ctx->flags & RMDF_FLAG_PIPELINE) HIP_TRY(ctx, launch_render_pipeline(scene, q, stream, ctx->cus));
-        else                                 HIP_TRY(ctx, launch_render_mb8(q, stream, ctx->cus));
+        q.work_counter = ctx->d_work_counter;
+        HIP_TRY(ctx, launch_render_mb8(q, stream, ctx->cus));
         return RMDF_OK;
     }
 #endif
@@ -512,7 +507,7 @@ int fill_params(rmdf_ctx *ctx, int scene, int w, int h, float time, int max_step
     }
     p.wf = (float)w; p.hf = (float)h; p.aspect = p.wf / p.hf;
     p.w = w; p.h = h;
-    p.max_steps = max_steps <= 0 ? 128 : max_steps;
+    p.max_steps = max_steps <= 0 ? (int)shk::march_max_steps_default : max_steps;
     p.env_refl = CubeDev{ ctx->env[RMDF_ENV_REFLECTION].d_texels, ctx->env[RMDF_ENV_REFLECTION].W };
     p.env_cos1 = CubeDev{ ctx->env[RMDF_ENV_COS_1].d_texels, ctx->env[RMDF_ENV_COS_1].W };
     p.env_cos8 = CubeDev{ ctx->env[RMDF_ENV_COS_8].d_texels, ctx->env[RMDF_ENV_COS_8].W };
@@ -934,7 +929,7 @@ int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double t
         rc = ensure_frame(ctx, w, h, planes);
         if (rc != RMDF_OK) return rc;
         if (resized) { rc = clear_frame(ctx, w, h); if (rc != RMDF_OK) return rc; }
-        ctx->w = w; ctx->h = h; ctx->time = (float)time; ctx->max_steps = max_steps <= 0 ? 128 : max_steps;
+        ctx->w = w; ctx->h = h; ctx->time = (float)time; ctx->max_steps = max_steps <= 0 ? (int)shk::march_max_steps_default : max_steps;
         ctx->latched = true;
     }
     FrameParams p;
@@ -952,7 +947,7 @@ int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double t
     bool direct = false;
     if (whole && out_rgba8 && !planes
 #ifdef RMDF_XCHECK
-        && !(ctx->flags & (RMDF_FLAG_PIPELINE | RMDF_FLAG_FLAT_MARCH))
+        && !(ctx->flags & RMDF_FLAG_FLAT_MARCH)
 #endif
     ) {
         for (auto &r : ctx->host_regs)
@@ -1086,7 +1081,6 @@ void rmdf_destroy(rmdf_ctx *ctx)
 #ifdef RMDF_XCHECK
     if (ctx->d_gbuf_nao) (void)hipFree(ctx->d_gbuf_nao);
     if (ctx->d_gbuf_meta) (void)hipFree(ctx->d_gbuf_meta);
-    if (ctx->d_hit_list) (void)hipFree(ctx->d_hit_list);
     if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
     if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
 #endif
@@ -1353,6 +1347,30 @@ int rmdf_render_shard_device(rmdf_ctx *ctx, int scene, int w, int h, double time
     p.rgba8 = (uint32_t *)d_packed_rgba8;
     return launch_scene(ctx, scene, p, stream ? (hipStream_t)stream : ctx->stream);
     RMDF_GUARD_END(ctx)
+}
+
+int rmdf_get_cornell_vertices(float out[96 * 3])
+{
+    if (!out) return RMDF_E_INVALID;
+    cornell_triangles(out);
+    return RMDF_OK;
+}
+
+int rmdf_get_shader_constants(const char **names, float *values, int cap)
+{
+    static const char *const k_names[] = {
+#define RMDF_X(name, value) #name,
+        RMDF_SHADER_CONSTANTS(RMDF_X)
+#undef RMDF_X
+    };
+    static const float k_values[] = {
+#define RMDF_X(name, value) shk::name,
+        RMDF_SHADER_CONSTANTS(RMDF_X)
+#undef RMDF_X
+    };
+    const int n = (int)(sizeof k_values / sizeof k_values[0]);
+    for (int i = 0; i < n && i < cap; i++) { if (names) names[i] = k_names[i]; if (values) values[i] = k_values[i]; }
+    return n;
 }
 
 int rmdf_shard_tiles(int rank, int nranks, int tiles[64])

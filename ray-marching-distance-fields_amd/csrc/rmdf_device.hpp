@@ -15,6 +15,31 @@
 
 namespace rmdf {
 
+// The constants the reference's shader states, by name (value, fragment.shd line).  The kernels and the host code use these names;
+// rmdf_get_shader_constants hands the table out, and tests/test_reference_pins.py compares it with the values a script extracted from
+// the reference itself (tests/golden/reference_pins.json) -- a typo here cannot hide behind "oracle == kernel".
+#define RMDF_SHADER_CONSTANTS(X)                                                                                                  \
+    X(mb_bailout, 4.0f)              /* :121 */  X(mb_iterations, 25.0f)         /* :122 */                                        \
+    X(march_max_steps_default, 128.0f) /* :634 */ X(march_min_dist, 0.001f)      /* :635 */                                        \
+    X(bsphere_r_power8, 1.15f)       /* :643 */  X(bsphere_r_general, 1.5f)      /* :645 */  X(bsphere_r_other, 1.0f)  /* :648 */  \
+    X(ao_w0, 0.5f) X(ao_d0, 0.016f)  /* :548-549 */ X(ao_w1, 0.25f) X(ao_d1, 0.081f) /* :552-553 */                                \
+    X(ao_bias, 0.29f)                /* :558 */  X(ao_gain, 3.5f)                /* :559 */                                        \
+    X(cornell_ao_w0, 0.1f) X(cornell_ao_d0, 0.1f) X(cornell_ao_w1, 0.2f) X(cornell_ao_d1, 0.2f)             /* :571-576 */        \
+    X(cornell_ao_w2, 0.125f) X(cornell_ao_d2, 0.4f) X(cornell_ao_w3, 0.0625f) X(cornell_ao_d3, 0.5f)        /* :579-584 */        \
+    X(normal_eps, 0.00001f)          /* :466 */  X(isec_step_back, 0.00001f)     /* :751 */                                        \
+    X(fresnel_eta, 0.4f) X(fresnel_k, 0.8f)      /* :799 */  X(diff_weight, 0.5f) /* :801 */                                       \
+    X(diff_r, 1.0f) X(diff_g, 0.8f) X(diff_b, 0.8f) /* :802 */ X(spec_r, 0.8f) X(spec_g, 0.8f) X(spec_b, 1.0f) /* :803 */          \
+    X(spec_weight_one_minus, 1.0f)   /* :804 */  X(phong_lobe_n, 8.0f)           /* :808 */  X(refl_weight, 0.1f)      /* :809 */  \
+    X(exposure, 3.0f)                /* :810 */  X(phong_lobe_plus, 2.0f) X(phong_lobe_div, 2.0f)             /* :723 */           \
+    X(camera_distance, 2.414213562373095f) /* :897 */ X(camera_cornell_radius, 0.4f) /* :888 */ X(camera_cornell_z, -2.0f) /* :889 */ \
+    X(hfov_deg_a, 45.0f) X(hfov_deg_b, 1.5f)     /* :910 */  X(gamma, 2.2f)      /* :959 */
+namespace shk {
+#define RMDF_X(name, value) constexpr float name = value;
+RMDF_SHADER_CONSTANTS(RMDF_X)
+#undef RMDF_X
+constexpr int mb_iterations_i = (int)mb_iterations;
+}  // namespace shk
+
 struct v3 { float x, y, z; };
 
 __device__ __forceinline__ v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -287,6 +312,7 @@ __device__ __forceinline__ float div_by_dr(float a, float dr)
 //  * triplex_pow8 is inlined so that its x^2 + y^2 is shared with the dot product (the same two products, one addition);
 //  * the five scalings by a power of two ride on FMAs at the end of their chains, behind an underflow guard (mb8_iterate_t).
 #define RMDF_MB8_D4   16.000001907348633f      /* 16 + 2^-19 = 0x41800001 */
+static_assert(shk::mb_bailout == 4.0f && shk::mb_iterations_i == 25, "RMDF_MB8_D4 (the bailout test on the squared radius) is derived for bailout = 4");
 #define RMDF_MB8_K3MIN 0x1p-14f
 // The two roots of one Mandelbulb iteration that did not escape: r = RN(sqrt d), k2 = RN(1 / RN(sqrt q)) with q = k3^7,
 // k3 <= d <= 16 + 2^-19.  One guard for both (see de_mandelbulb8).
@@ -383,7 +409,7 @@ __device__ __forceinline__ float de_mandelbulb8_written_inl(v3 pos, unsigned &it
     pos = mk3(pos.z, pos.x, pos.y);
     v3 w = pos;
     float dr = 1.0f, r = 0.0f, d = 0.0f, m = 1.0f;
-    mb8_iterate_t<false>(w, pos, dr, r, d, 0, 25, iters, m);
+    mb8_iterate_t<false>(w, pos, dr, r, d, 0, shk::mb_iterations_i, iters, m);
     return mb8_finish(dr, r, d);
 }
 __device__ __noinline__ float de_mandelbulb8_written(v3 pos, unsigned &iters) { return de_mandelbulb8_written_inl(pos, iters); }
@@ -397,7 +423,7 @@ __device__ __forceinline__ float de_mandelbulb8(v3 pos, unsigned &iters, float f
     v3 w = p;
     float dr = 1.0f, r = 0.0f, d = 0.0f, m = 1.0f;
     unsigned n = 0u;
-    mb8_iterate_t<true>(w, p, dr, r, d, 0, 25, n, m);
+    mb8_iterate_t<true>(w, p, dr, r, d, 0, shk::mb_iterations_i, n, m);
     float dist = mb8_finish(dr, r, d);
     const bool redo = mb8_fold_failed(m, fold_min);
     if (__builtin_expect(__ballot(redo) != 0ull, 0)) {

@@ -44,18 +44,15 @@ struct FrameParams {
     const unsigned *block_order;
     unsigned *block_cost;
 #ifdef RMDF_XCHECK
-    // librmdf_xcheck.so only: the alternative schedules (xcheck/*.hip) and the measurement aids
-    // G-buffer written by k_march_mb8 / k_march_refill, read by k_shade; indexed px + py*gw over the frame padded to even
+    // librmdf_xcheck.so only: the alternative schedule (xcheck/rmdf_march.hip) and the measurement aids
+    // G-buffer written by k_march_mb8, read by k_shade; indexed px + py*gw over the frame padded to even
     // dimensions (helper pixels of odd sizes)
     float4   *gbuf_nao;       // normal.xyz, ao (hit pixels only)
     unsigned *gbuf_meta;      // bits 0..14 steps, bit 15 hit, bits 16..31 escape iterations (saturated)
     int       gw;
     int      *work_counter;   // zeroed before every march launch
-    int      *hit_count;      // = work_counter + 1 (rmdf_pipeline.hip): entries in hit_list
-    int      *hit_list;       // G-buffer indices of the hit pixels, filled by k_march_refill
-    const unsigned *tile_order;   // optional dispatch order of the 8x8 tiles (rmdf_pipeline.hip)
     int       total_items, items_per_shard_tile;
-    int       tail_t, shade_t, refill_t, chunk, pool_low;   // scheduling thresholds of k_march_mb8 (rmdf_march.hip)
+    int       tail_t, shade_t, refill_t, chunk;   // scheduling thresholds of k_march_mb8 (rmdf_march.hip)
     unsigned long long *dbg;  // optional per-wave counters (8 or 16 x u64 per wave), may be null
     float     fold_min;       // underflow bound of the folded Mandelbulb passes (RMDF_MB8_FOLD_MIN; +inf under RMDF_FLAG_FORCE_WRITTEN)
 #endif
@@ -136,8 +133,6 @@ hipError_t launch_prefilter(const float *d_src, int w, int h, float power, const
 #ifdef RMDF_XCHECK
 hipError_t launch_march_stats(const FrameParams &p, hipStream_t stream);                               // xcheck/rmdf_stats.hip
 hipError_t launch_render_mb8(const FrameParams &p, hipStream_t stream, int num_cus);                   // xcheck/rmdf_march.hip
-hipError_t launch_render_pipeline(int scene, const FrameParams &p, hipStream_t stream, int num_cus);   // xcheck/rmdf_pipeline.hip
-hipError_t launch_march_pool(const FrameParams &p, int blocks, hipStream_t stream);                    // xcheck/rmdf_pool.hip
 #endif
 // where[tile idx] = rank << 8 | slot under the deal in effect (built by the caller, cached per ctx)
 struct ShardWhere { unsigned short v[64]; };

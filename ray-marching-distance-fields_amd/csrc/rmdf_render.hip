@@ -58,7 +58,7 @@ __device__ __forceinline__ float distance_estimator(v3 pos, const FrameParams &p
 }
 
 template <int SCENE>
-__device__ __forceinline__ float bsphere_r() { return SCENE == 2 ? 1.15f : (SCENE == 3 ? 1.5f : 1.0f); }
+__device__ __forceinline__ float bsphere_r() { return SCENE == 2 ? shk::bsphere_r_power8 : (SCENE == 3 ? shk::bsphere_r_general : shk::bsphere_r_other); }
 
 // ------------------------------------------------------------------------------------
 // v1 render kernel: per-lane nested loops (march loop around the DE loop)
@@ -185,7 +185,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
                 float dist = distance_estimator<SCENE>(pos, p, iters, tri_hint, cgrid, s_ctab);
                 t += dist;
                 if (t > tmax) break;
-                if (dist < 0.001f) { hit = true; break; }
+                if (dist < shk::march_min_dist) { hit = true; break; }
             }
         }
 #ifdef RMDF_XCHECK
@@ -290,7 +290,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
                 const float dist = distance_estimator<SCENE>(pos, p, it, tri_hint, cgrid);
                 tt += dist;
                 const bool out = tt > tmx;
-                const bool h2 = !out && (dist < 0.001f);
+                const bool h2 = !out && (dist < shk::march_min_dist);
                 bool done = out || h2;
                 if (!done) { st++; done = st >= p.max_steps; }
                 if (done) {
@@ -318,13 +318,14 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
         // Cornell box: the normal's four estimates and the four AO taps as ONE loop around one copy of the estimate (inlined nine
         // times the kernel was 130 KB of code, twice the instruction cache)
         isec = mk3(origin.x + dir.x * t, origin.y + dir.y * t, origin.z + dir.z * t);
-        const v3 np = mk3(isec.x - dir.x * 0.00001f, isec.y - dir.y * 0.00001f, isec.z - dir.z * 0.00001f);
-        const float eps = 0.00001f;
+        const v3 np = mk3(isec.x - dir.x * shk::isec_step_back, isec.y - dir.y * shk::isec_step_back, isec.z - dir.z * shk::isec_step_back);
+        const float eps = shk::normal_eps;
         float d0 = 0.0f, ddx = 0.0f, ddy = 0.0f, ddz = 0.0f, occl = 0.0f;
 #pragma unroll 1
         for (int k = 0; k < 8; k++) {
             if (k == 4) n = normalize3(mk3(ddx, ddy, ddz));
-            const float dlk = k == 4 ? 0.1f : (k == 5 ? 0.2f : (k == 6 ? 0.4f : 0.5f)), wtk = k == 4 ? 0.1f : (k == 5 ? 0.2f : (k == 6 ? 0.125f : 0.0625f));
+            const float dlk = k == 4 ? shk::cornell_ao_d0 : (k == 5 ? shk::cornell_ao_d1 : (k == 6 ? shk::cornell_ao_d2 : shk::cornell_ao_d3));
+            const float wtk = k == 4 ? shk::cornell_ao_w0 : (k == 5 ? shk::cornell_ao_w1 : (k == 6 ? shk::cornell_ao_w2 : shk::cornell_ao_w3));
             const v3 pos = k < 4 ? mk3(np.x - (k == 1 ? eps : 0.0f), np.y - (k == 2 ? eps : 0.0f), np.z - (k == 3 ? eps : 0.0f))
                                  : mk3(isec.x + n.x * dlk, isec.y + n.y * dlk, isec.z + n.z * dlk);
             const float d = distance_estimator<SCENE>(pos, p, iters, tri_hint, cgrid, s_ctab);
@@ -333,7 +334,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
             else if (k == 2) ddy = d0 - d;
             else if (k == 3) ddz = d0 - d;
             else {
-                const float ylk = k == 4 ? 1.0f / 0.1f : (k == 5 ? 1.0f / 0.2f : (k == 6 ? 1.0f / 0.4f : 1.0f / 0.5f));
+                const float ylk = k == 4 ? 1.0f / shk::cornell_ao_d0 : (k == 5 ? 1.0f / shk::cornell_ao_d1 : (k == 6 ? 1.0f / shk::cornell_ao_d2 : 1.0f / shk::cornell_ao_d3));
                 occl += wtk * ao_term<RMDF_SHADE_FAST>(d, dlk, ylk);
             }
         }
@@ -341,8 +342,8 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
     }
     if (SCENE != 0 && hit) {
         isec = mk3(origin.x + dir.x * t, origin.y + dir.y * t, origin.z + dir.z * t);
-        v3 np = mk3(isec.x - dir.x * 0.00001f, isec.y - dir.y * 0.00001f, isec.z - dir.z * 0.00001f);
-        const float eps = 0.00001f;
+        v3 np = mk3(isec.x - dir.x * shk::isec_step_back, isec.y - dir.y * shk::isec_step_back, isec.z - dir.z * shk::isec_step_back);
+        const float eps = shk::normal_eps;
         float d0 = distance_estimator<SCENE>(np, p, iters, tri_hint, cgrid);
         float dx = distance_estimator<SCENE>(mk3(np.x - eps, np.y - 0.0f, np.z - 0.0f), p, iters, tri_hint, cgrid);
         float dy = distance_estimator<SCENE>(mk3(np.x - 0.0f, np.y - eps, np.z - 0.0f), p, iters, tri_hint, cgrid);
@@ -350,7 +351,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
         n = normalize3(mk3(d0 - dx, d0 - dy, d0 - dz));
     }
     // distance_ao (fragment.shd:542-591)
-    const float w0 = 0.5f, e0 = 0.016f, w1 = 0.25f, e1 = 0.081f;
+    const float w0 = shk::ao_w0, e0 = shk::ao_d0, w1 = shk::ao_w1, e1 = shk::ao_d1;
     float ao_dist[2] = { 0.0f, 0.0f };
     if (AO_POOL) {
         // the two estimates with their stragglers set aside (see AO_CUT above); every wave of the workgroup comes through here
@@ -388,7 +389,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
                         s_ao_q[mine][1] = make_float4(pos.x, pos.y, pos.z, r);
                     } else {
                         float m = 1.0f;
-                        mb8_iterate_t<false>(w, pos, dr, r, d, AO_CUT, 25, iters, m);      // queue full: finish in place (written form)
+                        mb8_iterate_t<false>(w, pos, dr, r, d, AO_CUT, shk::mb_iterations_i, iters, m);      // queue full: finish in place (written form)
                     }
                 }
             }
@@ -404,10 +405,10 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
                 float dr = a.w, r = b.w, d = 0.0f;
                 unsigned it2 = 0u;
                 float m = 1.0f;
-                mb8_iterate_t<true>(w, pos, dr, r, d, AO_CUT, 25, it2, m);
+                mb8_iterate_t<true>(w, pos, dr, r, d, AO_CUT, shk::mb_iterations_i, it2, m);
                 const bool redo = mb8_fold_failed(m, fold_min_of(p));
                 if (__builtin_expect(__ballot(redo) != 0ull, 0)) {
-                    if (redo) { w = mk3(a.x, a.y, a.z); dr = a.w; r = b.w; d = 0.0f; it2 = 0u; mb8_iterate_t<false>(w, pos, dr, r, d, AO_CUT, 25, it2, m); }
+                    if (redo) { w = mk3(a.x, a.y, a.z); dr = a.w; r = b.w; d = 0.0f; it2 = 0u; mb8_iterate_t<false>(w, pos, dr, r, d, AO_CUT, shk::mb_iterations_i, it2, m); }
                 }
                 s_ao_out[tsk] = make_float2(mb8_finish(dr, r, d), __uint_as_float(it2));
             }
@@ -427,12 +428,12 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
             occl += w0 * ao_term<RMDF_SHADE_FAST>(ao_dist[0], e0, 1.0f / e0);      // rmdf_device.hpp: the quotient by a constant offset
             occl += w1 * ao_term<RMDF_SHADE_FAST>(ao_dist[1], e1, 1.0f / e1);
             occl = 1.0f - occl;
-            occl -= 0.29f;
-            occl *= 3.5f;
+            occl -= shk::ao_bias;
+            occl *= shk::ao_gain;
             occl *= occl;
             ao = gclamp(occl, 0.0f, 1.0f);
         }   // Cornell box: the four taps (fragment.shd:568-589) ran above, in the loop with the normal
-        fresnel = fresnel_conductor(dot3(mk3(-dir.x, -dir.y, -dir.z), n), 0.4f, 0.8f);
+        fresnel = fresnel_conductor(dot3(mk3(-dir.x, -dir.y, -dir.z), n), shk::fresnel_eta, shk::fresnel_k);
         refl = reflect3(dir, n);
     }
 
@@ -449,17 +450,18 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
         v3 t1 = cube_texture(p.env_cos1, n, hit_h, n_h, hit_v, n_v);
         v3 t8 = cube_texture(p.env_cos8, refl, hit_h, refl_h, hit_v, refl_v);
         v3 tr = cube_texture(p.env_refl, refl, hit_h, refl_h, hit_v, refl_v);
-        const float diff_weight = 0.5f, spec_weight = 1.0f - 0.5f, npl = (8.0f + 2.0f) / 2.0f;
-        color.x = (t1.x * 1.0f * diff_weight + t8.x * 0.8f * npl * fresnel * spec_weight + tr.x * spec_weight * fresnel * 0.1f) * 3.0f * ao;
-        color.y = (t1.y * 0.8f * diff_weight + t8.y * 0.8f * npl * fresnel * spec_weight + tr.y * spec_weight * fresnel * 0.1f) * 3.0f * ao;
-        color.z = (t1.z * 0.8f * diff_weight + t8.z * 1.0f * npl * fresnel * spec_weight + tr.z * spec_weight * fresnel * 0.1f) * 3.0f * ao;
+        const float diff_weight = shk::diff_weight, spec_weight = shk::spec_weight_one_minus - shk::diff_weight;
+        const float npl = (shk::phong_lobe_n + shk::phong_lobe_plus) / shk::phong_lobe_div;
+        color.x = (t1.x * shk::diff_r * diff_weight + t8.x * shk::spec_r * npl * fresnel * spec_weight + tr.x * spec_weight * fresnel * shk::refl_weight) * shk::exposure * ao;
+        color.y = (t1.y * shk::diff_g * diff_weight + t8.y * shk::spec_g * npl * fresnel * spec_weight + tr.y * spec_weight * fresnel * shk::refl_weight) * shk::exposure * ao;
+        color.z = (t1.z * shk::diff_b * diff_weight + t8.z * shk::spec_b * npl * fresnel * spec_weight + tr.z * spec_weight * fresnel * shk::refl_weight) * shk::exposure * ao;
     } else {
         // fragment.shd:823
         color = cube_texture(p.env_refl, dir, !hit_h, dir_h, !hit_v, dir_v);   // neighbours in the hit branch: undefined derivative -> minified
     }
 
     // fragment.shd:959-960 and the RGBA8 conversion of the colour attachment
-    const float inv_gamma = 1.0f / 2.2f;
+    const float inv_gamma = 1.0f / shk::gamma;
     const float gr = pow_pinned(color.x, inv_gamma), gg = pow_pinned(color.y, inv_gamma), gb = pow_pinned(color.z, inv_gamma);
     // Stage the 32x8 strip in LDS so that every store instruction writes whole 128-byte lines (a wave's own
     // 8x8 packet would write 32-byte pieces of 8 different rows).  Thread t stores pixel (t % 32, t / 32).

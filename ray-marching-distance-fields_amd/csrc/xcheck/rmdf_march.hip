@@ -426,7 +426,7 @@ hipError_t launch_render_mb8(const FrameParams &p_in, hipStream_t stream, int nu
     // persistent grid: `wps` waves per SIMD on every CU.  The march loop is VALU-bound and two waves
     // per SIMD already saturate VALU issue while letting every wave run at the single-wave issue rate,
     // which matters because the longest ray of the frame is a serial chain (DESIGN.md "critical path")
-    static int wps = 0, env_tail = 0, env_shade = 0, env_refill = 0, env_chunk = 0, env_pool = 1, env_low = 32;
+    static int wps = 0, env_tail = 0, env_shade = 0, env_refill = 0, env_chunk = 0;
     if (!wps) {
         const char *e;
         wps = (e = getenv("RMDF_WAVES_PER_SIMD")) ? atoi(e) : 2;
@@ -434,23 +434,16 @@ hipError_t launch_render_mb8(const FrameParams &p_in, hipStream_t stream, int nu
         env_shade = (e = getenv("RMDF_SHADE_T")) ? atoi(e) : 16;
         env_refill = (e = getenv("RMDF_REFILL_T")) ? atoi(e) : 16;
         env_chunk = (e = getenv("RMDF_CHUNK")) ? atoi(e) : 128;
-        env_pool = (e = getenv("RMDF_MARCH")) ? (strcmp(e, "flat") != 0) : 1;
-        env_low = (e = getenv("RMDF_POOL_LOW")) ? atoi(e) : 32;
         if (wps < 1) wps = 1;
         if (wps > 8) wps = 8;
     }
-    p.tail_t = env_tail; p.shade_t = env_shade; p.refill_t = env_refill; p.chunk = env_chunk; p.pool_low = env_low;
+    p.tail_t = env_tail; p.shade_t = env_shade; p.refill_t = env_refill; p.chunk = env_chunk;
     int blocks = num_cus * wps;
     const int max_useful = (p.total_items + 255) / 256;
     if (blocks > max_useful) blocks = max_useful;
     if (blocks < 1) blocks = 1;
-    if (env_pool) {
-        if (wps > 2) blocks = blocks / wps * 2;          // LDS (72 KiB per block) admits 2 blocks per CU
-        e = launch_march_pool(p, blocks, stream);
-    } else {
-        hipLaunchKernelGGL(k_march_mb8, dim3(blocks), dim3(256), 0, stream, p);
-        e = hipGetLastError();
-    }
+    hipLaunchKernelGGL(k_march_mb8, dim3(blocks), dim3(256), 0, stream, p);
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_shade(p, ew, eh, nz, stream);
 }

@@ -90,14 +90,6 @@ def sr_alt(rmdf, env_oracle):
     r.close()
 
 
-@pytest.fixture(scope="session")
-def sr_pipe(rmdf, env_oracle):
-    """librmdf_xcheck.so: the three-kernel schedule (RMDF_FLAG_PIPELINE)."""
-    r = _renderer_with_product_env(rmdf, env_oracle, flags=rmdf.FLAG_PIPELINE)
-    yield r
-    r.close()
-
-
 def rel_err(a, b, floor=1e-6):
     """max relative error with an absolute floor; NaN matches NaN, inf matches inf."""
     a = np.asarray(a, np.float64)

@@ -49,7 +49,7 @@ def test_product_library_holds_no_alternative_schedules_or_debug_knobs(rmdf):
                  "RMDF_DBG_SKIP", "RMDF_WPB", "RMDF_OCC_LDS", "RMDF_MERGE", "RMDF_PRIO_STRIPS", "RMDF_NESTED_STATS"):
         assert word not in syms, word
     xsyms = os.popen("strings -a %s" % rmdf.XCHECK_LIB_PATH).read()
-    assert "k_march_mb8" in xsyms and "k_march_refill" in xsyms
+    assert "k_march_mb8" in xsyms and "k_march_stats" in xsyms
 
 
 def test_rccl_is_not_a_link_dependency(rmdf):

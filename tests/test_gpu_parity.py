@@ -257,25 +257,6 @@ def test_supersample_resolve(sr, orc, rmdf):
     assert np.array_equal(frame.cpu().numpy().view(np.uint32), sr.render_supersampled(2, W, H, 1, 0.0, max_steps=ms))
 
 
-@pytest.mark.parametrize("scene,ms", [(2, 256), (0, 128), (1, 128), (3, 128)])
-def test_pipeline_schedule_agrees(sr_pipe, sr, orc, env_oracle, rmdf, scene, ms):
-    """march-with-refill + normal/AO on the hit list + shade: a third schedule of the same arithmetic, all scenes."""
-    for (w, h, t) in ((64, 36, 0.0), (250, 130, 2.5), (33, 17, 1.0), (480, 270, 7.0)):
-        a = sr_pipe.render(scene, w, h, t, max_steps=ms)
-        if w <= 250:
-            assert_frame_parity(a, orc.render(scene, w, h, t, ms, env_oracle), "pipeline s%d %dx%d" % (scene, w, h))
-        b = sr.render(scene, w, h, t, max_steps=ms)
-        for k in ("rgba8", "steps", "iters"):
-            assert np.array_equal(a[k], b[k]), (k, w, h)
-        assert np.array_equal(a["rgba_f32"].view(np.uint32), b["rgba_f32"].view(np.uint32))
-    w, h = 120, 72
-    full = sr.render(scene, w, h, 1.0, max_steps=ms)["rgba8"]
-    fb = rmdf.FrameBuffer(w, h)
-    for idx in range(64):
-        sr_pipe.draw_shader_tile(scene, idx, w, h, 1.0, fb.vec, max_steps=ms)
-    assert np.array_equal(fb.vec.reshape(h, w), full)
-
-
 def test_exact_math_exhaustive(sr, orc):
     """The kernels replace hipcc's ~17/14-instruction sqrtf / division expansions by short sequences
     (rmdf_device.hpp: sqrt_rn, rcp_rn, div_known_range inside log_pinned).  They must return the SAME bits: checked
@@ -671,7 +652,7 @@ def test_shading_math_exhaustive(sr):
     Markstein quotients on a correctly rounded reciprocal.  Checked on the device against the compiler's IEEE division: the
     quotient on 2^33 operand pairs of its range, the AO term for every distance, fresnel for every cosine, and whole cube-map
     lookups on 2^30 direction triples including the degenerate ones (rmdf_util.hip: k_selftest_shading_math).  The frames of the
-    alternative schedules (librmdf_xcheck) keep the compiler's division, so test_both_mandelbulb_schedules_agree and test_pipeline_schedule_agrees compare the two forms on real frames too."""
+    alternative schedules (librmdf_xcheck) keep the compiler's division, so test_both_mandelbulb_schedules_agree compares the two forms on real frames too."""
     mism = sr.selftest_shading_math()
     assert mism.tolist() == [0] * 4, mism
 
@@ -839,8 +820,8 @@ def test_extra_planes_are_allocated_on_demand_and_tiles_accumulate(rmdf, orc, en
         r.close()
 
 
-def test_alternative_schedules_live_in_the_xcheck_library_only(rmdf, sr_alt, sr_pipe):
-    """librmdf.so rejects the alternative-schedule flag bits; in librmdf_xcheck.so they keep one scratch set per ctx, so a
+def test_alternative_schedule_lives_in_the_xcheck_library_only(rmdf, sr_alt):
+    """librmdf.so rejects the alternative-schedule flag bits; in librmdf_xcheck.so the schedule keeps one scratch set per ctx, so a
     launch on another stream is refused (RMDF_E_UNSUPPORTED) instead of corrupting a frame in flight on the ctx stream."""
     import ctypes as C
     import torch
@@ -848,15 +829,15 @@ def test_alternative_schedules_live_in_the_xcheck_library_only(rmdf, sr_alt, sr_
 
     class Cfg(C.Structure):
         _fields_ = [("device", C.c_int), ("reserved", C.c_int * 7)]
-    for flag in (rmdf.FLAG_FLAT_MARCH, rmdf.FLAG_PIPELINE, rmdf.FLAG_FORCE_WRITTEN, 1 << 20):
+    for flag in (rmdf.FLAG_FLAT_MARCH, 8, rmdf.FLAG_FORCE_WRITTEN, 1 << 20):
         cfg = Cfg(device=0)
         cfg.reserved[0] = flag
         ctx = C.c_void_p()
         assert L.rmdf_create(C.byref(ctx), C.byref(cfg)) == -6 and not ctx.value
-    assert sr_alt.xcheck and sr_pipe.xcheck
+    assert sr_alt.xcheck
     st = torch.cuda.Stream()
     buf = dev_zeros((72, 128), dtype=torch.int32, device="cuda")
-    for r in (sr_alt, sr_pipe):
+    for r in (sr_alt,):
         with pytest.raises(rmdf.RmdfError) as e:
             r.render_rect_device(2, 128, 72, 0.0, 64, (0, 0, 128, 72), d_rgba8=buf.data_ptr(), stream=st.cuda_stream)
         assert e.value.code == -6
@@ -906,7 +887,7 @@ def test_exchange_behind_the_c_abi_world_size_one(sr, rmdf):
         r.close()
 
 
-SS_CASES = sorted(f for f in glob.glob(os.path.join(GOLD, "swiftshader_s[0-2]_*.npz")) if not f.endswith("_gbuf.npz"))
+SS_CASES = sorted(f for f in glob.glob(os.path.join(GOLD, "swiftshader_s[0-3]_*.npz")) if not f.endswith("_gbuf.npz"))
 
 
 @pytest.mark.parametrize("fn", SS_CASES, ids=[os.path.basename(c)[:-4] for c in SS_CASES])
@@ -915,13 +896,20 @@ def test_hip_planes_vs_reference_shader_fixtures(sr, fn):
     produced on SwiftShader (tests/golden/swiftshader_*.npz, made by make_swiftshader_vectors.py from
     /root/reference/fragment.shd; the oracle is not involved): hit mask identical, march step counts identical (<= 8 px off
     by one), escape-iteration totals identical on every missed pixel and on >= 95 % of the hit pixels (whose normal / AO
-    taps sit on the fractal surface, see tests/test_oracle_vs_glsl.py)."""
+    taps sit on the fractal surface, see tests/test_oracle_vs_glsl.py).  The general-power Mandelbulb (scene 3) evaluates
+    acos / atan / sin / cos / pow in every fractal iteration, SwiftShader's versions of those are few-ulp approximations and the
+    iteration is chaotic: for it the agreement is statistical, with the bars tests/test_oracle_vs_glsl.py holds the oracle to."""
     m = re.match(r"swiftshader_s(\d)_(\d+)x(\d+)_t(\d+)p(\d+)_m(\d+)\.npz", os.path.basename(fn))
     scene, w, h, t, ms = int(m.group(1)), int(m.group(2)), int(m.group(3)), float(m.group(4) + "." + m.group(5)), int(m.group(6))
     g = np.load(fn)
     got = sr.render(scene, w, h, t, max_steps=ms, want_f32=False)
     hit = (got["steps"] >> 15).astype(bool)
     ds = np.abs((got["steps"] & 0x7FFF).astype(int) - g["steps"].astype(int))
+    if scene == 3:
+        assert (hit != g["hit"]).mean() < 1e-3 and abs(hit.mean() - g["hit"].mean()) < 1e-3
+        assert (ds > 0).mean() < 0.05
+        assert abs(int(got["iters"].sum()) - int(g["iters"].sum())) < 2e-3 * int(g["iters"].sum())
+        return
     assert np.array_equal(hit, g["hit"])
     assert (ds > 0).sum() <= 8 and ds.max() <= 1
     di = got["iters"].astype(int) - g["iters"].astype(int)
