@@ -965,7 +965,10 @@ def secondary_workloads(sr, torch, dev, stream, cus, streams=()):
     out["tile_mode_64_calls_1920x1080"] = {"ms_per_tile_call": round(t_tile, 4), "ms_per_frame": round(64 * t_tile, 3),
                                            "mpixels_s": round(2.0736 / (64 * t_tile * 1e-3), 1),
                                            "note": "rmdf_render_tile with tile_idx 0..63, host buffer handed back whole on every call "
-                                                   "(FrameBuffer.hs:129,207-213), wall clock, PCIe included"}
+                                                   "(FrameBuffer.hs:129,207-213), wall clock, PCIe included.  Round 4: the next three tiles of "
+                                                   "the latched frame are rendered ahead of their calls into scratch tiles (mirrored into page-"
+                                                   "locked host memory by the kernel), the caller's buffer is filled from a page-locked shadow "
+                                                   "of the frame by host threads: only the new tile crosses PCIe (round 3: 21-22 ms per frame)"}
     # the other two FragmentShader values (ShaderRendering.hs:46-47,119-122) at the size and view of their committed digests
     for name, sc, tv in (("scene1_detest_1280x720_m128", 1, 2.5), ("scene3_mbgeneral_1280x720_m128", 3, 3.0)):
         fs = lambda sc=sc, tv=tv: sr.render_rect_device(sc, 1280, 720, tv, 128, (0, 0, 1280, 720), d_rgba8=fb.data_ptr(), stream=sp)

@@ -80,7 +80,8 @@ typedef struct rmdf_ctx rmdf_ctx;
 
 typedef struct {
     int device;      /* HIP device ordinal                                              */
-    int reserved[7]; /* [0] = RMDF_FLAG_* bits, rest zero                               */
+    int reserved[7]; /* [0] = RMDF_FLAG_* bits; [1] = host threads that copy the frame to the caller in tile mode, the calling
+                        thread included (0 = chosen by core count: 16 on >= 64 cores, 8 on > 8); rest zero */
 } rmdf_config;
 
 /* ---- lifetime: withShaderRenderer (ShaderRendering.hs:60-110) --------------------- */
@@ -135,7 +136,9 @@ int rmdf_resize_latlong(rmdf_ctx *ctx, const float *rgb, int w, int h, int dstw,
  * rmdf_prefilter_env_powers: `npowers` powers of one map, the job of the reference's mapConcurrently (ShaderRendering.hs:142);
  * out = npowers * w*h*3 floats.  The reference's own set 1, 8, 64, 512 (or three of it) of a map up to 256 texels wide is ONE
  * kernel launch whose squaring chains share their prefix; other sets run their powers side by side on four streams.
- * rmdf_prefilter_env_device: one power, device-resident source and destination, asynchronous on `stream`. */
+ * rmdf_prefilter_env_device: one power, device-resident source and destination, asynchronous on `stream`.
+ * The host-buffer entry points share one set of device scratch per ctx (kept between calls for maps up to 256x128, per call above
+ * that): like every call on a ctx they must not run concurrently on the same ctx. */
 int rmdf_prefilter_env(rmdf_ctx *ctx, const float *rgb, int w, int h, float power, float *out);
 int rmdf_prefilter_env_powers(rmdf_ctx *ctx, const float *rgb, int w, int h, const float *powers, int npowers, float *out);
 int rmdf_prefilter_env_device(rmdf_ctx *ctx, const void *d_rgb, int w, int h, float power, void *d_out, void *stream);
@@ -283,8 +286,10 @@ int rmdf_selftest_pinned_math(rmdf_ctx *ctx, uint64_t mismatches[7]);
  * compiler's IEEE expansion) against the compiler's division: mismatches[0] = the quotient itself on 2^33 operand pairs inside its
  * range, [1] = clamp(1 - d / e) for every distance d (inf and NaN included) and each tap offset e, [2] = fresnel_conductor for every cosine
  * in [-2, 2], inf and NaN, [3] = whole cube-map lookups on 2^30 (direction, neighbour, neighbour) triples of the kind normalize() can
- * produce, degenerate ones included.  All must be 0.  A few seconds on an MI355X. */
-int rmdf_selftest_shading_math(rmdf_ctx *ctx, uint64_t mismatches[4]);
+ * produce, degenerate ones included; [4] = generate_ray's own quotients EXHAUSTIVELY over the frames the library accepts (1 <= w, h <=
+ * 32768): (px + 0.5) / w for every side and every pixel centre of it, and for every (w, h) the reciprocal of the aspect ratio plus
+ * ndc.y * fov / aspect on three rows.  All must be 0.  A few seconds on an MI355X. */
+int rmdf_selftest_shading_math(rmdf_ctx *ctx, uint64_t mismatches[5]);
 
 /* The clock the shader engines run at right now: one wave (issuing vector instructions) stamps the shader-cycle counter against the
  * 100 MHz real-time counter over `spin_us` microseconds, on a highest-priority stream of the library's own -- launched while the

@@ -217,13 +217,14 @@ class ShaderRenderer:
     """The `ShaderRenderer` record (ShaderRendering.hs:36-44): owns the device-side env cube maps,
     the Cornell geometry table and the accumulating frame."""
 
-    def __init__(self, device=0, flags=0, xcheck=False):
+    def __init__(self, device=0, flags=0, xcheck=False, copy_threads=0):
         """xcheck=True (implied by FLAG_FLAT_MARCH / FLAG_FORCE_WRITTEN): run on librmdf_xcheck.so, the cross-check build."""
         self.xcheck = bool(xcheck or (flags & (FLAG_FLAT_MARCH | FLAG_FORCE_WRITTEN)))
         self._lib = load_library(self.xcheck)
         self._ctx = C.c_void_p()
         cfg = _Config(device=device)
         cfg.reserved[0] = flags
+        cfg.reserved[1] = copy_threads             # tile mode: host threads of the frame copy (0 = library default)
         err = C.create_string_buffer(1024)
         rc = self._lib.rmdf_create_ex(C.byref(self._ctx), C.byref(cfg), err, 1024)
         if rc != 0:
@@ -439,8 +440,9 @@ class ShaderRenderer:
         return out
 
     def selftest_shading_math(self):
-        """Mismatch counts (quotient, AO term, fresnel, cube-map lookup) of the shading tail's short quotients vs the compiler's division."""
-        out = np.zeros(4, np.uint64)
+        """Mismatch counts (quotient, AO term, fresnel, cube-map lookup, generate_ray's quotients over every legal frame size) of the
+        shading tail's short quotients vs the compiler's division."""
+        out = np.zeros(5, np.uint64)
         self._check(self._lib.rmdf_selftest_shading_math(self._ctx, out.ctypes.data))
         return out
 

@@ -10,6 +10,7 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <exception>
 #include <mutex>
 #include <new>
@@ -56,6 +57,85 @@ struct LobeTable { int w = 0, h = 0; float *d_lutT = nullptr; float2 *d_tcs = nu
 
 }  // namespace
 
+// A few host threads that copy byte ranges side by side (tile mode hands the caller its whole 8.3 MB frame on every call: one
+// thread moves that at ~10 GB/s, sixteen at the rate of the PCIe link it replaces).  A job is cut into one part per worker plus
+// one for the calling thread, which takes it when it has nothing else to do (finish).  Claiming 256 KiB chunks one at a time
+// under the lock was measured slower (0.181 against 0.163 ms per tile call).  Created on first use, joined when the ctx goes.
+struct CopyPool {
+    struct Seg { char *dst; const char *src; size_t bytes; };
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    Seg seg[2] = { { nullptr, nullptr, 0 }, { nullptr, nullptr, 0 } };
+    size_t total = 0;
+    unsigned gen = 0;
+    int pending = 0, nparts = 1;
+    bool stop = false;
+
+    static void copy_part(const Seg sg[2], size_t total, int part, int nparts)
+    {
+        // part `part` of `nparts` of the two segments laid end to end, cut at 4 KiB boundaries
+        size_t lo = (total * (size_t)part / (size_t)nparts) & ~(size_t)4095, hi = (total * (size_t)(part + 1) / (size_t)nparts) & ~(size_t)4095;
+        if (part == nparts - 1) hi = total;
+        size_t base = 0;
+        for (int k = 0; k < 2; k++) {
+            const size_t a = lo > base ? lo - base : 0, b = hi > base ? (hi - base < sg[k].bytes ? hi - base : sg[k].bytes) : 0;
+            if (b > a) memcpy(sg[k].dst + a, sg[k].src + a, b - a);
+            base += sg[k].bytes;
+        }
+    }
+    void worker(int idx)
+    {
+        unsigned seen = 0;
+        for (;;) {
+            Seg sg[2]; size_t tot; int np;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_work.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen; sg[0] = seg[0]; sg[1] = seg[1]; tot = total; np = nparts;
+            }
+            if (idx + 1 < np) copy_part(sg, tot, idx + 1, np);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (--pending == 0) cv_done.notify_one();
+            }
+        }
+    }
+    void start(int n)
+    {
+        if (!threads.empty() || n < 1) return;
+        try { for (int i = 0; i < n; i++) threads.emplace_back([this, i] { worker(i); }); } catch (...) { /* fewer threads: still correct */ }
+    }
+    // start copying both segments (either may be empty) on the workers; finish() copies the caller's part and waits.  One job at a time.
+    void begin(Seg a, Seg b)
+    {
+        const size_t tot = a.bytes + b.bytes;
+        const int nw = tot >= ((size_t)1 << 20) ? (int)threads.size() : 0;        // small jobs: not worth a wake-up
+        {
+            std::lock_guard<std::mutex> lk(m);
+            seg[0] = a; seg[1] = b; total = tot; nparts = nw + 1; pending = nw ? (int)threads.size() : 0;
+            if (nw) gen++;
+        }
+        if (nw) cv_work.notify_all();
+    }
+    void finish()
+    {
+        if (!total) return;
+        const Seg sg[2] = { seg[0], seg[1] };
+        copy_part(sg, total, 0, nparts);
+        if (nparts > 1) { std::unique_lock<std::mutex> lk(m); cv_done.wait(lk, [&] { return pending == 0; }); }
+        total = 0;
+    }
+    void run(Seg a, Seg b) { begin(a, b); finish(); }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv_work.notify_all();
+        for (auto &t : threads) if (t.joinable()) t.join();
+    }
+};
+
 struct rmdf_ctx {
     int          device = 0;
     hipStream_t  stream = nullptr;
@@ -69,9 +149,12 @@ struct rmdf_ctx {
     CubeSlot     env[RMDF_ENV_SLOTS];
     std::vector<UvTable>   uv_tables;
     std::vector<LobeTable> lobe_tables;
-    // device scratch of the host-buffer env entry points (rmdf_prefilter_env_powers: source + one map per power), grow-only: a
-    // hipMalloc / hipFree pair per call cost more than the kernels of a 256x128 map
+    // device scratch of the host-buffer env entry points (rmdf_prefilter_env_powers: source + one map per power): kept between
+    // calls for maps up to the reference's own 256x128 (a hipMalloc / hipFree pair per call cost more than the kernels of such a
+    // map); larger maps get per-call buffers, so that one call at the accepted maximum (8192x4096, 16 powers: 6.8 GB) holds nothing
+    // afterwards.  One set per ctx: the env entry points are not re-entrant per ctx (rmdf.h: one caller thread per ctx).
     struct Scratch { void *p = nullptr; size_t bytes = 0; };
+    static constexpr size_t kEnvScratchKeepBytes = (size_t)256 * 128 * 12;
     Scratch      env_scratch[17];
     // frame latched on the first tile (ShaderRendering.hs:162-176)
     int          w = 0, h = 0, max_steps = 128;
@@ -83,6 +166,29 @@ struct rmdf_ctx {
     uint16_t    *d_steps = nullptr;
     uint16_t    *d_iters = nullptr;
     size_t       cap_px = 0, cap_planes_px = 0;
+    // tile mode (rmdf_render_tile with tile_idx >= 0): a page-locked host copy of the accumulating frame.  A tile call moves only the
+    // rows the tile touched over PCIe and hands the caller its whole frame from here (render_common).  shadow_valid: the copy equals
+    // the device frame.
+    uint32_t    *h_shadow = nullptr;
+    size_t       shadow_px = 0;
+    bool         shadow_valid = false;
+    CopyPool     copy_pool;
+    // ... and the tile jobs of that mode: a tile is rendered in the packed shard form (one slot) into a device scratch tile AND, by the
+    // kernel's mirror store, into a page-locked host tile, on a stream of its own.  RMDF_TILE_JOBS sets of those: the call for tile
+    // i issues the jobs of tiles i + 1 .. i + RMDF_TILE_JOBS - 1 of the same frame ahead of their calls, so they run side by side (a
+    // tile's kernel lasts as long as its longest ray, however few rays it has) while the calls before them copy.  A job is used only
+    // by the call whose (scene, tile, latched frame) it was issued for; anything else ignores it.
+#define RMDF_TILE_JOBS 4
+    struct TileJob {
+        uint32_t *d_tile = nullptr, *h_tile = nullptr, *h_tile_dev = nullptr;
+        size_t    px = 0;
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr, copied = nullptr;     // the kernel has finished; the scratch tile has been copied into the frame
+        bool      issued = false;
+        int       scene = 0, idx = 0, w = 0, h = 0, max_steps = 0;
+        float     time = 0.0f;
+    };
+    TileJob      tile_job[RMDF_TILE_JOBS];
     // host buffers registered for direct GPU writes (rmdf_register_host_buffer)
     struct HostReg { char *host; size_t bytes; char *dev; };
     std::vector<HostReg> host_regs;
@@ -117,6 +223,7 @@ struct rmdf_ctx {
     ncclComm_t   comm = nullptr;
     int          comm_rank = 0, comm_nranks = 1;
     int          flags = 0;            // rmdf_config.reserved[0]
+    int          copy_threads = 0;     // rmdf_config.reserved[1]: host threads of the tile-mode frame copy (0 = by core count)
     std::string  err;
     char         dev_name[256] = { 0 };
     int          cus = 0;
@@ -347,7 +454,7 @@ int ensure_frame(rmdf_ctx *ctx, int w, int h, bool planes)
     const size_t npx = (size_t)w * (size_t)h;
     if (!(npx <= ctx->cap_px && ctx->d_rgba8)) {
         if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
-        ctx->d_rgba8 = nullptr; ctx->cap_px = 0;
+        ctx->d_rgba8 = nullptr; ctx->cap_px = 0; ctx->shadow_valid = false;
         HIP_TRY(ctx, hipMalloc((void **)&ctx->d_rgba8, npx * 4));
         ctx->cap_px = npx;
     }
@@ -371,6 +478,7 @@ int ensure_frame(rmdf_ctx *ctx, int w, int h, bool planes)
 int clear_frame(rmdf_ctx *ctx, int w, int h)
 {
     const size_t npx = (size_t)w * (size_t)h;
+    ctx->shadow_valid = false;
     HIP_TRY(ctx, launch_fill_u32(ctx->d_rgba8, 0xff000000u, npx, ctx->stream));
     if (ctx->d_rgba_f32 && npx <= ctx->cap_planes_px) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_rgba_f32, 0, npx * 16, ctx->stream));
@@ -490,7 +598,8 @@ int fill_params(rmdf_ctx *ctx, int scene, int w, int h, float time, int max_step
 {
     if (scene < RMDF_FS_DE_CORNELL_BOX || scene > RMDF_FS_MB_GENERAL)
         return fail(ctx, RMDF_E_INVALID, "unknown FragmentShader value");
-    if (w <= 0 || h <= 0 || w > 32768 || h > 32768) return fail(ctx, RMDF_E_INVALID, "bad frame size");
+    // (primary_dir's short quotients are checked for exactly this range: rmdf_selftest_shading_math [4])
+    if (w <= 0 || h <= 0 || w > RMDF_MAX_FRAME_SIDE || h > RMDF_MAX_FRAME_SIDE) return fail(ctx, RMDF_E_INVALID, "bad frame size");
     if (max_steps > 32767) return fail(ctx, RMDF_E_INVALID, "max_steps > 32767");
     for (int s = RMDF_ENV_REFLECTION; s <= RMDF_ENV_COS_8; s++)
         if (!ctx->env[s].d_texels)
@@ -514,7 +623,11 @@ int fill_params(rmdf_ctx *ctx, int scene, int w, int h, float time, int max_step
     p.cornell = ctx->d_cornell;
     // pooling the last rays of a workgroup pays for both Mandelbulbs (+5 %, +8 %) and the test scene (+8 %);
     // it costs 6 % for the Cornell box, whose distance estimate has the same cost for every ray
+#ifdef RMDF_AB_CORNELL_MERGE
+    p.merge_stragglers = (ctx->flags & RMDF_FLAG_NO_MERGE) ? 0 : (scene == RMDF_FS_DE_CORNELL_BOX ? RMDF_AB_CORNELL_MERGE : 32);
+#else
     p.merge_stragglers = ((ctx->flags & RMDF_FLAG_NO_MERGE) || scene == RMDF_FS_DE_CORNELL_BOX) ? 0 : 32;
+#endif
     p.cornell_tab = ctx->d_cornell_tab;
     p.cornell_grid = ctx->d_cornell_grid;
     p.cornell_prune = (ctx->flags & RMDF_FLAG_NO_PRUNE) ? 0 : 1;
@@ -911,6 +1024,90 @@ int load_rccl(rmdf_ctx *ctx)
         }                                                                                                 \
     } while (0)
 
+// one tile job: render tile `idx` of the latched frame in the packed shard form into job buffer `b` (tile stream), mirror to the host tile
+int issue_tile_job(rmdf_ctx *ctx, int b, int scene, int idx)
+{
+    rmdf_ctx::TileJob &j = ctx->tile_job[b];
+    const size_t tpx = (size_t)(ctx->w / 8) * (size_t)(ctx->h / 8);
+    if (!j.stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&j.stream, hipStreamNonBlocking));
+    if (!j.done) HIP_TRY(ctx, hipEventCreateWithFlags(&j.done, hipEventDisableTiming));
+    if (!j.copied) HIP_TRY(ctx, hipEventCreateWithFlags(&j.copied, hipEventDisableTiming));
+    if (j.px < tpx) {
+        HIP_TRY(ctx, hipStreamSynchronize(j.stream));
+        if (j.d_tile) (void)hipFree(j.d_tile);
+        if (j.h_tile) (void)hipHostFree(j.h_tile);
+        j.d_tile = j.h_tile = j.h_tile_dev = nullptr; j.px = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&j.d_tile, tpx * 4));
+        HIP_TRY(ctx, hipHostMalloc((void **)&j.h_tile, tpx * 4, hipHostMallocMapped));
+        HIP_TRY(ctx, hipHostGetDevicePointer((void **)&j.h_tile_dev, j.h_tile, 0));
+        j.px = tpx;
+    }
+    j.issued = false;
+    FrameParams q;
+    int rc = fill_params(ctx, scene, ctx->w, ctx->h, ctx->time, ctx->max_steps, q);
+    if (rc != RMDF_OK) return rc;
+    q.n_shard_tiles = 1;
+    q.shard_tile[0] = (unsigned char)(idx % 64);
+    q.shard_key = 0x7fff0000 + (idx % 64);
+    q.rgba8 = j.d_tile;
+    q.rgba8_mirror = j.h_tile_dev;
+    rc = launch_scene(ctx, scene, q, j.stream);
+    if (rc != RMDF_OK) return rc;
+    HIP_TRY(ctx, hipEventRecord(j.done, j.stream));
+    j.issued = true; j.scene = scene; j.idx = idx % 64; j.w = ctx->w; j.h = ctx->h; j.max_steps = ctx->max_steps; j.time = ctx->time;
+    return RMDF_OK;
+}
+
+int render_tile_fast(rmdf_ctx *ctx, int scene, int tile_idx, const FrameParams &p, uint32_t *out_rgba8)
+{
+    const size_t npx = (size_t)ctx->w * ctx->h;
+    const int midx = tile_idx % 64, b = midx % RMDF_TILE_JOBS;
+    if (ctx->shadow_px != npx || !ctx->h_shadow) {
+        if (ctx->h_shadow) { (void)hipHostFree(ctx->h_shadow); ctx->h_shadow = nullptr; ctx->shadow_px = 0; }
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_shadow, npx * 4, hipHostMallocDefault));
+        ctx->shadow_px = npx; ctx->shadow_valid = false;
+        unsigned hc = std::thread::hardware_concurrency();
+        ctx->copy_pool.start(ctx->copy_threads ? ctx->copy_threads - 1 : (hc >= 64 ? 15 : (hc > 8 ? 7 : (hc > 1 ? (int)hc - 1 : 0))));
+    }
+    // this call's job: the one issued speculatively by the previous call if it is for exactly this tile of this frame, else now
+    rmdf_ctx::TileJob &j = ctx->tile_job[b];
+    auto is_for = [&](const rmdf_ctx::TileJob &t, int idx) {
+        return t.issued && t.scene == scene && t.idx == idx && t.w == ctx->w && t.h == ctx->h && t.max_steps == ctx->max_steps &&
+               memcmp(&t.time, &ctx->time, sizeof(float)) == 0;
+    };
+    if (!is_for(j, midx)) { int rc = issue_tile_job(ctx, b, scene, midx); if (rc != RMDF_OK) return rc; }
+    char *sh = (char *)ctx->h_shadow, *dst = (char *)out_rgba8;
+    if (!ctx->shadow_valid) {
+        // first tile call after a whole-frame render, a clear or a resize: the shadow is stale everywhere
+        HIP_TRY(ctx, hipMemcpyAsync(sh, ctx->d_rgba8, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->shadow_valid = true;
+    }
+    // the frame as it was goes to the caller on the worker threads ...
+    ctx->copy_pool.begin(CopyPool::Seg{ dst, sh, npx * 4 }, CopyPool::Seg{ nullptr, nullptr, 0 });
+    // ... while this thread issues the next tiles of the same frame ahead of their calls (tile 63 is followed by a frame with another
+    // time: nothing to guess), joins the copy, and waits for its own tile
+    for (int t = midx + 1; t < midx + RMDF_TILE_JOBS && t < 64; t++)
+        if (!is_for(ctx->tile_job[t % RMDF_TILE_JOBS], t)) (void)issue_tile_job(ctx, t % RMDF_TILE_JOBS, scene, t);
+    ctx->copy_pool.finish();
+    HIP_TRY(ctx, hipEventSynchronize(j.done));
+    j.issued = false;
+    // ... then the tile: host tile -> shadow and caller (rows of the tile's width), scratch tile -> device frame behind everything
+    // queued on the ctx stream so far
+    const int tw = p.x1 - p.x0, th = p.y1 - p.y0;
+    for (int y = 0; y < th; y++) {
+        const size_t off = ((size_t)(p.y0 + y) * ctx->w + p.x0) * 4;
+        memcpy(sh + off, j.h_tile + (size_t)y * tw, (size_t)tw * 4);
+        memcpy(dst + off, j.h_tile + (size_t)y * tw, (size_t)tw * 4);
+    }
+    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->d_rgba8 + (size_t)p.y0 * ctx->w + p.x0, (size_t)ctx->w * 4, j.d_tile, (size_t)tw * 4,
+                                  (size_t)tw * 4, (size_t)th, hipMemcpyDeviceToDevice, ctx->stream));
+    // the scratch tile may be overwritten by its next job only once this copy has read it
+    HIP_TRY(ctx, hipEventRecord(j.copied, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(j.stream, j.copied, 0));
+    return RMDF_OK;
+}
+
 int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double time, int max_steps,
                   uint32_t *out_rgba8, float *out_rgba_f32, uint16_t *out_steps, uint16_t *out_iters)
 {
@@ -961,8 +1158,56 @@ int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double t
     // by the copy of its rows, so that a band's copy overlaps the later bands' rendering.  A copy into PAGEABLE memory holds the
     // calling thread and pays its page pinning per call: 0.69 ms per 1080p frame against 0.62 ms for one launch + one copy,
     // 1.19 ms with launches and copies interleaved.  Overlap needs a pinned destination: rmdf_register_host_buffer above.)
+    // Tile mode hands back the WHOLE accumulating frame on every call (the reference maps a freshly orphaned PBO each time:
+    // FrameBuffer.hs:129,207-213), 64 times per frame, and every call has to wait for its tile's kernel -- whose run time is its
+    // longest ray's, not 1/64 of the frame's.  What the call does instead of `launch, copy 8.3 MB over PCIe, wait`:
+    //  * tiles are rendered as JOBS in the packed shard form on a stream of their own, into a device scratch tile and (the kernel's
+    //    mirror store) a page-locked host tile; the job of tile i + 1 is issued speculatively as soon as call i has found its own,
+    //    so it runs while call i copies and while the caller is between calls;
+    //  * the library keeps a page-locked shadow of the frame; a few host threads copy it into the caller's buffer while the job
+    //    finishes; then the tile goes from the host tile into the shadow and the caller's buffer (130 KB), and from the scratch
+    //    tile into the device frame (asynchronously: nothing waits for it but later renders).
+    // Frames whose sides 8 does not divide (no packed form) take the plain path below.
+    if (!whole && out_rgba8 && !planes && p.y1 > p.y0 && ctx->w % 8 == 0 && ctx->h % 8 == 0
+#ifdef RMDF_XCHECK
+        && !(ctx->flags & RMDF_FLAG_FLAT_MARCH)
+#endif
+    ) {
+        rc = render_tile_fast(ctx, scene, tile_idx, p, out_rgba8);
+        if (rc != RMDF_E_UNSUPPORTED) return rc;              // (the fast path declines nothing today; kept as the one fall-back point)
+    }
     rc = launch_scene(ctx, scene, p, ctx->stream);
     if (rc != RMDF_OK) return rc;
+    // The plain tile path: the frame's page-locked shadow as above, but the tile rendered in place and its rows fetched by a copy
+    // behind the kernel (1/8 of the frame), while the host threads already copy every other row.
+    if (!whole && out_rgba8 && !planes && p.y1 > p.y0) {
+        if (ctx->shadow_px != npx || !ctx->h_shadow) {
+            if (ctx->h_shadow) { (void)hipHostFree(ctx->h_shadow); ctx->h_shadow = nullptr; ctx->shadow_px = 0; }
+            HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_shadow, npx * 4, hipHostMallocDefault));
+            ctx->shadow_px = npx; ctx->shadow_valid = false;
+            unsigned hc = std::thread::hardware_concurrency();
+            ctx->copy_pool.start(ctx->copy_threads ? ctx->copy_threads - 1 : (hc >= 64 ? 15 : (hc > 8 ? 7 : (hc > 1 ? (int)hc - 1 : 0))));
+        }
+        const size_t row = (size_t)ctx->w * 4;
+        char *sh = (char *)ctx->h_shadow, *dst = (char *)out_rgba8;
+        if (!ctx->shadow_valid) {
+            // first tile call after a whole-frame render, a clear or a resize: the shadow is stale everywhere
+            HIP_TRY(ctx, hipMemcpyAsync(sh, ctx->d_rgba8, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->shadow_valid = true;
+            ctx->copy_pool.run(CopyPool::Seg{ dst, sh, npx * 4 }, CopyPool::Seg{ nullptr, nullptr, 0 });
+            return RMDF_OK;
+        }
+        const size_t lo = (size_t)p.y0 * row, hi = (size_t)p.y1 * row;
+        ctx->shadow_valid = false;                              // until the rows below have landed (an error leaves it stale)
+        HIP_TRY(ctx, hipMemcpyAsync(sh + lo, (const char *)ctx->d_rgba8 + lo, hi - lo, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->copy_pool.run(CopyPool::Seg{ dst, sh, lo }, CopyPool::Seg{ dst + hi, sh + hi, npx * 4 - hi });
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->shadow_valid = true;
+        ctx->copy_pool.run(CopyPool::Seg{ dst + lo, sh + lo, hi - lo }, CopyPool::Seg{ nullptr, nullptr, 0 });
+        return RMDF_OK;
+    }
+    if (whole || planes) ctx->shadow_valid = false;          // the device frame moves on without the shadow
     if (out_rgba8 && !direct) HIP_TRY(ctx, hipMemcpyAsync(out_rgba8, ctx->d_rgba8, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (out_rgba_f32) HIP_TRY(ctx, hipMemcpyAsync(out_rgba_f32, ctx->d_rgba_f32, npx * 16, hipMemcpyDeviceToHost, ctx->stream));
     if (out_steps) HIP_TRY(ctx, hipMemcpyAsync(out_steps, ctx->d_steps, npx * 2, hipMemcpyDeviceToHost, ctx->stream));
@@ -1027,6 +1272,8 @@ int rmdf_create(rmdf_ctx **out, const rmdf_config *cfg)
     if (!ctx) return fail(nullptr, RMDF_E_NOMEM, "out of host memory");
     ctx->device = dev;
     ctx->flags = flags;
+    ctx->copy_threads = cfg ? cfg->reserved[1] : 0;
+    if (ctx->copy_threads < 0 || ctx->copy_threads > 64) { delete ctx; return fail(nullptr, RMDF_E_INVALID, "rmdf_config.reserved[1] (host copy threads): 0 .. 64"); }
     ctx->cus = prop.multiProcessorCount;
     snprintf(ctx->dev_name, sizeof ctx->dev_name, "%s (%s)", prop.name, prop.gcnArchName);
     float tri[96 * 3];
@@ -1075,6 +1322,14 @@ void rmdf_destroy(rmdf_ctx *ctx)
     if (ctx->probe_stream) (void)hipStreamDestroy(ctx->probe_stream);
     if (ctx->probe_host) (void)hipHostFree(ctx->probe_host);
     if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
+    if (ctx->h_shadow) (void)hipHostFree(ctx->h_shadow);
+    for (auto &j : ctx->tile_job) {
+        if (j.d_tile) (void)hipFree(j.d_tile);
+        if (j.h_tile) (void)hipHostFree(j.h_tile);
+        if (j.done) (void)hipEventDestroy(j.done);
+        if (j.copied) (void)hipEventDestroy(j.copied);
+        if (j.stream) (void)hipStreamDestroy(j.stream);
+    }
     if (ctx->d_rgba_f32) (void)hipFree(ctx->d_rgba_f32);
     if (ctx->d_steps) (void)hipFree(ctx->d_steps);
     if (ctx->d_iters) (void)hipFree(ctx->d_iters);
@@ -1194,19 +1449,31 @@ int rmdf_prefilter_env_powers(rmdf_ctx *ctx, const float *rgb, int w, int h, con
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::vector<float *> d_out((size_t)npowers);
     const size_t b = (size_t)w * h * 12;
+    const bool keep = b <= rmdf_ctx::kEnvScratchKeepBytes;
+    std::vector<DevBuf> once(keep ? 0 : (size_t)npowers + 1);   // larger maps: freed when the call returns (hipFree waits for the device)
+    void *d_src = nullptr;
     for (int i = 0; i <= npowers; i++) {                   // slot 0 = the source, 1 + i = power i
-        rmdf_ctx::Scratch &sc = ctx->env_scratch[i];
-        if (sc.bytes < b) {
-            if (sc.p) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(sc.p); sc.p = nullptr; sc.bytes = 0; }
-            HIP_TRY(ctx, hipMalloc(&sc.p, b));
-            sc.bytes = b;
+        void *p = nullptr;
+        if (keep) {
+            rmdf_ctx::Scratch &sc = ctx->env_scratch[i];
+            if (sc.bytes < b) {
+                if (sc.p) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(sc.p); sc.p = nullptr; sc.bytes = 0; }
+                HIP_TRY(ctx, hipMalloc(&sc.p, b));
+                sc.bytes = b;
+            }
+            p = sc.p;
+        } else {
+            HIP_TRY(ctx, hipMalloc(&once[(size_t)i].p, b));
+            p = once[(size_t)i].p;
         }
-        if (i > 0) d_out[i - 1] = (float *)sc.p;
+        if (i > 0) d_out[i - 1] = (float *)p; else d_src = p;
     }
-    struct { void *p; } src = { ctx->env_scratch[0].p };
-    HIP_TRY(ctx, hipMemcpyAsync(src.p, rgb, b, hipMemcpyHostToDevice, ctx->stream));
-    int rc = prefilter_powers_device(ctx, (const float *)src.p, w, h, powers, npowers, d_out.data());
-    if (rc != RMDF_OK) { (void)hipDeviceSynchronize(); return rc; }
+    // From here on copies into the caller's `out` may be in flight: every exit waits for the device first (the per-call buffers'
+    // hipFree would, the kept scratch does not)
+    struct Drain { ~Drain() { (void)hipDeviceSynchronize(); } } drain;
+    HIP_TRY(ctx, hipMemcpyAsync(d_src, rgb, b, hipMemcpyHostToDevice, ctx->stream));
+    int rc = prefilter_powers_device(ctx, (const float *)d_src, w, h, powers, npowers, d_out.data());
+    if (rc != RMDF_OK) return rc;
     for (int i = 0; i < npowers; i++)
         HIP_TRY(ctx, hipMemcpyAsync(out + (size_t)i * w * h * 3, d_out[i], b, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1773,18 +2040,18 @@ int rmdf_selftest_pinned_math(rmdf_ctx *ctx, uint64_t mismatches[7])
     return RMDF_OK;
 }
 
-int rmdf_selftest_shading_math(rmdf_ctx *ctx, uint64_t mismatches[4])
+int rmdf_selftest_shading_math(rmdf_ctx *ctx, uint64_t mismatches[5])
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
     if (!mismatches) return fail(ctx, RMDF_E_INVALID, "null output");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int face_w = 64;                                  // a cube map of its own: 6 faces of 64 x 64 texels plus the seam padding
     DevBuf d, t;
-    HIP_TRY(ctx, hipMalloc(&d.p, 4 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMalloc(&d.p, 5 * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMalloc(&t.p, (size_t)6 * (face_w + 2) * (face_w + 2) * 8));
-    HIP_TRY(ctx, hipMemsetAsync(d.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
-    HIP_TRY(ctx, launch_selftest_shading_math((unsigned long long *)d.p, t.p, face_w, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(mismatches, d.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d.p, 0, 5 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, launch_selftest_shading_math((unsigned long long *)d.p, t.p, face_w, host_fov_xs(), ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(mismatches, d.p, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RMDF_OK;
 }

@@ -220,8 +220,9 @@ __global__ __launch_bounds__(64 * PREFILTER_WAVES) void k_prefilter(const float 
                                                   float *__restrict__ out, int nbuf)
 {
     extern __shared__ float lds_dyn[];                  // [nbuf][row_stride] source rows, then [w][64] cosine table when LUT_IN_LDS
-    // nbuf = 2: the next row is written while this one is still being read by slower waves; nbuf = 1 (rows too wide for two
-    // buffers in 160 KB: w > 6800): one more barrier per row separates the two
+    // nbuf = 2: the next row is written while this one is still being read by slower waves; nbuf = 1: one more barrier per row
+    // separates the two.  The launcher takes one buffer as soon as two would exceed 80 KB (w > 3413), so that two workgroups
+    // still fit a CU; tests/test_gpu_env.py runs a width on each side of that boundary
     const int row_stride = (w * 3 + 3) & ~3;            // floats per staged row, a multiple of 4 (ds_read_b128)
     float *lds_row = lds_dyn, *lds_lut = lds_dyn + nbuf * row_stride;
     // the wave index is wave-uniform, but the compiler cannot know that of threadIdx.x >> 6: say so, or every address

@@ -117,7 +117,8 @@ hipError_t launch_order_blocks(const unsigned *d_cost, int n, unsigned *d_order,
 hipError_t launch_resolve_box2(const uint32_t *d_src, int sw, int sh, uint32_t *d_dst, hipStream_t stream);
 hipError_t launch_selftest_exact_math(unsigned long long *d_counts, const float *d_cornell_tab, hipStream_t stream);
 hipError_t launch_selftest_pinned_math(unsigned long long *d_counts, hipStream_t stream);
-hipError_t launch_selftest_shading_math(unsigned long long *d_counts, void *d_texels, int face_w, hipStream_t stream);
+hipError_t launch_selftest_shading_math(unsigned long long *d_counts, void *d_texels, int face_w, float fov_xs, hipStream_t stream);
+#define RMDF_MAX_FRAME_SIDE 32768     // fill_params: 1 <= w, h <= this (rays per side, super-sampling included)
 hipError_t launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t stream);
 hipError_t launch_clock_probe(unsigned long long *d_out, unsigned long long ticks, int busy, hipStream_t stream);
 // rmdf_env.hip: d_uv = per-texel environment (u, v) of the faces (host-built, cube_uv_table_host); d_lutT / d_tcs = the

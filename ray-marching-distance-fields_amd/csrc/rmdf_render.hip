@@ -287,7 +287,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
             // one march step (fragment.shd:661-672) for the rays in flight
             if (act) {
                 const v3 pos = mk3(origin.x + tt * dx, origin.y + tt * dy, origin.z + tt * dz);
-                const float dist = distance_estimator<SCENE>(pos, p, it, tri_hint, cgrid);
+                const float dist = distance_estimator<SCENE>(pos, p, it, tri_hint, cgrid, s_ctab);
                 tt += dist;
                 const bool out = tt > tmx;
                 const bool h2 = !out && (dist < shk::march_min_dist);

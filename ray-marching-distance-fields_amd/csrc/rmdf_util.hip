@@ -267,7 +267,42 @@ __global__ void k_selftest_fill_cube(uint2 *texels, int n)
     texels[i] = make_uint2(*reinterpret_cast<const uint32_t *>(&rg), *reinterpret_cast<const uint32_t *>(&b0));
 }
 
-hipError_t launch_selftest_shading_math(unsigned long long *d_counts, void *d_texels, int face_w, hipStream_t stream)
+// generate_ray's three quotients over EVERY frame fill_params accepts (1 <= w, h <= RMDF_MAX_FRAME_SIDE): counts[4] +=
+//  * blockIdx.y = 0: (px + 0.5) / w for every side w and every pixel centre 0 .. w of it (one helper pixel past the edge included);
+//    the same table serves (py + 0.5) / h;
+//  * blockIdx.y = 1: for every (w, h) the reciprocal of aspect = w / h (a correctly rounded reciprocal makes the Markstein quotient
+//    the IEEE one for EVERY numerator that does not underflow), and the quotient ndc.y * fov / aspect itself for the first, the
+//    middle and the last row of that frame.
+// The short forms against the compiler's division, as everywhere in this file.
+__global__ void k_selftest_frame_quotients(unsigned long long *counts, float fov_xs)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t S = RMDF_MAX_FRAME_SIDE;
+    unsigned long long c = 0;
+    if (blockIdx.y == 0) {
+        for (uint64_t i = tid; i < S * (S + 1); i += stride) {
+            const uint32_t w = (uint32_t)(i / (S + 1)) + 1u, px = (uint32_t)(i % (S + 1));
+            if (px > w) continue;
+            const float a = (float)px + 0.5f, b = (float)w;
+            c += !same_bits(div_known_range(a, b), a / b);
+        }
+    } else {
+        for (uint64_t i = tid; i < S * S; i += stride) {
+            const uint32_t w = (uint32_t)(i / S) + 1u, h = (uint32_t)(i % S) + 1u;
+            const float wf = (float)w, hf = (float)h, aspect = wf / hf;
+            c += !same_bits(rcp_core(aspect), 1.0f / aspect);
+            const uint32_t rows[3] = { 0u, h / 2u, h - 1u };
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float ndcy = div_known_range((float)rows[k] + 0.5f, hf) * 2.0f - 1.0f, n = ndcy * fov_xs;
+                c += !same_bits(div_known_range(n, aspect), n / aspect);
+            }
+        }
+    }
+    if (c) atomicAdd(&counts[4], c);
+}
+
+hipError_t launch_selftest_shading_math(unsigned long long *d_counts, void *d_texels, int face_w, float fov_xs, hipStream_t stream)
 {
     const int n = 6 * (face_w + 2) * (face_w + 2);
     hipLaunchKernelGGL(k_selftest_fill_cube, dim3((n + 255) / 256), dim3(256), 0, stream, (uint2 *)d_texels, n);
@@ -275,6 +310,7 @@ hipError_t launch_selftest_shading_math(unsigned long long *d_counts, void *d_te
     cube.texels = (const uint2 *)d_texels;
     cube.W = face_w;
     hipLaunchKernelGGL(k_selftest_shading_math, dim3(8192), dim3(256), 0, stream, d_counts, cube);
+    hipLaunchKernelGGL(k_selftest_frame_quotients, dim3(4096, 2), dim3(256), 0, stream, d_counts, fov_xs);
     return hipGetLastError();
 }
 

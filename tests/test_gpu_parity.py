@@ -100,6 +100,47 @@ def test_tiled_frame_equals_full_frame(sr, rmdf):
     assert np.array_equal(fb.vec.reshape(h, w)[y0:y1, x0:x1], other["rgba8"][y0:y1, x0:x1])
 
 
+def test_tile_jobs_issued_ahead_never_show(sr, rmdf):
+    """Round 4: in tile mode the library renders the next tiles of the latched frame AHEAD of their calls (jobs into scratch tiles).
+    A job may only ever be used by the call it was issued for: a caller that changes the shader in the middle of a frame, jumps
+    around in the tile order, repeats a tile, renders a whole frame in between or changes the size gets exactly the tiles it asked
+    for, with the shader it asked for -- compared with full frames composed on the host."""
+    w, h, ms = 128, 72, 64
+    sr.render(2, w, h, 0.0, max_steps=ms)                    # a whole frame: the accumulating frame = scene 2 at t = 0
+    mb = {t: sr.render(2, w, h, t, max_steps=ms)["rgba8"] for t in (0.0, 1.0, 2.5)}
+    cb = {t: sr.render(0, w, h, t, max_steps=ms)["rgba8"] for t in (1.0, 2.5)}
+    expect = sr.render(2, w, h, 0.0, max_steps=ms)["rgba8"].copy()
+    fb = rmdf.FrameBuffer(w, h)
+
+    def tile(scene, idx, t, src):
+        sr.draw_shader_tile(scene, idx, w, h, t, fb.vec, max_steps=ms)
+        x0, y0, x1, y1 = rmdf.tile_rect(idx, w, h)
+        expect[y0:y1, x0:x1] = src[y0:y1, x0:x1]
+        assert np.array_equal(fb.vec.reshape(h, w), expect), (scene, idx, t)
+    for idx in range(0, 11):                                 # a frame at t = 1 begins ...
+        tile(2, idx, 1.0, mb[1.0])
+    for idx in range(11, 20):                                # ... the shader changes in the middle of it (time stays latched)
+        tile(0, idx, 77.0, cb[1.0])
+    for idx in (40, 5, 63, 6, 6, 7, 30):                     # the caller jumps around and repeats a tile
+        tile(2, idx, 55.0, mb[1.0])
+    full = sr.render(0, w, h, 2.5, max_steps=ms)["rgba8"]    # a whole frame in between: latches t = 2.5, replaces everything
+    expect[:] = full
+    for idx in (8, 9, 10):                                   # tiles after it continue at the time the whole frame latched
+        tile(2, idx, 123.0, mb[2.5])
+    tile(0, 64, 1.0, cb[1.0])                                # a new frame: tile 0 latches t = 1 again
+    tile(0, 1, 9.0, cb[1.0])
+    # another size: the frame is cleared, jobs of the old size must not be used
+    w2, h2 = 64, 40
+    f2 = rmdf.FrameBuffer(w2, h2)
+    sr.draw_shader_tile(2, 2, w2, h2, 1.0, f2.vec, max_steps=ms)
+    want = np.full((h2, w2), 0xFF000000, np.uint32)
+    x0, y0, x1, y1 = rmdf.tile_rect(2, w2, h2)
+    want[y0:y1, x0:x1] = sr.render(2, w2, h2, 1.0, max_steps=ms)["rgba8"][y0:y1, x0:x1]
+    sr.draw_shader_tile(2, 2, w2, h2, 1.0, f2.vec, max_steps=ms)      # (the render() above replaced the frame: ask again)
+    got = f2.vec.reshape(h2, w2)
+    assert np.array_equal(got[y0:y1, x0:x1], want[y0:y1, x0:x1])
+
+
 def test_determinism(sr):
     a = sr.render(2, 256, 144, 0.0, max_steps=256)
     b = sr.render(2, 256, 144, 0.0, max_steps=256)
@@ -653,8 +694,9 @@ def test_shading_math_exhaustive(sr):
     quotient on 2^33 operand pairs of its range, the AO term for every distance, fresnel for every cosine, and whole cube-map
     lookups on 2^30 direction triples including the degenerate ones (rmdf_util.hip: k_selftest_shading_math).  The frames of the
     alternative schedules (librmdf_xcheck) keep the compiler's division, so test_both_mandelbulb_schedules_agree compares the two forms on real frames too."""
+    # [4] (round 4): generate_ray's pixel-centre and aspect quotients exhaustively over every frame size fill_params accepts
     mism = sr.selftest_shading_math()
-    assert mism.tolist() == [0] * 4, mism
+    assert mism.tolist() == [0] * 5, mism
 
 
 @pytest.mark.parametrize("scene", [0, 1, 2, 3])
