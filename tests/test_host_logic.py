@@ -236,3 +236,30 @@ def test_dpp_products_of_the_prefilter_have_no_read_after_write_hazard(tmp_path)
                 lo, hi = (int(d.group(1)), int(d.group(2))) if d.group(1) else (int(d.group(3)), int(d.group(3)))
                 assert not (lo <= src0 <= hi), (ins[i - back], t)
     assert n_dpp > 1000                                      # both kernels are there, fully unrolled
+
+
+def test_bench_self_launcher_without_a_gpu():
+    """`python bench.py --gpus N` with no launcher around it becomes the launcher itself (bench.py: self_launch) before anything touches
+    the GPU.  On a box that shows fewer than N GPUs (this container shows none) it must say so and exit 2 at once -- no rendezvous, no
+    hang, nothing on stdout; with a fake launcher environment (WORLD_SIZE set) it must NOT try to launch again."""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the GPUs the launcher would use")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RMDF_BENCH_SELF_LAUNCH", "RMDF_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and not r.stdout.strip(), (r.returncode, r.stdout)
+    assert "this node shows" in r.stderr
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                           cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "needs a GPU" in r.stderr and "starting" not in r.stderr
+
+
+def test_copy_pool_and_deal_fingerprint_symbols(rmdf):
+    """the round-4 entry points are exported and refuse null arguments without touching a device"""
+    lib = rmdf.load_library()
+    assert lib.rmdf_comm_verify_deal(None, None) == -1
+    assert lib.rmdf_get_cornell_vertices(None) == -1
+    assert lib.rmdf_get_shader_constants(None, None, 0) >= 40

@@ -177,8 +177,9 @@ static void regroup_sims(const std::vector<unsigned short> &n)
     // the product's schedule with the same A, B for comparison: event-driven host pooling, T = 32
     {
         const int T = 32;
-        double c = 0.0, by_live[5] = { 0, 0, 0, 0, 0 }, longest = 0.0;
+        double c = 0.0, by_live[5] = { 0, 0, 0, 0, 0 }, longest = 0.0, quad_steps = 0, quad_iter_cost = 0, quad_cost = 0, quad_entries = 0, quad_cost_any = 0;
         for (int by = 0; by < PY; by++) for (int sx = 0; sx < (PX + 3) / 4; sx++) {
+            bool in_quad[1] = { false };
             std::vector<Ray> wv[4], mail;
             double clk[4] = { 0, 0, 0, 0 };
             bool alive[4] = { false, false, false, false };
@@ -201,6 +202,9 @@ static void regroup_sims(const std::vector<unsigned short> &n)
                 c += cost; clk[w] += cost;
                 const int live = (int)r.size();
                 by_live[live <= 4 ? 0 : live <= 8 ? 1 : live <= 16 ? 2 : live <= 32 ? 3 : 4] += cost;
+                // lane groups as they could be built: only the host, only once no mail can arrive any more (it is the last wave marching)
+                if (w == host && nalive == 1 && mail.empty() && live <= 16) { quad_steps += 1.0; quad_iter_cost += A * mk; quad_cost += cost; if (!in_quad[0]) { in_quad[0] = true; quad_entries += 1.0; } }
+                if (w == host && live <= 16) quad_cost_any += cost;
                 std::vector<Ray> nr;
                 for (auto &x : r) { x.step++; if (x.step < g_n[x.pix]) nr.push_back(x); }
                 r.swap(nr);
@@ -210,6 +214,12 @@ static void regroup_sims(const std::vector<unsigned short> &n)
         printf("product schedule (host pooling, T = 32) %8.1f M wave-instr (x%.3f of nested) lane utilisation %.3f\n", c / 1e6, c / c_nested, ideal / c);
         printf("  of which wave-steps with <= 4 / 5-8 / 9-16 / 17-32 / > 32 live rays: %.1f / %.1f / %.1f / %.1f / %.1f M; longest wave: %.0f instructions\n",
                by_live[0] / 1e6, by_live[1] / 1e6, by_live[2] / 1e6, by_live[3] / 1e6, by_live[4] / 1e6, longest);
+        printf("  host alone with <= 16 rays and no mail to come: %.1f M wave-instr in %.2f M wave-steps (%.1f M of it iteration passes), %.0f workgroups enter; "
+               "any host step with <= 16 rays: %.1f M\n", quad_cost / 1e6, quad_steps / 1e6, quad_iter_cost / 1e6, quad_entries, quad_cost_any / 1e6);
+        for (double aq : { 40.0, 45.0, 50.0 }) {
+            const double saved = quad_iter_cost * (1.0 - aq / A) - 150.0 * quad_entries;
+            printf("  4 lanes per ray there, %.0f instructions per pass, 150 per switch: %8.1f M wave-instr (x%.3f of the product schedule)\n", aq, (c - saved) / 1e6, (c - saved) / c);
+        }
         // the same schedule with G lanes per ray once a wave is down to 64 / G rays (the lanes of a group evaluate one ray's iteration
         // together: a pass costs A / speedup(G), the tail B / speedup_tail(G))
         for (double sp4 : { 2.0, 2.5 }) for (double sp2 : { 1.0, 1.5 }) {
