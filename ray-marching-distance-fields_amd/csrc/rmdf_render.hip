@@ -89,7 +89,7 @@ enum { OUT_RGBA8 = 0, OUT_MIRROR = 1, OUT_PLANES = 2 };
 
 // Everything a lane derives from (strip, thread id): the rectangle of its launch / shard slot, its pixel, its primary ray.
 // (Deriving it a second time after the march from laundered inputs, so that none of it occupies registers across the march
-// loop, was measured in round 3: 1.5 % slower -- the kernel needs 53 VGPRs, nothing is short.)
+// loop, was measured in round 3: 1.5 % slower -- the kernel stays under the 64 VGPRs of 8 waves per SIMD (profiles/*_kernel_resources.txt), nothing is short.)
 struct PixelGeom {
     int rx0, ry0, rx1, ry1, pitch, ox, oy;
     size_t obase;

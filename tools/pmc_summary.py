@@ -87,7 +87,7 @@ if cornell:
 # VGPR_Count / SGPR_Count as rocprofv3 prints them are allocation figures of the dispatch packet, not the compiler's register counts
 if "_resources" in counters:
     counters["_resources"]["note"] = ("as printed by rocprofv3 for the dispatch (allocation units of the packet); the compiler's counts are in "
-                                      "`make -C ray-marching-distance-fields_amd/csrc resources`: 53 VGPRs, 78 SGPRs, scratch 0 for k_render<2, true, 0>")
+                                      "profiles/*_kernel_resources.txt (tools/resources.sh: hipcc's own remarks for every k_render instantiation)")
 json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 
 
