@@ -933,9 +933,11 @@ def secondary_workloads(sr, torch, dev, stream, cus, streams=()):
         f(); f()
         t = ev(f, 5)
         per["power_%d" % int(p)] = {"kernel_ms": round(t, 3), "g_pair_terms_s": round(pair_terms / (t * 1e-3) / 1e9, 1)}
+    sr.prefilter_env_powers(src, (1.0, 8.0, 64.0, 512.0))           # first call: the ctx allocates its scratch and tables
     t0 = time.perf_counter()
-    sr.prefilter_env_powers(src, (1.0, 8.0, 64.0, 512.0))
-    four = time.perf_counter() - t0
+    for _ in range(3):
+        sr.prefilter_env_powers(src, (1.0, 8.0, 64.0, 512.0))
+    four = (time.perf_counter() - t0) / 3
     # config 4 on ONE GPU: frame-buffer scale 2 (App.hs:105-106,131-133) = 7680x4320 rays, one launch, then one mip level of the
     # RGBA8 frame (k_resolve_box2).  Two frames in flight like the headline's schedule would need 2 x 133 MB more; one at a time.
     big = torch.empty((4320, 7680), dtype=torch.int32, device=dev)

@@ -1468,15 +1468,16 @@ int rmdf_prefilter_env_powers(rmdf_ctx *ctx, const float *rgb, int w, int h, con
         }
         if (i > 0) d_out[i - 1] = (float *)p; else d_src = p;
     }
-    // From here on copies into the caller's `out` may be in flight: every exit waits for the device first (the per-call buffers'
-    // hipFree would, the kept scratch does not)
-    struct Drain { ~Drain() { (void)hipDeviceSynchronize(); } } drain;
+    // From here on copies into the caller's `out` may be in flight: every ERROR exit waits for the device first (the per-call
+    // buffers' hipFree would, the kept scratch does not)
+    struct Drain { bool armed = true; ~Drain() { if (armed) (void)hipDeviceSynchronize(); } } drain;
     HIP_TRY(ctx, hipMemcpyAsync(d_src, rgb, b, hipMemcpyHostToDevice, ctx->stream));
     int rc = prefilter_powers_device(ctx, (const float *)d_src, w, h, powers, npowers, d_out.data());
     if (rc != RMDF_OK) return rc;
     for (int i = 0; i < npowers; i++)
         HIP_TRY(ctx, hipMemcpyAsync(out + (size_t)i * w * h * 3, d_out[i], b, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    drain.armed = false;                                   // everything has landed: no device-wide wait on the way out
     return RMDF_OK;
     RMDF_GUARD_END(ctx)
 }
