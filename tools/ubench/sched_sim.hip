@@ -229,6 +229,111 @@ static void regroup_sims(const std::vector<unsigned short> &n)
     }
 }
 
+// Round 4: hand-over ACROSS workgroups without a G-buffer: a host wave that is alone in its workgroup with <= T2 rays (no mail to
+// come) either joins an ACCEPTOR -- another such host anywhere on the chip with enough idle lanes: it hands its rays over, WAITS for
+// their results and then shades as before -- or, if nobody accepts, becomes an acceptor itself.  Acceptors never wait for anybody.
+// Replay: (1) every workgroup alone (product schedule) -> its duration, the clock at which its host is alone with <= T2 rays, and
+// those rays; (2) workgroups dispatched longest-first over `slots` workgroup slots, each running at speed 1 (instructions = time);
+// (3) the tails replayed in global time order with the pairing rule.  Reported: instructions of the march part with and without.
+static void cross_wg_sim(const std::vector<unsigned short> &n)
+{
+    const double A = 87.0, B = 100.0;
+    const int PX = (W + 7) / 8, PY = (H + 7) / 8, T = 32;
+    auto packet = [&](int bx, int by, std::vector<Ray> &rays) {
+        for (int ly = 0; ly < 8; ly++) for (int lx = 0; lx < 8; lx++) {
+            const int x = bx * 8 + lx, y = by * 8 + ly;
+            if (x < W && y < H && n[(size_t)y * W + x] > 0) rays.push_back(Ray{ y * W + x, 0 });
+        }
+    };
+    struct WG { double dur = 0, head = 0, tail_start = 0; std::vector<Ray> tail; double start = 0; };
+    for (int T2 : { 8, 16, 24, 32 }) {
+        std::vector<WG> wgs;
+        double total = 0;
+        for (int by = 0; by < PY; by++) for (int sx = 0; sx < (PX + 3) / 4; sx++) {
+            WG g;
+            std::vector<Ray> wv[4], mail;
+            double clk[4] = { 0, 0, 0, 0 }, cost_sum = 0;
+            bool alive[4] = { false, false, false, false };
+            int host = -1, nalive = 0;
+            bool in_tail = false;
+            for (int q = 0; q < 4; q++) { const int bx = sx * 4 + q; if (bx >= PX) break; packet(bx, by, wv[q]); alive[q] = !wv[q].empty(); nalive += alive[q]; }
+            while (nalive > 0) {
+                int w = -1;
+                for (int q = 0; q < 4; q++) if (alive[q] && (w < 0 || clk[q] < clk[w])) w = q;
+                std::vector<Ray> &r = wv[w];
+                if ((int)r.size() <= T && host < 0) host = w;
+                if (w == host) { while (r.size() < 64 && !mail.empty()) { r.push_back(mail.back()); mail.pop_back(); } }
+                else if ((int)r.size() <= T && host >= 0) { mail.insert(mail.end(), r.begin(), r.end()); r.clear(); }
+                if (r.empty()) {
+                    if (w == host && nalive > 1) { double nxt = 1e300; for (int q = 0; q < 4; q++) if (alive[q] && q != w && clk[q] < nxt) nxt = clk[q]; clk[w] = nxt + 1e-9; continue; }
+                    alive[w] = false; nalive--; continue;
+                }
+                if (w == host && nalive == 1 && mail.empty() && (int)r.size() <= T2) { in_tail = true; g.tail_start = clk[w]; g.tail = r; break; }
+                int mk = 0;
+                for (auto &x : r) { const int k = kof(x.pix, x.step); if (k > mk) mk = k; }
+                const double cost = A * mk + B;
+                cost_sum += cost; clk[w] += cost;
+                std::vector<Ray> nr;
+                for (auto &x : r) { x.step++; if (x.step < g_n[x.pix]) nr.push_back(x); }
+                r.swap(nr);
+            }
+            g.head = cost_sum;
+            double mx = 0; for (int q = 0; q < 4; q++) if (clk[q] > mx) mx = clk[q];
+            if (!in_tail) g.tail_start = mx;
+            // the tail marched alone (product schedule)
+            double tc = 0; { std::vector<Ray> t = g.tail; tc = run_wave(t, 0, A, B, &total); }
+            g.dur = g.tail_start + tc;
+            total = 0;
+            wgs.push_back(g);
+            (void)cost_sum;
+        }
+        // (2) longest-first dispatch over the workgroup slots
+        const int slots = 2048;
+        std::vector<size_t> order(wgs.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return wgs[a].dur > wgs[b].dur; });
+        std::vector<double> freeat(slots, 0.0);
+        for (size_t i : order) { auto it = std::min_element(freeat.begin(), freeat.end()); wgs[i].start = *it; *it += wgs[i].dur; }
+        // (3) tails in global time order
+        struct Acc { std::vector<Ray> rays; double clk; bool open; };
+        std::vector<size_t> tl;
+        for (size_t i = 0; i < wgs.size(); i++) if (!wgs[i].tail.empty()) tl.push_back(i);
+        std::sort(tl.begin(), tl.end(), [&](size_t a, size_t b) { return wgs[a].start + wgs[a].tail_start < wgs[b].start + wgs[b].tail_start; });
+        std::vector<Acc> accs;
+        double base = 0, alone_tails = 0, merged_tails = 0; size_t donors = 0;
+        for (auto &g : wgs) base += g.head;
+        // advance an acceptor to time t (marching its rays), return cost spent
+        auto advance = [&](Acc &a, double t) {
+            double c = 0;
+            while (a.clk < t && !a.rays.empty()) {
+                int mk = 0;
+                for (auto &x : a.rays) { const int k = kof(x.pix, x.step); if (k > mk) mk = k; }
+                const double cost = A * mk + B;
+                c += cost; a.clk += cost;
+                std::vector<Ray> nr;
+                for (auto &x : a.rays) { x.step++; if (x.step < g_n[x.pix]) nr.push_back(x); }
+                a.rays.swap(nr);
+            }
+            if (a.rays.empty()) a.open = false;
+            return c;
+        };
+        for (size_t i : tl) {
+            const double t = wgs[i].start + wgs[i].tail_start;
+            { double d = 0; std::vector<Ray> tt = wgs[i].tail; alone_tails += run_wave(tt, 0, A, B, &d); }
+            // bring the open acceptors up to now; pick the one with the most rays that still has room
+            Acc *best = nullptr;
+            for (auto &a : accs) if (a.open) { merged_tails += advance(a, t); if (a.open && a.rays.size() + wgs[i].tail.size() <= 64 && (!best || a.rays.size() > best->rays.size())) best = &a; }
+            if (best) { best->rays.insert(best->rays.end(), wgs[i].tail.begin(), wgs[i].tail.end()); merged_tails += 150.0; donors++; }
+            else { Acc a; a.rays = wgs[i].tail; a.clk = t; a.open = true; accs.push_back(a); }
+            // forget closed acceptors now and then
+            if (accs.size() > 4096) { std::vector<Acc> keep; for (auto &a : accs) if (a.open) keep.push_back(a); accs.swap(keep); }
+        }
+        for (auto &a : accs) if (a.open) merged_tails += advance(a, 1e300);
+        printf("cross-workgroup hand-over with waiting donors, T2 = %2d: %zu of %zu workgroups have such a tail, %zu donate; march %.1f M alone -> %.1f M (x%.3f)\n",
+               T2, tl.size(), wgs.size(), donors, (base + alone_tails) / 1e6, (base + merged_tails) / 1e6, (base + merged_tails) / (base + alone_tails));
+    }
+}
+
 int main(int argc, char **argv)
 {
     Cam cam;
@@ -258,6 +363,7 @@ int main(int argc, char **argv)
         hipMemcpy(n_prev10.data(), d_n, npx * 2, hipMemcpyDeviceToHost);
     }
     if (argc > 1 && !strcmp(argv[1], "regroup")) { regroup_sims(n); return 0; }
+    if (argc > 1 && !strcmp(argv[1], "crosswg")) { cross_wg_sim(n); return 0; }
     double evals = 0, iters = 0; int maxn = 0;
     for (size_t i = 0; i < npx; i++) { evals += n[i]; if (n[i] > maxn) maxn = n[i]; for (int s = 0; s < n[i]; s++) iters += kof((int)i, s); }
     printf("rays with estimates: march estimates %.4e  escape iterations %.4e  mean k %.2f  longest ray %d estimates\n", evals, iters, iters / evals, maxn);
