@@ -136,3 +136,80 @@ def test_cosine_convolve_second_reading(orc):
         if power in (1.0, 8.0):                                     # the pinned squaring chain stays within the same distance of both
             pin = orc.cosine_convolve(src, power, pow_mode=1)
             assert (np.abs(pin.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-6)).max() < 5e-6
+
+
+# ---- Fractal2D.hs (BASELINE config 1, the CPU plumbing path): the same second reading ------------------------------------------
+
+def _escape_time(zr, zi, cr, ci, max_iter=40):
+    """`go` of Fractal2D.hs:46-52 / 85-90, all pixels at once: (iCnt, escZ)"""
+    zr, zi = zr.astype(f32).copy(), zi.astype(f32).copy()
+    it = np.zeros(zr.shape, np.int32)
+    done = np.zeros(zr.shape, bool)
+    cnt = np.zeros(zr.shape, np.int32)
+    er, ei = np.zeros_like(zr), np.zeros_like(zi)
+    for _ in range(max_iter + 1):
+        mag = (zr * zr + zi * zi).astype(f32)
+        stop = ~done & ((it == max_iter) | (mag > f32(16)))
+        cnt[stop], er[stop], ei[stop] = it[stop], zr[stop], zi[stop]
+        done |= stop
+        nr = ((zr * zr).astype(f32) - (zi * zi).astype(f32) + cr).astype(f32)        # (a :+ b) * (a :+ b) + c in Float
+        ni = ((zr * zi).astype(f32) + (zi * zr).astype(f32) + ci).astype(f32)
+        cyc = ~done & (nr == zr) & (ni == zi)                                        # 1-cycle: (maxIter, z)
+        cnt[cyc], er[cyc], ei[cyc] = max_iter, zr[cyc], zi[cyc]
+        done |= cyc
+        go = ~done
+        zr, zi = np.where(go, nr, zr), np.where(go, ni, zi)
+        it = it + go.astype(np.int32)
+    assert done.all()
+    return cnt, er, ei
+
+
+def _to_green(cnt, er, ei, smooth, max_iter=40):
+    if smooth:
+        with np.errstate(invalid="ignore", divide="ignore"):
+            mag = (er * er + ei * ei).astype(f32)
+            frac = np.maximum(f32(0), cnt.astype(f32) - (np.log(np.log(mag, dtype=f32), dtype=f32) / np.log(f32(2))).astype(f32)).astype(f32)
+        v = np.where(cnt == max_iter, f32(max_iter), frac).astype(f32)
+    else:
+        v = cnt.astype(f32)
+    return (np.trunc((v / f32(max_iter)).astype(f32) * f32(255)).astype(np.uint32)) << 8
+
+
+def _julia(w, h, smooth, tick):
+    ft = f32(tick)
+    frac = lambda x: f32(x - np.trunc(x))                                          # snd . properFraction
+    s1, s2, s3 = frac(f32(ft / f32(17))), frac(f32(ft / f32(61))), frac(f32(ft / f32(71)))
+    two_pi = f32(f32(s1 * f32(2)) * PI)
+    jr = f32(np.sin(two_pi, dtype=f32) * max(f32(0.7), s2))
+    ji = f32(np.cos(two_pi, dtype=f32) * max(f32(0.7), s3))
+    fw, fh = f32(w), f32(h)
+    ratio = f32(fw / fh)
+    xshift = f32(f32(1.45) * ratio)
+    px, py = np.meshgrid(np.arange(w, dtype=f32), np.arange(h, dtype=f32))
+    y = ((py / fh).astype(f32) * f32(2.9) - f32(1.45)).astype(f32)
+    x = (((px / fw).astype(f32) * f32(2.9)).astype(f32) * ratio - xshift).astype(f32)
+    return _to_green(*_escape_time(x, y, jr, ji), smooth)
+
+
+def _mandelbrot(w, h, smooth):
+    fw, fh = f32(w), f32(h)
+    ratio = f32(fw / fh)
+    xshift = f32(f32(-2) - f32(f32(f32(2) * ratio - f32(2.5)) * f32(0.5)))
+    px, py = np.meshgrid(np.arange(w, dtype=f32), np.arange(h, dtype=f32))
+    y = ((py / fh).astype(f32) * f32(2) - f32(1)).astype(f32)
+    x = (((px / fw).astype(f32) * f32(2)).astype(f32) * ratio + xshift).astype(f32)
+    return _to_green(*_escape_time(np.zeros_like(x), np.zeros_like(y), x, y), smooth)
+
+
+def test_fractal2d_second_reading(orc):
+    for (w, h) in ((64, 64), (96, 40)):
+        for tick in (0.0, 3.7, 123.4):
+            got = orc.julia_animated(w, h, 0, tick).reshape(h, w)
+            assert np.array_equal(got, _julia(w, h, False, tick)), (w, h, tick)          # iteration counts: identical
+            gs = orc.julia_animated(w, h, 1, tick).reshape(h, w).astype(np.int64) >> 8
+            ws = _julia(w, h, True, tick).astype(np.int64) >> 8
+            assert np.abs(gs - ws).max() <= 1 and (gs != ws).mean() < 5e-3               # smooth: log of numpy vs glibc, at truncation steps
+        assert np.array_equal(orc.mandelbrot(w, h, 0).reshape(h, w), _mandelbrot(w, h, False))
+        gs = orc.mandelbrot(w, h, 1).reshape(h, w).astype(np.int64) >> 8
+        ws = _mandelbrot(w, h, True).astype(np.int64) >> 8
+        assert np.abs(gs - ws).max() <= 1 and (gs != ws).mean() < 5e-3
