@@ -12,6 +12,8 @@
              that the full-size digests below do not depend on the libm of the box that checks them).
 * --digests  tests/golden/full_size_digests.json: sha256 of the oracle's rgba8 / steps / iters planes of BASELINE
              configs 2 and 3 at full size (1280x720 @128 Cornell, 1920x1080 @256 Mandelbulb), from those cube maps.
+* --grid     tests/golden/grid_256x144_digests.json: sha256 of the oracle's planes for every FragmentShader value at in_time 0, 1, 2.5 and 7
+             at 256x144 (SURVEY 8c's fixture grid), from the committed cube maps.
 * --digest4  adds BASELINE config 4 (7680x4320 rays @256 -> box-resolved 3840x2160) to that file (~4 min on 8 cores).
 * --renders  tests/golden/render_<scene>_<w>x<h>_t<time>.npz : oracle float RGBA / RGBA8 / steps / iters.
 * --env      tests/golden/env_*.npz : cube faces for the procedural test env map, pixelAtBilinear probes,
@@ -61,10 +63,10 @@ def render_name(scene, w, h, t, ms):
 
 def main():
     ap = argparse.ArgumentParser()
-    for f in ("caches", "renders", "env", "fractals", "cubes", "digests", "digest4"):
+    for f in ("caches", "renders", "env", "fractals", "cubes", "digests", "digest4", "grid"):
         ap.add_argument("--" + f, action="store_true")
     a = ap.parse_args()
-    if not (a.caches or a.renders or a.env or a.fractals or a.cubes or a.digests or a.digest4):
+    if not (a.caches or a.renders or a.env or a.fractals or a.cubes or a.digests or a.digest4 or a.grid):
         a.caches = a.renders = a.env = a.fractals = a.cubes = a.digests = True
 
     if a.caches:
@@ -97,6 +99,24 @@ def main():
                          "counters": r["counters"]}
             print(name, out[name])
         json.dump(out, open(os.path.join(GOLD, "full_size_digests.json"), "w"), indent=1, sort_keys=True)
+
+    if a.grid:
+        # SURVEY 8c's fixture grid at 256x144 -- every FragmentShader value at in_time 0, 1, 2.5 and 7 -- as digests of the oracle's
+        # planes (the full arrays of two of them are committed as render_*_256x144_*.npz; sixteen would be 8 MB)
+        import hashlib
+        import json
+        z = np.load(os.path.join(GOLD, "env_cubes_uffizi.npz"))
+        env = orc.EnvSet(z["refl"], z["cos1"], z["cos8"])
+        out = {}
+        for scene, ms in ((orc.SCENE_CORNELL, 128), (orc.SCENE_DETEST, 128), (orc.SCENE_MB_POWER8, 256), (orc.SCENE_MB_GENERAL, 128)):
+            for t in (0.0, 1.0, 2.5, 7.0):
+                r = orc.render(scene, 256, 144, t, ms, env)
+                out["s%d_t%s_m%d" % (scene, ("%.1f" % t).replace(".", "p"), ms)] = {
+                    "scene": scene, "w": 256, "h": 144, "time": t, "max_steps": ms,
+                    "sha256": {k: hashlib.sha256(np.ascontiguousarray(r[k]).tobytes()).hexdigest() for k in ("rgba8", "steps", "iters", "rgba_f32")},
+                    "hit_pixels": int((r["steps"] >> 15).sum())}
+        json.dump(out, open(os.path.join(GOLD, "grid_256x144_digests.json"), "w"), indent=1, sort_keys=True)
+        print("wrote grid_256x144_digests.json (%d frames)" % len(out))
 
     if a.digest4:
         # BASELINE config 4 on every pixel: 7680x4320 rays @256 (frame-buffer scale 2, App.hs:105-106,131-133), one mip level of the

@@ -4,6 +4,7 @@ Bars (BASELINE.json north_star): step counts, hit mask and escape-iteration coun
 1e-4 relative (absolute floor 1e-6).  The renderer under test (`sr`) builds its environment with the product's own pipeline
 (rmdf_load_env_hdr); the oracle side builds its own (tests/conftest.py checks the two sets of cube maps are bit-equal)."""
 import glob
+import json
 import os
 import re
 
@@ -800,6 +801,28 @@ def test_full_size_frames_match_the_committed_oracle_digests(rmdf, name):
         assert int(hit) == d["counters"]["hit_pixels"]
         if d["scene"] in (2, 3) and int(got["iters"].max()) < 65535:
             assert int(got["iters"].astype(np.int64).sum()) == d["counters"]["triplex_iters"]
+    finally:
+        r.close()
+
+
+GRID = json.load(open(os.path.join(GOLD, "grid_256x144_digests.json"))) if os.path.exists(os.path.join(GOLD, "grid_256x144_digests.json")) else {}
+
+
+@pytest.mark.parametrize("name", sorted(GRID))
+def test_fixture_grid_256x144(rmdf, name):
+    """SURVEY 8c's fixture grid: every FragmentShader value at in_time 0, 1, 2.5 and 7, 256x144 -- sha256 of the HIP planes against the
+    committed digests of the oracle's (make_fixtures.py --grid, committed cube maps).  steps / hit and escape iterations must be
+    bit-exact by the contract; RGBA8 and the float plane have been bit-identical in every run so far and are held to that here (the
+    contract's own bars -- 1e-4 on colour -- are asserted against the full arrays elsewhere in this file)."""
+    import hashlib
+    d = GRID[name]
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    r = _committed_cube_renderer(rmdf)
+    try:
+        got = r.render(d["scene"], d["w"], d["h"], d["time"], max_steps=d["max_steps"])
+        for k in ("steps", "iters", "rgba8", "rgba_f32"):
+            assert sha(got[k]) == d["sha256"][k], (name, k)
+        assert int((got["steps"] >> 15).sum()) == d["hit_pixels"]
     finally:
         r.close()
 

@@ -32,6 +32,21 @@ def test_render_matches_golden(orc, env_oracle, fn):
     assert list(r["counters"].values()) == [int(x) for x in g["counters"]]
 
 
+def test_fixture_grid_256x144_pins_the_oracle(orc):
+    """SURVEY 8c's fixture grid (every FragmentShader value at in_time 0, 1, 2.5, 7 at 256x144) as digests: the oracle must reproduce its
+    own committed planes from the committed cube maps (the GPU tier holds the HIP planes to the same digests)."""
+    import hashlib
+    import json
+    grid = json.load(open(os.path.join(GOLD, "grid_256x144_digests.json")))
+    assert len(grid) == 16
+    z = np.load(os.path.join(GOLD, "env_cubes_uffizi.npz"))
+    env = orc.EnvSet(z["refl"], z["cos1"], z["cos8"])
+    for name, d in sorted(grid.items()):
+        r = orc.render(d["scene"], d["w"], d["h"], d["time"], d["max_steps"], env)
+        for k in ("steps", "iters", "rgba8", "rgba_f32"):
+            assert hashlib.sha256(np.ascontiguousarray(r[k]).tobytes()).hexdigest() == d["sha256"][k], (name, k)
+
+
 def test_render_is_thread_count_invariant(orc, env_oracle):
     a = orc.render(orc.SCENE_MB_POWER8, 64, 36, 0.0, 256, env_oracle, nthreads=1)
     b = orc.render(orc.SCENE_MB_POWER8, 64, 36, 0.0, 256, env_oracle, nthreads=5)
