@@ -142,6 +142,17 @@ def test_tile_jobs_issued_ahead_never_show(sr, rmdf):
     assert np.array_equal(got[y0:y1, x0:x1], want[y0:y1, x0:x1])
 
 
+def test_tile_mode_fuzz():
+    """tools/tile_mode_fuzz.py: 1500 random boundary calls -- sequential tiles, jumps, repeats, shader changes, whole frames, sizes that 8
+    does and does not divide -- each compared with a model of the reference's accumulating frame buffer (two seeds)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    for seed in ("3", "11"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "tile_mode_fuzz.py"), "1500", seed], cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "1500 calls equal to the model" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
+
+
 def test_determinism(sr):
     a = sr.render(2, 256, 144, 0.0, max_steps=256)
     b = sr.render(2, 256, 144, 0.0, max_steps=256)
