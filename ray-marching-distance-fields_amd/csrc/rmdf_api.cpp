@@ -173,8 +173,8 @@ struct rmdf_ctx {
     size_t       shadow_px = 0;
     bool         shadow_valid = false;
     CopyPool     copy_pool;
-    // ... and the tile jobs of that mode: a tile is rendered in the packed shard form (one slot) into a device scratch tile AND, by the
-    // kernel's mirror store, into a page-locked host tile, on a stream of its own.  RMDF_TILE_JOBS sets of those: the call for tile
+    // ... and the tile jobs of that mode: a tile is rendered into a device scratch tile AND, by the kernel's mirror store, into a
+    // page-locked host tile (both at the frame's row pitch), on a stream of its own.  RMDF_TILE_JOBS sets of those: the call for tile
     // i issues the jobs of tiles i + 1 .. i + RMDF_TILE_JOBS - 1 of the same frame ahead of their calls, so they run side by side (a
     // tile's kernel lasts as long as its longest ray, however few rays it has) while the calls before them copy.  A job is used only
     // by the call whose (scene, tile, latched frame) it was issued for; anything else ignores it.
@@ -1024,11 +1024,17 @@ int load_rccl(rmdf_ctx *ctx)
         }                                                                                                 \
     } while (0)
 
-// one tile job: render tile `idx` of the latched frame in the packed shard form into job buffer `b` (tile stream), mirror to the host tile
+// one tile job: render tile `idx` of the latched frame into job buffer `b` on the job's stream, mirrored to the host tile.  The scratch
+// tile keeps the FRAME's row pitch (rows y0 .. y1 of the frame, the tile's columns first): the kernel's rectangle form then needs
+// nothing but a base pointer moved back by the rectangle's origin, and any frame size works -- the packed shard form of the first
+// version needed sides 8 divides.
 int issue_tile_job(rmdf_ctx *ctx, int b, int scene, int idx)
 {
     rmdf_ctx::TileJob &j = ctx->tile_job[b];
-    const size_t tpx = (size_t)(ctx->w / 8) * (size_t)(ctx->h / 8);
+    int x0, y0, x1, y1;
+    tile_rect_host(idx, ctx->w, ctx->h, &x0, &y0, &x1, &y1);
+    if (x1 <= x0 || y1 <= y0) { j.issued = false; return RMDF_OK; }                 // a tile without pixels (frames smaller than 8 x 8)
+    const size_t tpx = (size_t)((ctx->h + 7) / 8 + 1) * (size_t)ctx->w;                // rows of the tallest tile, at the frame's pitch
     if (!j.stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&j.stream, hipStreamNonBlocking));
     if (!j.done) HIP_TRY(ctx, hipEventCreateWithFlags(&j.done, hipEventDisableTiming));
     if (!j.copied) HIP_TRY(ctx, hipEventCreateWithFlags(&j.copied, hipEventDisableTiming));
@@ -1046,11 +1052,12 @@ int issue_tile_job(rmdf_ctx *ctx, int b, int scene, int idx)
     FrameParams q;
     int rc = fill_params(ctx, scene, ctx->w, ctx->h, ctx->time, ctx->max_steps, q);
     if (rc != RMDF_OK) return rc;
-    q.n_shard_tiles = 1;
-    q.shard_tile[0] = (unsigned char)(idx % 64);
-    q.shard_key = 0x7fff0000 + (idx % 64);
-    q.rgba8 = j.d_tile;
-    q.rgba8_mirror = j.h_tile_dev;
+    q.x0 = x0; q.y0 = y0; q.x1 = x1; q.y1 = y1;
+    // pixel (qx, qy) of the frame goes to base[qx + qy * w]: with the base moved back by the rectangle's origin that is
+    // tile[(qx - x0) + (qy - y0) * w]; only addresses inside the scratch tile are ever formed into accesses
+    const ptrdiff_t origin = (ptrdiff_t)y0 * ctx->w + x0;
+    q.rgba8 = j.d_tile - origin;
+    q.rgba8_mirror = j.h_tile_dev - origin;
     rc = launch_scene(ctx, scene, q, j.stream);
     if (rc != RMDF_OK) return rc;
     HIP_TRY(ctx, hipEventRecord(j.done, j.stream));
@@ -1097,10 +1104,10 @@ int render_tile_fast(rmdf_ctx *ctx, int scene, int tile_idx, const FrameParams &
     const int tw = p.x1 - p.x0, th = p.y1 - p.y0;
     for (int y = 0; y < th; y++) {
         const size_t off = ((size_t)(p.y0 + y) * ctx->w + p.x0) * 4;
-        memcpy(sh + off, j.h_tile + (size_t)y * tw, (size_t)tw * 4);
-        memcpy(dst + off, j.h_tile + (size_t)y * tw, (size_t)tw * 4);
+        memcpy(sh + off, j.h_tile + (size_t)y * ctx->w, (size_t)tw * 4);
+        memcpy(dst + off, j.h_tile + (size_t)y * ctx->w, (size_t)tw * 4);
     }
-    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->d_rgba8 + (size_t)p.y0 * ctx->w + p.x0, (size_t)ctx->w * 4, j.d_tile, (size_t)tw * 4,
+    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->d_rgba8 + (size_t)p.y0 * ctx->w + p.x0, (size_t)ctx->w * 4, j.d_tile, (size_t)ctx->w * 4,
                                   (size_t)tw * 4, (size_t)th, hipMemcpyDeviceToDevice, ctx->stream));
     // the scratch tile may be overwritten by its next job only once this copy has read it
     HIP_TRY(ctx, hipEventRecord(j.copied, ctx->stream));
@@ -1161,14 +1168,13 @@ int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double t
     // Tile mode hands back the WHOLE accumulating frame on every call (the reference maps a freshly orphaned PBO each time:
     // FrameBuffer.hs:129,207-213), 64 times per frame, and every call has to wait for its tile's kernel -- whose run time is its
     // longest ray's, not 1/64 of the frame's.  What the call does instead of `launch, copy 8.3 MB over PCIe, wait`:
-    //  * tiles are rendered as JOBS in the packed shard form on a stream of their own, into a device scratch tile and (the kernel's
-    //    mirror store) a page-locked host tile; the job of tile i + 1 is issued speculatively as soon as call i has found its own,
+    //  * tiles are rendered as JOBS on streams of their own, into a device scratch tile and (the kernel's mirror store) a
+    //    page-locked host tile; the job of tile i + 1 is issued speculatively as soon as call i has found its own,
     //    so it runs while call i copies and while the caller is between calls;
     //  * the library keeps a page-locked shadow of the frame; a few host threads copy it into the caller's buffer while the job
     //    finishes; then the tile goes from the host tile into the shadow and the caller's buffer (130 KB), and from the scratch
     //    tile into the device frame (asynchronously: nothing waits for it but later renders).
-    // Frames whose sides 8 does not divide (no packed form) take the plain path below.
-    if (!whole && out_rgba8 && !planes && p.y1 > p.y0 && ctx->w % 8 == 0 && ctx->h % 8 == 0
+    if (!whole && out_rgba8 && !planes && p.y1 > p.y0 && p.x1 > p.x0
 #ifdef RMDF_XCHECK
         && !(ctx->flags & RMDF_FLAG_FLAT_MARCH)
 #endif
