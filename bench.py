@@ -976,7 +976,18 @@ def secondary_workloads(sr, torch, dev, stream, cus, streams=()):
         fs = lambda sc=sc, tv=tv: sr.render_rect_device(sc, 1280, 720, tv, 128, (0, 0, 1280, 720), d_rgba8=fb.data_ptr(), stream=sp)
         warm(fs, 0.1)
         tt = ev(fs, 20)
+        # ... and with two frames in flight on two streams, as for the Cornell box above
+        n2s = 60
+        for i in range(6):
+            sr.render_rect_device(sc, 1280, 720, tv, 128, (0, 0, 1280, 720), d_rgba8=bufs[i & 1].data_ptr(), stream=sps[i & 1])
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(n2s):
+            sr.render_rect_device(sc, 1280, 720, tv, 128, (0, 0, 1280, 720), d_rgba8=bufs[i & 1].data_ptr(), stream=sps[i & 1])
+        torch.cuda.synchronize(dev)
+        t2s = (time.perf_counter() - t0) / n2s * 1e3
         out[name] = {"kernel_ms_avg": round(tt, 4), "mpixels_s": round(0.9216 / (tt * 1e-3), 1), "in_time": tv,
+                     "two_frames_in_flight_ms_per_frame": round(t2s, 4), "two_frames_in_flight_mpixels_s": round(0.9216 / (t2s * 1e-3), 1),
                      "valu_instructions_per_launch": scene_pmc(name), "note": "one frame at a time, HIP events; instruction count from profiles/ (rocprofv3 --pmc of this scene) when present"}
     # the headline scene from the SURVEY's other camera times
     fbv = torch.empty((1080, 1920), dtype=torch.int32, device=dev)
