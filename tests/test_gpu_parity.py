@@ -142,6 +142,26 @@ def test_tile_jobs_issued_ahead_never_show(sr, rmdf):
     assert np.array_equal(got[y0:y1, x0:x1], want[y0:y1, x0:x1])
 
 
+@pytest.mark.parametrize("threads", [1, 3, 64])
+def test_tile_mode_copy_thread_counts(rmdf, threads):
+    """rmdf_config.reserved[1]: tile mode with the calling thread alone (no pool), with two workers and with the maximum; a frame large
+    enough for the pool to split (>= 1 MiB) and a tiny one; tiled == full frame."""
+    r = rmdf.ShaderRenderer(0, copy_threads=threads)
+    try:
+        r.load_env_hdr(rmdf.DEFAULT_ENV_HDR)
+        for (w, h) in ((640, 480), (40, 24)):
+            full = np.empty(w * h, np.uint32)
+            r.draw_shader_tile(2, None, w, h, 1.5, full, max_steps=64)
+            fb = np.zeros(w * h, np.uint32)
+            for idx in range(64):
+                r.draw_shader_tile(2, idx, w, h, 1.5, fb, max_steps=64)
+            assert np.array_equal(fb, full), (threads, w, h)
+    finally:
+        r.close()
+    with pytest.raises(rmdf.RmdfError):
+        rmdf.ShaderRenderer(0, copy_threads=65)
+
+
 def test_tile_mode_fuzz():
     """tools/tile_mode_fuzz.py: 1500 random boundary calls -- sequential tiles, jumps, repeats, shader changes, whole frames, sizes that 8
     does and does not divide -- each compared with a model of the reference's accumulating frame buffer (two seeds)."""
