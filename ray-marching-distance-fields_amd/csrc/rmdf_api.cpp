@@ -1174,46 +1174,18 @@ int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double t
     //  * the library keeps a page-locked shadow of the frame; a few host threads copy it into the caller's buffer while the job
     //    finishes; then the tile goes from the host tile into the shadow and the caller's buffer (130 KB), and from the scratch
     //    tile into the device frame (asynchronously: nothing waits for it but later renders).
-    if (!whole && out_rgba8 && !planes && p.y1 > p.y0 && p.x1 > p.x0
+    // Frames beyond 1 GiB keep the plain path below (launch in place, whole frame copied): nobody page-locks a shadow of that size.
+    if (!whole && out_rgba8 && !planes && p.y1 > p.y0 && p.x1 > p.x0 && npx * 4 <= ((size_t)1 << 30)
 #ifdef RMDF_XCHECK
         && !(ctx->flags & RMDF_FLAG_FLAT_MARCH)
 #endif
-    ) {
-        rc = render_tile_fast(ctx, scene, tile_idx, p, out_rgba8);
-        if (rc != RMDF_E_UNSUPPORTED) return rc;              // (the fast path declines nothing today; kept as the one fall-back point)
-    }
+    )
+        return render_tile_fast(ctx, scene, tile_idx, p, out_rgba8);
     rc = launch_scene(ctx, scene, p, ctx->stream);
     if (rc != RMDF_OK) return rc;
-    // The plain tile path: the frame's page-locked shadow as above, but the tile rendered in place and its rows fetched by a copy
-    // behind the kernel (1/8 of the frame), while the host threads already copy every other row.
-    if (!whole && out_rgba8 && !planes && p.y1 > p.y0) {
-        if (ctx->shadow_px != npx || !ctx->h_shadow) {
-            if (ctx->h_shadow) { (void)hipHostFree(ctx->h_shadow); ctx->h_shadow = nullptr; ctx->shadow_px = 0; }
-            HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_shadow, npx * 4, hipHostMallocDefault));
-            ctx->shadow_px = npx; ctx->shadow_valid = false;
-            unsigned hc = std::thread::hardware_concurrency();
-            ctx->copy_pool.start(ctx->copy_threads ? ctx->copy_threads - 1 : (hc >= 64 ? 15 : (hc > 8 ? 7 : (hc > 1 ? (int)hc - 1 : 0))));
-        }
-        const size_t row = (size_t)ctx->w * 4;
-        char *sh = (char *)ctx->h_shadow, *dst = (char *)out_rgba8;
-        if (!ctx->shadow_valid) {
-            // first tile call after a whole-frame render, a clear or a resize: the shadow is stale everywhere
-            HIP_TRY(ctx, hipMemcpyAsync(sh, ctx->d_rgba8, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            ctx->shadow_valid = true;
-            ctx->copy_pool.run(CopyPool::Seg{ dst, sh, npx * 4 }, CopyPool::Seg{ nullptr, nullptr, 0 });
-            return RMDF_OK;
-        }
-        const size_t lo = (size_t)p.y0 * row, hi = (size_t)p.y1 * row;
-        ctx->shadow_valid = false;                              // until the rows below have landed (an error leaves it stale)
-        HIP_TRY(ctx, hipMemcpyAsync(sh + lo, (const char *)ctx->d_rgba8 + lo, hi - lo, hipMemcpyDeviceToHost, ctx->stream));
-        ctx->copy_pool.run(CopyPool::Seg{ dst, sh, lo }, CopyPool::Seg{ dst + hi, sh + hi, npx * 4 - hi });
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->shadow_valid = true;
-        ctx->copy_pool.run(CopyPool::Seg{ dst + lo, sh + lo, hi - lo }, CopyPool::Seg{ nullptr, nullptr, 0 });
-        return RMDF_OK;
-    }
-    if (whole || planes) ctx->shadow_valid = false;          // the device frame moves on without the shadow
+    // (every other case -- whole frames, the test planes, frames too large for a page-locked shadow, the cross-check schedule --
+    // copies what was asked for behind the launch)
+    ctx->shadow_valid = false;                               // the device frame moves on without the shadow
     if (out_rgba8 && !direct) HIP_TRY(ctx, hipMemcpyAsync(out_rgba8, ctx->d_rgba8, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (out_rgba_f32) HIP_TRY(ctx, hipMemcpyAsync(out_rgba_f32, ctx->d_rgba_f32, npx * 16, hipMemcpyDeviceToHost, ctx->stream));
     if (out_steps) HIP_TRY(ctx, hipMemcpyAsync(out_steps, ctx->d_steps, npx * 2, hipMemcpyDeviceToHost, ctx->stream));
