@@ -308,6 +308,9 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
         iters = __float_as_uint(rr.z);
     }
 
+#ifdef RMDF_AB_TAIL_PRIO
+    __builtin_amdgcn_s_setprio(RMDF_AB_TAIL_PRIO);           // everything after the march: finish the workgroup and free its slots
+#endif
     // render_ray hit branch up to the texture lookups (fragment.shd:743-799)
     const v3 dir = g.dir;
     const int lane = g.lane, wave = g.wave, lx = g.lx, ly = g.ly;
