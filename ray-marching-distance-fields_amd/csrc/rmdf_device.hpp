@@ -82,6 +82,17 @@ __device__ __forceinline__ float rcp_of_root(float s, float y)
     return __builtin_fmaf(e, y, y);
 }
 __device__ __forceinline__ bool root_needs_slow_rcp(float s) { return (uint16_t)__float_as_uint(s) == (uint16_t)0xffffu; }
+// The same test for the whole wave, as the mask of (active) lanes that need it.  Written as the 16-bit compare itself because the compiler's
+// form of the line above is v_cmp_eq_u32_sdwa ... src0_sel:WORD_0, and on gfx950 an SDWA instruction among ordinary VALU work costs
+// about one and a half issue slots more than a plain one (tools/ubench/valu_rates sdwa -> profiles/r04_sdwa_cost.txt: 7 v_mul + 1
+// compare run at 0.87 G instructions/s/SIMD with the SDWA compare, 0.93 with v_cmp_eq_u16).  Used by the guards of the power-8 iteration,
+// the hottest loop of the library (-2 % on the headline frame); rsqrt_ieee keeps the compiler's form, which measured 1 % better on the Cornell box.
+__device__ __forceinline__ unsigned long long root_needs_slow_rcp_lanes(float s)
+{
+    unsigned long long lanes;
+    asm("v_cmp_eq_u16_e64 %0, %1, %2" : "=s"(lanes) : "v"(__float_as_uint(s)), "s"(0xffffu));
+    return lanes;
+}
 __device__ __forceinline__ float rcp_core(float x)         // |x| in [2^-100, 2^100]
 {
     const float y0 = __builtin_amdgcn_rcpf(x);                            // <= 1 ulp
@@ -322,8 +333,10 @@ __device__ __forceinline__ void mb8_roots(float d, float k3, float q, float &r, 
     float y0;
     const float sq = sqrt_core_y(q, y0);
     k2 = rcp_of_root(sq, y0);
-    const bool slow = (int)(k3 < RMDF_MB8_K3MIN) | (int)root_needs_slow_rcp(sq);
-    if (__builtin_expect(__ballot(slow) != 0ull, 0)) { if (slow) { r = sqrtf(d); k2 = 1.0f / sqrtf(q); } }
+    const bool small = k3 < RMDF_MB8_K3MIN;
+    if (__builtin_expect((__ballot(small) | root_needs_slow_rcp_lanes(sq)) != 0ull, 0)) {
+        if ((int)small | (int)root_needs_slow_rcp(sq)) { r = sqrtf(d); k2 = 1.0f / sqrtf(q); }
+    }
 }
 // Iterations i0 .. i1-1 of the loop (i1 <= 25) on the state (w, dr, r, d); a lane whose squared radius d exceeds the bailout
 // leaves early.  Afterwards the estimate is complete iff d > RMDF_MB8_D4 (escaped) or i1 == 25; otherwise the same function
@@ -383,8 +396,9 @@ __device__ __forceinline__ void mb8_iterate_t(v3 &w, const v3 pos, float &dr, fl
             const float sq = sqrt_core_y(q, y0);
             float k2 = rcp_of_root(sq, y0);
             const bool small = k3 < RMDF_MB8_K3MIN;
-            const bool slow = (int)small | (int)root_needs_slow_rcp(sq);
-            if (__builtin_expect(__ballot(slow) != 0ull, 0)) { if (slow) { r = sqrtf(d); k2 = 1.0f / sqrtf(q); if (small) m = 0.0f; } }
+            if (__builtin_expect((__ballot(small) | root_needs_slow_rcp_lanes(sq)) != 0ull, 0)) {
+                if ((int)small | (int)root_needs_slow_rcp(sq)) { r = sqrtf(d); k2 = 1.0f / sqrtf(q); if (small) m = 0.0f; }
+            }
             const float a = a_ * k2, b = b_ * k2;
             m = __builtin_fminf(__builtin_fminf(m, __builtin_fabsf(a)), __builtin_fabsf(b));     // v_min3_f32 with |.| modifiers
             m = __builtin_fminf(__builtin_fminf(m, c), t);                                       // c, t >= 0

@@ -114,6 +114,101 @@ __global__ void k_scalar(float *out, float c)
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
 
+// Round 4: what does an SDWA instruction cost?  The compiler turns "(uint16_t)bits == 0xffff" into v_cmp_eq_u32_sdwa ... src0_sel:WORD_0
+// (the guard of the power-8 iteration) and half->float unpacking into v_cvt_f32_f16_sdwa ... src0_sel:WORD_1.  K = 0 the SDWA compare into
+// an SGPR pair, 1 the same compare as plain VOP3, 2 v_and_b32 + v_cmp (what -amdgpu-sdwa-peephole=0 emits), 3 v_cmp_eq_u16, 4/5/6 =
+// 0/1/3 mixed 1:7 with v_mul_f32, 7 v_cvt_f32_f16_sdwa WORD_1, 8 v_lshrrev_b32 16 + v_cvt_f32_f16, 9/10 = 7/8 mixed 1:7 (2:6) with v_mul.
+template <int K>
+__global__ void k_sdwa(float *out, float c)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const unsigned k16 = 0xffffu + (unsigned)(c > 2.0f);
+#define CLOB "s20","s21","s22","s23","s24","s25","s26","s27"
+#define MUL7 "v_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %7, %7, %8"
+#define ARGS : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "s"(k16) : CLOB, "vcc"
+    for (int i = 0; i < REPS; i++) {
+        if (K == 0) asm volatile("v_cmp_eq_u32_sdwa s[20:21], %0, %9 src0_sel:WORD_0 src1_sel:DWORD\n\tv_cmp_eq_u32_sdwa s[22:23], %1, %9 src0_sel:WORD_0 src1_sel:DWORD\n\t"
+                                 "v_cmp_eq_u32_sdwa s[24:25], %2, %9 src0_sel:WORD_0 src1_sel:DWORD\n\tv_cmp_eq_u32_sdwa s[26:27], %3, %9 src0_sel:WORD_0 src1_sel:DWORD\n\t"
+                                 "v_cmp_eq_u32_sdwa s[20:21], %4, %9 src0_sel:WORD_0 src1_sel:DWORD\n\tv_cmp_eq_u32_sdwa s[22:23], %5, %9 src0_sel:WORD_0 src1_sel:DWORD\n\t"
+                                 "v_cmp_eq_u32_sdwa s[24:25], %6, %9 src0_sel:WORD_0 src1_sel:DWORD\n\tv_cmp_eq_u32_sdwa s[26:27], %7, %9 src0_sel:WORD_0 src1_sel:DWORD" ARGS);
+        if (K == 1) asm volatile("v_cmp_eq_u32_e64 s[20:21], %0, %9\n\tv_cmp_eq_u32_e64 s[22:23], %1, %9\n\tv_cmp_eq_u32_e64 s[24:25], %2, %9\n\tv_cmp_eq_u32_e64 s[26:27], %3, %9\n\t"
+                                 "v_cmp_eq_u32_e64 s[20:21], %4, %9\n\tv_cmp_eq_u32_e64 s[22:23], %5, %9\n\tv_cmp_eq_u32_e64 s[24:25], %6, %9\n\tv_cmp_eq_u32_e64 s[26:27], %7, %9" ARGS);
+        if (K == 2) asm volatile("v_and_b32 %4, %9, %0\n\tv_cmp_eq_u32_e64 s[20:21], %4, %9\n\tv_and_b32 %5, %9, %1\n\tv_cmp_eq_u32_e64 s[22:23], %5, %9\n\t"
+                                 "v_and_b32 %6, %9, %2\n\tv_cmp_eq_u32_e64 s[24:25], %6, %9\n\tv_and_b32 %7, %9, %3\n\tv_cmp_eq_u32_e64 s[26:27], %7, %9" ARGS);
+        if (K == 3) asm volatile("v_cmp_eq_u16_e64 s[20:21], %0, %9\n\tv_cmp_eq_u16_e64 s[22:23], %1, %9\n\tv_cmp_eq_u16_e64 s[24:25], %2, %9\n\tv_cmp_eq_u16_e64 s[26:27], %3, %9\n\t"
+                                 "v_cmp_eq_u16_e64 s[20:21], %4, %9\n\tv_cmp_eq_u16_e64 s[22:23], %5, %9\n\tv_cmp_eq_u16_e64 s[24:25], %6, %9\n\tv_cmp_eq_u16_e64 s[26:27], %7, %9" ARGS);
+        if (K == 4) asm volatile("v_cmp_eq_u32_sdwa s[20:21], %0, %9 src0_sel:WORD_0 src1_sel:DWORD\n\t" MUL7 ARGS);
+        if (K == 5) asm volatile("v_cmp_eq_u32_e64 s[20:21], %0, %9\n\t" MUL7 ARGS);
+        if (K == 6) asm volatile("v_cmp_eq_u16_e64 s[20:21], %0, %9\n\t" MUL7 ARGS);
+        if (K == 7) asm volatile("v_cvt_f32_f16_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\tv_cvt_f32_f16_sdwa %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+                                 "v_cvt_f32_f16_sdwa %2, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\tv_cvt_f32_f16_sdwa %3, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+                                 "v_cvt_f32_f16_sdwa %4, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\tv_cvt_f32_f16_sdwa %5, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+                                 "v_cvt_f32_f16_sdwa %6, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\tv_cvt_f32_f16_sdwa %7, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" ARGS);
+        if (K == 8) asm volatile("v_lshrrev_b32 %0, 16, %0\n\tv_cvt_f32_f16 %0, %0\n\tv_lshrrev_b32 %1, 16, %1\n\tv_cvt_f32_f16 %1, %1\n\t"
+                                 "v_lshrrev_b32 %2, 16, %2\n\tv_cvt_f32_f16 %2, %2\n\tv_lshrrev_b32 %3, 16, %3\n\tv_cvt_f32_f16 %3, %3" ARGS);
+        if (K == 9) asm volatile("v_cvt_f32_f16_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t" MUL7 ARGS);
+        if (K == 10) asm volatile("v_lshrrev_b32 %0, 16, %0\n\tv_cvt_f32_f16 %0, %0\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %7, %7, %8" ARGS);
+    }
+#undef ARGS
+#undef MUL7
+#undef CLOB
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+// Round 4: instruction FORMS of the power-8 iteration, each as 1 instruction among 7 v_mul_f32 (an expensive form only shows in a mix:
+// the SDWA compare runs at the plain rate back to back).  8 instructions per group; a full-rate form gives the v_mul figure.
+template <int K>
+__global__ void k_mix(float *out, float c)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const float ks = c * 3.0f; const unsigned long long msk = 0x5555555555555555ull + (unsigned long long)(c > 2.0f);
+#define MUL7 "v_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %7, %7, %8"
+#define ARGS : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "s"(ks), "s"(msk) : "s20", "s21", "vcc", "scc"
+#define MIX(X) asm volatile(X "\n\t" MUL7 ARGS)
+    for (int i = 0; i < REPS; i++) {
+        if (K == 0) MIX("v_mul_f32 %0, %0, %8");
+        if (K == 1) MIX("v_min3_f32 %0, %0, |%1|, |%2|");
+        if (K == 2) MIX("v_fma_f32 %0, -%0, %1, 1.0");
+        if (K == 3) MIX("v_mul_f32 %0, 0x41e00000, %0");
+        if (K == 4) MIX("v_fmac_f32 %0, 0xc1800000, %1");
+        if (K == 5) MIX("v_cmp_gt_f32_e64 s[20:21], %9, %0");
+        if (K == 6) MIX("v_cmp_lt_f32_e32 vcc, %9, %0");
+        if (K == 7) MIX("v_mov_b32 %0, %1");
+        if (K == 8) MIX("v_cndmask_b32_e64 %0, %0, %1, %10");
+        if (K == 9) MIX("v_fma_f32 %0, %0, %9, 1.0");
+        if (K == 10) MIX("v_mul_f32 %0, %9, %0");
+        if (K == 11) MIX("v_mul_f32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+        if (K == 12) MIX("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf");
+        if (K == 13) MIX("v_readlane_b32 s20, %0, 3");
+        if (K == 14) MIX("v_readfirstlane_b32 s20, %0");
+        if (K == 15) MIX("s_or_b64 s[20:21], %10, %10");
+        if (K == 16) MIX("s_nop 0");
+        if (K == 17) MIX("v_cvt_f32_u32 %0, %0");
+        if (K == 18) MIX("v_ldexp_f32 %0, %0, %1");
+        if (K == 19) MIX("v_fmamk_f32 %0, %0, 0xc1000000, %1");
+        if (K == 20) MIX("v_and_b32 %0, 0xffff, %0");
+        if (K == 21) MIX("v_bfe_u32 %0, %0, 8, 8");
+        if (K == 22) MIX("v_mul_f32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD");
+        if (K == 23) MIX("v_mul_legacy_f32 %0, %0, %1");
+        if (K == 24) MIX("v_med3_f32 %0, %0, %1, %2");
+        if (K == 25) MIX("v_add_co_u32 %0, vcc, %0, %1");
+        if (K == 26) MIX("v_mul_lo_u32 %0, %0, %1");
+        if (K == 27) MIX("v_mad_u32_u24 %0, %0, %1, %2");
+        if (K == 28) MIX("v_lshlrev_b32 %0, 3, %0");
+        if (K == 29) MIX("v_exp_f32 %0, %0");
+        if (K == 30) MIX("v_cvt_f16_f32 %0, %0");
+        if (K == 31) MIX("v_cvt_pkrtz_f16_f32 %0, %0, %1");
+        if (K == 32) MIX("v_perm_b32 %0, %0, %1, %2");
+        if (K == 33) MIX("v_floor_f32 %0, %0");
+        if (K == 34) MIX("v_fract_f32 %0, %0");
+        if (K == 35) MIX("v_cvt_i32_f32 %0, %0");
+    }
+#undef MIX
+#undef ARGS
+#undef MUL7
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
 template <int K>
@@ -209,6 +304,41 @@ static void exec_halves()
         }
 }
 
+// ~100 ms of v_mul on every SIMD: the shader clock of a load that starts from idle ramps for ~20 ms (tools/clock_probe_check.py), and
+// the first rows of a listing would be taken below the others
+static void warm()
+{
+    hipDeviceProp_t prop;
+    (void)hipGetDeviceProperties(&prop, 0);
+    float *out;
+    (void)hipMalloc(&out, (size_t)prop.multiProcessorCount * 4 * 256 * 4);
+    for (int rep = 0; rep < 120; rep++) hipLaunchKernelGGL(k_scalar<0>, dim3(prop.multiProcessorCount * 4), dim3(256), 0, 0, out, 1.0001f);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(out);
+}
+static void sdwa_cost()
+{
+    warm();
+#define W(K, NAME) run(NAME, [](int b, int t, float *o) { hipLaunchKernelGGL(k_sdwa<K>, dim3(b), dim3(t), 0, 0, o, 1.0001f); }, 1)
+    W(0, "v_cmp_eq_u32_sdwa WORD_0"); W(1, "v_cmp_eq_u32_e64"); W(2, "v_and + v_cmp_eq_u32"); W(3, "v_cmp_eq_u16_e64");
+    W(4, "7 mul : 1 cmp_sdwa"); W(5, "7 mul : 1 cmp_e64"); W(6, "7 mul : 1 cmp_u16");
+    W(7, "v_cvt_f32_f16_sdwa WORD_1"); W(8, "v_lshrrev + v_cvt_f32_f16"); W(9, "7 mul : 1 cvt_sdwa"); W(10, "6 mul : lshr + cvt");
+#undef W
+}
+
+static void form_costs()
+{
+    warm();
+#define W(K, NAME) run("7 mul : 1 " NAME, [](int b, int t, float *o) { hipLaunchKernelGGL(k_mix<K>, dim3(b), dim3(t), 0, 0, o, 1.0001f); }, 1)
+    W(0, "v_mul (reference)"); W(1, "v_min3 |a||b|"); W(2, "v_fma -a,b,1.0"); W(3, "v_mul literal"); W(4, "v_fmac literal"); W(5, "v_cmp e64 ->sgpr");
+    W(6, "v_cmp e32 ->vcc"); W(7, "v_mov"); W(8, "v_cndmask sgpr"); W(9, "v_fma a,sgpr,1.0"); W(10, "v_mul sgpr"); W(11, "v_mul dpp quad");
+    W(12, "v_mov dpp row_shr"); W(13, "v_readlane"); W(14, "v_readfirstlane"); W(15, "s_or_b64"); W(16, "s_nop 0"); W(17, "v_cvt_f32_u32");
+    W(18, "v_ldexp_f32"); W(19, "v_fmamk literal"); W(20, "v_and literal"); W(21, "v_bfe_u32"); W(22, "v_mul_f32_sdwa DWORD"); W(23, "v_mul_legacy");
+    W(24, "v_med3_f32"); W(25, "v_add_co_u32"); W(26, "v_mul_lo_u32"); W(27, "v_mad_u32_u24"); W(28, "v_lshlrev_b32"); W(29, "v_exp_f32");
+    W(30, "v_cvt_f16_f32"); W(31, "v_cvt_pkrtz"); W(32, "v_perm_b32"); W(33, "v_floor_f32"); W(34, "v_fract_f32"); W(35, "v_cvt_i32_f32");
+#undef W
+}
+
 static void clock_under_load()
 {
     hipDeviceProp_t prop;
@@ -266,6 +396,8 @@ static void sustained()
 int main(int argc, char **argv)
 {
     if (argc > 1 && !strcmp(argv[1], "exec")) { exec_halves(); return 0; }
+    if (argc > 1 && !strcmp(argv[1], "sdwa")) { sdwa_cost(); return 0; }
+    if (argc > 1 && !strcmp(argv[1], "forms")) { form_costs(); return 0; }
     clock_under_load();
     sustained();
 #define S(K, NAME) run(NAME, [](int b, int t, float *o) { hipLaunchKernelGGL(k_scalar<K>, dim3(b), dim3(t), 0, 0, o, 1.0001f); }, 1)
