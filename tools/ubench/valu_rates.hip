@@ -202,6 +202,18 @@ __global__ void k_mix(float *out, float c)
         if (K == 33) MIX("v_floor_f32 %0, %0");
         if (K == 34) MIX("v_fract_f32 %0, %0");
         if (K == 35) MIX("v_cvt_i32_f32 %0, %0");
+        if (K == 40) asm volatile("v_cmp_gt_f32_e64 s[20:21], %9, %0\n\tv_cmp_lt_f32_e32 vcc, %9, %1\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %7, %7, %8" ARGS);
+        if (K == 41) asm volatile("v_cmp_gt_f32_e64 s[20:21], %9, %0\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_cmp_lt_f32_e32 vcc, %9, %1\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %7, %7, %8" ARGS);
+        if (K == 42) asm volatile("v_min3_f32 %0, %0, |%2|, |%3|\n\tv_min3_f32 %0, %0, %4, %5\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %7, %7, %8" ARGS);
+        if (K == 43) asm volatile("v_min3_f32 %0, %0, |%2|, |%3|\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_min3_f32 %1, %1, %4, %5\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %7, %7, %8" ARGS);
+        if (K == 44) asm volatile("v_cmp_lt_f32_e32 vcc, %9, %1\n\tv_min3_f32 %0, %0, |%2|, |%3|\n\tv_min3_f32 %0, %0, %4, %5\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %7, %7, %8" ARGS);
+        if (K == 45) asm volatile("v_cmp_lt_f32_e32 vcc, %9, %1\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_min3_f32 %0, %0, |%2|, |%3|\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_min3_f32 %1, %1, %4, %5\n\tv_mul_f32 %7, %7, %8" ARGS);
+        if (K == 46) asm volatile("v_fma_f32 %0, -%2, %2, %3\n\tv_fmac_f32 %1, %0, %4\n\tv_cmp_gt_f32_e64 s[20:21], %9, %5\n\tv_cmp_lt_f32_e32 vcc, %9, %6\n\tv_fma_f32 %0, -%1, %7, 1.0\n\tv_fmac_f32 %7, %0, %7\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %5, %5, %8" ARGS);
+        if (K == 47) asm volatile("v_fma_f32 %0, -%2, %2, %3\n\tv_mul_f32 %6, %6, %8\n\tv_cmp_gt_f32_e64 s[20:21], %9, %5\n\tv_fmac_f32 %1, %0, %4\n\tv_cmp_lt_f32_e32 vcc, %9, %6\n\tv_mul_f32 %5, %5, %8\n\tv_fma_f32 %0, -%1, %7, 1.0\n\tv_fmac_f32 %7, %0, %7" ARGS);
+        if (K == 50) asm volatile("v_rsq_f32 %0, %0\n\tv_rsq_f32 %7, %7\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8" ARGS);
+        if (K == 51) asm volatile("v_rsq_f32 %0, %0\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_rsq_f32 %7, %7\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8" ARGS);
+        if (K == 52) asm volatile("v_rsq_f32 %0, %0\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_rsq_f32 %7, %7\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8" ARGS);
+        if (K == 53) asm volatile("v_rsq_f32 %0, %0\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_rsq_f32 %7, %7\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\tv_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8" ARGS);
     }
 #undef MIX
 #undef ARGS
@@ -249,7 +261,7 @@ static void run(const char *name, F launch, int ops_per_instr, double instr_scal
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     printf("%-26s", name);
-    for (int wps : { 1, 2, 4 }) {               // waves per SIMD
+    for (int wps : { 1, 2, 4, 8 }) {               // waves per SIMD
         const int blocks = cus * wps, threads = 256; // 4 waves per block -> one per SIMD
         launch(blocks, threads, out);
         hipDeviceSynchronize();
@@ -335,6 +347,10 @@ static void form_costs()
     W(12, "v_mov dpp row_shr"); W(13, "v_readlane"); W(14, "v_readfirstlane"); W(15, "s_or_b64"); W(16, "s_nop 0"); W(17, "v_cvt_f32_u32");
     W(18, "v_ldexp_f32"); W(19, "v_fmamk literal"); W(20, "v_and literal"); W(21, "v_bfe_u32"); W(22, "v_mul_f32_sdwa DWORD"); W(23, "v_mul_legacy");
     W(24, "v_med3_f32"); W(25, "v_add_co_u32"); W(26, "v_mul_lo_u32"); W(27, "v_mad_u32_u24"); W(28, "v_lshlrev_b32"); W(29, "v_exp_f32");
+    W(40, "[2 cmp adjacent]"); W(41, "[2 cmp apart]"); W(42, "[2 min3 adjacent dep]"); W(43, "[2 min3 apart indep]"); W(44, "[cmp,min3,min3 adjacent]"); W(45, "[cmp,min3,min3 apart]"); W(46, "[fma,fmac,cmp,cmp,fma,fmac,2mul]"); W(47, "[same, interleaved]");
+#define W4(K, NAME) run("30 mul : 2 rsq " NAME, [](int b, int t, float *o) { hipLaunchKernelGGL(k_mix<K>, dim3(b), dim3(t), 0, 0, o, 1.0001f); }, 1, 4.0)
+    W4(50, "[adjacent]"); W4(51, "[16 apart]"); W4(52, "[2 between]"); W4(53, "[4 between]");
+#undef W4
     W(30, "v_cvt_f16_f32"); W(31, "v_cvt_pkrtz"); W(32, "v_perm_b32"); W(33, "v_floor_f32"); W(34, "v_fract_f32"); W(35, "v_cvt_i32_f32");
 #undef W
 }
