@@ -161,9 +161,6 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
     unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (p.block_order) lin = p.block_order[lin];
     const PixelGeom g = pixel_geom(p, lin, threadIdx.x);
-#ifdef RMDF_AB_CPRIO_WG
-    if (SCENE == 0 && p.block_order && (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x < RMDF_AB_CPRIO_WG) __builtin_amdgcn_s_setprio(3);
-#endif
 #ifdef RMDF_XCHECK
     const unsigned long long dbg_t0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;   // wave timeline (tools/nested_timeline.py)
     const unsigned long long dbg_c0 = p.dbg ? __builtin_amdgcn_s_memtime() : 0ull;       // shader cycles: the clock the kernel really runs at
