@@ -341,31 +341,48 @@ void cornell_table(const float tri[96 * 3], float tab[CORNELL_TAB_FLOATS])
         const float len12 = hdot(e12, e12);
         t[22] = len12;
         t[23] = 1.0f / dot00; t[24] = 1.0f / dot11; t[25] = 1.0f / len12;
-        // pruning bounds of de_cornell_box_table (double arithmetic, rounded once): unit normal, plane offset,
-        // bounding sphere about the centroid
+        // pruning bounds (double arithmetic, rounded once).  Every one is a plane the whole triangle lies on one side of, so the
+        // distance of a point to the triangle is at least its distance to that plane (on the far side): the triangle's own plane
+        // (both sides: |n.p - o|) and, new in round 4, the three planes through its edges perpendicular to it (outward unit
+        // normal n_e in the triangle's plane: n_e.q <= o_e for every q of the triangle, the offset rounded up by 1e-6).  t[26..27]
+        // pad; t[28..31] plane; t[32..43] edges.  The wave-uniform estimate (de_cornell_box_table) keeps plane + bounding sphere
+        // about the centroid, in the compact copy behind the rows.
         {
             const double a[3] = { e0.x, e0.y, e0.z }, b[3] = { e1.x, e1.y, e1.z };
             double n[3] = { a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0] };
             const double nl = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
             for (int k = 0; k < 3; k++) n[k] /= nl;
-            t[26] = (float)n[0]; t[27] = (float)n[1]; t[28] = (float)n[2];
-            t[29] = (float)(n[0] * v0[0] + n[1] * v0[1] + n[2] * v0[2]);
-            double c[3], R = 0.0;
-            for (int k = 0; k < 3; k++) c[k] = ((double)v0[k] + v1[k] + v2[k]) / 3.0;
-            for (int k = 0; k < 3; k++) t[30 + k] = (float)c[k];
+            t[26] = t[27] = 0.0f;
+            t[28] = (float)n[0]; t[29] = (float)n[1]; t[30] = (float)n[2];
+            t[31] = (float)(n[0] * v0[0] + n[1] * v0[1] + n[2] * v0[2]);
             const float *vs[3] = { v0, v1, v2 };
             for (int j = 0; j < 3; j++) {
+                const float *pa = vs[j], *pb = vs[(j + 1) % 3], *pc = vs[(j + 2) % 3];       // edge pa -> pb, pc opposite
+                const double e[3] = { (double)pb[0] - pa[0], (double)pb[1] - pa[1], (double)pb[2] - pa[2] };
+                double m[3] = { e[1] * n[2] - e[2] * n[1], e[2] * n[0] - e[0] * n[2], e[0] * n[1] - e[1] * n[0] };
+                const double ml = sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+                for (int k = 0; k < 3; k++) m[k] /= ml;
+                const double side = m[0] * ((double)pc[0] - pa[0]) + m[1] * ((double)pc[1] - pa[1]) + m[2] * ((double)pc[2] - pa[2]);
+                if (side > 0.0) for (int k = 0; k < 3; k++) m[k] = -m[k];                      // away from the opposite vertex
+                double o = -1e30;
+                for (int q = 0; q < 3; q++) { const double d = m[0] * vs[q][0] + m[1] * vs[q][1] + m[2] * vs[q][2]; if (d > o) o = d; }
+                float *eb = t + 32 + 4 * j;
+                eb[0] = (float)m[0]; eb[1] = (float)m[1]; eb[2] = (float)m[2]; eb[3] = (float)(o + 1e-6);
+            }
+            // compact copy behind the rows (read four triangles at a time by de_cornell_box_table): plane, bounding sphere
+            float *cb = tab + 32 * CORNELL_STRIDE + i * 8;
+            for (int k = 0; k < 4; k++) cb[k] = t[28 + k];
+            double c[3], R = 0.0;
+            for (int k = 0; k < 3; k++) c[k] = ((double)v0[k] + v1[k] + v2[k]) / 3.0;
+            for (int k = 0; k < 3; k++) cb[4 + k] = (float)c[k];
+            for (int j = 0; j < 3; j++) {
                 double d2 = 0.0;
-                for (int k = 0; k < 3; k++) { const double d = (double)vs[j][k] - (double)t[30 + k]; d2 += d * d; }
+                for (int k = 0; k < 3; k++) { const double d = (double)vs[j][k] - (double)cb[4 + k]; d2 += d * d; }
                 if (sqrt(d2) > R) R = sqrt(d2);
             }
-            t[33] = (float)(R * (1.0 + 1e-6));
-            t[34] = t[35] = 0.0f;
+            cb[7] = (float)(R * (1.0 + 1e-6));
         }
     }
-    // compact copy of the pruning bounds behind the rows (read four triangles at a time)
-    for (int i = 0; i < 32; i++)
-        for (int k = 0; k < 8; k++) tab[32 * CORNELL_STRIDE + i * 8 + k] = tab[i * CORNELL_STRIDE + 26 + k];
 }
 
 // Candidate grid of de_cornell_box_table (rmdf_device.hpp: cornell_cell_mask).  Per cell: the triangles t with

@@ -787,8 +787,10 @@ __device__ __forceinline__ float de_cornell_box(v3 pos, const float *__restrict_
 //     quotient for these 96 divisors (checked for every numerator bit pattern by rmdf_selftest_exact_math); numerators
 //     outside 2^-60..2^60 (zeros included) take the compiler's division;
 //   * min over sqrt(x_i) = sqrt(min over x_i): correctly rounded sqrt is monotone, and 999 = sqrt(998001) exactly.
-// Behind the 32 rows: a compact copy of the pruning bounds, 32 x 8 floats (t[26..33] of every row).
-#define CORNELL_STRIDE 36
+// t[28..43] of a row: the pruning planes of the per-lane estimate (below).  Behind the 32 rows: a compact table of the wave-uniform
+// estimate's bounds, 32 x 8 floats (plane, bounding sphere).
+#define CORNELL_STRIDE 44
+#define CORNELL_BOUNDS 28              /* t[28..43]: the triangle's plane and its three edge planes, four floats each */
 #define CORNELL_TAB_FLOATS (32 * CORNELL_STRIDE + 32 * 8)
 __device__ __forceinline__ float div_by_table(float x, float len, float rlen)
 {
@@ -810,10 +812,13 @@ __device__ __forceinline__ float seg_dist_sq_table(v3 a, v3 ab, float len, float
     return dot3(d, d);
 }
 // Pruning (prune != 0).  min() over the 32 triangles is exact and order-independent, so a triangle whose distance
-// provably cannot undercut the running minimum may be skipped without changing a bit.  Two lower bounds of the
-// point-triangle distance come from four more table entries per triangle (unit normal + plane offset t[26..29],
-// bounding-sphere centre + radius t[30..33], computed in double on the host): the distance to the triangle's plane
-// and |p - c| - R.  The triangle is skipped when either exceeds dmax = 1.001 * sqrt(running minimum) + 1e-5 -- a
+// provably cannot undercut the running minimum may be skipped without changing a bit.  Lower bounds of the
+// point-triangle distance come from more table entries per triangle (computed in double on the host): the distance to the
+// triangle's plane and, in the wave-uniform estimate, |p - c| - R for a bounding sphere; in the per-lane estimate, since round 4,
+// the distances beyond the three planes through the triangle's edges (a point over triangle A of a wall is at least its
+// in-plane distance to the diagonal away from the wall's other triangle -- the plane and sphere tests always let that one
+// through: 0.50 -> 0.32 full evaluations per estimate beyond the first, 0.32 -> 0.06 for the rays grazing the ceiling
+// that were the launch's critical path).  The triangle is skipped when a bound exceeds dmax = 1.001 * sqrt(running minimum) + 1e-5 -- a
 // margin four orders of magnitude above the float32 rounding of the bounds and of the reference's formulas (1e-7).
 // The test is 13 instructions against ~130 for the distance; a wave skips a triangle when all its lanes do (rays of
 // an 8x8 packet are close together): of 32 triangles ~5 survive on average.
@@ -903,11 +908,16 @@ __device__ __forceinline__ float de_cornell_box_lanes(v3 pos, const float *rows,
         if (my != 0u) {
             const int i = (int)__builtin_ctz(my);
             my &= my - 1u;
-            const float *b = rows + i * CORNELL_STRIDE + 26;
-            const float pd = fabsf(((b[0] * pos.x + b[1] * pos.y) + b[2] * pos.z) - b[3]);
-            const v3 dc = mk3(pos.x - b[4], pos.y - b[5], pos.z - b[6]);
-            const float rs = b[7] + dmax;
-            if (!((pd > dmax) || (dot3(dc, dc) > rs * rs))) surv |= 1u << i;
+            // lower bounds of the distance to triangle i: to its plane, and beyond each of its three edge planes (rmdf_api.cpp:
+            // cornell_table).  Not part of the parity contract (they only drop provable losers), so the dot products are FMAs.
+            const float4 *b = (const float4 *)(rows + i * CORNELL_STRIDE + CORNELL_BOUNDS);
+            const float4 pl = b[0], ea = b[1], eb = b[2], ec = b[3];
+            const float pd = fabsf(__builtin_fmaf(pl.z, pos.z, __builtin_fmaf(pl.y, pos.y, pl.x * pos.x)) - pl.w);
+            const float sa = __builtin_fmaf(ea.z, pos.z, __builtin_fmaf(ea.y, pos.y, ea.x * pos.x)) - ea.w;
+            const float sb = __builtin_fmaf(eb.z, pos.z, __builtin_fmaf(eb.y, pos.y, eb.x * pos.x)) - eb.w;
+            const float sc = __builtin_fmaf(ec.z, pos.z, __builtin_fmaf(ec.y, pos.y, ec.x * pos.x)) - ec.w;
+            const float bound = __builtin_fmaxf(__builtin_fmaxf(pd, sa), __builtin_fmaxf(sb, sc));
+            if (!(bound > dmax)) surv |= 1u << i;
         }
     }
     while (__ballot(surv != 0u) != 0ull) {
