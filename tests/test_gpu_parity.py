@@ -473,9 +473,10 @@ def test_cost_aware_tile_deal(sr, rmdf):
 
 
 def test_cornell_pruning_is_invisible(rmdf, sr, orc, env_oracle, env_faces):
-    """The Cornell distance estimate looks at the triangles of its cell's candidate mask only (host-built 16^3 grid, 1-Lipschitz
-    bound) and among those skips triangles whose lower bounds (plane distance, bounding sphere) exceed the running minimum by a
-    safety margin (rmdf_device.hpp: de_cornell_box_table, cornell_cell_mask).  min() is exact and order-independent, so the
+    """The Cornell distance estimate looks at the triangles of its cell's candidate mask only (host-built 64^3 grid, 1-Lipschitz
+    bound) and among those skips triangles whose lower bounds (distance to the triangle's plane and beyond its three edge planes;
+    plane and bounding sphere in the wave-uniform form) exceed the running minimum by a safety margin (rmdf_device.hpp:
+    de_cornell_box_lanes, de_cornell_box_table, cornell_cell_mask).  min() is exact and order-independent, so the
     result must be the same bits as evaluating all 32 triangles (RMDF_FLAG_NO_PRUNE) -- checked on whole frames (march
     positions, the 1e-5 finite-difference normals, the four AO taps, which reach 0.5 beyond the surfaces) at camera positions
     around the whole orbit (period 4 pi), and against the oracle."""
