@@ -817,8 +817,8 @@ __device__ __forceinline__ float seg_dist_sq_table(v3 a, v3 ab, float len, float
 // triangle's plane and, in the wave-uniform estimate, |p - c| - R for a bounding sphere; in the per-lane estimate, since round 4,
 // the distances beyond the three planes through the triangle's edges (a point over triangle A of a wall is at least its
 // in-plane distance to the diagonal away from the wall's other triangle -- the plane and sphere tests always let that one
-// through: 0.50 -> 0.32 full evaluations per estimate beyond the first, 0.32 -> 0.06 for the rays grazing the ceiling
-// that were the launch's critical path).  The triangle is skipped when a bound exceeds dmax = 1.001 * sqrt(running minimum) + 1e-5 -- a
+// through; the two combine as orthogonal components: 0.50 -> 0.12 full evaluations per estimate beyond the first, 0.32 ->
+// 0.003 for the rays grazing the ceiling that were the launch's critical path).  The triangle is skipped when a bound exceeds dmax = 1.001 * sqrt(running minimum) + 1e-5 -- a
 // margin four orders of magnitude above the float32 rounding of the bounds and of the reference's formulas (1e-7).
 // The test is 13 instructions against ~130 for the distance; a wave skips a triangle when all its lanes do (rays of
 // an 8x8 packet are close together): of 32 triangles ~5 survive on average.
@@ -902,7 +902,7 @@ __device__ __forceinline__ float de_cornell_box_lanes(v3 pos, const float *rows,
     const unsigned m = cornell_cell_mask_n<CORNELL_FINE_N>(pos, fine);
     int g = hint & 31;
     float best = cornell_tri_dist2(pos, rows + g * CORNELL_STRIDE);
-    const float dmax = __builtin_amdgcn_sqrtf(best) * 1.001f + 1e-5f;
+    const float dmax = __builtin_amdgcn_sqrtf(best) * 1.001f + 1e-5f, dmax2 = dmax * dmax;
     unsigned my = m & ~(1u << g), surv = 0u;
     while (__ballot(my != 0u) != 0ull) {
         if (my != 0u) {
@@ -912,12 +912,15 @@ __device__ __forceinline__ float de_cornell_box_lanes(v3 pos, const float *rows,
             // cornell_table).  Not part of the parity contract (they only drop provable losers), so the dot products are FMAs.
             const float4 *b = (const float4 *)(rows + i * CORNELL_STRIDE + CORNELL_BOUNDS);
             const float4 pl = b[0], ea = b[1], eb = b[2], ec = b[3];
-            const float pd = fabsf(__builtin_fmaf(pl.z, pos.z, __builtin_fmaf(pl.y, pos.y, pl.x * pos.x)) - pl.w);
+            // The plane distance and the in-plane distance are orthogonal components of the true distance, and the in-plane distance
+            // to the triangle is at least the largest of the three edge-plane distances: d^2 >= pd^2 + max(0, sa, sb, sc)^2.
+            const float pd = __builtin_fmaf(pl.z, pos.z, __builtin_fmaf(pl.y, pos.y, pl.x * pos.x)) - pl.w;
             const float sa = __builtin_fmaf(ea.z, pos.z, __builtin_fmaf(ea.y, pos.y, ea.x * pos.x)) - ea.w;
             const float sb = __builtin_fmaf(eb.z, pos.z, __builtin_fmaf(eb.y, pos.y, eb.x * pos.x)) - eb.w;
             const float sc = __builtin_fmaf(ec.z, pos.z, __builtin_fmaf(ec.y, pos.y, ec.x * pos.x)) - ec.w;
-            const float bound = __builtin_fmaxf(__builtin_fmaxf(pd, sa), __builtin_fmaxf(sb, sc));
-            if (!(bound > dmax)) surv |= 1u << i;
+            const float sm = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(sa, sb), sc), 0.0f);
+            const float bound2 = __builtin_fmaf(sm, sm, pd * pd);
+            if (!(bound2 > dmax2)) surv |= 1u << i;
         }
     }
     while (__ballot(surv != 0u) != 0ull) {
