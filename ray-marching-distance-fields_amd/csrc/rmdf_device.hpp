@@ -876,6 +876,19 @@ __device__ __forceinline__ unsigned cornell_cell_mask_n(v3 p, const unsigned *gr
     return grid[(iz * N + iy) * N + ix];
 }
 __device__ __forceinline__ unsigned cornell_cell_mask(v3 p, const unsigned *grid) { return cornell_cell_mask_n<CORNELL_GRID_N>(p, grid); }
+// The same cell with one FMA and one floor-and-convert per axis (the per-lane estimate's lookup in the fine grid).  Which cell a point on
+// a cell border falls into is not part of any contract: the grid's margin covers the rounding of the index (rmdf_api.cpp: cornell_grid).
+template <int N>
+__device__ __forceinline__ unsigned cornell_cell_mask_fast(v3 p, const unsigned *grid)
+{
+    const float s = (float)N / (2.0f * CORNELL_GRID_H), hs = CORNELL_GRID_H * s;
+    int ix, iy, iz;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ix) : "v"(__builtin_fmaf(p.x, s, hs)));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iy) : "v"(__builtin_fmaf(p.y, s, hs)));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iz) : "v"(__builtin_fmaf(p.z, s, hs)));
+    if ((unsigned)ix >= (unsigned)N || (unsigned)iy >= (unsigned)N || (unsigned)iz >= (unsigned)N) return 0xffffffffu;
+    return grid[(iz * N + iy) * N + ix];
+}
 // OR of `m` over the active lanes of the wave (exec-safe: reads only lanes that are active, one per distinct missing bit set)
 __device__ __forceinline__ unsigned wave_or_active(unsigned m)
 {
@@ -899,10 +912,12 @@ __device__ __forceinline__ unsigned wave_or_active(unsigned m)
 // needed before ~140 instructions have run, and its latency hides.
 __device__ __forceinline__ float de_cornell_box_lanes(v3 pos, const float *rows, const unsigned *fine, int &hint)
 {
-    const unsigned m = cornell_cell_mask_n<CORNELL_FINE_N>(pos, fine);
+    const unsigned m = cornell_cell_mask_fast<CORNELL_FINE_N>(pos, fine);
     int g = hint & 31;
     float best = cornell_tri_dist2(pos, rows + g * CORNELL_STRIDE);
-    const float dmax = __builtin_amdgcn_sqrtf(best) * 1.001f + 1e-5f, dmax2 = dmax * dmax;
+    // dmax^2 for dmax = 1.001 sqrt(best) + 1e-5 (the margin of de_cornell_box_table) without the root:
+    // (1.001 r + 1e-5)^2 = 1.002001 b + 2.002e-5 r + 1e-10 <= 1.0031 b + 1.02e-7  (2 r <= b / 0.01 + 0.01)
+    const float dmax2 = __builtin_fmaf(best, 1.0031f, 1.02e-7f);
     unsigned my = m & ~(1u << g), surv = 0u;
     while (__ballot(my != 0u) != 0ull) {
         if (my != 0u) {
