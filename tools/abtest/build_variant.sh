@@ -1,7 +1,7 @@
 #!/bin/bash
-# build_variant.sh <name> [-DKNOB | -mllvm ... ...]: another build of the product sources as tools/abtest/<name>.so (A/B with ab.sh).
-# Goes through csrc/Makefile (objects under csrc/build/ab/<name>), so a variant differs from the product by the given flags only --
-# they are appended to every compile, after the per-scene scheduler flags.
-here="$(cd "$(dirname "$0")" && pwd)"
+# build_variant.sh <name> [-DKNOB ...]: another build of the product sources as tools/abtest/<name>.so (A/B with ab.sh)
+cd "$(dirname "$0")/../../ray-marching-distance-fields_amd/csrc" || exit 1
 name=$1; shift
-make -s -C "$here/../../ray-marching-distance-fields_amd/csrc" -j4 OBJDIR=build/ab/$name OUT="$here/$name.so" EXTRA="$*" "$here/$name.so"
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize \
+  -fno-gpu-flush-denormals-to-zero -Wno-unused-function "$@" -shared -x hip rmdf_render.hip rmdf_env.hip rmdf_util.hip rmdf_api.cpp \
+  -o ../../tools/abtest/$name.so -lz -ldl
