@@ -36,6 +36,12 @@ int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_wav
  * cells from the 16^3 grid the way rmdf_create builds its 64^3 one.  out: n^3 uint32 masks. */
 int rmdf_debug_cornell_masks(int n, int brute_force, uint32_t *out);
 
+/* Host-only check aid: the per-triangle table of the Cornell box's distance estimate as rmdf_create uploads it (rmdf_device.hpp:
+ * CORNELL_STRIDE floats per triangle -- the reference's constants, then the pruning planes of the per-lane estimate: the triangle's
+ * plane and its three edge planes, four floats each from float CORNELL_BOUNDS on).  out: 32 * stride floats; *stride and *bounds
+ * (either may be NULL) receive the two offsets.  tests/test_host_logic.py holds every plane to "a lower bound of the distance". */
+int rmdf_debug_cornell_table(float *out, int *stride, int *bounds);
+
 #ifdef __cplusplus
 }
 #endif

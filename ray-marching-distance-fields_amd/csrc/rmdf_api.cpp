@@ -2069,6 +2069,18 @@ int rmdf_debug_cornell_masks(int n, int brute_force, uint32_t *out)
     return RMDF_OK;
 }
 
+int rmdf_debug_cornell_table(float *out, int *stride, int *bounds)
+{
+    if (stride) *stride = CORNELL_STRIDE;
+    if (bounds) *bounds = CORNELL_BOUNDS;
+    if (!out) return RMDF_OK;
+    float tri[96 * 3], tab[CORNELL_TAB_FLOATS];
+    cornell_triangles(tri);
+    cornell_table(tri, tab);
+    memcpy(out, tab, sizeof(float) * 32 * CORNELL_STRIDE);
+    return RMDF_OK;
+}
+
 int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_waves)
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");

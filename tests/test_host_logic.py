@@ -200,6 +200,86 @@ def test_cornell_candidate_grid_built_by_halving_equals_brute_force():
 
 
 
+def test_cornell_pruning_planes_are_lower_bounds_of_the_distance():
+    """The per-lane Cornell estimate skips a triangle when pd^2 + max(0, s_a, s_b, s_c)^2 -- its plane distance and the largest of its
+    three edge-plane distances, from the table rmdf_create uploads -- exceeds the squared margin around the running minimum
+    (rmdf_device.hpp: de_cornell_box_lanes).  That is only invisible if the expression never exceeds the true squared distance.  Host
+    arithmetic, no GPU: the table's planes evaluated in float32 the way the kernel does, against a float64 point-triangle distance, on
+    300 000 points of the grid's cube, on points near the triangles' own planes, edges and vertices, and the structural facts the bound
+    rests on (unit normals, the triangle on the inner side of each edge plane, edge planes perpendicular to the triangle)."""
+    import ctypes as C
+    import rmdf_amd
+    L = rmdf_amd.load_library(xcheck=True)
+    stride, bounds = C.c_int(), C.c_int()
+    assert L.rmdf_debug_cornell_table(None, C.byref(stride), C.byref(bounds)) == 0
+    S, B = stride.value, bounds.value
+    tab = np.zeros((32, S), np.float32)
+    assert L.rmdf_debug_cornell_table(tab.ctypes.data, None, None) == 0
+    tri = tab[:, :9].astype(np.float64).reshape(32, 3, 3)
+    assert np.array_equal(tab[:, :9].reshape(96, 3), rmdf_amd.cornell_vertices().reshape(96, 3))
+    planes = tab[:, B:B + 16].reshape(32, 4, 4)                      # [triangle][plane, edge a, b, c][nx, ny, nz, offset]
+    nrm = planes[:, :, :3].astype(np.float64)
+    assert np.allclose(np.linalg.norm(nrm, axis=2), 1.0, atol=1e-6)
+    assert np.abs(np.einsum("tk,tek->te", nrm[:, 0], nrm[:, 1:])).max() < 1e-6          # edge planes stand on the triangle's plane
+    for t in range(32):
+        assert np.abs(tri[t] @ nrm[t, 0] - planes[t, 0, 3]).max() < 1e-6                 # the vertices lie in the plane
+        for e in range(1, 4):
+            assert (tri[t] @ nrm[t, e] - planes[t, e, 3]).max() <= 0.0                   # the triangle is on the inner side of every edge plane
+
+    def true_dist(p):                                                                    # [n, 3] float64 -> [n, 32] (Ericson 5.1.5)
+        a, b, c = tri[None, :, 0], tri[None, :, 1], tri[None, :, 2]
+        P = p[:, None, :]
+        ab, ac, ap = b - a, c - a, P - a
+        d1, d2 = (ab * ap).sum(-1), (ac * ap).sum(-1)
+        bp, cp = P - b, P - c
+        d3, d4, d5, d6 = (ab * bp).sum(-1), (ac * bp).sum(-1), (ab * cp).sum(-1), (ac * cp).sum(-1)
+        vc, vb, va = d1 * d4 - d3 * d2, d5 * d2 - d1 * d6, d3 * d6 - d5 * d4
+        n = p.shape[0]
+        q, done = np.zeros((n, 32, 3)), np.zeros((n, 32), bool)
+        A, Bv, Cv = (np.broadcast_to(x, (n, 32, 3)) for x in (a, b, c))
+        def put(mask, val):
+            m = mask & ~done
+            q[m] = val[m]
+            done[m] = True
+        with np.errstate(all="ignore"):
+            put((d1 <= 0) & (d2 <= 0), A)
+            put((d3 >= 0) & (d4 <= d3), Bv)
+            put((vc <= 0) & (d1 >= 0) & (d3 <= 0), A + (d1 / (d1 - d3))[..., None] * ab)
+            put((d6 >= 0) & (d5 <= d6), Cv)
+            put((vb <= 0) & (d2 >= 0) & (d6 <= 0), A + (d2 / (d2 - d6))[..., None] * ac)
+            put((va <= 0) & ((d4 - d3) >= 0) & ((d5 - d6) >= 0), Bv + ((d4 - d3) / ((d4 - d3) + (d5 - d6)))[..., None] * (c - b))
+            den = 1.0 / (va + vb + vc)
+            put(np.ones((n, 32), bool), A + ab * (vb * den)[..., None] + ac * (vc * den)[..., None])
+        return np.sqrt(((P - q) ** 2).sum(-1))
+
+    def kernel_bound2(p32):                                                              # float32, the kernel's operations
+        x, y, z = (p32[:, None, None, k] for k in range(3))
+        pl = planes[None]
+        f32 = np.float32
+        dots = (f32(pl[..., 2] * z) + f32(f32(pl[..., 1] * y) + f32(pl[..., 0] * x))) - pl[..., 3]      # FMAs in the kernel: rounding differs by ulps
+        pd, sm = dots[..., 0], np.maximum(dots[..., 1:].max(axis=-1), f32(0.0))
+        return (sm * sm + pd * pd).astype(np.float64)
+
+    rng = np.random.default_rng(7)
+    pts = [rng.uniform(-1.1, 1.1, (300000, 3))]
+    w = rng.dirichlet((1.0, 1.0, 1.0), (32, 400))                                         # points on the triangles, pushed off a little
+    on = np.einsum("tnk,tkc->tnc", w, tri).reshape(-1, 3)
+    pts.append(on + rng.normal(0.0, 1e-3, on.shape))
+    pts.append(on + rng.normal(0.0, 5e-2, on.shape))
+    pts.append(np.repeat(tri.reshape(-1, 3), 50, axis=0) + rng.normal(0.0, 2e-2, (96 * 50, 3)))   # around the vertices
+    worst = 0.0
+    for p in pts:
+        for lo in range(0, len(p), 50000):
+            q = p[lo:lo + 50000]
+            d, b2 = true_dist(q), kernel_bound2(q.astype(np.float32))
+            # the kernel compares with 1.0031 best + 1.02e-7 >= (1.001 sqrt(best) + 1e-5)^2: a bound may exceed the true squared distance
+            # by rounding only, far inside that margin
+            over = np.sqrt(b2) - d
+            worst = max(worst, float(over.max()))
+            assert over.max() < 2e-6, (float(over.max()), np.unravel_index(over.argmax(), over.shape))
+    assert worst > -1.0                                                                   # (ran)
+
+
 def test_dpp_products_of_the_prefilter_have_no_read_after_write_hazard(tmp_path):
     """k_prefilter_chan / k_prefilter_fused4 multiply source texels through `v_mul_f32_dpp ... row_newbcast` written as inline asm
     (hipcc does not fold update_dpp into the multiply).  The compiler's hazard recogniser does not look inside inline asm, and gfx9
