@@ -207,29 +207,48 @@ def self_launch(n_gpus, json_fd):
     if have < n_gpus and os.environ.get("RMDF_BENCH_SHARE_GPU") != "1":
         sys.stderr.write("bench.py --gpus %d: this node shows %d GPU(s)\n" % (n_gpus, have))
         return 2
-    with socket.socket() as sk:                             # a free rendezvous port
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.pop("RMDF_BENCH_SELF_LAUNCH", None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: the only kind this pool's host driver supports
     env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.stderr.write("bench.py: no launcher in the environment -- starting %d rank(s): %s\n" % (n_gpus, " ".join(cmd)))
-    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
-    line = None
-    for raw in child.stdout:
-        txt = raw.decode("utf-8", "replace")
-        if txt.lstrip().startswith("{") and line is None:
-            try:
-                json.loads(txt)
-                line = txt
-                continue
-            except ValueError:
-                pass
-        sys.stderr.write(txt)                               # anything else a rank wrote to fd 1
-    rc = child.wait()
+    rc, line = 1, None
+    for attempt in range(4):
+        # a free rendezvous port -- free NOW: somebody else may take it before the launcher's store binds it (seen once in 30 runs of
+        # the test tier: EADDRINUSE), so a launch that dies of exactly that, before any rank has run, is repeated on another port
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stderr.write("bench.py: no launcher in the environment -- starting %d rank(s): %s\n" % (n_gpus, " ".join(cmd)))
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        import threading
+        err_tail = []
+        def pump(src=child.stderr):
+            for raw in src:
+                txt = raw.decode("utf-8", "replace")
+                sys.stderr.write(txt)
+                err_tail.append(txt)
+                del err_tail[:-200]
+        th = threading.Thread(target=pump, daemon=True)
+        th.start()
+        line = None
+        for raw in child.stdout:
+            txt = raw.decode("utf-8", "replace")
+            if txt.lstrip().startswith("{") and line is None:
+                try:
+                    json.loads(txt)
+                    line = txt
+                    continue
+                except ValueError:
+                    pass
+            sys.stderr.write(txt)                           # anything else a rank wrote to fd 1
+        rc = child.wait()
+        th.join(timeout=5)
+        if rc != 0 and line is None and any("EADDRINUSE" in t or "address already in use" in t.lower() for t in err_tail):
+            sys.stderr.write("bench.py: rendezvous port %d was taken in the meantime -- launching again on another\n" % port)
+            continue
+        break
     if line is not None and rc == 0:
         os.write(json_fd, line.encode())
         return 0

@@ -526,24 +526,35 @@ def test_config4_full_size_sharded_supersample(sr, rmdf, orc, env_oracle):
         assert d.max() <= 1 and (d > 0).mean() <= 1e-3, (y0, d.max(), (d > 0).mean())
 
 
+def _run_torchrun(nproc, env, args, timeout):
+    """python -m torch.distributed.run ... bench.py on a rendezvous port that was free a moment ago; if the port is taken before the
+    launcher binds it (EADDRINUSE: once in 30 runs of this tier), again on another port."""
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    for attempt in range(4):
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + list(args)
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+        if r.returncode != 0 and "EADDRINUSE" in r.stderr:
+            continue
+        return r
+    return r
+
+
 def test_multirank_bench_logic_on_one_gpu():
     """bench.py's N > 1 path with three real processes that share cuda:0 (RMDF_BENCH_SHARE_GPU=1: gloo transport through
     host staging, because RCCL cannot put several ranks on one device): every rank probes the tile costs by itself, the
     ranks agree on the deal, render their shards with frames in flight, rank 0 gathers and assembles -- and every
     assembled frame equals the oracle's 1920x1080 frame bit for bit (--check)."""
     import json
-    import subprocess
-    import sys
-    from conftest import ROOT
-    import socket
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
     env = dict(os.environ, RMDF_BENCH_SHARE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "9", "--warmup", "3", "--check"]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    r = _run_torchrun(3, env, ["--steps", "9", "--warmup", "3", "--check"], 600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout                        # exactly one JSON line on stdout, from rank 0
@@ -555,18 +566,7 @@ def test_multirank_bench_logic_on_one_gpu():
 
 def _run_bench_distributed(nproc, extra_env, args, timeout=900):
     import json
-    import socket
-    import subprocess
-    import sys
-    from conftest import ROOT
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    env = dict(os.environ, **extra_env)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + list(args)
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    r = _run_torchrun(nproc, dict(os.environ, **extra_env), args, timeout)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout                        # exactly one JSON line on stdout, from rank 0
