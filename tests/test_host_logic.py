@@ -298,7 +298,11 @@ def test_dpp_products_of_the_prefilter_have_no_read_after_write_hazard(tmp_path)
         pytest.skip("no hipcc")
     csrc = os.path.join(ROOT, "ray-marching-distance-fields_amd", "csrc")
     out = str(tmp_path / "env.s")
-    flags = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fno-gpu-flush-denormals-to-zero".split()
+    # the product's own flags, read from csrc/Makefile (CXXFLAGS and, should the file ever get flags of its own, FLAGS_rmdf_env)
+    mk = open(os.path.join(csrc, "Makefile")).read().replace("\\\n", " ")
+    var = lambda name: (re.search(r"^%s\s*=\s*(.*)$" % name, mk, re.M) or [None, ""])[1]
+    flags = (var("CXXFLAGS") + " " + var("FLAGS_rmdf_env")).replace("$(ARCH)", "gfx950").split()
+    assert "-ffp-contract=off" in flags and "--offload-arch=gfx950" in flags, flags
     subprocess.run([hipcc] + flags + ["-Wno-unused-function", "--cuda-device-only", "-S", os.path.join(csrc, "rmdf_env.hip"), "-o", out],
                    check=True, capture_output=True, timeout=600)
     ins = []
