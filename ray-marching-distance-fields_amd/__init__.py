@@ -91,13 +91,23 @@ def tile_rect(tile_idx, w, h):
     return ((2 * tx * w + 7) // 16, (2 * ty * h + 7) // 16, (2 * (tx + 1) * w + 7) // 16, (2 * (ty + 1) * h + 7) // 16)
 
 
+def _source_files():
+    """The SOURCES the two libraries are built from: csrc/Makefile, csrc/**/*.{hip,hpp,cpp} outside the object directories, the two
+    public headers.  Build products (csrc/build*/), caches and editor droppings never take part: `make clean`, or a pytest run
+    started inside csrc/, must not turn a current library into a "stale" one (and send a GPU box looking for hipcc)."""
+    files = []
+    for r, ds, fs in os.walk(CSRC):
+        ds[:] = sorted(d for d in ds if not d.startswith("build") and not d.startswith(".") and d != "__pycache__")
+        files += [os.path.join(r, f) for f in fs if f == "Makefile" or f.endswith((".hip", ".hpp", ".cpp", ".h"))]
+    files.sort()
+    return files + [os.path.join(_HERE, "..", "include", h) for h in ("rmdf.h", "rmdf_xcheck.h")]
+
+
 def _source_digest():
-    """sha256 over the contents of everything the two libraries are built from (csrc/**, the two headers)."""
+    """sha256 over the contents of everything the two libraries are built from (_source_files)."""
     import hashlib
-    files = sorted(os.path.join(r, f) for r, _, fs in os.walk(CSRC) for f in fs)
-    files += [os.path.join(_HERE, "..", "include", h) for h in ("rmdf.h", "rmdf_xcheck.h")]
     h = hashlib.sha256()
-    for fn in files:
+    for fn in _source_files():
         h.update(os.path.relpath(fn, _HERE).encode() + b"\0")
         with open(fn, "rb") as f:
             h.update(f.read())

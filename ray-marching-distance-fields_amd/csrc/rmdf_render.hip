@@ -522,6 +522,42 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
 template <int SCENE, bool MERGE, int OUT>
 __global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : ((SCENE == 0 && OUT != OUT_PLANES) ? 6 : 1)) void k_render(const FrameParams p) { render_body<SCENE, MERGE, OUT>(p); }
 
+// One source, one object -- or five (csrc/Makefile, `make SPLIT=1`: the build the GPU-memory-fault hunt of rounds 4 and 5 needs).
+// Compiled with -DRMDF_RENDER_SCENE=N this file yields the kernels of FragmentShader N and their launcher launch_render_scene_N, with
+// -DRMDF_RENDER_SPLIT the host side they share (grid, strip order, dispatch); with neither, everything.  Same kernels byte for byte.
+#define RMDF_CAT2(a, b) a##b
+#define RMDF_CAT(a, b) RMDF_CAT2(a, b)
+#ifndef RMDF_RENDER_SPLIT
+template <int SCENE>
+static void launch_render_scene(const FrameParams &p, dim3 grid, hipStream_t stream)
+{
+    const bool merge = p.merge_stragglers != 0;
+    const int out = (p.rgba_f32 || p.steps || p.iters) ? OUT_PLANES : (p.rgba8_mirror ? OUT_MIRROR : OUT_RGBA8);
+#define RMDF_LAUNCH(O)                                                                                       \
+    do {                                                                                                     \
+        if (merge) hipLaunchKernelGGL((k_render<SCENE, true, O>), grid, dim3(WPB * 64), 0, stream, p);       \
+        else       hipLaunchKernelGGL((k_render<SCENE, false, O>), grid, dim3(WPB * 64), 0, stream, p);      \
+    } while (0)
+    if (out == OUT_PLANES)      RMDF_LAUNCH(OUT_PLANES);
+    else if (out == OUT_MIRROR) RMDF_LAUNCH(OUT_MIRROR);
+    else                        RMDF_LAUNCH(OUT_RGBA8);
+#undef RMDF_LAUNCH
+}
+#endif
+#ifdef RMDF_RENDER_SCENE
+void RMDF_CAT(launch_render_scene_, RMDF_RENDER_SCENE)(const FrameParams &p, dim3 grid, hipStream_t stream) { launch_render_scene<RMDF_RENDER_SCENE>(p, grid, stream); }
+#else
+#ifdef RMDF_RENDER_SPLIT
+void launch_render_scene_0(const FrameParams &p, dim3 grid, hipStream_t stream);
+void launch_render_scene_1(const FrameParams &p, dim3 grid, hipStream_t stream);
+void launch_render_scene_2(const FrameParams &p, dim3 grid, hipStream_t stream);
+void launch_render_scene_3(const FrameParams &p, dim3 grid, hipStream_t stream);
+#else
+static void launch_render_scene_0(const FrameParams &p, dim3 grid, hipStream_t stream) { launch_render_scene<0>(p, grid, stream); }
+static void launch_render_scene_1(const FrameParams &p, dim3 grid, hipStream_t stream) { launch_render_scene<1>(p, grid, stream); }
+static void launch_render_scene_2(const FrameParams &p, dim3 grid, hipStream_t stream) { launch_render_scene<2>(p, grid, stream); }
+static void launch_render_scene_3(const FrameParams &p, dim3 grid, hipStream_t stream) { launch_render_scene<3>(p, grid, stream); }
+#endif
 static void render_grid(const FrameParams &p, dim3 &grid)
 {
     int rx0, ry0, rx1, ry1, nz = 1;
@@ -576,34 +612,19 @@ hipError_t launch_order_blocks(const unsigned *d_cost, int n, unsigned *d_order,
     return hipGetLastError();
 }
 
-template <int SCENE>
-static void launch_render_scene(const FrameParams &p, dim3 grid, hipStream_t stream)
-{
-    const bool merge = p.merge_stragglers != 0;
-    const int out = (p.rgba_f32 || p.steps || p.iters) ? OUT_PLANES : (p.rgba8_mirror ? OUT_MIRROR : OUT_RGBA8);
-#define RMDF_LAUNCH(O)                                                                                       \
-    do {                                                                                                     \
-        if (merge) hipLaunchKernelGGL((k_render<SCENE, true, O>), grid, dim3(WPB * 64), 0, stream, p);       \
-        else       hipLaunchKernelGGL((k_render<SCENE, false, O>), grid, dim3(WPB * 64), 0, stream, p);      \
-    } while (0)
-    if (out == OUT_PLANES)      RMDF_LAUNCH(OUT_PLANES);
-    else if (out == OUT_MIRROR) RMDF_LAUNCH(OUT_MIRROR);
-    else                        RMDF_LAUNCH(OUT_RGBA8);
-#undef RMDF_LAUNCH
-}
-
 hipError_t launch_render(int scene, const FrameParams &p, hipStream_t stream)
 {
     dim3 grid;
     render_grid(p, grid);
     if (grid.x == 0) return hipSuccess;
     if (!p.rgba8 && !(p.rgba_f32 || p.steps || p.iters)) return hipErrorInvalidValue;
-    if (scene == 2)      launch_render_scene<2>(p, grid, stream);
-    else if (scene == 0) launch_render_scene<0>(p, grid, stream);
-    else if (scene == 1) launch_render_scene<1>(p, grid, stream);
-    else if (scene == 3) launch_render_scene<3>(p, grid, stream);
+    if (scene == 2)      launch_render_scene_2(p, grid, stream);
+    else if (scene == 0) launch_render_scene_0(p, grid, stream);
+    else if (scene == 1) launch_render_scene_1(p, grid, stream);
+    else if (scene == 3) launch_render_scene_3(p, grid, stream);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
+#endif
 
 }  // namespace rmdf
