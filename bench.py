@@ -167,6 +167,64 @@ def flops_model(c):
     return 79 * c["triplex_iters"] + 11 * c["de_evals"] + 9 * c["march_steps"] + 150 * c["hit_pixels"] + 30 * c["pixels"]
 
 
+# As-written operation counts of the other three FragmentShader values, in SURVEY.md 8(d)'s style (every IEEE operation 1, and sqrt,
+# inversesqrt, /, pow, log, exp, sin, cos, acos, atan each 1 as well; min / max / abs / compare 1, clamp 2; texel fetches 0).
+#   Cornell box (fragment.shd:312-411): compute_barycentric = 3 vector differences (9) + 5 dot products (25) + inv_denom (4) + u, v (8) +
+#     the prism test (4) = 50; prism branch: point on plane (17) + distance (9) = 26 -> 76 per triangle; edge branch: 3 x
+#     line_seg_min_dist_sq (36: ab 3, len_sq 5, p - a 3, dot 5, / 1, clamp 2, a + t ab 6, two p - proj 6, dot 5) + 2 min + sqrt = 111
+#     -> 161 per triangle; + 32 min per estimate.  T_in (estimate, triangle) pairs take the prism branch (oracle counter tri_inside), the
+#     other 32 E - T_in the edge branch.  Hit pixel: distance_ao has four taps instead of two -> 170 instead of 150.
+#   DE test scene (fragment.shd:21-33, 413-456): de_sphere 7 + 3 x de_torus (10) + 3 x de_rounded_box (16) + 5 x smin (2 mul, 2 exp,
+#     add, log, neg, / = 8) + 1 min = 126 per estimate.
+#   General-power Mandelbulb (fragment.shd:42-72, 101-158): one full iteration = length 6 + compare 1 + triplex_pow 22
+#     (cartesian_to_spherical: length 6, / 1, acos 1, atan 1; pow 1; two angle products 2; spherical_to_cartesian: 3 sin, 2 cos, 5 mul)
+#     + w += pos 3 + the running derivative 5 (power - 1, pow, 2 mul, add) = 37; breaking iteration 7 + estimate tail 4 = 11 per estimate.
+# Counters I, E, S, H, P, T_in: the instrumented oracle's, committed with the full-size digests (tests/golden/full_size_digests.json).
+# NOTE what the fraction means for these scenes: a transcendental priced at ONE operation costs this implementation (and any other
+# without hardware acos / atan / sincos / pow at full precision) dozens of instructions, so scenes 1 and 3 sit far below the roof by
+# construction of the count; and the Cornell box's count is the REFERENCE's work -- all 32 triangles per estimate -- of which the pruned
+# estimate evaluates ~1.1 (bit-identical result), so its fraction exceeds 1.  `issue_frac_of_spec_peak` (instructions actually issued,
+# from the committed PMC pass) is the figure that says how busy the vector pipes are.
+def secondary_ops(scene, c):
+    if scene == 0:
+        t_in = c["tri_inside"]
+        return 76 * t_in + 161 * (32 * c["de_evals"] - t_in) + 32 * c["de_evals"] + 9 * c["march_steps"] + 170 * c["hit_pixels"] + 30 * c["pixels"]
+    if scene == 1:
+        return 126 * c["de_evals"] + 9 * c["march_steps"] + 150 * c["hit_pixels"] + 30 * c["pixels"]
+    if scene == 3:
+        return 37 * c["triplex_iters"] + 11 * c["de_evals"] + 9 * c["march_steps"] + 150 * c["hit_pixels"] + 30 * c["pixels"]
+    return flops_model(c)
+
+
+SECONDARY_FORMULA = {0: "76 T_in + 161 (32 E - T_in) + 32 E + 9 S + 170 H + 30 P", 1: "126 E + 9 S + 150 H + 30 P",
+                     3: "37 I + 11 E + 9 S + 150 H + 30 P", 2: "79 I + 11 E + 9 S + 150 H + 30 P"}
+
+
+def secondary_roofline(digest_name, scene, kernel_ms, valu_instr, cus):
+    """roofline object of a secondary scene: as-written operations of the committed view / measured kernel time against 78.6 T lane-ops/s"""
+    try:
+        c = json.load(open(os.path.join(ROOT, "tests", "golden", "full_size_digests.json")))[digest_name]["counters"]
+    except Exception as e:                                      # noqa: BLE001
+        return {"bound": "valu", "achieved": None, "frac": None, "note": "no committed counters for %s: %s" % (digest_name, e)}
+    F = secondary_ops(scene, c)
+    ach = F / (kernel_ms * 1e-3) / 1e12
+    r = {"bound": "valu", "achieved": round(ach, 3), "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s", "frac": round(ach / VALU_PEAK_TLANEOPS, 4),
+         "ops_per_launch": F, "formula": SECONDARY_FORMULA[scene], "op_counters": c,
+         "op_counters_source": "instrumented oracle, committed with the digests (tests/golden/full_size_digests.json: %s)" % digest_name,
+         "traffic": None}
+    if valu_instr:
+        rate = valu_instr / (cus * 4) / (kernel_ms * 1e-3) / 1e9
+        r["issue_g_wave_instr_s_simd"] = round(rate, 3)
+        r["issue_frac_of_spec_peak"] = round(rate / VALU_ISSUE_SPEC, 3)
+    if scene == 0:
+        r["note"] = ("as-written count = the reference's 32 full triangle distances per estimate; the pruned per-lane estimate evaluates ~1.1 of "
+                     "them (bit-identical minimum), so frac > 1 measures the algorithmic saving, not pipe utilisation: see issue_frac_of_spec_peak")
+    elif scene in (1, 3):
+        r["note"] = ("exp / log / pow / sin / cos / acos / atan priced at ONE operation each (SURVEY 8d's convention) while each costs dozens of "
+                     "instructions at the pinned precision: frac is low by construction of the count; issue_frac_of_spec_peak says how busy the pipes are")
+    return r
+
+
 def sha256_file(path):
     h = hashlib.sha256()
     with open(path, "rb") as f:
@@ -939,7 +997,8 @@ def secondary_workloads(sr, torch, dev, stream, cus, streams=()):
     t2 = (time.perf_counter() - t0) / n2 * 1e3
     out["config2_cornell_1280x720_m128"] = {"kernel_ms_avg": round(t, 4), "mpixels_s": round(0.9216 / (t * 1e-3), 1),
                                             "two_frames_in_flight_ms_per_frame": round(t2, 4),
-                                            "two_frames_in_flight_mpixels_s": round(0.9216 / (t2 * 1e-3), 1)}
+                                            "two_frames_in_flight_mpixels_s": round(0.9216 / (t2 * 1e-3), 1),
+                                            "roofline": secondary_roofline("config2_cornell_1280x720_m128", 0, t, scene_pmc("config2_cornell_1280x720_m128"), cus)}
     # config 5: the prefilter kernel, 256x128, each reference power alone, then the four concurrently through the host entry
     rng = np.random.RandomState(3)
     src = rng.uniform(0.0, 4.0, (128, 256, 3)).astype(np.float32)
@@ -1007,7 +1066,8 @@ def secondary_workloads(sr, torch, dev, stream, cus, streams=()):
         t2s = (time.perf_counter() - t0) / n2s * 1e3
         out[name] = {"kernel_ms_avg": round(tt, 4), "mpixels_s": round(0.9216 / (tt * 1e-3), 1), "in_time": tv,
                      "two_frames_in_flight_ms_per_frame": round(t2s, 4), "two_frames_in_flight_mpixels_s": round(0.9216 / (t2s * 1e-3), 1),
-                     "valu_instructions_per_launch": scene_pmc(name), "note": "one frame at a time, HIP events; instruction count from profiles/ (rocprofv3 --pmc of this scene) when present"}
+                     "valu_instructions_per_launch": scene_pmc(name), "note": "one frame at a time, HIP events; instruction count from profiles/ (rocprofv3 --pmc of this scene) when present",
+                     "roofline": secondary_roofline({1: "detest_1280x720_t2p5_m128", 3: "mbgeneral_1280x720_t3p0_m128"}[sc], sc, tt, scene_pmc(name), cus)}
     # the headline scene from the SURVEY's other camera times
     fbv = torch.empty((1080, 1920), dtype=torch.int32, device=dev)
     views = {}

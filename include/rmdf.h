@@ -80,8 +80,10 @@ typedef struct rmdf_ctx rmdf_ctx;
 
 typedef struct {
     int device;      /* HIP device ordinal                                              */
-    int reserved[7]; /* [0] = RMDF_FLAG_* bits; [1] = host threads that copy the frame to the caller in tile mode, the calling
-                        thread included (0 = chosen by core count: 16 on >= 64 cores, 8 on > 8); rest zero */
+    int reserved[7]; /* [0] = RMDF_FLAG_* bits; [1] = host threads that copy frames to the caller, the calling thread included
+                        (0 = chosen by core count: 16 on >= 64 cores, 8 on > 8); [2] = row bands a whole-frame call into host
+                        memory keeps in flight (0 = the library's choice, 1 = one launch; at most 16); [3] = 1: those bands reach
+                        the host by the render kernel's own stores instead of a copy behind it; rest zero */
 } rmdf_config;
 
 /* ---- lifetime: withShaderRenderer (ShaderRendering.hs:60-110) --------------------- */
@@ -233,15 +235,14 @@ int rmdf_render_supersampled(rmdf_ctx *ctx, int scene, int w, int h, int levels,
  *                                                                    + (rank 0) rmdf_assemble_shards_device, all on `stream`
  * rmdf_gather_shards_device: every rank's packed shard (ceil(64/nranks) tile slots of (w/8)*(h/8) uint32) lands in
  * d_gathered[rank] on rank 0 (grouped ncclRecv fan-in; the other ranks ncclSend).  ALL ranks must have set the same costs /
- * handicap, or none (rmdf_set_shard_costs).  With the static deal, or once rmdf_comm_verify_deal has found every rank holding the
- * same cost-aware deal, only the tiles a rank owns travel (the root derives every peer's count from the common deal); before that
- * every rank sends its whole fixed-size region, so that a rank with different costs mis-assembles a frame instead of hanging the
- * job on mismatched sizes.  Rank 0 may pass d_shard == d_gathered (it rendered straight into its own slot).  d_gathered is
- * ignored on the other ranks.
+ * handicap, or none (rmdf_set_shard_costs).  Every rank always sends its WHOLE fixed-size region: the size on the wire depends on
+ * (w, h, nranks) alone, so that a rank whose costs differ mis-assembles a frame (which rmdf_comm_verify_deal detects) instead of
+ * hanging the job on mismatched sizes; for the rank counts that divide 64 that is exactly the tiles a rank owns.  Rank 0 may pass
+ * d_shard == d_gathered (it rendered straight into its own slot).  d_gathered is ignored on the other ranks.
  * rmdf_comm_verify_deal: COLLECTIVE over the ctx's communicator (every rank calls it, after its last rmdf_set_shard_costs /
  * rmdf_set_shard_root_handicap): the peers send a fingerprint of the deal they hold to rank 0 (8 bytes), rank 0 compares and
  * answers; RMDF_OK on every rank iff all deals are equal, RMDF_E_COMM on every rank otherwise.  Blocks until `stream` (NULL = ctx
- * stream) has drained.  Any later change of costs or handicap on a rank drops the verification on that rank.
+ * stream) has drained.
  * rmdf_comm_selftest_loopback: the exchange's own calls against this rank itself -- a grouped ncclRecv from self + ncclSend to
  * self of `bytes` bytes on `stream` (NULL = ctx stream), compared word for word; on the ctx's communicator, or on a private
  * one-rank communicator when the ctx has none (a single-GPU box can run it).  *mismatches (may be NULL) = differing words. */

@@ -45,7 +45,7 @@ class Frame(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("de_evals", "triplex_iters", "march_steps", "hit_pixels",
-                                          "sphere_pixels", "pixels")]
+                                          "sphere_pixels", "pixels", "tri_inside")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -364,7 +364,7 @@ typedef struct {
     int      scene;
     float    time;
     const float *cornell;    /* 96*3 */
-    uint64_t de_evals, triplex_iters;
+    uint64_t de_evals, triplex_iters, tri_inside;
     float    power;          /* FSMBGeneralShader: fragment.shd:116-119 */
 } de_ctx;
 
@@ -492,10 +492,11 @@ static int compute_barycentric(v3 pos, v3 v0, v3 v1, v3 v2, float *u, float *v)
 }
 
 /* fragment.shd:348-372 */
-static float de_triangle(v3 pos, v3 v0, v3 v1, v3 v2)
+static float de_triangle(v3 pos, v3 v0, v3 v1, v3 v2, uint64_t *n_inside)
 {
     float u, v;
     if (compute_barycentric(pos, v0, v1, v2, &u, &v)) {
+        (*n_inside)++;                          /* the prism branch (roofline operation count: bench.py) */
         float k = 1.0f - (u + v);
         /* v2*u + v1*v + v0*(1-(u+v)) */
         v3 pp = V3(v2.x * u + v1.x * v + v0.x * k,
@@ -515,7 +516,7 @@ static float de_cornell_box(v3 pos, de_ctx *c)
     float dist = 999.0f;
     for (int i = 0; i < 32; i++) {
         const float *t = c->cornell + i * 9;
-        dist = rm_min(dist, de_triangle(pos, V3(t[0], t[1], t[2]), V3(t[3], t[4], t[5]), V3(t[6], t[7], t[8])));
+        dist = rm_min(dist, de_triangle(pos, V3(t[0], t[1], t[2]), V3(t[3], t[4], t[5]), V3(t[6], t[7], t[8]), &c->tri_inside));
     }
     return dist;
 }
@@ -591,7 +592,7 @@ static const float *cornell_table(void)
 
 float orc_de(int scene, float time, const float pos[3])
 {
-    de_ctx c = { scene, time, cornell_table(), 0, 0, general_power(time) };
+    de_ctx c = { scene, time, cornell_table(), 0, 0, 0, general_power(time) };
     return distance_estimator(V3(pos[0], pos[1], pos[2]), &c);
 }
 
@@ -1005,7 +1006,7 @@ static v3 generate_ray_dir(const render_job *j, int px, int py)
 static void trace_pixel(render_job *j, int px, int py, px_state *s)
 {
     const orc_frame *f = j->f;
-    de_ctx c = { f->scene, f->time, cornell_table(), 0, 0, general_power(f->time) };
+    de_ctx c = { f->scene, f->time, cornell_table(), 0, 0, 0, general_power(f->time) };
     v3 origin = V3(j->cam[9], j->cam[10], j->cam[11]);
     uint64_t march_steps = 0;
     float t = 0.0f;
@@ -1025,6 +1026,7 @@ static void trace_pixel(render_job *j, int px, int py, px_state *s)
     s->iters = (unsigned)c.triplex_iters;
     j->ctr.de_evals += c.de_evals;
     j->ctr.triplex_iters += c.triplex_iters;
+    j->ctr.tri_inside += c.tri_inside;
     j->ctr.march_steps += march_steps;
     j->ctr.hit_pixels += (uint64_t)s->hit;
     j->ctr.sphere_pixels += (uint64_t)s->entered;
@@ -1212,6 +1214,7 @@ int orc_render_ex(const orc_frame *f, int x0, int y0, int x1, int y1, float *rgb
         for (int i = 0; i < n; i++) {
             ctr->de_evals += jobs[i].ctr.de_evals;
             ctr->triplex_iters += jobs[i].ctr.triplex_iters;
+            ctr->tri_inside += jobs[i].ctr.tri_inside;
             ctr->march_steps += jobs[i].ctr.march_steps;
             ctr->hit_pixels += jobs[i].ctr.hit_pixels;
             ctr->sphere_pixels += jobs[i].ctr.sphere_pixels;

@@ -72,6 +72,7 @@ typedef struct {
     uint64_t hit_pixels;
     uint64_t sphere_pixels;  /* rays that entered the bounding sphere             */
     uint64_t pixels;
+    uint64_t tri_inside;     /* Cornell box: (estimate, triangle) pairs that took de_triangle's prism branch (the other 32 * de_evals - this took the edge branch) */
 } orc_counters;
 
 /* ---- hot path (fragment.shd) ------------------------------------------------ */

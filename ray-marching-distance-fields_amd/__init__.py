@@ -228,14 +228,16 @@ class ShaderRenderer:
     """The `ShaderRenderer` record (ShaderRendering.hs:36-44): owns the device-side env cube maps,
     the Cornell geometry table and the accumulating frame."""
 
-    def __init__(self, device=0, flags=0, xcheck=False, copy_threads=0):
+    def __init__(self, device=0, flags=0, xcheck=False, copy_threads=0, frame_bands=0, frame_mirror=0):
         """xcheck=True (implied by FLAG_FLAT_MARCH / FLAG_FORCE_WRITTEN): run on librmdf_xcheck.so, the cross-check build."""
         self.xcheck = bool(xcheck or (flags & (FLAG_FLAT_MARCH | FLAG_FORCE_WRITTEN)))
         self._lib = load_library(self.xcheck)
         self._ctx = C.c_void_p()
         cfg = _Config(device=device)
         cfg.reserved[0] = flags
-        cfg.reserved[1] = copy_threads             # tile mode: host threads of the frame copy (0 = library default)
+        cfg.reserved[1] = copy_threads             # host threads of the frame copies (0 = library default)
+        cfg.reserved[2] = frame_bands              # whole-frame host calls: row bands in flight (0 = library default, 1 = one launch)
+        cfg.reserved[3] = frame_mirror             # ... their rows reach the host by the kernel's own stores (1) instead of a copy behind it (0)
         err = C.create_string_buffer(1024)
         rc = self._lib.rmdf_create_ex(C.byref(self._ctx), C.byref(cfg), err, 1024)
         if rc != 0:
@@ -483,9 +485,9 @@ def with_shader_renderer(refl_map_fn=DEFAULT_ENV_HDR, device=0):
         sr.close()
 
 
-def comm_get_unique_id():
+def comm_get_unique_id(xcheck=False):
     """Rank 0: the RCCL unique id (128 bytes) the other ranks need for ShaderRenderer.comm_init (ship it by any channel)."""
-    L = load_library()
+    L = load_library(xcheck)
     buf = C.create_string_buffer(COMM_ID_BYTES)
     rc = L.rmdf_comm_get_unique_id(buf)
     if rc != 0:

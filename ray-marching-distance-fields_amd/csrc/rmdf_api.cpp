@@ -10,7 +10,7 @@
 #include <zlib.h>
 
 #include <atomic>
-#include <condition_variable>
+#include <functional>
 #include <exception>
 #include <mutex>
 #include <new>
@@ -25,6 +25,7 @@
 #include "../../include/rmdf_xcheck.h"
 #endif
 #include "rmdf_internal.hpp"
+#include "rmdf_host.hpp"
 
 using namespace rmdf;
 
@@ -56,85 +57,6 @@ struct UvTable  { int cw = 0; float2 *d_uv = nullptr; };
 struct LobeTable { int w = 0, h = 0; float *d_lutT = nullptr; float2 *d_tcs = nullptr; };
 
 }  // namespace
-
-// A few host threads that copy byte ranges side by side (tile mode hands the caller its whole 8.3 MB frame on every call: one
-// thread moves that at ~10 GB/s, sixteen at the rate of the PCIe link it replaces).  A job is cut into one part per worker plus
-// one for the calling thread, which takes it when it has nothing else to do (finish).  Claiming 256 KiB chunks one at a time
-// under the lock was measured slower (0.181 against 0.163 ms per tile call).  Created on first use, joined when the ctx goes.
-struct CopyPool {
-    struct Seg { char *dst; const char *src; size_t bytes; };
-    std::vector<std::thread> threads;
-    std::mutex m;
-    std::condition_variable cv_work, cv_done;
-    Seg seg[2] = { { nullptr, nullptr, 0 }, { nullptr, nullptr, 0 } };
-    size_t total = 0;
-    unsigned gen = 0;
-    int pending = 0, nparts = 1;
-    bool stop = false;
-
-    static void copy_part(const Seg sg[2], size_t total, int part, int nparts)
-    {
-        // part `part` of `nparts` of the two segments laid end to end, cut at 4 KiB boundaries
-        size_t lo = (total * (size_t)part / (size_t)nparts) & ~(size_t)4095, hi = (total * (size_t)(part + 1) / (size_t)nparts) & ~(size_t)4095;
-        if (part == nparts - 1) hi = total;
-        size_t base = 0;
-        for (int k = 0; k < 2; k++) {
-            const size_t a = lo > base ? lo - base : 0, b = hi > base ? (hi - base < sg[k].bytes ? hi - base : sg[k].bytes) : 0;
-            if (b > a) memcpy(sg[k].dst + a, sg[k].src + a, b - a);
-            base += sg[k].bytes;
-        }
-    }
-    void worker(int idx)
-    {
-        unsigned seen = 0;
-        for (;;) {
-            Seg sg[2]; size_t tot; int np;
-            {
-                std::unique_lock<std::mutex> lk(m);
-                cv_work.wait(lk, [&] { return stop || gen != seen; });
-                if (stop) return;
-                seen = gen; sg[0] = seg[0]; sg[1] = seg[1]; tot = total; np = nparts;
-            }
-            if (idx + 1 < np) copy_part(sg, tot, idx + 1, np);
-            {
-                std::lock_guard<std::mutex> lk(m);
-                if (--pending == 0) cv_done.notify_one();
-            }
-        }
-    }
-    void start(int n)
-    {
-        if (!threads.empty() || n < 1) return;
-        try { for (int i = 0; i < n; i++) threads.emplace_back([this, i] { worker(i); }); } catch (...) { /* fewer threads: still correct */ }
-    }
-    // start copying both segments (either may be empty) on the workers; finish() copies the caller's part and waits.  One job at a time.
-    void begin(Seg a, Seg b)
-    {
-        const size_t tot = a.bytes + b.bytes;
-        const int nw = tot >= ((size_t)1 << 20) ? (int)threads.size() : 0;        // small jobs: not worth a wake-up
-        {
-            std::lock_guard<std::mutex> lk(m);
-            seg[0] = a; seg[1] = b; total = tot; nparts = nw + 1; pending = nw ? (int)threads.size() : 0;
-            if (nw) gen++;
-        }
-        if (nw) cv_work.notify_all();
-    }
-    void finish()
-    {
-        if (!total) return;
-        const Seg sg[2] = { seg[0], seg[1] };
-        copy_part(sg, total, 0, nparts);
-        if (nparts > 1) { std::unique_lock<std::mutex> lk(m); cv_done.wait(lk, [&] { return pending == 0; }); }
-        total = 0;
-    }
-    void run(Seg a, Seg b) { begin(a, b); finish(); }
-    ~CopyPool()
-    {
-        { std::lock_guard<std::mutex> lk(m); stop = true; }
-        cv_work.notify_all();
-        for (auto &t : threads) if (t.joinable()) t.join();
-    }
-};
 
 struct rmdf_ctx {
     int          device = 0;
@@ -169,10 +91,20 @@ struct rmdf_ctx {
     // tile mode (rmdf_render_tile with tile_idx >= 0): a page-locked host copy of the accumulating frame.  A tile call moves only the
     // rows the tile touched over PCIe and hands the caller its whole frame from here (render_common).  shadow_valid: the copy equals
     // the device frame.
-    uint32_t    *h_shadow = nullptr;
+    uint32_t    *h_shadow = nullptr, *h_shadow_dev = nullptr;
     size_t       shadow_px = 0;
     bool         shadow_valid = false;
-    CopyPool     copy_pool;
+    WorkPool     pool;                 // host threads: frame copies, staging copies, table builders (ctx_pool() starts them)
+    Staging      staging;              // the page-locked chunks between caller memory and the device (rmdf_host.hpp)
+    // whole-frame calls into pageable memory (render_whole_frame_host): row bands on streams of their own
+#define RMDF_WF_MAX_BANDS 16
+#define RMDF_WF_DEFAULT_BANDS 6
+    hipStream_t  wf_stream[RMDF_WF_MAX_BANDS] = { nullptr };
+    hipEvent_t   wf_done[RMDF_WF_MAX_BANDS] = { nullptr };
+    hipEvent_t   wf_fork = nullptr;
+    int          wf_bands = 0, wf_mirror = 0;      // rmdf_config.reserved[2], [3]
+    unsigned     spec_dropped = 0;     // tile jobs that could not be issued ahead of their call (render_tile_fast)
+    unsigned     env_gen = 0;          // bumped whenever a cube-map slot changes: tile jobs rendered ahead belong to ONE environment
     // ... and the tile jobs of that mode: a tile is rendered into a device scratch tile AND, by the kernel's mirror store, into a
     // page-locked host tile (both at the frame's row pitch), on a stream of its own.  RMDF_TILE_JOBS sets of those: the call for tile
     // i issues the jobs of tiles i + 1 .. i + RMDF_TILE_JOBS - 1 of the same frame ahead of their calls, so they run side by side (a
@@ -187,6 +119,7 @@ struct rmdf_ctx {
         bool      issued = false;
         int       scene = 0, idx = 0, w = 0, h = 0, max_steps = 0;
         float     time = 0.0f;
+        unsigned  env_gen = 0;
     };
     TileJob      tile_job[RMDF_TILE_JOBS];
     // host buffers registered for direct GPU writes (rmdf_register_host_buffer)
@@ -200,10 +133,6 @@ struct rmdf_ctx {
     // the deal of the last (nranks, cost generation) asked for: per-frame calls must not redo the sort
     int          deal_nranks = 0;
     unsigned     deal_gen = ~0u;
-    // the (cost set, handicap) generation and rank count for which rmdf_comm_verify_deal found every rank holding the same deal; the
-    // exchange sends exact tile counts only then (otherwise whole fixed-size slots: sizes on the wire cannot disagree)
-    unsigned     deal_verified_gen = 0;
-    int          deal_verified_nranks = 0;
     unsigned char deal_tiles[64][64];
     int          deal_count[64];
     ShardWhere   deal_where;
@@ -222,6 +151,7 @@ struct rmdf_ctx {
     // the job's RCCL communicator (rmdf_comm_init): one rank per GPU, this ctx is rank comm_rank of comm_nranks
     ncclComm_t   comm = nullptr;
     int          comm_rank = 0, comm_nranks = 1;
+    uint64_t    *d_verify = nullptr;   // rmdf_comm_verify_deal: one fingerprint per rank + the verdict (allocated with the communicator)
     int          flags = 0;            // rmdf_config.reserved[0]
     int          copy_threads = 0;     // rmdf_config.reserved[1]: host threads of the tile-mode frame copy (0 = by core count)
     std::string  err;
@@ -245,6 +175,33 @@ int fail(rmdf_ctx *ctx, int code, const std::string &msg)
         if (e_ != hipSuccess)                                                                     \
             return fail(ctx, RMDF_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
     } while (0)
+
+// the ctx's host threads, started on first use: rmdf_config.reserved[1] threads with the caller's, or by core count
+WorkPool &ctx_pool(rmdf_ctx *ctx)
+{
+    if (ctx->pool.workers() == 0) {
+        const unsigned hc = std::thread::hardware_concurrency();
+        ctx->pool.start(ctx->copy_threads ? ctx->copy_threads - 1 : (hc >= 64 ? 15 : (hc > 8 ? 7 : (hc > 1 ? (int)hc - 1 : 0))));
+    }
+    return ctx->pool;
+}
+
+// Host memory <-> device memory, always through the ctx's page-locked staging (rmdf_host.hpp): the HIP runtime never sees a pointer
+// into memory the library did not page-lock itself.  upload() may return before the DMA ends (h_src is not read after it returns);
+// download() returns with the bytes in h_dst.
+int upload(rmdf_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return RMDF_OK;
+    const hipError_t e = ctx->staging.upload(ctx_pool(ctx), d_dst, h_src, bytes, st);
+    return e == hipSuccess ? RMDF_OK : fail(ctx, RMDF_E_HIP, std::string("upload through staging: ") + hipGetErrorString(e));
+}
+int download(rmdf_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return RMDF_OK;
+    const hipError_t e = ctx->staging.download(ctx_pool(ctx), h_dst, d_src, bytes, st);
+    return e == hipSuccess ? RMDF_OK : fail(ctx, RMDF_E_HIP, std::string("download through staging: ") + hipGetErrorString(e));
+}
+#define RMDF_TRY(expr) do { const int rc_ = (expr); if (rc_ != RMDF_OK) return rc_; } while (0)
 
 // Nothing may unwind through the C ABI into a foreign host (the Haskell viewer): every entry point that can allocate wraps
 // its body in these.
@@ -522,13 +479,16 @@ int ensure_gbuf(rmdf_ctx *ctx, int w, int h)
 }
 #endif
 
-int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t stream)
+// after_render (optional): queued on `stream` right behind the render kernel, before the sort of next frame's strip order -- what a caller
+// waits for (an event, a copy of the rows) must not wait for that sort too
+int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t stream, const std::function<int()> *after_render = nullptr)
 {
 #ifdef RMDF_XCHECK
     // librmdf_xcheck.so: the alternative schedule of the same per-ray arithmetic (cross-check tests, A/B measurements).
     // It keeps ONE G-buffer / work counter per ctx, so it runs on the ctx stream only.
     if (scene == RMDF_FS_MB_POWER8 && ctx->d_dbg && getenv("RMDF_NESTED_STATS")) {
         HIP_TRY(ctx, launch_march_stats(p, stream));
+        if (after_render) RMDF_TRY((*after_render)());
         return RMDF_OK;
     }
     if (scene == RMDF_FS_MB_POWER8 && (ctx->flags & RMDF_FLAG_FLAT_MARCH)) {
@@ -540,6 +500,7 @@ int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t str
         q.gbuf_nao = ctx->d_gbuf_nao; q.gbuf_meta = ctx->d_gbuf_meta; q.gw = (p.w + 1) & ~1;
         q.work_counter = ctx->d_work_counter;
         HIP_TRY(ctx, launch_render_mb8(q, stream, ctx->cus));
+        if (after_render) RMDF_TRY((*after_render)());
         return RMDF_OK;
     }
 #endif
@@ -580,11 +541,13 @@ int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t str
         q.block_cost = os->d_cost;
         q.block_order = same ? os->d_order : nullptr;
         HIP_TRY(ctx, launch_render(scene, q, stream));
+        if (after_render) RMDF_TRY((*after_render)());
         HIP_TRY(ctx, launch_order_blocks(os->d_cost, nblk, os->d_order, stream));
         memcpy(os->key, key, sizeof key);
         os->n = nblk; os->valid = true;
     } else {
         HIP_TRY(ctx, launch_render(scene, q, stream));
+        if (after_render) RMDF_TRY((*after_render)());
     }
     return RMDF_OK;
 }
@@ -600,14 +563,6 @@ void ensure_deal(rmdf_ctx *ctx, int nranks)
         for (int s = 0; s < ctx->deal_count[r]; s++) ctx->deal_where.v[ctx->deal_tiles[r][s]] = (unsigned short)((r << 8) | s);
     }
     ctx->deal_nranks = nranks; ctx->deal_gen = ctx->shard_cost_gen;
-}
-
-// is the deal in effect known to be the same on every rank of the communicator?  The static deal depends on the rank count alone;
-// a deal steered by costs or a root handicap only after rmdf_comm_verify_deal compared it (and nothing changed since).
-bool deal_is_common(const rmdf_ctx *ctx, int nranks)
-{
-    if (!ctx->shard_cost_set && ctx->shard_root_handicap == 0.0f) return true;
-    return ctx->deal_verified_nranks == nranks && ctx->deal_verified_gen == ctx->shard_cost_gen;
 }
 
 
@@ -788,24 +743,6 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
 };
 
-// Run fn(lo, hi) over [0, n) in row segments on the host cores, as forSegmentsConcurrently does for the reference's
-// cube-map resampler (HDREnvMap.hs:139).
-template <typename F>
-void host_segments(int n, F fn)
-{
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt < 1) nt = 1;
-    if (nt > 64) nt = 64;
-    if ((int)nt > n) nt = (unsigned)(n > 0 ? n : 1);
-    if (nt == 1 || n < 64) { fn(0, n); return; }
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; t++) {
-        const int lo = (int)((long long)n * t / nt), hi = (int)((long long)n * (t + 1) / nt);
-        th.emplace_back([=] { fn(lo, hi); });
-    }
-    for (auto &t : th) t.join();
-}
-
 const float kPi = 3.14159265358979323846f;       // `pi :: Float`
 
 // GHC's class-default RealFloat atan2 (Float has no specialised one), atan = libm atanf
@@ -824,11 +761,12 @@ float hs_atan2f(float y, float x)
 // Environment (u, v) of every texel of the six cw x cw faces: cubeMapPixelToDir (HDREnvMap.hs:76-87, Linear.normalize's
 // near-unit short cut), worldToLocal (CoordTransf.hs:46-50), cartesianToSpherical (35-44), sphericalToEnvironmentUV
 // (60-70).  A function of the face size alone, so it is evaluated once per size on the host -- with glibc's acosf / atanf,
-// the very functions GHC's Float acos / atan call in the reference -- and k_latlong_to_cube only gathers.
-void cube_uv_table_host(int cw, std::vector<float> &uv)
+// the very functions GHC's Float acos / atan call in the reference -- and k_latlong_to_cube only gathers.  Row segments on the ctx's
+// host threads, as forSegmentsConcurrently does for the reference's resampler (HDREnvMap.hs:139).
+void cube_uv_table_host(WorkPool &pool, int cw, std::vector<float> &uv)
 {
     uv.resize((size_t)6 * cw * cw * 2);
-    host_segments(6 * cw, [&](int lo, int hi) {
+    pool.segments(6 * cw, [&](int lo, int hi) {
         for (int r = lo; r < hi; r++) {
             const int face = r / cw, y = r % cw;
             for (int x = 0; x < cw; x++) {
@@ -874,12 +812,12 @@ int get_uv_table(rmdf_ctx *ctx, int cw, const float2 **d_uv)
 {
     for (auto &t : ctx->uv_tables) if (t.cw == cw) { *d_uv = t.d_uv; return RMDF_OK; }
     std::vector<float> uv;
-    cube_uv_table_host(cw, uv);
+    cube_uv_table_host(ctx_pool(ctx), cw, uv);
     UvTable t;
     t.cw = cw;
     HIP_TRY(ctx, hipMalloc((void **)&t.d_uv, uv.size() * sizeof(float)));
-    hipError_t e = hipMemcpy(t.d_uv, uv.data(), uv.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(t.d_uv); return fail(ctx, RMDF_E_HIP, std::string("uv table upload: ") + hipGetErrorString(e)); }
+    const int urc = upload(ctx, t.d_uv, uv.data(), uv.size() * sizeof(float), ctx->stream);     // every user of the table runs on the ctx stream or after an event of it
+    if (urc != RMDF_OK) { (void)hipFree(t.d_uv); return urc; }
     if (ctx->uv_tables.size() >= 8) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->uv_tables[0].d_uv); ctx->uv_tables.erase(ctx->uv_tables.begin()); }
     ctx->uv_tables.push_back(t);
     *d_uv = t.d_uv;
@@ -889,11 +827,11 @@ int get_uv_table(rmdf_ctx *ctx, int cw, const float2 **d_uv)
 // Cosine tables of cosineConvolveHDREnvMap (HDREnvMap.hs:222-239) for a w x h map, host glibc cosf / sinf:
 //   lutT[(blk*w + x)*64 + lane] = cos |pxToPhi(blk*64+lane) - pxToPhi(x)|   (absPhiDiffCosLookup, per destination column)
 //   tcs[2y], tcs[2y+1]          = cos, sin of pxToTheta(y)
-void lobe_tables_host(int w, int h, std::vector<float> &lutT, std::vector<float> &tcs)
+void lobe_tables_host(WorkPool &pool, int w, int h, std::vector<float> &lutT, std::vector<float> &tcs)
 {
     const int nblk = (w + 63) / 64;
     lutT.resize((size_t)nblk * w * 64);
-    host_segments(nblk * w, [&](int lo, int hi) {
+    pool.segments(nblk * w, [&](int lo, int hi) {
         for (int r = lo; r < hi; r++) {
             const int blk = r / w, x = r % w;
             const float phi_x = (float)x / (float)(w - 1) * 2.0f * kPi;
@@ -916,16 +854,19 @@ int get_lobe_tables(rmdf_ctx *ctx, int w, int h, const float **d_lutT, const flo
 {
     for (auto &t : ctx->lobe_tables) if (t.w == w && t.h == h) { *d_lutT = t.d_lutT; *d_tcs = t.d_tcs; return RMDF_OK; }
     std::vector<float> lutT, tcs;
-    lobe_tables_host(w, h, lutT, tcs);
+    lobe_tables_host(ctx_pool(ctx), w, h, lutT, tcs);
     LobeTable t;
     t.w = w; t.h = h;
     HIP_TRY(ctx, hipMalloc((void **)&t.d_lutT, lutT.size() * sizeof(float)));
     hipError_t e = hipMalloc((void **)&t.d_tcs, tcs.size() * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpy(t.d_lutT, lutT.data(), lutT.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(t.d_tcs, tcs.data(), tcs.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
+    int urc = e == hipSuccess ? RMDF_OK : fail(ctx, RMDF_E_HIP, std::string("lobe table: ") + hipGetErrorString(e));
+    // (a caller's stream may launch the prefilter, rmdf_prefilter_env_device: the tables are complete before this returns)
+    if (urc == RMDF_OK) urc = upload(ctx, t.d_lutT, lutT.data(), lutT.size() * sizeof(float), ctx->stream);
+    if (urc == RMDF_OK) urc = upload(ctx, t.d_tcs, tcs.data(), tcs.size() * sizeof(float), ctx->stream);
+    if (urc == RMDF_OK && (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) urc = fail(ctx, RMDF_E_HIP, std::string("lobe table upload: ") + hipGetErrorString(e));
+    if (urc != RMDF_OK) {
         (void)hipFree(t.d_lutT); if (t.d_tcs) (void)hipFree(t.d_tcs);
-        return fail(ctx, RMDF_E_HIP, std::string("lobe table upload: ") + hipGetErrorString(e));
+        return urc;
     }
     if (ctx->lobe_tables.size() >= 4) {
         (void)hipDeviceSynchronize();
@@ -948,6 +889,7 @@ int set_env_from_device_faces(rmdf_ctx *ctx, int slot, const float *d_faces, int
     if (ctx->env[slot].d_texels) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->env[slot].d_texels); }
     ctx->env[slot].d_texels = d_padded;
     ctx->env[slot].W = W;
+    ctx->env_gen++;                 // tile jobs rendered ahead of their calls saw the old map: they are not for this environment
     return RMDF_OK;
 }
 
@@ -1008,7 +950,16 @@ int load_rccl(rmdf_ctx *ctx)
 {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.handle) return RMDF_OK;
-    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    void *h = nullptr;
+#ifdef RMDF_XCHECK
+    // the cross-check build only: a test double of the eight entry points below (tests/fake_rccl.c), so that the N > 1 branches of the
+    // exchange run with N processes on ONE GPU.  librmdf.so never looks at the variable.
+    if (const char *over = getenv("RMDF_RCCL_LIB")) {
+        h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        if (!h) return fail(ctx, RMDF_E_UNSUPPORTED, std::string("RMDF_RCCL_LIB: cannot load ") + over + ": " + dlerror());
+    }
+#endif
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return fail(ctx, RMDF_E_UNSUPPORTED, std::string("cannot load librccl.so.1: ") + dlerror());
@@ -1079,6 +1030,21 @@ int issue_tile_job(rmdf_ctx *ctx, int b, int scene, int idx)
     if (rc != RMDF_OK) return rc;
     HIP_TRY(ctx, hipEventRecord(j.done, j.stream));
     j.issued = true; j.scene = scene; j.idx = idx % 64; j.w = ctx->w; j.h = ctx->h; j.max_steps = ctx->max_steps; j.time = ctx->time;
+    j.env_gen = ctx->env_gen;
+    return RMDF_OK;
+}
+
+// the page-locked host copy of the accumulating frame (tile mode, whole-frame calls into pageable memory)
+int ensure_shadow(rmdf_ctx *ctx, size_t npx)
+{
+    if (ctx->shadow_px == npx && ctx->h_shadow) return RMDF_OK;
+    if (ctx->h_shadow) {
+        HIP_TRY(ctx, hipDeviceSynchronize());            // a band's copy or mirror store of an earlier, failed call may still target it
+        (void)hipHostFree(ctx->h_shadow); ctx->h_shadow = nullptr; ctx->h_shadow_dev = nullptr; ctx->shadow_px = 0;
+    }
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_shadow, npx * 4, hipHostMallocMapped));
+    HIP_TRY(ctx, hipHostGetDevicePointer((void **)&ctx->h_shadow_dev, ctx->h_shadow, 0));
+    ctx->shadow_px = npx; ctx->shadow_valid = false;
     return RMDF_OK;
 }
 
@@ -1086,18 +1052,13 @@ int render_tile_fast(rmdf_ctx *ctx, int scene, int tile_idx, const FrameParams &
 {
     const size_t npx = (size_t)ctx->w * ctx->h;
     const int midx = tile_idx % 64, b = midx % RMDF_TILE_JOBS;
-    if (ctx->shadow_px != npx || !ctx->h_shadow) {
-        if (ctx->h_shadow) { (void)hipHostFree(ctx->h_shadow); ctx->h_shadow = nullptr; ctx->shadow_px = 0; }
-        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_shadow, npx * 4, hipHostMallocDefault));
-        ctx->shadow_px = npx; ctx->shadow_valid = false;
-        unsigned hc = std::thread::hardware_concurrency();
-        ctx->copy_pool.start(ctx->copy_threads ? ctx->copy_threads - 1 : (hc >= 64 ? 15 : (hc > 8 ? 7 : (hc > 1 ? (int)hc - 1 : 0))));
-    }
+    RMDF_TRY(ensure_shadow(ctx, npx));
+    WorkPool &pool = ctx_pool(ctx);
     // this call's job: the one issued speculatively by the previous call if it is for exactly this tile of this frame, else now
     rmdf_ctx::TileJob &j = ctx->tile_job[b];
     auto is_for = [&](const rmdf_ctx::TileJob &t, int idx) {
         return t.issued && t.scene == scene && t.idx == idx && t.w == ctx->w && t.h == ctx->h && t.max_steps == ctx->max_steps &&
-               memcmp(&t.time, &ctx->time, sizeof(float)) == 0;
+               t.env_gen == ctx->env_gen && memcmp(&t.time, &ctx->time, sizeof(float)) == 0;
     };
     if (!is_for(j, midx)) { int rc = issue_tile_job(ctx, b, scene, midx); if (rc != RMDF_OK) return rc; }
     char *sh = (char *)ctx->h_shadow, *dst = (char *)out_rgba8;
@@ -1108,12 +1069,26 @@ int render_tile_fast(rmdf_ctx *ctx, int scene, int tile_idx, const FrameParams &
         ctx->shadow_valid = true;
     }
     // the frame as it was goes to the caller on the worker threads ...
-    ctx->copy_pool.begin(CopyPool::Seg{ dst, sh, npx * 4 }, CopyPool::Seg{ nullptr, nullptr, 0 });
+    {
+        const int parts = npx * 4 >= ((size_t)1 << 20) ? pool.workers() + 1 : 1;           // small frames: not worth a wake-up
+        const size_t bytes = npx * 4;
+        pool.begin(parts, [=](int part) {
+            size_t lo, hi;
+            WorkPool::slice(bytes, part, parts, 4096, lo, hi);
+            if (hi > lo) memcpy(dst + lo, sh + lo, hi - lo);
+        });
+    }
     // ... while this thread issues the next tiles of the same frame ahead of their calls (tile 63 is followed by a frame with another
     // time: nothing to guess), joins the copy, and waits for its own tile
+    // (a job that cannot be issued ahead is issued -- and fails, with its message -- by its own call: speculation leaves ctx->err alone)
     for (int t = midx + 1; t < midx + RMDF_TILE_JOBS && t < 64; t++)
-        if (!is_for(ctx->tile_job[t % RMDF_TILE_JOBS], t)) (void)issue_tile_job(ctx, t % RMDF_TILE_JOBS, scene, t);
-    ctx->copy_pool.finish();
+        if (!is_for(ctx->tile_job[t % RMDF_TILE_JOBS], t)) {
+            std::string keep;
+            keep.swap(ctx->err);
+            if (issue_tile_job(ctx, t % RMDF_TILE_JOBS, scene, t) != RMDF_OK) ctx->spec_dropped++;
+            ctx->err.swap(keep);
+        }
+    pool.finish();
     HIP_TRY(ctx, hipEventSynchronize(j.done));
     j.issued = false;
     // ... then the tile: host tile -> shadow and caller (rows of the tile's width), scratch tile -> device frame behind everything
@@ -1129,6 +1104,75 @@ int render_tile_fast(rmdf_ctx *ctx, int scene, int tile_idx, const FrameParams &
     // the scratch tile may be overwritten by its next job only once this copy has read it
     HIP_TRY(ctx, hipEventRecord(j.copied, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(j.stream, j.copied, 0));
+    return RMDF_OK;
+}
+
+// Whole frame into PAGEABLE caller memory: `rmdf_render_tile(tile_idx = -1, ptr)`, the call the reference's viewer makes every frame
+// (Main.hs:67 starts it with tiling off; App.hs:154-166 -> fillFrameBuffer, FrameBuffer.hs:117-158).  Launch, copy 8.3 MB, return
+// costs 0.59 ms at 1080p against 0.38 ms for the kernel: the copy (and the runtime's page-locking of the caller's pages for it) stands
+// behind the kernel.  Here the frame is rendered as ROW BANDS on streams of their own, all in flight together; each band's rows go into
+// the page-locked shadow frame as soon as ITS kernel is over (an SDMA copy queued behind it -- or the kernel's own mirror store,
+// wf_mirror), and from there into the caller's frame by the ctx's host threads while the other bands are still rendering.  What stays
+// exposed is the last band's copy.  The bands are cut at multiples of eight rows (whole strips, whole GL quads: same pixels as one
+// launch -- tests/test_gpu_parity.py), launched middle first: the scenes sit in the middle of the frame, where the long rays are.
+int render_whole_frame_host(rmdf_ctx *ctx, int scene, const FrameParams &p, uint32_t *out_rgba8)
+{
+    const int w = ctx->w, h = ctx->h;
+    const size_t npx = (size_t)w * h;
+    RMDF_TRY(ensure_shadow(ctx, npx));
+    WorkPool &pool = ctx_pool(ctx);
+    int nb = ctx->wf_bands > 0 ? ctx->wf_bands : RMDF_WF_DEFAULT_BANDS;
+    if (npx * 4 < ((size_t)2 << 20)) nb = 1;                         // small frames: one launch, one copy
+    if (nb > h / 64) nb = h / 64 > 0 ? h / 64 : 1;                   // a band is at least 64 rows
+    const bool mirror = ctx->wf_mirror != 0;
+    int ys[RMDF_WF_MAX_BANDS + 1];
+    for (int k = 0; k <= nb; k++) ys[k] = k == nb ? h : (int)(((long long)h * k / nb) & ~7ll);
+    for (int k = 0; k < nb; k++) {
+        if (!ctx->wf_stream[k]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->wf_stream[k], hipStreamNonBlocking));
+        if (!ctx->wf_done[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wf_done[k], hipEventDisableTiming));
+    }
+    if (!ctx->wf_fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wf_fork, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(ctx->wf_fork, ctx->stream));          // behind whatever the ctx stream still holds (a clear, an env upload)
+    char *sh = (char *)ctx->h_shadow, *dst = (char *)out_rgba8;
+    int order[RMDF_WF_MAX_BANDS];
+    for (int lo = (nb - 1) / 2, hi = lo + 1, n = 0; n < nb;) {        // middle first, then outwards
+        if (lo >= 0) order[n++] = lo--;
+        if (hi < nb && n < nb) order[n++] = hi++;
+    }
+    int rc = RMDF_OK;
+    for (int i = 0; i < nb && rc == RMDF_OK; i++) {
+        const int k = order[i];
+        hipStream_t st = ctx->wf_stream[k];
+        FrameParams q = p;
+        q.x0 = 0; q.x1 = w; q.y0 = ys[k]; q.y1 = ys[k + 1];
+        q.rgba8 = ctx->d_rgba8;
+        if (mirror) q.rgba8_mirror = ctx->h_shadow_dev;
+        const size_t off = (size_t)ys[k] * w * 4, bytes = (size_t)(ys[k + 1] - ys[k]) * w * 4;
+        const std::function<int()> after = [&]() -> int {
+            if (!mirror) HIP_TRY(ctx, hipMemcpyAsync(sh + off, (const char *)ctx->d_rgba8 + off, bytes, hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipEventRecord(ctx->wf_done[k], st));
+            return RMDF_OK;
+        };
+        hipError_t e = hipStreamWaitEvent(st, ctx->wf_fork, 0);
+        if (e != hipSuccess) { rc = fail(ctx, RMDF_E_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e)); break; }
+        rc = launch_scene(ctx, scene, q, st, &after);
+    }
+    if (rc != RMDF_OK) { (void)hipDeviceSynchronize(); ctx->shadow_valid = false; return rc; }   // bands already issued still write frame and shadow
+    // the bands to the caller as they land
+    unsigned pending = nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u);
+    while (pending) {
+        for (int k = 0; k < nb; k++) {
+            if (!((pending >> k) & 1u)) continue;
+            const hipError_t e = hipEventQuery(ctx->wf_done[k]);
+            if (e == hipErrorNotReady) continue;
+            if (e != hipSuccess) { (void)hipDeviceSynchronize(); ctx->shadow_valid = false; return fail(ctx, RMDF_E_HIP, std::string("whole-frame band: ") + hipGetErrorString(e)); }
+            const size_t off = (size_t)ys[k] * w * 4, bytes = (size_t)(ys[k + 1] - ys[k]) * w * 4;
+            pool.copy(dst + off, sh + off, bytes);
+            pending &= ~(1u << k);
+        }
+        if (pending) __builtin_ia32_pause();
+    }
+    ctx->shadow_valid = true;                                          // (every band is over: the device frame is complete as well)
     return RMDF_OK;
 }
 
@@ -1178,10 +1222,6 @@ int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double t
                 break;
             }
     }
-    // (Round 3, measured and not adopted: the whole frame as three row bands on three streams of descending priority, each followed
-    // by the copy of its rows, so that a band's copy overlaps the later bands' rendering.  A copy into PAGEABLE memory holds the
-    // calling thread and pays its page pinning per call: 0.69 ms per 1080p frame against 0.62 ms for one launch + one copy,
-    // 1.19 ms with launches and copies interleaved.  Overlap needs a pinned destination: rmdf_register_host_buffer above.)
     // Tile mode hands back the WHOLE accumulating frame on every call (the reference maps a freshly orphaned PBO each time:
     // FrameBuffer.hs:129,207-213), 64 times per frame, and every call has to wait for its tile's kernel -- whose run time is its
     // longest ray's, not 1/64 of the frame's.  What the call does instead of `launch, copy 8.3 MB over PCIe, wait`:
@@ -1198,15 +1238,22 @@ int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double t
 #endif
     )
         return render_tile_fast(ctx, scene, tile_idx, p, out_rgba8);
+    // whole frame into caller memory that is not registered: row bands through the page-locked shadow (render_whole_frame_host)
+    if (whole && out_rgba8 && !planes && !direct && npx * 4 <= ((size_t)1 << 30)
+#ifdef RMDF_XCHECK
+        && !(ctx->flags & RMDF_FLAG_FLAT_MARCH)
+#endif
+    )
+        return render_whole_frame_host(ctx, scene, p, out_rgba8);
     rc = launch_scene(ctx, scene, p, ctx->stream);
     if (rc != RMDF_OK) return rc;
-    // (every other case -- whole frames, the test planes, frames too large for a page-locked shadow, the cross-check schedule --
-    // copies what was asked for behind the launch)
+    // (every other case -- the test planes, frames too large for a page-locked shadow, the cross-check schedule, no output at all --
+    // copies what was asked for behind the launch, through the staging chunks)
     ctx->shadow_valid = false;                               // the device frame moves on without the shadow
-    if (out_rgba8 && !direct) HIP_TRY(ctx, hipMemcpyAsync(out_rgba8, ctx->d_rgba8, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (out_rgba_f32) HIP_TRY(ctx, hipMemcpyAsync(out_rgba_f32, ctx->d_rgba_f32, npx * 16, hipMemcpyDeviceToHost, ctx->stream));
-    if (out_steps) HIP_TRY(ctx, hipMemcpyAsync(out_steps, ctx->d_steps, npx * 2, hipMemcpyDeviceToHost, ctx->stream));
-    if (out_iters) HIP_TRY(ctx, hipMemcpyAsync(out_iters, ctx->d_iters, npx * 2, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_rgba8 && !direct) RMDF_TRY(download(ctx, out_rgba8, ctx->d_rgba8, npx * 4, ctx->stream));
+    if (out_rgba_f32) RMDF_TRY(download(ctx, out_rgba_f32, ctx->d_rgba_f32, npx * 16, ctx->stream));
+    if (out_steps) RMDF_TRY(download(ctx, out_steps, ctx->d_steps, npx * 2, ctx->stream));
+    if (out_iters) RMDF_TRY(download(ctx, out_iters, ctx->d_iters, npx * 2, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RMDF_OK;
 }
@@ -1279,15 +1326,26 @@ int rmdf_create(rmdf_ctx **out, const rmdf_config *cfg)
     if ((e = hipSetDevice(dev)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc((void **)&ctx->d_cornell, sizeof tri)) != hipSuccess ||
-        (e = hipMemcpy(ctx->d_cornell, tri, sizeof tri, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMalloc((void **)&ctx->d_cornell_tab, sizeof tab)) != hipSuccess ||
-        (e = hipMemcpy(ctx->d_cornell_tab, tab, sizeof tab, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMalloc((void **)&ctx->d_cornell_grid, cgrid.size() * 4)) != hipSuccess ||
-        (e = hipMemcpy(ctx->d_cornell_grid, cgrid.data(), cgrid.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) {
         std::string msg = std::string("device init: ") + hipGetErrorString(e);
         rmdf_destroy(ctx);
         return fail(nullptr, RMDF_E_HIP, msg);
+    }
+    // the tables go up through the staging chunks like everything else (caller streams may render from them: complete before return)
+    if (upload(ctx, ctx->d_cornell, tri, sizeof tri, ctx->stream) != RMDF_OK || upload(ctx, ctx->d_cornell_tab, tab, sizeof tab, ctx->stream) != RMDF_OK ||
+        upload(ctx, ctx->d_cornell_grid, cgrid.data(), cgrid.size() * 4, ctx->stream) != RMDF_OK ||
+        (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) {
+        std::string msg = "device init: " + (e != hipSuccess ? std::string(hipGetErrorString(e)) : ctx->err);
+        rmdf_destroy(ctx);
+        return fail(nullptr, RMDF_E_HIP, msg);
+    }
+    ctx->wf_bands = cfg ? cfg->reserved[2] : 0;
+    ctx->wf_mirror = cfg ? cfg->reserved[3] : 0;
+    if (ctx->wf_bands < 0 || ctx->wf_bands > RMDF_WF_MAX_BANDS || ctx->wf_mirror < 0 || ctx->wf_mirror > 1) {
+        rmdf_destroy(ctx);
+        return fail(nullptr, RMDF_E_INVALID, "rmdf_config.reserved[2] (whole-frame row bands): 0 .. 16; reserved[3] (mirror stores): 0 / 1");
     }
     for (int k = 0; k < 4; k++)
         if ((e = hipStreamCreateWithFlags(&ctx->pstream[k], hipStreamNonBlocking)) != hipSuccess ||
@@ -1318,6 +1376,12 @@ void rmdf_destroy(rmdf_ctx *ctx)
     if (ctx->probe_host) (void)hipHostFree(ctx->probe_host);
     if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
     if (ctx->h_shadow) (void)hipHostFree(ctx->h_shadow);
+    ctx->staging.destroy();
+    for (int k = 0; k < RMDF_WF_MAX_BANDS; k++) {
+        if (ctx->wf_done[k]) (void)hipEventDestroy(ctx->wf_done[k]);
+        if (ctx->wf_stream[k]) (void)hipStreamDestroy(ctx->wf_stream[k]);
+    }
+    if (ctx->wf_fork) (void)hipEventDestroy(ctx->wf_fork);
     for (auto &j : ctx->tile_job) {
         if (j.d_tile) (void)hipFree(j.d_tile);
         if (j.h_tile) (void)hipHostFree(j.h_tile);
@@ -1371,7 +1435,7 @@ int rmdf_set_env_cube(rmdf_ctx *ctx, int slot, const float *faces_rgb, int face_
     DevBuf faces;
     size_t bytes = (size_t)6 * face_w * face_w * 3 * sizeof(float);
     HIP_TRY(ctx, hipMalloc(&faces.p, bytes));
-    HIP_TRY(ctx, hipMemcpyAsync(faces.p, faces_rgb, bytes, hipMemcpyHostToDevice, ctx->stream));
+    RMDF_TRY(upload(ctx, faces.p, faces_rgb, bytes, ctx->stream));
     return set_env_from_device_faces(ctx, slot, (const float *)faces.p, face_w);
     RMDF_GUARD_END(ctx)
 }
@@ -1391,7 +1455,7 @@ int rmdf_set_env_latlong(rmdf_ctx *ctx, int slot, const float *rgb, int w, int h
     size_t ll_bytes = (size_t)w * h * 3 * sizeof(float), f_bytes = (size_t)6 * cw * cw * 3 * sizeof(float);
     HIP_TRY(ctx, hipMalloc(&ll.p, ll_bytes));
     HIP_TRY(ctx, hipMalloc(&faces.p, f_bytes));
-    HIP_TRY(ctx, hipMemcpyAsync(ll.p, rgb, ll_bytes, hipMemcpyHostToDevice, ctx->stream));
+    RMDF_TRY(upload(ctx, ll.p, rgb, ll_bytes, ctx->stream));
     HIP_TRY(ctx, launch_latlong_to_cube((const float *)ll.p, w, h, d_uv, (float *)faces.p, ctx->stream));
     return set_env_from_device_faces(ctx, slot, (const float *)faces.p, cw);
     RMDF_GUARD_END(ctx)
@@ -1406,8 +1470,7 @@ int rmdf_get_env_cube_padded(rmdf_ctx *ctx, int slot, uint16_t *out, int *face_w
     if (face_w) *face_w = W;
     if (!out) return RMDF_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpy(out, ctx->env[slot].d_texels, (size_t)6 * (W + 2) * (W + 2) * 8, hipMemcpyDeviceToHost));
-    return RMDF_OK;
+    return download(ctx, out, ctx->env[slot].d_texels, (size_t)6 * (W + 2) * (W + 2) * 8, ctx->stream);
 }
 
 int rmdf_resize_latlong(rmdf_ctx *ctx, const float *rgb, int w, int h, int dstw, float *out, int *dsth)
@@ -1427,11 +1490,9 @@ int rmdf_resize_latlong(rmdf_ctx *ctx, const float *rgb, int w, int h, int dstw,
     size_t sb = (size_t)w * h * 12, db = (size_t)dstw * dh * 12;
     HIP_TRY(ctx, hipMalloc(&src.p, sb));
     HIP_TRY(ctx, hipMalloc(&dst.p, db));
-    HIP_TRY(ctx, hipMemcpyAsync(src.p, rgb, sb, hipMemcpyHostToDevice, ctx->stream));
+    RMDF_TRY(upload(ctx, src.p, rgb, sb, ctx->stream));
     HIP_TRY(ctx, launch_resize_latlong((const float *)src.p, w, h, dstw, dh, (float *)dst.p, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(out, dst.p, db, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return RMDF_OK;
+    return download(ctx, out, dst.p, db, ctx->stream);
     RMDF_GUARD_END(ctx)
 }
 
@@ -1463,16 +1524,13 @@ int rmdf_prefilter_env_powers(rmdf_ctx *ctx, const float *rgb, int w, int h, con
         }
         if (i > 0) d_out[i - 1] = (float *)p; else d_src = p;
     }
-    // From here on copies into the caller's `out` may be in flight: every ERROR exit waits for the device first (the per-call
-    // buffers' hipFree would, the kept scratch does not)
-    struct Drain { bool armed = true; ~Drain() { if (armed) (void)hipDeviceSynchronize(); } } drain;
-    HIP_TRY(ctx, hipMemcpyAsync(d_src, rgb, b, hipMemcpyHostToDevice, ctx->stream));
+    // (the kept scratch is reused by the next call and the per-call buffers are freed on the way out -- hipFree waits for the device --
+    // so an error exit needs no wait of its own: nothing the device still touches belongs to the caller, only to the staging chunks)
+    RMDF_TRY(upload(ctx, d_src, rgb, b, ctx->stream));
     int rc = prefilter_powers_device(ctx, (const float *)d_src, w, h, powers, npowers, d_out.data());
     if (rc != RMDF_OK) return rc;
     for (int i = 0; i < npowers; i++)
-        HIP_TRY(ctx, hipMemcpyAsync(out + (size_t)i * w * h * 3, d_out[i], b, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    drain.armed = false;                                   // everything has landed: no device-wide wait on the way out
+        RMDF_TRY(download(ctx, out + (size_t)i * w * h * 3, d_out[i], b, ctx->stream));
     return RMDF_OK;
     RMDF_GUARD_END(ctx)
 }
@@ -1702,9 +1760,8 @@ int rmdf_probe_tile_costs(rmdf_ctx *ctx, int scene, int w, int h, double time, i
     p.steps = (uint16_t *)steps.p; p.iters = (uint16_t *)iters.p;
     HIP_TRY(ctx, launch_render(scene, p, ctx->stream));
     std::vector<uint16_t> hs(npx), hi(npx);
-    HIP_TRY(ctx, hipMemcpyAsync(hs.data(), steps.p, npx * 2, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(hi.data(), iters.p, npx * 2, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    RMDF_TRY(download(ctx, hs.data(), steps.p, npx * 2, ctx->stream));
+    RMDF_TRY(download(ctx, hi.data(), iters.p, npx * 2, ctx->stream));
     // cost of a ray ~ escape iterations (march + normal + AO) + march steps, plus a constant per pixel
     double acc[64] = { 0 };
     const int tw = pw / 8, th = ph / 8;
@@ -1760,6 +1817,7 @@ int rmdf_comm_init(rmdf_ctx *ctx, const void *id, int rank, int nranks)
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
     ncclComm_t comm = nullptr;
+    if (!ctx->d_verify) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_verify, (size_t)64 * 8 + 8));
     RCCL_TRY(ctx, g_rccl.CommInitRank(&comm, nranks, uid, rank));
     ctx->comm = comm; ctx->comm_rank = rank; ctx->comm_nranks = nranks;
     return RMDF_OK;
@@ -1774,6 +1832,7 @@ int rmdf_comm_destroy(rmdf_ctx *ctx)
     (void)hipDeviceSynchronize();
     ncclComm_t c = ctx->comm;
     ctx->comm = nullptr; ctx->comm_rank = 0; ctx->comm_nranks = 1;
+    if (ctx->d_verify) { (void)hipFree(ctx->d_verify); ctx->d_verify = nullptr; }
     RCCL_TRY(ctx, g_rccl.CommDestroy(c));
     return RMDF_OK;
 }
@@ -1799,13 +1858,14 @@ int rmdf_gather_shards_device(rmdf_ctx *ctx, int w, int h, const void *d_shard, 
     const size_t slots = (size_t)((64 + n - 1) / n);
     const size_t tile_bytes = (size_t)(w / 8) * (size_t)(h / 8) * 4;
     const size_t bytes = slots * tile_bytes;                                       // the stride of a rank's region in d_gathered
-    // A rank sends the tiles it OWNS under the deal in effect -- when every rank is known to hold that deal: the static deal is a pure
-    // function of the rank count, a cost-aware one counts once rmdf_comm_verify_deal has compared it across the ranks.  Until then
-    // every rank sends its whole fixed-size region, so that a rank whose costs differ mis-assembles a frame instead of leaving the
-    // root waiting for bytes that never come.  Unused slots stay where they are.
+    // Every rank sends its WHOLE fixed-size region (ceil(64 / n) tile slots), whatever the deal in effect: the size on the wire is a
+    // function of (w, h, n) alone, so no state a rank may hold alone -- costs set on one rank, a handicap, a verification another rank
+    // has not seen -- can make a send and its receive disagree (round 4 sent exact tile counts once rmdf_comm_verify_deal had
+    // succeeded; a rank that changed its costs afterwards would have left the root waiting.  For the rank counts that divide 64 the two
+    // are the same bytes anyway; for the others the difference is at most one tile per rank).  A rank whose deal differs mis-assembles a
+    // frame -- which rmdf_comm_verify_deal exists to detect -- and nothing hangs.  Unused slots stay where they are.
     ensure_deal(ctx, n);
-    const bool exact = deal_is_common(ctx, n);
-    auto count_of = [&](int r) -> size_t { return exact ? (size_t)ctx->deal_count[r] * tile_bytes : bytes; };
+    auto count_of = [&](int) -> size_t { return bytes; };
     if (rank == 0) {
         // fan-in: one receive per peer, grouped so that they progress together over the seven xGMI links of the root
         if (n > 1) {
@@ -1844,25 +1904,21 @@ int rmdf_comm_verify_deal(rmdf_ctx *ctx, void *stream)
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     const int n = ctx->comm_nranks, rank = ctx->comm_rank;
     const uint64_t mine = deal_fingerprint(ctx, n);
-    const unsigned gen = ctx->shard_cost_gen;
-    ctx->deal_verified_nranks = 0;
     uint32_t verdict = 1;
     if (n > 1) {
-        // peers -> root: 8 bytes each; root -> peers: the verdict.  Fixed sizes: nothing here depends on the deal.
-        DevBuf buf;
-        HIP_TRY(ctx, hipMalloc(&buf.p, (size_t)n * 8 + 8));
-        uint64_t *d_fp = (uint64_t *)buf.p;
+        // peers -> root: 8 bytes each; root -> peers: the verdict.  Fixed sizes: nothing here depends on the deal.  The device words were
+        // allocated with the communicator (rmdf_comm_init): no allocation -- an implicit device-wide wait -- in the middle of a collective.
+        uint64_t *d_fp = ctx->d_verify;
         uint32_t *d_verdict = (uint32_t *)(d_fp + n);
-        HIP_TRY(ctx, hipMemcpyAsync(d_fp + rank, &mine, 8, hipMemcpyHostToDevice, st));
+        RMDF_TRY(upload(ctx, d_fp + rank, &mine, 8, st));
         if (rank == 0) {
             RCCL_TRY(ctx, g_rccl.GroupStart());
             for (int r = 1; r < n; r++) RCCL_GROUP_TRY(ctx, g_rccl.Recv(d_fp + r, 8, ncclChar, r, ctx->comm, st));
             RCCL_TRY(ctx, g_rccl.GroupEnd());
             std::vector<uint64_t> all((size_t)n);
-            HIP_TRY(ctx, hipMemcpyAsync(all.data(), d_fp, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(ctx, hipStreamSynchronize(st));
+            RMDF_TRY(download(ctx, all.data(), d_fp, (size_t)n * 8, st));
             for (int r = 1; r < n; r++) if (all[(size_t)r] != mine) verdict = 0;
-            HIP_TRY(ctx, hipMemcpyAsync(d_verdict, &verdict, 4, hipMemcpyHostToDevice, st));
+            RMDF_TRY(upload(ctx, d_verdict, &verdict, 4, st));
             RCCL_TRY(ctx, g_rccl.GroupStart());
             for (int r = 1; r < n; r++) RCCL_GROUP_TRY(ctx, g_rccl.Send(d_verdict, 4, ncclChar, r, ctx->comm, st));
             RCCL_TRY(ctx, g_rccl.GroupEnd());
@@ -1870,14 +1926,12 @@ int rmdf_comm_verify_deal(rmdf_ctx *ctx, void *stream)
         } else {
             RCCL_TRY(ctx, g_rccl.Send(d_fp + rank, 8, ncclChar, 0, ctx->comm, st));
             RCCL_TRY(ctx, g_rccl.Recv(d_verdict, 4, ncclChar, 0, ctx->comm, st));
-            HIP_TRY(ctx, hipMemcpyAsync(&verdict, d_verdict, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(ctx, hipStreamSynchronize(st));
+            RMDF_TRY(download(ctx, &verdict, d_verdict, 4, st));
         }
     }
     if (!verdict)
         return fail(ctx, RMDF_E_COMM, "rmdf_comm_verify_deal: the ranks hold different tile deals (rmdf_set_shard_costs / rmdf_set_shard_root_handicap "
-                                      "must be called with the same values on every rank); the exchange keeps whole fixed-size slots");
-    ctx->deal_verified_gen = gen; ctx->deal_verified_nranks = n;
+                                      "must be called with the same values on every rank): frames would be assembled from the wrong tiles");
     return RMDF_OK;
     RMDF_GUARD_END(ctx)
 }
@@ -1911,15 +1965,14 @@ int rmdf_comm_selftest_loopback(rmdf_ctx *ctx, size_t bytes, void *stream, uint6
     DevBuf src, dst;
     HIP_TRY(ctx, hipMalloc(&src.p, bytes));
     HIP_TRY(ctx, hipMalloc(&dst.p, bytes));
-    HIP_TRY(ctx, hipMemcpyAsync(src.p, host.data(), bytes, hipMemcpyHostToDevice, st));
+    RMDF_TRY(upload(ctx, src.p, host.data(), bytes, st));
     HIP_TRY(ctx, hipMemsetAsync(dst.p, 0, bytes, st));
     // exactly the calls of the exchange step: a grouped receive (the root's side) and a send (a peer's side), on the caller's stream
     RCCL_TRY(ctx, g_rccl.GroupStart());
     RCCL_GROUP_TRY(ctx, g_rccl.Recv(dst.p, bytes, ncclChar, me, comm, st));
     RCCL_GROUP_TRY(ctx, g_rccl.Send(src.p, bytes, ncclChar, me, comm, st));
     RCCL_TRY(ctx, g_rccl.GroupEnd());
-    HIP_TRY(ctx, hipMemcpyAsync(back.data(), dst.p, bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    RMDF_TRY(download(ctx, back.data(), dst.p, bytes, st));
     uint64_t bad = 0;
     for (size_t i = 0; i < nw; i++) bad += back[i] != host[i];
     if (mismatches) *mismatches = bad;
@@ -1979,9 +2032,7 @@ int rmdf_render_supersampled(rmdf_ctx *ctx, int scene, int w, int h, int levels,
         void *t = cur; cur = other; other = t;
         cw /= 2; ch /= 2;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(out_rgba8, cur, (size_t)w * h * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return RMDF_OK;
+    return download(ctx, out_rgba8, cur, (size_t)w * h * 4, ctx->stream);
     RMDF_GUARD_END(ctx)
 }
 
@@ -1994,9 +2045,7 @@ int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[10])
     HIP_TRY(ctx, hipMalloc(&d.p, 10 * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMemsetAsync(d.p, 0, 10 * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, launch_selftest_exact_math((unsigned long long *)d.p, ctx->d_cornell_tab, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(mismatches, d.p, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return RMDF_OK;
+    return download(ctx, mismatches, d.p, 10 * sizeof(unsigned long long), ctx->stream);
 }
 
 int rmdf_probe_shader_clock(rmdf_ctx *ctx, double spin_us, double *mhz)
@@ -2031,9 +2080,7 @@ int rmdf_selftest_pinned_math(rmdf_ctx *ctx, uint64_t mismatches[7])
     HIP_TRY(ctx, hipMalloc(&d.p, 8 * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMemsetAsync(d.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, launch_selftest_pinned_math((unsigned long long *)d.p, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(mismatches, d.p, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return RMDF_OK;
+    return download(ctx, mismatches, d.p, 7 * sizeof(unsigned long long), ctx->stream);
 }
 
 int rmdf_selftest_shading_math(rmdf_ctx *ctx, uint64_t mismatches[5])
@@ -2047,9 +2094,7 @@ int rmdf_selftest_shading_math(rmdf_ctx *ctx, uint64_t mismatches[5])
     HIP_TRY(ctx, hipMalloc(&t.p, (size_t)6 * (face_w + 2) * (face_w + 2) * 8));
     HIP_TRY(ctx, hipMemsetAsync(d.p, 0, 5 * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, launch_selftest_shading_math((unsigned long long *)d.p, t.p, face_w, host_fov_xs(), ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(mismatches, d.p, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return RMDF_OK;
+    return download(ctx, mismatches, d.p, 5 * sizeof(unsigned long long), ctx->stream);
 }
 
 
@@ -2094,7 +2139,7 @@ int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_wav
         HIP_TRY(ctx, hipDeviceSynchronize());
         size_t n = (size_t)(max_waves < 0 ? 0 : max_waves);
         if (n > cap) n = cap;
-        HIP_TRY(ctx, hipMemcpy(out, ctx->d_dbg, n * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        RMDF_TRY(download(ctx, out, ctx->d_dbg, n * 16 * sizeof(unsigned long long), ctx->stream));
         HIP_TRY(ctx, hipMemset(ctx->d_dbg, 0, cap * 16 * sizeof(unsigned long long)));
     }
     if (!enable && ctx->d_dbg) { (void)hipFree(ctx->d_dbg); ctx->d_dbg = nullptr; }
@@ -2200,9 +2245,7 @@ int rmdf_copy_to_host(rmdf_ctx *ctx, void *host_dst, const void *d_src, size_t b
     if (!host_dst || !d_src) return fail(ctx, RMDF_E_INVALID, "rmdf_copy_to_host: null pointer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    return RMDF_OK;
+    return download(ctx, host_dst, d_src, bytes, st);
 }
 
 int rmdf_synchronize(rmdf_ctx *ctx, void *stream)

@@ -242,6 +242,11 @@ __device__ __forceinline__ float exp_core_t(float x)
     float c = r - tt * (P1 + tt * P2);
     const float num = r * c, den = 2.0f - c;                              // den in [1.6, 2.4], |num| <= 0.13 or 0
     float y = 1.0f - ((lo - (FAST_DIV ? RMDF_FAST_DIV(num, den) : num / den)) - hi);
+    // y * 2^k as the oracle writes it: two multiplications by 2^(k/2) and 2^(k - k/2).  For -87 <= x <= 88.5 the result is a NORMAL number
+    // (exp(-87) = 1.6e-38 > FLT_MIN, exp(88.5) < FLT_MAX) and y in [0.7, 1.5], so neither product rounds and one v_ldexp_f32 returns the
+    // same bits (round 5: nine instructions fewer per exp; the test scene evaluates ten per estimate).  The straight-line form takes the
+    // ldexp, the branchy reference keeps the two products, and rmdf_selftest_pinned_math compares the two for ALL 2^32 inputs.
+    if (FAST_DIV) return __builtin_ldexpf(y, k);
     int32_t k1 = k / 2, k2 = k - k1;
     y = y * __int_as_float((k1 + 127) << 23);
     y = y * __int_as_float((k2 + 127) << 23);
@@ -512,7 +517,9 @@ __device__ __forceinline__ void sincos_pinned(float x, float &s, float &c)
     c = ((q + 1) & 2) ? -c0 : c0;
     if (bad) { s = x - x; c = x - x; }
 }
-__device__ __noinline__ float acos_full(float x)
+// (the branchy forms are inlined where the straight-line functions fall back on them -- a CALL inside k_render costs a private segment
+// and pins every value that lives across it to a callee-saved register -- and exist as functions of their own for the device self-test)
+__device__ __forceinline__ float acos_full_inl(float x)
 {
     const float pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f, pi = 3.1415925026e+00f;
     const float pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f,
@@ -548,6 +555,7 @@ __device__ __noinline__ float acos_full(float x)
         return 2.0f * (df + w);
     }
 }
+__device__ __noinline__ float acos_full(float x) { return acos_full_inl(x); }
 // Branch-free main path for 2^-26 < |x| < 1 (one p/q, one sqrt, one division for the upper-range correction, results
 // selected); |x| >= 1, tiny |x| and NaN go through acos_full on a wave-uniform branch.  Lanes of one wave span the whole
 // [-1, 1] in the general-power Mandelbulb, so the three-way branch of acos_full used to run all its arms.
@@ -574,10 +582,10 @@ __device__ __forceinline__ float acos_pinned(float x)
     const float wp = r * s + c;
     const float r_pos = 2.0f * (df + wp);
     float res = small ? r_small : ((x < 0.0f) ? r_neg : r_pos);
-    if (__builtin_expect(__ballot(special) != 0ull, 0)) { if (special) res = acos_full(x); }
+    if (__builtin_expect(__ballot(special) != 0ull, 0)) { if (special) res = acos_full_inl(x); }
     return res;
 }
-__device__ __noinline__ float atan_full(float x)
+__device__ __forceinline__ float atan_full_inl(float x)
 {
     const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
                 aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
@@ -609,6 +617,7 @@ __device__ __noinline__ float atan_full(float x)
     const float zz = hi - ((t * (s1 + s2) - lo) - t);
     return neg ? -zz : zz;
 }
+__device__ __noinline__ float atan_full(float x) { return atan_full_inl(x); }
 // Branch-free main path for 2^-12 <= |x| < 2^26: the argument reduction picks numerator and denominator by selects
 // and divides once (the four reduced ranges of atan_full each carried their own division); everything else (tiny, huge,
 // NaN) goes through atan_full on a wave-uniform branch.
@@ -637,11 +646,11 @@ __device__ __forceinline__ float atan_pinned(float x)
     const float r_small = t - t * (s1 + s2);
     const float zz = hi - ((t * (s1 + s2) - lo) - t);
     float res = small ? r_small : (neg ? -zz : zz);
-    if (__builtin_expect(__ballot(special) != 0ull, 0)) { if (special) res = atan_full(x); }
+    if (__builtin_expect(__ballot(special) != 0ull, 0)) { if (special) res = atan_full_inl(x); }
     return res;
 }
 // GLSL atan(y, x), every special case
-__device__ __noinline__ float atan2_full(float y, float x)
+__device__ __forceinline__ float atan2_full_inl(float y, float x)
 {
     const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f, pio2 = 1.5707963705e+00f;
     const float inf = __builtin_inff();
@@ -659,6 +668,8 @@ __device__ __noinline__ float atan2_full(float y, float x)
     return (m == 0) ? z : (m == 1) ? -z : (m == 2) ? pi - (z - pi_lo) : (z - pi_lo) - pi;
 }
 
+__device__ __noinline__ float atan2_full(float y, float x) { return atan2_full_inl(y, x); }
+
 // GLSL atan(y, x): finite non-zero operands take the straight-line path; zeros, infinities and NaN go through atan2_full.
 // (Its division has operands of any magnitude; widening the range test to [2^-40, 2^40) so that it could take the short quotient
 // too was measured: 1.915 -> 1.922 ms for the general-power frame, not adopted.)
@@ -670,17 +681,25 @@ __device__ __forceinline__ float atan2_pinned(float y, float x)
     const int m = (int)((__float_as_uint(y) >> 31) | ((__float_as_uint(x) >> 30) & 2u));
     const float z = atan_pinned(special ? 1.0f : ay / ax);
     float res = (m == 0) ? z : (m == 1) ? -z : (m == 2) ? pi - (z - pi_lo) : (z - pi_lo) - pi;
-    if (__builtin_expect(__ballot(special) != 0ull, 0)) { if (special) res = atan2_full(y, x); }
+    if (__builtin_expect(__ballot(special) != 0ull, 0)) { if (special) res = atan2_full_inl(y, x); }
     return res;
 }
 
-// fragment.shd:42-72
-__device__ __forceinline__ v3 triplex_pow_general(v3 w, float power)
+// pow(x, y) = exp(y * log(x)) with the logarithm supplied: lx = log_pinned(x > 0 ? x : 1) (pow_pinned's own first step).  The general-power
+// iteration raises the same r to `power` and to `power - 1` (fragment.shd:64,148): one logarithm serves both -- the same operations on
+// the same operands, evaluated once.
+__device__ __forceinline__ float pow_with_log(float x, float lx, float y)
 {
-    const float r = length3(w);
+    const float r = exp_pinned(y * lx);
+    return !(x > 0.0f) ? 0.0f : r;
+}
+
+// fragment.shd:42-72; r = length(w) and lr = log_pinned(r > 0 ? r : 1) come from the caller (de_mandelbulb_general has both)
+__device__ __forceinline__ v3 triplex_pow_general(v3 w, float power, float r, float lr)
+{
     float theta = acos_pinned(w.z / r);
     float phi = atan2_pinned(w.y, w.x);
-    const float zr = pow_pinned(r, power);
+    const float zr = pow_with_log(r, lr, power);
     theta = theta * power;
     phi = phi * power;
     float st, ct, sp, cp;
@@ -699,9 +718,10 @@ __device__ __forceinline__ float de_mandelbulb_general(v3 pos, float power, unsi
     for (int i = 0; i < 25; i++) {
         r = length3(w);
         if (r > 4.0f) break;
-        w = triplex_pow_general(w, power);
+        const float lr = log_pinned(!(r > 0.0f) ? 1.0f : r);
+        w = triplex_pow_general(w, power, r, lr);
         w = add3(w, pos);
-        dr = pow_pinned(r, power - 1.0f) * power * dr + 1.0f;
+        dr = pow_with_log(r, lr, power - 1.0f) * power * dr + 1.0f;
         iters++;
     }
     return div_by_dr(0.5f * log_pinned(r) * r, dr);

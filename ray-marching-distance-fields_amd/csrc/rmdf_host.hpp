@@ -1,0 +1,214 @@
+// rmdf_host.hpp -- host-side plumbing of the C ABI (rmdf_api.cpp): the ctx's worker threads and the page-locked staging through which
+// EVERY byte travels between caller memory and the device.
+//
+// Why staging (round 5).  A copy between device memory and pageable host memory makes the HIP runtime page-lock the caller's pages on
+// the fly (hsa_amd_memory_lock: a userptr mapping of those pages into the GPU's address space, created and torn down per call, the
+// queue drained around it).  The library does not want the driver to build GPU mappings of memory it does not own -- a numpy array, a
+// Haskell storable vector, a std::vector of its own that is freed a line later: the intermittent GPU memory fault of round 4 was first
+// caught under exactly such a call -- and it does not want to pay for them: 0.59 ms for a 1080p frame into pageable memory
+// against 0.38 ms for the kernel.  So the runtime only ever sees device memory and memory the library page-locked itself, once:
+//   upload():   caller -> staging (host threads) -> device (async: the call may return before the DMA ends, the caller's memory is
+//               not read after return);
+//   download(): device -> staging -> caller (host threads), chunk by chunk, the copy of chunk i overlapping the DMA of chunk i + 1.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace rmdf {
+
+// A few host threads owned by the ctx.  run(parts, fn): fn(part) for part = 0 .. parts - 1, part 0 on the calling thread, the others
+// on the workers; begin() / finish() split that so that the caller can issue device work in between.  One job at a time, one caller
+// thread (rmdf.h: a ctx is used by one thread at a time).  A worker that has just finished a part spins for the next job for a few
+// dozen microseconds before it goes to sleep on the condition variable: the band-by-band frame copy (render_whole_frame_host) hands out
+// several jobs per frame, and a futex wake-up per job would cost more than the copy.
+class WorkPool {
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_work_, cv_done_;
+    std::function<void(int)> fn_;
+    std::atomic<unsigned> gen_{ 0 };
+    std::atomic<bool> stop_{ false };
+    std::atomic<int> pending_{ 0 };
+    int parts_ = 1;
+    bool open_ = false;
+
+    void worker(int idx)
+    {
+        using clock = std::chrono::steady_clock;
+        unsigned seen = 0;
+        clock::time_point hot_until = clock::now();
+        for (;;) {
+            bool got = false;
+            while (clock::now() < hot_until) {
+                if (gen_.load(std::memory_order_acquire) != seen || stop_.load(std::memory_order_relaxed)) { got = true; break; }
+                __builtin_ia32_pause();
+            }
+            std::function<void(int)> fn;
+            int np;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                if (!got) cv_work_.wait(lk, [&] { return stop_.load() || gen_.load() != seen; });
+                if (stop_.load()) return;
+                seen = gen_.load(); fn = fn_; np = parts_;
+            }
+            if (idx + 1 < np) fn(idx + 1);
+            if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> lk(m_); cv_done_.notify_one(); }
+            hot_until = clock::now() + std::chrono::microseconds(60);
+        }
+    }
+
+public:
+    // n worker threads (besides the calling thread); idempotent.  Fewer threads than asked for (thread creation failed) is still correct.
+    void start(int n)
+    {
+        if (!threads_.empty() || n < 1) return;
+        try { for (int i = 0; i < n; i++) threads_.emplace_back([this, i] { worker(i); }); } catch (...) { }
+    }
+    int workers() const { return (int)threads_.size(); }
+    // parts is clamped to workers() + 1
+    void begin(int parts, std::function<void(int)> fn)
+    {
+        if (parts > workers() + 1) parts = workers() + 1;
+        if (parts < 1) parts = 1;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = std::move(fn); parts_ = parts; open_ = true;
+            if (parts > 1) { pending_.store(workers(), std::memory_order_relaxed); gen_.fetch_add(1, std::memory_order_release); }
+        }
+        if (parts > 1) cv_work_.notify_all();
+    }
+    void finish()
+    {
+        if (!open_) return;
+        fn_(0);
+        if (parts_ > 1) {
+            // the parts are short: look a few times before sleeping
+            for (int i = 0; i < 2000 && pending_.load(std::memory_order_acquire) != 0; i++) __builtin_ia32_pause();
+            if (pending_.load(std::memory_order_acquire) != 0) {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_done_.wait(lk, [&] { return pending_.load() == 0; });
+            }
+        }
+        open_ = false;
+    }
+    void run(int parts, std::function<void(int)> fn) { begin(parts, std::move(fn)); finish(); }
+    // part `part` of `parts` of [0, n), cut at multiples of `align`
+    static void slice(size_t n, int part, int parts, size_t align, size_t &lo, size_t &hi)
+    {
+        lo = (n * (size_t)part / (size_t)parts) / align * align;
+        hi = part == parts - 1 ? n : (n * (size_t)(part + 1) / (size_t)parts) / align * align;
+    }
+    // memcpy(dst, src, bytes) on all threads (small copies: on the caller's)
+    void copy(void *dst, const void *src, size_t bytes)
+    {
+        if (bytes < ((size_t)1 << 20) || workers() == 0) { memcpy(dst, src, bytes); return; }
+        const int parts = workers() + 1;
+        run(parts, [=](int part) {
+            size_t lo, hi;
+            slice(bytes, part, parts, 4096, lo, hi);
+            if (hi > lo) memcpy((char *)dst + lo, (const char *)src + lo, hi - lo);
+        });
+    }
+    // fn(lo, hi) over [0, n) in row segments (forSegmentsConcurrently, ConcurrentSegments.hs:14-28)
+    template <typename F>
+    void segments(int n, F fn)
+    {
+        int parts = workers() + 1;
+        if (parts > n / 16) parts = n / 16;
+        if (parts <= 1) { fn(0, n); return; }
+        run(parts, [&](int part) {
+            size_t lo, hi;
+            slice((size_t)n, part, parts, 1, lo, hi);
+            if (hi > lo) fn((int)lo, (int)hi);
+        });
+    }
+    ~WorkPool()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_.store(true); }
+        cv_work_.notify_all();
+        for (auto &t : threads_) if (t.joinable()) t.join();
+    }
+};
+
+// Two page-locked chunks and their events.  Not a cache of anything: a chunk is reused as soon as the DMA that read or wrote it is over.
+struct Staging {
+    static constexpr size_t kChunk = (size_t)8 << 20;
+    char      *buf[2] = { nullptr, nullptr };
+    size_t     cap = 0;
+    hipEvent_t ev[2] = { nullptr, nullptr };
+    bool       busy[2] = { false, false };     // an upload's DMA may still be reading the chunk
+    unsigned   next = 0;
+
+    hipError_t reserve(size_t want)
+    {
+        if (want > kChunk) want = kChunk;
+        want = (want + 65535) & ~(size_t)65535;
+        hipError_t e;
+        for (int b = 0; b < 2; b++) if (!ev[b] && (e = hipEventCreateWithFlags(&ev[b], hipEventDisableTiming)) != hipSuccess) return e;
+        if (want <= cap) return hipSuccess;
+        if ((e = drain()) != hipSuccess) return e;
+        for (int b = 0; b < 2; b++) { if (buf[b]) (void)hipHostFree(buf[b]); buf[b] = nullptr; }
+        cap = 0;
+        for (int b = 0; b < 2; b++) if ((e = hipHostMalloc((void **)&buf[b], want, hipHostMallocDefault)) != hipSuccess) return e;
+        cap = want;
+        return hipSuccess;
+    }
+    hipError_t wait(int b)
+    {
+        if (!busy[b]) return hipSuccess;
+        busy[b] = false;
+        return hipEventSynchronize(ev[b]);
+    }
+    hipError_t drain() { hipError_t e = wait(0), f = wait(1); return e != hipSuccess ? e : f; }
+    hipError_t upload(WorkPool &pool, void *d_dst, const void *h_src, size_t bytes, hipStream_t st)
+    {
+        hipError_t e = reserve(bytes);
+        for (size_t off = 0; e == hipSuccess && off < bytes; off += cap) {
+            const size_t n = bytes - off < cap ? bytes - off : cap;
+            const int b = (int)(next++ & 1u);
+            if ((e = wait(b)) != hipSuccess) break;
+            pool.copy(buf[b], (const char *)h_src + off, n);
+            if ((e = hipMemcpyAsync((char *)d_dst + off, buf[b], n, hipMemcpyHostToDevice, st)) != hipSuccess) break;
+            if ((e = hipEventRecord(ev[b], st)) != hipSuccess) break;
+            busy[b] = true;
+        }
+        return e;
+    }
+    // returns with the bytes in h_dst (it waits for ITS copies, not for the stream)
+    hipError_t download(WorkPool &pool, void *h_dst, const void *d_src, size_t bytes, hipStream_t st)
+    {
+        hipError_t e = reserve(bytes);
+        int pb = -1;
+        size_t poff = 0, pn = 0;
+        for (size_t off = 0; e == hipSuccess && off < bytes; off += cap) {
+            const size_t n = bytes - off < cap ? bytes - off : cap;
+            const int b = (int)(next++ & 1u);
+            if ((e = wait(b)) != hipSuccess) break;
+            if ((e = hipMemcpyAsync(buf[b], (const char *)d_src + off, n, hipMemcpyDeviceToHost, st)) != hipSuccess) break;
+            if ((e = hipEventRecord(ev[b], st)) != hipSuccess) break;
+            busy[b] = true;
+            if (pb >= 0) { if ((e = wait(pb)) != hipSuccess) break; pool.copy((char *)h_dst + poff, buf[pb], pn); }
+            pb = b; poff = off; pn = n;
+        }
+        if (e == hipSuccess && pb >= 0 && (e = wait(pb)) == hipSuccess) pool.copy((char *)h_dst + poff, buf[pb], pn);
+        if (e != hipSuccess) (void)drain();
+        return e;
+    }
+    void destroy()
+    {
+        (void)drain();
+        for (int b = 0; b < 2; b++) { if (buf[b]) (void)hipHostFree(buf[b]); if (ev[b]) (void)hipEventDestroy(ev[b]); buf[b] = nullptr; ev[b] = nullptr; }
+        cap = 0;
+    }
+};
+
+}  // namespace rmdf

@@ -343,7 +343,33 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
         }
         ao = 1.0f - occl;
     }
-    if (SCENE != 0 && hit) {
+    // distance_ao (fragment.shd:542-591)
+    const float w0 = shk::ao_w0, e0 = shk::ao_d0, w1 = shk::ao_w1, e1 = shk::ao_d1;
+    float ao_dist[2] = { 0.0f, 0.0f };
+    if ((SCENE == 1 || SCENE == 3) && hit) {
+        // the test scene and the general-power Mandelbulb: the normal's four estimates and the two AO taps as ONE loop around one copy of
+        // the estimate, like the Cornell box above (inlined seven times the general-power kernel was 12 000 lines of assembly, most of it
+        // transcendental functions: round 5).  x - 0.0f == x for every x, so the sample points are the written ones bit for bit.
+        isec = mk3(origin.x + dir.x * t, origin.y + dir.y * t, origin.z + dir.z * t);
+        const v3 np = mk3(isec.x - dir.x * shk::isec_step_back, isec.y - dir.y * shk::isec_step_back, isec.z - dir.z * shk::isec_step_back);
+        const float eps = shk::normal_eps;
+        float d0 = 0.0f, ddx = 0.0f, ddy = 0.0f, ddz = 0.0f;
+#pragma unroll 1
+        for (int k = 0; k < 6; k++) {
+            if (k == 4) n = normalize3(mk3(ddx, ddy, ddz));
+            const float e = k == 4 ? e0 : e1;
+            const v3 pos = k < 4 ? mk3(np.x - (k == 1 ? eps : 0.0f), np.y - (k == 2 ? eps : 0.0f), np.z - (k == 3 ? eps : 0.0f))
+                                 : mk3(isec.x + n.x * e, isec.y + n.y * e, isec.z + n.z * e);
+            const float d = distance_estimator<SCENE>(pos, p, iters, tri_hint, cgrid);
+            if (k == 0) d0 = d;
+            else if (k == 1) ddx = d0 - d;
+            else if (k == 2) ddy = d0 - d;
+            else if (k == 3) ddz = d0 - d;
+            else if (k == 4) ao_dist[0] = d;
+            else ao_dist[1] = d;
+        }
+    }
+    if (SCENE == 2 && hit) {
         isec = mk3(origin.x + dir.x * t, origin.y + dir.y * t, origin.z + dir.z * t);
         v3 np = mk3(isec.x - dir.x * shk::isec_step_back, isec.y - dir.y * shk::isec_step_back, isec.z - dir.z * shk::isec_step_back);
         const float eps = shk::normal_eps;
@@ -353,9 +379,6 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
         float dz = distance_estimator<SCENE>(mk3(np.x - 0.0f, np.y - 0.0f, np.z - eps), p, iters, tri_hint, cgrid);
         n = normalize3(mk3(d0 - dx, d0 - dy, d0 - dz));
     }
-    // distance_ao (fragment.shd:542-591)
-    const float w0 = shk::ao_w0, e0 = shk::ao_d0, w1 = shk::ao_w1, e1 = shk::ao_d1;
-    float ao_dist[2] = { 0.0f, 0.0f };
     if (AO_POOL) {
         // the two estimates with their stragglers set aside (see AO_CUT above); every wave of the workgroup comes through here
         int slot[2] = { -1, -1 };
@@ -424,7 +447,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
     if (hit) {
         float occl = 0.0f;
         if (SCENE != 0) {
-            if (!AO_POOL) {
+            if (!AO_POOL && SCENE == 2) {
                 ao_dist[0] = distance_estimator<SCENE>(mk3(isec.x + n.x * e0, isec.y + n.y * e0, isec.z + n.z * e0), p, iters, tri_hint, cgrid);
                 ao_dist[1] = distance_estimator<SCENE>(mk3(isec.x + n.x * e1, isec.y + n.y * e1, isec.z + n.z * e1), p, iters, tri_hint, cgrid);
             }

@@ -98,7 +98,10 @@ def main():
                          "sha256": {k: hashlib.sha256(np.ascontiguousarray(r[k]).tobytes()).hexdigest() for k in ("rgba8", "steps", "iters")},
                          "counters": r["counters"]}
             print(name, out[name])
-        json.dump(out, open(os.path.join(GOLD, "full_size_digests.json"), "w"), indent=1, sort_keys=True)
+        fn = os.path.join(GOLD, "full_size_digests.json")
+        if os.path.exists(fn):                                  # entries written by --digest4 stay
+            out = dict(json.load(open(fn)), **out)
+        json.dump(out, open(fn, "w"), indent=1, sort_keys=True)
 
     if a.grid:
         # SURVEY 8c's fixture grid at 256x144 -- every FragmentShader value at in_time 0, 1, 2.5 and 7 -- as digests of the oracle's

@@ -142,6 +142,69 @@ def test_tile_jobs_issued_ahead_never_show(sr, rmdf):
     assert np.array_equal(got[y0:y1, x0:x1], want[y0:y1, x0:x1])
 
 
+def test_tile_jobs_issued_ahead_belong_to_one_environment(rmdf, env_faces):
+    """Round 5: tiles i+1 .. i+3 are rendered ahead of their calls; a caller that replaces a cube map between two tile
+    calls of one frame must get the following tiles rendered with the NEW map, as the reference's uniforms would (every tile samples
+    the textures bound when it is drawn, ShaderRendering.hs:177-181)."""
+    w, h, ms = 256, 144, 64
+    r = rmdf.ShaderRenderer(0)
+    try:
+        a = {k: env_faces[k] for k in ("refl", "cos1", "cos8")}
+        b = {k: np.ascontiguousarray(env_faces[k][:, ::-1, :, :] * np.float32(0.5)) for k in ("refl", "cos1", "cos8")}
+        slots = ((rmdf.ENV_REFLECTION, "refl"), (rmdf.ENV_COS_1, "cos1"), (rmdf.ENV_COS_8, "cos8"))
+
+        def bind(env):
+            for slot, k in slots:
+                r.set_env_cube(slot, env[k])
+        bind(b)
+        full_b = r.render(2, w, h, 1.0, max_steps=ms)["rgba8"].copy()
+        bind(a)
+        full_a = r.render(2, w, h, 1.0, max_steps=ms)["rgba8"].copy()
+        assert not np.array_equal(full_a, full_b)
+        fb = rmdf.FrameBuffer(w, h)
+        expect = full_a.copy()                               # the accumulating frame after the whole-frame render above
+        for idx in range(64):
+            if idx == 21:
+                bind(b)                                      # tiles 21 .. 23 were rendered ahead with map A by now
+            if idx == 40:
+                r.set_env_cube(rmdf.ENV_COS_1, b["cos1"])    # the same values again: still a new generation, still the right pixels
+            r.draw_shader_tile(2, idx, w, h, 1.0, fb.vec, max_steps=ms)
+            x0, y0, x1, y1 = rmdf.tile_rect(idx, w, h)
+            src = full_a if idx < 21 else full_b
+            expect[y0:y1, x0:x1] = src[y0:y1, x0:x1]
+            assert np.array_equal(fb.vec.reshape(h, w), expect), idx
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("bands,mirror", [(0, 0), (1, 0), (3, 0), (16, 0), (0, 1), (5, 1)])
+def test_whole_frame_host_call_in_row_bands(rmdf, env_faces, bands, mirror):
+    """Round 5: rmdf_render_tile(tile_idx = -1, pageable pointer) -- the reference viewer's per-frame call (Main.hs:67, App.hs:154-166) --
+    renders the frame as row bands on streams of their own and moves each band to the caller through the page-locked shadow while the
+    others render (rmdf_api.cpp: render_whole_frame_host).  Whatever the band count (rmdf_config.reserved[2]) and whichever way the rows
+    reach the host (reserved[3]), the frame equals the single-launch plane-writing variant; sizes with ragged last strips, a size
+    too small for bands; a tiled call afterwards starts from that frame (the shadow is valid)."""
+    r = rmdf.ShaderRenderer(0, frame_bands=bands, frame_mirror=mirror)
+    try:
+        for slot, k in ((rmdf.ENV_REFLECTION, "refl"), (rmdf.ENV_COS_1, "cos1"), (rmdf.ENV_COS_8, "cos8")):
+            r.set_env_cube(slot, env_faces[k])
+        for scene, w, h, ms in ((2, 1920, 1080, 64), (0, 1283, 721, 32), (2, 200, 100, 64), (3, 1000, 999, 24)):
+            ref = r.render(scene, w, h, 0.7, max_steps=ms, want_f32=False)["rgba8"]
+            for rep in range(2):                             # the second call runs cost-ordered, band by band
+                fb = np.full(w * h + 64, 0xDEADBEEF, np.uint32)
+                r.draw_shader_tile(scene, None, w, h, 0.7, fb[32:32 + w * h], max_steps=ms)
+                assert np.array_equal(fb[32:32 + w * h].reshape(h, w), ref), (scene, w, h, rep)
+                assert (fb[:32] == 0xDEADBEEF).all() and (fb[32 + w * h:] == 0xDEADBEEF).all()
+            tiled = np.zeros(w * h, np.uint32)
+            r.draw_shader_tile(scene, 9, w, h, 0.7, tiled, max_steps=ms)      # not tile 0: keeps the latched frame
+            assert np.array_equal(tiled.reshape(h, w), ref), (scene, w, h, "tile after whole frame")
+    finally:
+        r.close()
+    if bands == 0 and mirror == 0:
+        with pytest.raises(rmdf.RmdfError):
+            rmdf.ShaderRenderer(0, frame_bands=17)
+
+
 @pytest.mark.parametrize("threads", [1, 3, 64])
 def test_tile_mode_copy_thread_counts(rmdf, threads):
     """rmdf_config.reserved[1]: tile mode with the calling thread alone (no pool), with two workers and with the maximum; a frame large
@@ -985,6 +1048,61 @@ def test_exchange_behind_the_c_abi_world_size_one(sr, rmdf):
 
 
 SS_CASES = sorted(f for f in glob.glob(os.path.join(GOLD, "swiftshader_s[0-3]_*.npz")) if not f.endswith("_gbuf.npz"))
+
+
+def _fake_rccl_lib():
+    """tests/libfake_rccl.so, built from tests/fake_rccl.c when missing (gcc; __graft_entry__.build() builds it too)."""
+    import subprocess
+    from conftest import ROOT
+    so = os.path.join(ROOT, "tests", "libfake_rccl.so")
+    src = os.path.join(ROOT, "tests", "fake_rccl.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", so,
+                               "-L/opt/rocm/lib", "-lamdhip64"])
+    return so
+
+
+@pytest.mark.parametrize("nranks,frames_in_flight", [(2, 3), (8, 8), (3, 2)])
+def test_exchange_with_n_ranks_against_the_rccl_double(rmdf, tmp_path, nranks, frames_in_flight):
+    """Round 5: the N > 1 branches of the exchange step -- the peers' ncclSend, the root's grouped ncclRecv fan-in, the collective deal
+    check with equal and with unequal deals, several frames in flight on one communicator -- executed by N processes that share this one
+    GPU, against a test double of RCCL (tests/fake_rccl.c, loaded by librmdf_xcheck.so through RMDF_RCCL_LIB; the product library never
+    looks at that variable).  Rank 0's last assembled frame must be the committed oracle digest of BASELINE config 3.  Readiness
+    evidence for the 8-GPU run, not a scaling number: the double moves bytes through /dev/shm.  3 ranks: a count that does not divide 64."""
+    import hashlib
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    d = json.load(open(os.path.join(GOLD, "full_size_digests.json")))["config3_mandelbulb8_1920x1080_m256"]
+    env = dict(os.environ, RMDF_RCCL_LIB=_fake_rccl_lib(), FAKE_RCCL_TIMEOUT_S="120", OMP_NUM_THREADS="1")
+    idfile = str(tmp_path / "uid.bin")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "fake_rccl_worker.py"), str(r), str(nranks), idfile,
+                               str(d["w"]), str(d["h"]), str(d["max_steps"]), str(frames_in_flight)],
+                              cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(nranks)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=900))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("rank %d ok" % r) in so, (r, so[-500:], se[-3000:])
+    sha = outs[0][0].strip().split()[-1]
+    assert sha == d["sha256"]["rgba8"]
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("fakerccl_")], "the double left messages behind"
+
+
+def test_the_product_library_ignores_the_rccl_override(rmdf, monkeypatch):
+    """RMDF_RCCL_LIB is honoured by librmdf_xcheck.so only: librmdf.so loads the real RCCL whatever the variable says."""
+    monkeypatch.setenv("RMDF_RCCL_LIB", "/nonexistent/librccl.so")
+    r = rmdf.ShaderRenderer(0)
+    try:
+        assert r.comm_selftest_loopback(4096) == 0
+    finally:
+        r.close()
 
 
 @pytest.mark.parametrize("fn", SS_CASES, ids=[os.path.basename(c)[:-4] for c in SS_CASES])

@@ -29,7 +29,8 @@ def test_render_matches_golden(orc, env_oracle, fn):
     assert np.array_equal(r["iters"], g["iters"])          # bit-exact escape-iteration counts
     assert np.array_equal(r["rgba8"], g["rgba8"])
     assert np.array_equal(r["rgba_f32"].view(np.uint32), g["rgba_f32"].view(np.uint32))
-    assert list(r["counters"].values()) == [int(x) for x in g["counters"]]
+    # (the fixtures hold the first six counters; tri_inside joined the struct in round 5, behind them)
+    assert list(r["counters"].values())[:6] == [int(x) for x in g["counters"]]
 
 
 def test_fixture_grid_256x144_pins_the_oracle(orc):
