@@ -427,19 +427,19 @@ int ensure_frame(rmdf_ctx *ctx, int w, int h, bool planes)
 {
     const size_t npx = (size_t)w * (size_t)h;
     if (!(npx <= ctx->cap_px && ctx->d_rgba8)) {
-        if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
+        if (ctx->d_rgba8) (void)dev_free(ctx->d_rgba8);
         ctx->d_rgba8 = nullptr; ctx->cap_px = 0; ctx->shadow_valid = false;
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_rgba8, npx * 4));
+        HIP_TRY(ctx, dev_malloc((void **)&ctx->d_rgba8, npx * 4));
         ctx->cap_px = npx;
     }
     if (planes && !(npx <= ctx->cap_planes_px && ctx->d_rgba_f32)) {
-        if (ctx->d_rgba_f32) (void)hipFree(ctx->d_rgba_f32);
-        if (ctx->d_steps) (void)hipFree(ctx->d_steps);
-        if (ctx->d_iters) (void)hipFree(ctx->d_iters);
+        if (ctx->d_rgba_f32) (void)dev_free(ctx->d_rgba_f32);
+        if (ctx->d_steps) (void)dev_free(ctx->d_steps);
+        if (ctx->d_iters) (void)dev_free(ctx->d_iters);
         ctx->d_rgba_f32 = nullptr; ctx->d_steps = nullptr; ctx->d_iters = nullptr; ctx->cap_planes_px = 0;
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_rgba_f32, npx * 16));
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_steps, npx * 2));
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_iters, npx * 2));
+        HIP_TRY(ctx, dev_malloc((void **)&ctx->d_rgba_f32, npx * 16));
+        HIP_TRY(ctx, dev_malloc((void **)&ctx->d_steps, npx * 2));
+        HIP_TRY(ctx, dev_malloc((void **)&ctx->d_iters, npx * 2));
         ctx->cap_planes_px = npx;
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_rgba_f32, 0, npx * 16, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_steps, 0, npx * 2, ctx->stream));
@@ -467,13 +467,13 @@ int ensure_gbuf(rmdf_ctx *ctx, int w, int h)
 {
     const size_t gw = (size_t)((w + 1) & ~1), gh = (size_t)((h + 1) & ~1);
     const size_t need = gw * gh;
-    if (!ctx->d_work_counter) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_work_counter, 256));
+    if (!ctx->d_work_counter) HIP_TRY(ctx, dev_malloc((void **)&ctx->d_work_counter, 256));
     if (need <= ctx->gbuf_cap) return RMDF_OK;
-    if (ctx->d_gbuf_nao) (void)hipFree(ctx->d_gbuf_nao);
-    if (ctx->d_gbuf_meta) (void)hipFree(ctx->d_gbuf_meta);
+    if (ctx->d_gbuf_nao) (void)dev_free(ctx->d_gbuf_nao);
+    if (ctx->d_gbuf_meta) (void)dev_free(ctx->d_gbuf_meta);
     ctx->d_gbuf_nao = nullptr; ctx->d_gbuf_meta = nullptr; ctx->gbuf_cap = 0;
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_gbuf_nao, need * sizeof(float4)));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_gbuf_meta, need * sizeof(unsigned)));
+    HIP_TRY(ctx, dev_malloc((void **)&ctx->d_gbuf_nao, need * sizeof(float4)));
+    HIP_TRY(ctx, dev_malloc((void **)&ctx->d_gbuf_meta, need * sizeof(unsigned)));
     ctx->gbuf_cap = need;
     return RMDF_OK;
 }
@@ -528,11 +528,11 @@ int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t str
         os->last_use = ++ctx->order_tick;
         if (nblk > os->cap) {
             if (os->cap) HIP_TRY(ctx, hipStreamSynchronize(stream));
-            if (os->d_cost) (void)hipFree(os->d_cost);
-            if (os->d_order) (void)hipFree(os->d_order);
+            if (os->d_cost) (void)dev_free(os->d_cost);
+            if (os->d_order) (void)dev_free(os->d_order);
             os->d_cost = os->d_order = nullptr; os->cap = 0; os->valid = false;
-            HIP_TRY(ctx, hipMalloc((void **)&os->d_cost, (size_t)nblk * 4));
-            HIP_TRY(ctx, hipMalloc((void **)&os->d_order, (size_t)nblk * 4));
+            HIP_TRY(ctx, dev_malloc((void **)&os->d_cost, (size_t)nblk * 4));
+            HIP_TRY(ctx, dev_malloc((void **)&os->d_order, (size_t)nblk * 4));
             os->cap = nblk;
         }
         const int key[10] = { scene, p.w, p.h, p.x0, p.y0, p.x1, p.y1, p.max_steps,
@@ -740,7 +740,7 @@ bool write_file_atomic(const std::string &path, const std::vector<uint8_t> &data
 
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { if (p) (void)dev_free(p); }
 };
 
 const float kPi = 3.14159265358979323846f;       // `pi :: Float`
@@ -815,10 +815,10 @@ int get_uv_table(rmdf_ctx *ctx, int cw, const float2 **d_uv)
     cube_uv_table_host(ctx_pool(ctx), cw, uv);
     UvTable t;
     t.cw = cw;
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_uv, uv.size() * sizeof(float)));
+    HIP_TRY(ctx, dev_malloc((void **)&t.d_uv, uv.size() * sizeof(float)));
     const int urc = upload(ctx, t.d_uv, uv.data(), uv.size() * sizeof(float), ctx->stream);     // every user of the table runs on the ctx stream or after an event of it
-    if (urc != RMDF_OK) { (void)hipFree(t.d_uv); return urc; }
-    if (ctx->uv_tables.size() >= 8) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->uv_tables[0].d_uv); ctx->uv_tables.erase(ctx->uv_tables.begin()); }
+    if (urc != RMDF_OK) { (void)dev_free(t.d_uv); return urc; }
+    if (ctx->uv_tables.size() >= 8) { (void)hipDeviceSynchronize(); (void)dev_free(ctx->uv_tables[0].d_uv); ctx->uv_tables.erase(ctx->uv_tables.begin()); }
     ctx->uv_tables.push_back(t);
     *d_uv = t.d_uv;
     return RMDF_OK;
@@ -857,20 +857,20 @@ int get_lobe_tables(rmdf_ctx *ctx, int w, int h, const float **d_lutT, const flo
     lobe_tables_host(ctx_pool(ctx), w, h, lutT, tcs);
     LobeTable t;
     t.w = w; t.h = h;
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_lutT, lutT.size() * sizeof(float)));
-    hipError_t e = hipMalloc((void **)&t.d_tcs, tcs.size() * sizeof(float));
+    HIP_TRY(ctx, dev_malloc((void **)&t.d_lutT, lutT.size() * sizeof(float)));
+    hipError_t e = dev_malloc((void **)&t.d_tcs, tcs.size() * sizeof(float));
     int urc = e == hipSuccess ? RMDF_OK : fail(ctx, RMDF_E_HIP, std::string("lobe table: ") + hipGetErrorString(e));
     // (a caller's stream may launch the prefilter, rmdf_prefilter_env_device: the tables are complete before this returns)
     if (urc == RMDF_OK) urc = upload(ctx, t.d_lutT, lutT.data(), lutT.size() * sizeof(float), ctx->stream);
     if (urc == RMDF_OK) urc = upload(ctx, t.d_tcs, tcs.data(), tcs.size() * sizeof(float), ctx->stream);
     if (urc == RMDF_OK && (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) urc = fail(ctx, RMDF_E_HIP, std::string("lobe table upload: ") + hipGetErrorString(e));
     if (urc != RMDF_OK) {
-        (void)hipFree(t.d_lutT); if (t.d_tcs) (void)hipFree(t.d_tcs);
+        (void)dev_free(t.d_lutT); if (t.d_tcs) (void)dev_free(t.d_tcs);
         return urc;
     }
     if (ctx->lobe_tables.size() >= 4) {
         (void)hipDeviceSynchronize();
-        (void)hipFree(ctx->lobe_tables[0].d_lutT); (void)hipFree(ctx->lobe_tables[0].d_tcs);
+        (void)dev_free(ctx->lobe_tables[0].d_lutT); (void)dev_free(ctx->lobe_tables[0].d_tcs);
         ctx->lobe_tables.erase(ctx->lobe_tables.begin());
     }
     ctx->lobe_tables.push_back(t);
@@ -882,11 +882,11 @@ int set_env_from_device_faces(rmdf_ctx *ctx, int slot, const float *d_faces, int
 {
     uint2 *d_padded = nullptr;
     size_t n = (size_t)6 * (W + 2) * (W + 2);
-    HIP_TRY(ctx, hipMalloc((void **)&d_padded, n * sizeof(uint2)));
+    HIP_TRY(ctx, dev_malloc((void **)&d_padded, n * sizeof(uint2)));
     hipError_t e = launch_cube_upload(d_faces, W, d_padded, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { (void)hipFree(d_padded); return fail(ctx, RMDF_E_HIP, std::string("cube upload: ") + hipGetErrorString(e)); }
-    if (ctx->env[slot].d_texels) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->env[slot].d_texels); }
+    if (e != hipSuccess) { (void)dev_free(d_padded); return fail(ctx, RMDF_E_HIP, std::string("cube upload: ") + hipGetErrorString(e)); }
+    if (ctx->env[slot].d_texels) { (void)hipDeviceSynchronize(); (void)dev_free(ctx->env[slot].d_texels); }
     ctx->env[slot].d_texels = d_padded;
     ctx->env[slot].W = W;
     ctx->env_gen++;                 // tile jobs rendered ahead of their calls saw the old map: they are not for this environment
@@ -1008,10 +1008,10 @@ int issue_tile_job(rmdf_ctx *ctx, int b, int scene, int idx)
     if (!j.copied) HIP_TRY(ctx, hipEventCreateWithFlags(&j.copied, hipEventDisableTiming));
     if (j.px < tpx) {
         HIP_TRY(ctx, hipStreamSynchronize(j.stream));
-        if (j.d_tile) (void)hipFree(j.d_tile);
+        if (j.d_tile) (void)dev_free(j.d_tile);
         if (j.h_tile) (void)hipHostFree(j.h_tile);
         j.d_tile = j.h_tile = j.h_tile_dev = nullptr; j.px = 0;
-        HIP_TRY(ctx, hipMalloc((void **)&j.d_tile, tpx * 4));
+        HIP_TRY(ctx, dev_malloc((void **)&j.d_tile, tpx * 4));
         HIP_TRY(ctx, hipHostMalloc((void **)&j.h_tile, tpx * 4, hipHostMallocMapped));
         HIP_TRY(ctx, hipHostGetDevicePointer((void **)&j.h_tile_dev, j.h_tile, 0));
         j.px = tpx;
@@ -1325,9 +1325,9 @@ int rmdf_create(rmdf_ctx **out, const rmdf_config *cfg)
     const std::vector<uint32_t> &cgrid = cornell_grids(tri);
     if ((e = hipSetDevice(dev)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipMalloc((void **)&ctx->d_cornell, sizeof tri)) != hipSuccess ||
-        (e = hipMalloc((void **)&ctx->d_cornell_tab, sizeof tab)) != hipSuccess ||
-        (e = hipMalloc((void **)&ctx->d_cornell_grid, cgrid.size() * 4)) != hipSuccess ||
+        (e = dev_malloc((void **)&ctx->d_cornell, sizeof tri)) != hipSuccess ||
+        (e = dev_malloc((void **)&ctx->d_cornell_tab, sizeof tab)) != hipSuccess ||
+        (e = dev_malloc((void **)&ctx->d_cornell_grid, cgrid.size() * 4)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) {
         std::string msg = std::string("device init: ") + hipGetErrorString(e);
         rmdf_destroy(ctx);
@@ -1365,16 +1365,16 @@ void rmdf_destroy(rmdf_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();              // caller streams may still be running launches that use the ctx's tables
     rmdf_comm_destroy(ctx);
-    for (auto &s : ctx->env) if (s.d_texels) (void)hipFree(s.d_texels);
-    for (auto &t : ctx->uv_tables) (void)hipFree(t.d_uv);
-    for (auto &t : ctx->lobe_tables) { (void)hipFree(t.d_lutT); (void)hipFree(t.d_tcs); }
-    for (auto &sc : ctx->env_scratch) if (sc.p) (void)hipFree(sc.p);
-    if (ctx->d_cornell) (void)hipFree(ctx->d_cornell);
-    if (ctx->d_cornell_tab) (void)hipFree(ctx->d_cornell_tab);
-    if (ctx->d_cornell_grid) (void)hipFree(ctx->d_cornell_grid);
+    for (auto &s : ctx->env) if (s.d_texels) (void)dev_free(s.d_texels);
+    for (auto &t : ctx->uv_tables) (void)dev_free(t.d_uv);
+    for (auto &t : ctx->lobe_tables) { (void)dev_free(t.d_lutT); (void)dev_free(t.d_tcs); }
+    for (auto &sc : ctx->env_scratch) if (sc.p) (void)dev_free(sc.p);
+    if (ctx->d_cornell) (void)dev_free(ctx->d_cornell);
+    if (ctx->d_cornell_tab) (void)dev_free(ctx->d_cornell_tab);
+    if (ctx->d_cornell_grid) (void)dev_free(ctx->d_cornell_grid);
     if (ctx->probe_stream) (void)hipStreamDestroy(ctx->probe_stream);
     if (ctx->probe_host) (void)hipHostFree(ctx->probe_host);
-    if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
+    if (ctx->d_rgba8) (void)dev_free(ctx->d_rgba8);
     if (ctx->h_shadow) (void)hipHostFree(ctx->h_shadow);
     ctx->staging.destroy();
     for (int k = 0; k < RMDF_WF_MAX_BANDS; k++) {
@@ -1383,25 +1383,25 @@ void rmdf_destroy(rmdf_ctx *ctx)
     }
     if (ctx->wf_fork) (void)hipEventDestroy(ctx->wf_fork);
     for (auto &j : ctx->tile_job) {
-        if (j.d_tile) (void)hipFree(j.d_tile);
+        if (j.d_tile) (void)dev_free(j.d_tile);
         if (j.h_tile) (void)hipHostFree(j.h_tile);
         if (j.done) (void)hipEventDestroy(j.done);
         if (j.copied) (void)hipEventDestroy(j.copied);
         if (j.stream) (void)hipStreamDestroy(j.stream);
     }
-    if (ctx->d_rgba_f32) (void)hipFree(ctx->d_rgba_f32);
-    if (ctx->d_steps) (void)hipFree(ctx->d_steps);
-    if (ctx->d_iters) (void)hipFree(ctx->d_iters);
+    if (ctx->d_rgba_f32) (void)dev_free(ctx->d_rgba_f32);
+    if (ctx->d_steps) (void)dev_free(ctx->d_steps);
+    if (ctx->d_iters) (void)dev_free(ctx->d_iters);
 #ifdef RMDF_XCHECK
-    if (ctx->d_gbuf_nao) (void)hipFree(ctx->d_gbuf_nao);
-    if (ctx->d_gbuf_meta) (void)hipFree(ctx->d_gbuf_meta);
-    if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
-    if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
+    if (ctx->d_gbuf_nao) (void)dev_free(ctx->d_gbuf_nao);
+    if (ctx->d_gbuf_meta) (void)dev_free(ctx->d_gbuf_meta);
+    if (ctx->d_work_counter) (void)dev_free(ctx->d_work_counter);
+    if (ctx->d_dbg) (void)dev_free(ctx->d_dbg);
 #endif
     for (auto &r : ctx->host_regs) (void)hipHostUnregister(r.host);
     for (auto &o : ctx->orders) {
-        if (o.d_cost) (void)hipFree(o.d_cost);
-        if (o.d_order) (void)hipFree(o.d_order);
+        if (o.d_cost) (void)dev_free(o.d_cost);
+        if (o.d_order) (void)dev_free(o.d_order);
     }
     for (int k = 0; k < 4; k++) {
         if (ctx->pstream[k]) (void)hipStreamDestroy(ctx->pstream[k]);
@@ -1434,7 +1434,7 @@ int rmdf_set_env_cube(rmdf_ctx *ctx, int slot, const float *faces_rgb, int face_
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf faces;
     size_t bytes = (size_t)6 * face_w * face_w * 3 * sizeof(float);
-    HIP_TRY(ctx, hipMalloc(&faces.p, bytes));
+    HIP_TRY(ctx, dev_malloc(&faces.p, bytes));
     RMDF_TRY(upload(ctx, faces.p, faces_rgb, bytes, ctx->stream));
     return set_env_from_device_faces(ctx, slot, (const float *)faces.p, face_w);
     RMDF_GUARD_END(ctx)
@@ -1453,8 +1453,8 @@ int rmdf_set_env_latlong(rmdf_ctx *ctx, int slot, const float *rgb, int w, int h
     if (rc != RMDF_OK) return rc;
     DevBuf ll, faces;
     size_t ll_bytes = (size_t)w * h * 3 * sizeof(float), f_bytes = (size_t)6 * cw * cw * 3 * sizeof(float);
-    HIP_TRY(ctx, hipMalloc(&ll.p, ll_bytes));
-    HIP_TRY(ctx, hipMalloc(&faces.p, f_bytes));
+    HIP_TRY(ctx, dev_malloc(&ll.p, ll_bytes));
+    HIP_TRY(ctx, dev_malloc(&faces.p, f_bytes));
     RMDF_TRY(upload(ctx, ll.p, rgb, ll_bytes, ctx->stream));
     HIP_TRY(ctx, launch_latlong_to_cube((const float *)ll.p, w, h, d_uv, (float *)faces.p, ctx->stream));
     return set_env_from_device_faces(ctx, slot, (const float *)faces.p, cw);
@@ -1488,8 +1488,8 @@ int rmdf_resize_latlong(rmdf_ctx *ctx, const float *rgb, int w, int h, int dstw,
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf src, dst;
     size_t sb = (size_t)w * h * 12, db = (size_t)dstw * dh * 12;
-    HIP_TRY(ctx, hipMalloc(&src.p, sb));
-    HIP_TRY(ctx, hipMalloc(&dst.p, db));
+    HIP_TRY(ctx, dev_malloc(&src.p, sb));
+    HIP_TRY(ctx, dev_malloc(&dst.p, db));
     RMDF_TRY(upload(ctx, src.p, rgb, sb, ctx->stream));
     HIP_TRY(ctx, launch_resize_latlong((const float *)src.p, w, h, dstw, dh, (float *)dst.p, ctx->stream));
     return download(ctx, out, dst.p, db, ctx->stream);
@@ -1513,13 +1513,13 @@ int rmdf_prefilter_env_powers(rmdf_ctx *ctx, const float *rgb, int w, int h, con
         if (keep) {
             rmdf_ctx::Scratch &sc = ctx->env_scratch[i];
             if (sc.bytes < b) {
-                if (sc.p) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(sc.p); sc.p = nullptr; sc.bytes = 0; }
-                HIP_TRY(ctx, hipMalloc(&sc.p, b));
+                if (sc.p) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)dev_free(sc.p); sc.p = nullptr; sc.bytes = 0; }
+                HIP_TRY(ctx, dev_malloc(&sc.p, b));
                 sc.bytes = b;
             }
             p = sc.p;
         } else {
-            HIP_TRY(ctx, hipMalloc(&once[(size_t)i].p, b));
+            HIP_TRY(ctx, dev_malloc(&once[(size_t)i].p, b));
             p = once[(size_t)i].p;
         }
         if (i > 0) d_out[i - 1] = (float *)p; else d_src = p;
@@ -1754,8 +1754,8 @@ int rmdf_probe_tile_costs(rmdf_ctx *ctx, int scene, int w, int h, double time, i
     p.aspect = (float)w / (float)h;
     DevBuf steps, iters;
     const size_t npx = (size_t)pw * ph;
-    HIP_TRY(ctx, hipMalloc(&steps.p, npx * 2));
-    HIP_TRY(ctx, hipMalloc(&iters.p, npx * 2));
+    HIP_TRY(ctx, dev_malloc(&steps.p, npx * 2));
+    HIP_TRY(ctx, dev_malloc(&iters.p, npx * 2));
     p.x0 = 0; p.y0 = 0; p.x1 = pw; p.y1 = ph;
     p.steps = (uint16_t *)steps.p; p.iters = (uint16_t *)iters.p;
     HIP_TRY(ctx, launch_render(scene, p, ctx->stream));
@@ -1817,7 +1817,7 @@ int rmdf_comm_init(rmdf_ctx *ctx, const void *id, int rank, int nranks)
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
     ncclComm_t comm = nullptr;
-    if (!ctx->d_verify) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_verify, (size_t)64 * 8 + 8));
+    if (!ctx->d_verify) HIP_TRY(ctx, dev_malloc((void **)&ctx->d_verify, (size_t)64 * 8 + 8));
     RCCL_TRY(ctx, g_rccl.CommInitRank(&comm, nranks, uid, rank));
     ctx->comm = comm; ctx->comm_rank = rank; ctx->comm_nranks = nranks;
     return RMDF_OK;
@@ -1832,7 +1832,7 @@ int rmdf_comm_destroy(rmdf_ctx *ctx)
     (void)hipDeviceSynchronize();
     ncclComm_t c = ctx->comm;
     ctx->comm = nullptr; ctx->comm_rank = 0; ctx->comm_nranks = 1;
-    if (ctx->d_verify) { (void)hipFree(ctx->d_verify); ctx->d_verify = nullptr; }
+    if (ctx->d_verify) { (void)dev_free(ctx->d_verify); ctx->d_verify = nullptr; }
     RCCL_TRY(ctx, g_rccl.CommDestroy(c));
     return RMDF_OK;
 }
@@ -1963,8 +1963,8 @@ int rmdf_comm_selftest_loopback(rmdf_ctx *ctx, size_t bytes, void *stream, uint6
     std::vector<uint32_t> host(nw), back(nw);
     for (size_t i = 0; i < nw; i++) { uint32_t h = (uint32_t)i * 2654435761u + 0x9e3779b9u; h ^= h >> 15; h *= 2246822519u; host[i] = h ^ (h >> 13); }
     DevBuf src, dst;
-    HIP_TRY(ctx, hipMalloc(&src.p, bytes));
-    HIP_TRY(ctx, hipMalloc(&dst.p, bytes));
+    HIP_TRY(ctx, dev_malloc(&src.p, bytes));
+    HIP_TRY(ctx, dev_malloc(&dst.p, bytes));
     RMDF_TRY(upload(ctx, src.p, host.data(), bytes, st));
     HIP_TRY(ctx, hipMemsetAsync(dst.p, 0, bytes, st));
     // exactly the calls of the exchange step: a grouped receive (the root's side) and a send (a peer's side), on the caller's stream
@@ -2019,8 +2019,8 @@ int rmdf_render_supersampled(rmdf_ctx *ctx, int scene, int w, int h, int levels,
     int rc = fill_params(ctx, scene, sw, sh, (float)time, max_steps, p);
     if (rc != RMDF_OK) return rc;
     DevBuf a, b;
-    HIP_TRY(ctx, hipMalloc(&a.p, (size_t)sw * sh * 4));
-    if (levels > 0) HIP_TRY(ctx, hipMalloc(&b.p, (size_t)(sw / 2) * (sh / 2) * 4));
+    HIP_TRY(ctx, dev_malloc(&a.p, (size_t)sw * sh * 4));
+    if (levels > 0) HIP_TRY(ctx, dev_malloc(&b.p, (size_t)(sw / 2) * (sh / 2) * 4));
     p.x0 = 0; p.y0 = 0; p.x1 = sw; p.y1 = sh;
     p.rgba8 = (uint32_t *)a.p;
     rc = launch_scene(ctx, scene, p, ctx->stream);
@@ -2042,7 +2042,7 @@ int rmdf_selftest_exact_math(rmdf_ctx *ctx, uint64_t mismatches[10])
     if (!mismatches) return fail(ctx, RMDF_E_INVALID, "null output");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf d;
-    HIP_TRY(ctx, hipMalloc(&d.p, 10 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, dev_malloc(&d.p, 10 * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMemsetAsync(d.p, 0, 10 * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, launch_selftest_exact_math((unsigned long long *)d.p, ctx->d_cornell_tab, ctx->stream));
     return download(ctx, mismatches, d.p, 10 * sizeof(unsigned long long), ctx->stream);
@@ -2077,7 +2077,7 @@ int rmdf_selftest_pinned_math(rmdf_ctx *ctx, uint64_t mismatches[7])
     if (!mismatches) return fail(ctx, RMDF_E_INVALID, "null output");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf d;
-    HIP_TRY(ctx, hipMalloc(&d.p, 8 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, dev_malloc(&d.p, 8 * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMemsetAsync(d.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, launch_selftest_pinned_math((unsigned long long *)d.p, ctx->stream));
     return download(ctx, mismatches, d.p, 7 * sizeof(unsigned long long), ctx->stream);
@@ -2090,8 +2090,8 @@ int rmdf_selftest_shading_math(rmdf_ctx *ctx, uint64_t mismatches[5])
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int face_w = 64;                                  // a cube map of its own: 6 faces of 64 x 64 texels plus the seam padding
     DevBuf d, t;
-    HIP_TRY(ctx, hipMalloc(&d.p, 5 * sizeof(unsigned long long)));
-    HIP_TRY(ctx, hipMalloc(&t.p, (size_t)6 * (face_w + 2) * (face_w + 2) * 8));
+    HIP_TRY(ctx, dev_malloc(&d.p, 5 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, dev_malloc(&t.p, (size_t)6 * (face_w + 2) * (face_w + 2) * 8));
     HIP_TRY(ctx, hipMemsetAsync(d.p, 0, 5 * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, launch_selftest_shading_math((unsigned long long *)d.p, t.p, face_w, host_fov_xs(), ctx->stream));
     return download(ctx, mismatches, d.p, 5 * sizeof(unsigned long long), ctx->stream);
@@ -2132,7 +2132,7 @@ int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_wav
     const size_t cap = 32768;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (enable && !ctx->d_dbg) {
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_dbg, cap * 16 * sizeof(unsigned long long)));
+        HIP_TRY(ctx, dev_malloc((void **)&ctx->d_dbg, cap * 16 * sizeof(unsigned long long)));
         HIP_TRY(ctx, hipMemset(ctx->d_dbg, 0, cap * 16 * sizeof(unsigned long long)));
     }
     if (out && ctx->d_dbg) {
@@ -2142,7 +2142,7 @@ int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_wav
         RMDF_TRY(download(ctx, out, ctx->d_dbg, n * 16 * sizeof(unsigned long long), ctx->stream));
         HIP_TRY(ctx, hipMemset(ctx->d_dbg, 0, cap * 16 * sizeof(unsigned long long)));
     }
-    if (!enable && ctx->d_dbg) { (void)hipFree(ctx->d_dbg); ctx->d_dbg = nullptr; }
+    if (!enable && ctx->d_dbg) { (void)dev_free(ctx->d_dbg); ctx->d_dbg = nullptr; }
     return RMDF_OK;
 }
 #endif
@@ -2226,7 +2226,7 @@ int rmdf_device_malloc(rmdf_ctx *ctx, size_t bytes, void **d_ptr)
     if (!d_ptr || bytes == 0) return fail(ctx, RMDF_E_INVALID, "rmdf_device_malloc: bad argument");
     *d_ptr = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMalloc(d_ptr, bytes));
+    HIP_TRY(ctx, dev_malloc(d_ptr, bytes));
     return RMDF_OK;
 }
 
@@ -2235,7 +2235,7 @@ int rmdf_device_free(rmdf_ctx *ctx, void *d_ptr)
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
     if (!d_ptr) return RMDF_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipFree(d_ptr));
+    HIP_TRY(ctx, dev_free(d_ptr));
     return RMDF_OK;
 }
 

@@ -970,6 +970,71 @@ __device__ __forceinline__ float de_cornell_box_lanes(v3 pos, const float *rows,
     return sqrt_rn(best);
 }
 
+// ---- the cross-lane form of the estimate (round 5): EIGHT lanes per ray ------------------------------------------------------------
+// The Cornell launch lasts as long as its slowest wave, and that wave spends most of its life marching a handful of grazing rays that run
+// all 128 steps: one step of the per-lane estimate above is a serial chain of ~430 instructions (the hinted triangle, a pass of bound
+// tests per candidate, the survivors) that a wave with one or two live lanes issues at one instruction per ~5 cycles -- 0.9 to 1.4 us a
+// step.  Once a wave is down to eight live rays (k_render), each ray moves into a GROUP of eight lanes that all hold its state, and the
+// candidates of its cell are measured side by side, one triangle per lane: no bounds, no second pass, the minimum by three DPP steps.
+// min() is exact and order-independent and every triangle's distance is computed by the same cornell_tri_dist2 on the same operands,
+// so the estimate has the bits of the per-lane form (and of the reference's 32-triangle loop).
+// Candidates: the cell's mask arrives from global memory (L2) -- a latency the per-lane form hides behind its hinted triangle; here the
+// lanes measure the PREVIOUS step's candidates while it is in flight (a superset of the cell's candidates gives the same minimum: every
+// value is a true triangle distance and the nearest triangle is among the cell's), and then whatever the new mask adds, usually nothing.
+
+// index of the set bit of rank k in m (k < popcount(m)), by halving
+__device__ __forceinline__ int nth_set_bit32(unsigned m, int k)
+{
+    int idx = 0;
+    unsigned c = (unsigned)__builtin_popcount(m & 0xffffu);
+    if (k >= (int)c) { k -= (int)c; m >>= 16; idx += 16; }
+    c = (unsigned)__builtin_popcount(m & 0xffu);
+    if (k >= (int)c) { k -= (int)c; m >>= 8; idx += 8; }
+    c = (unsigned)__builtin_popcount(m & 0xfu);
+    if (k >= (int)c) { k -= (int)c; m >>= 4; idx += 4; }
+    c = (unsigned)__builtin_popcount(m & 0x3u);
+    if (k >= (int)c) { k -= (int)c; m >>= 2; idx += 2; }
+    if (k >= (int)(m & 1u)) idx += 1;
+    return idx;
+}
+// min over the eight lanes of a group (lanes 8g .. 8g+7), result in all of them; `x < v ? x : v` as everywhere in this estimate
+__device__ __forceinline__ float group8_min(float v)
+{
+    float o;
+    o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]
+    v = (o < v) ? o : v;
+    o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
+    v = (o < v) ? o : v;
+    o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));    // row_half_mirror: lane i <-> 7 - i
+    v = (o < v) ? o : v;
+    return v;
+}
+// One estimate for the ray of this lane's group; EVERY lane of the wave calls it (live = the group has a ray; the others ignore the result).  sub = lane & 7.  prev: the candidates measured speculatively (in/out: this step's mask for the next step).
+__device__ __forceinline__ float de_cornell_box_group8(bool live, v3 pos, const float *rows, const unsigned *fine, int sub, unsigned &prev)
+{
+    // (a group without a ray measures nothing: empty masks)
+    const unsigned m = live ? cornell_cell_mask_fast<CORNELL_FINE_N>(pos, fine) : 0u;      // in flight while the previous candidates are measured
+    if (!live) prev = 0u;
+    float best = 998001.0f;                                                    // 999^2, the loop's start value (fragment.shd:400)
+    unsigned set = prev;
+#pragma unroll 1
+    for (int round = 0; round < 2; round++) {
+        // this lane's triangles of `set`: ranks sub, sub + 8, ...
+        int n = __builtin_popcount(set);
+        for (int k = sub; __ballot(k < n) != 0ull; k += 8) {
+            if (k < n) {
+                const int i = nth_set_bit32(set, k);
+                const float x = cornell_tri_dist2(pos, rows + i * CORNELL_STRIDE);
+                best = (x < best) ? x : best;
+            }
+        }
+        set = m & ~prev;                                                       // what the cell's own mask adds
+        if (round == 0 && __ballot(set != 0u) == 0ull) break;
+    }
+    prev = m == 0xffffffffu ? 0u : m;          // (a point outside the grid measures all 32: nothing to carry over)
+    return sqrt_rn(group8_min(best));
+}
+
 __device__ __forceinline__ float de_cornell_box_table(v3 pos, const float *__restrict__ tab, int prune, int &hint, const unsigned *grid = nullptr)
 {
     float dist2 = 998001.0f;                                   // 999^2

@@ -13,6 +13,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -210,5 +211,95 @@ struct Staging {
         cap = 0;
     }
 };
+
+// ---- device allocations -------------------------------------------------------------------------------------------------------------
+// dev_malloc / dev_free: hipMalloc / hipFree in the product.  In the cross-check build (librmdf_xcheck.so) the environment variable
+// RMDF_GUARD_ALLOC = "end" | "start" turns every device allocation of the library into an ELECTRIC-FENCE allocation: its own physical
+// pages (hipMemCreate) mapped into a reserved address range with one UNMAPPED granule before and one behind, the buffer flush against the
+// end (or the start) of the mapped part.  A kernel that reads or writes one element past a buffer then takes a GPU memory fault on the
+// spot -- every kernel, every access, the shipped code paths, no instrumentation -- instead of reading a neighbour's bytes that happen to
+// be mapped (GPU AddressSanitizer is not available on this pool).  tests/test_gpu_guard.py runs the library's workloads both ways.
+#ifdef RMDF_XCHECK
+struct GuardAlloc {
+    struct Rec { void *user; void *va; size_t va_bytes, map_bytes; hipMemGenericAllocationHandle_t handle; };
+    std::mutex m;
+    std::vector<Rec> recs;
+    int mode = -1;                     // -1 unread, 0 off, 1 end, 2 start
+    static GuardAlloc &get() { static GuardAlloc g; return g; }
+    int read_mode()
+    {
+        if (mode < 0) { const char *v = getenv("RMDF_GUARD_ALLOC"); mode = !v ? 0 : (v[0] == 'e' ? 1 : (v[0] == 's' ? 2 : 0)); }
+        return mode;
+    }
+    hipError_t alloc(void **p, size_t bytes)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        size_t gran = 0;
+        if ((e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum)) != hipSuccess) return e;
+        if (gran == 0) return hipErrorInvalidValue;
+        Rec r = {};
+        r.map_bytes = (bytes + gran - 1) / gran * gran;
+        r.va_bytes = r.map_bytes + 2 * gran;
+        if ((e = hipMemCreate(&r.handle, r.map_bytes, &prop, 0)) != hipSuccess) return e;
+        if ((e = hipMemAddressReserve(&r.va, r.va_bytes, gran, nullptr, 0)) != hipSuccess) { (void)hipMemRelease(r.handle); return e; }
+        char *mapped = (char *)r.va + gran;
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        if ((e = hipMemMap(mapped, r.map_bytes, 0, r.handle, 0)) != hipSuccess ||
+            (e = hipMemSetAccess(mapped, r.map_bytes, &acc, 1)) != hipSuccess) {
+            (void)hipMemUnmap(mapped, r.map_bytes); (void)hipMemAddressFree(r.va, r.va_bytes); (void)hipMemRelease(r.handle);
+            return e;
+        }
+        // flush against the end: the last byte of the buffer is the last mapped byte whenever 16 divides the size (the alignment the
+        // kernels' widest accesses need); flush against the start: hipMalloc's own alignment
+        r.user = mode == 1 ? mapped + r.map_bytes - (bytes + 15) / 16 * 16 : mapped;
+        std::lock_guard<std::mutex> lk(m);
+        recs.push_back(r);
+        *p = r.user;
+        return hipSuccess;
+    }
+    bool free_if_mine(void *p, hipError_t &e)
+    {
+        Rec r;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            size_t i = 0;
+            for (; i < recs.size(); i++) if (recs[i].user == p) break;
+            if (i == recs.size()) return false;
+            r = recs[i];
+            recs.erase(recs.begin() + (long)i);
+        }
+        e = hipDeviceSynchronize();                             // hipFree's implicit wait
+        char *mapped = (char *)r.va + (r.va_bytes - r.map_bytes) / 2;
+        (void)hipMemUnmap(mapped, r.map_bytes);
+        (void)hipMemRelease(r.handle);
+        (void)hipMemAddressFree(r.va, r.va_bytes);
+        return true;
+    }
+};
+inline hipError_t dev_malloc(void **p, size_t bytes)
+{
+    GuardAlloc &g = GuardAlloc::get();
+    if (g.read_mode() == 0 || bytes == 0) return hipMalloc(p, bytes);
+    return g.alloc(p, bytes);
+}
+inline hipError_t dev_free(void *p)
+{
+    if (!p) return hipSuccess;
+    hipError_t e = hipSuccess;
+    if (GuardAlloc::get().mode > 0 && GuardAlloc::get().free_if_mine(p, e)) return e;
+    return hipFree(p);
+}
+#else
+inline hipError_t dev_malloc(void **p, size_t bytes) { return hipMalloc(p, bytes); }
+inline hipError_t dev_free(void *p) { return hipFree(p); }
+#endif
 
 }  // namespace rmdf

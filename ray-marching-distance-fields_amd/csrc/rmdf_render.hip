@@ -86,6 +86,11 @@ __device__ __forceinline__ float bsphere_r() { return SCENE == 2 ? shk::bsphere_
 // iteration planes of rmdf_render_tile_ex (parity tests, cost probe).
 enum { OUT_RGBA8 = 0, OUT_MIRROR = 1, OUT_PLANES = 2 };
 #define WPB 4                       // waves per workgroup: a 32x8 strip
+#ifdef RMDF_AB_NO_XL                // A/B switch (tools/abtest): the Cornell march without the eight-lanes-per-ray tail
+#define XL_TAIL false
+#else
+#define XL_TAIL true
+#endif
 
 // Everything a lane derives from (strip, thread id): the rectangle of its launch / shard slot, its pixel, its primary ray.
 // (Deriving it a second time after the march from laundered inputs, so that none of it occupies registers across the march
@@ -177,7 +182,69 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
     int tri_hint = 0;               // Cornell: evaluation-order hint of the distance estimate (never a result)
     float t = 0.0f;
     float tmin, tmax;
-    if (!MERGE) {
+    if (!MERGE && SCENE == 0 && XL_TAIL) {
+        // Cornell box, pruned estimate: the wave marches lane by lane while more than eight of its rays are live, then moves every
+        // remaining ray into a group of eight lanes (rmdf_device.hpp: de_cornell_box_group8).  The march is the one below, statement
+        // for statement; a ray's (t, steps, hit) do not depend on where it was marched.
+        __shared__ float2 s_xl[WPB * 64];                     // results of rays finished in a group, by home lane: t, steps | hit << 15
+        bool act = g.active && ray_sphere(origin, g.dir, bsphere_r<SCENE>(), tmin, tmax) && p.max_steps > 0;
+        t = act ? gmax(0.0f, tmin) : 0.0f;
+        if (!act) tmax = 0.0f;
+        const int lane = g.lane, wave = __builtin_amdgcn_readfirstlane(g.wave);
+        bool moved = false;
+        for (;;) {
+            const unsigned long long am = __ballot(act);
+            if (am == 0ull) break;
+            if (cgrid && __popcll(am) <= 8) {
+                // group gi = the gi-th live lane's ray: every lane of the group takes a copy of its state
+                const int gi = lane >> 3, sub = lane & 7;
+                unsigned long long mm = am;
+                for (int i = 0; i < gi; i++) mm &= mm - 1ull;
+                const bool gact0 = mm != 0ull;
+                const int home = gact0 ? (int)__builtin_ctzll(mm) : lane;
+                moved = act;
+                float xt = __shfl(t, home, 64), xtmax = __shfl(tmax, home, 64);
+                int xs = __shfl(steps, home, 64);
+                const float xdx = __shfl(g.dir.x, home, 64), xdy = __shfl(g.dir.y, home, 64), xdz = __shfl(g.dir.z, home, 64);
+                bool gact = gact0;
+                unsigned prev = 0u;
+                while (__ballot(gact) != 0ull) {
+                    const v3 pos = mk3(origin.x + xt * xdx, origin.y + xt * xdy, origin.z + xt * xdz);
+                    const float dist = de_cornell_box_group8(gact, pos, s_ctab, cgrid, sub, prev);
+                    if (gact) {
+                        xt += dist;
+                        const bool out = xt > xtmax;
+                        const bool h2 = !out && (dist < shk::march_min_dist);
+                        bool done = out || h2;
+                        if (!done) { xs++; done = xs >= p.max_steps; }
+                        if (done) {
+                            if (sub == 0) s_xl[wave * 64 + home] = make_float2(xt, __int_as_float(xs | (h2 ? 0x8000 : 0)));
+                            gact = false;
+                        }
+                    }
+                }
+                break;
+            }
+            if (act) {
+                const v3 pos = mk3(origin.x + t * g.dir.x, origin.y + t * g.dir.y, origin.z + t * g.dir.z);
+                const float dist = distance_estimator<SCENE>(pos, p, iters, tri_hint, cgrid, s_ctab);
+                t += dist;
+                if (t > tmax) act = false;
+                else if (dist < shk::march_min_dist) { hit = true; act = false; }
+                else { steps++; if (steps >= p.max_steps) act = false; }
+            }
+        }
+        if (moved) {
+            const float2 r2 = s_xl[wave * 64 + lane];       // written by this wave (LDS operations of one wave complete in order)
+            t = r2.x;
+            const int sb = __float_as_int(r2.y);
+            steps = sb & 0x7fff;
+            hit = (sb >> 15) != 0;
+        }
+#ifdef RMDF_XCHECK
+        dbg_t_march = p.dbg ? (unsigned)((__builtin_amdgcn_s_memrealtime() - dbg_t0)) : 0u;
+#endif
+    } else if (!MERGE) {
         if (g.active && ray_sphere(origin, g.dir, bsphere_r<SCENE>(), tmin, tmax)) {
             t = gmax(0.0f, tmin);
             for (steps = 0; steps < p.max_steps; steps++) {

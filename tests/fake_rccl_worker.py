@@ -47,14 +47,14 @@ def main():
     frame = [torch.zeros((h, w), **i32) if rank == 0 else None for _ in range(S)]
     single = sr.render(2, w, h, 0.0, max_steps=ms, want_f32=False)["rgba8"] if rank == 0 else None
 
-    def frames(times, tag):
+    def frames(times, tag, check=True):
         """len(times) frames in flight on one communicator, frame i on stream i % S; rank 0 checks each against the single launch"""
         for i, t in enumerate(times):
             k = i % S
             sr.render_frame_sharded_device(2, w, h, t, ms, shard[k].data_ptr(), gath[k].data_ptr() if rank == 0 else 0,
                                            frame[k].data_ptr() if rank == 0 else 0, stream=streams[k].cuda_stream)
         torch.cuda.synchronize(dev)
-        if rank == 0:
+        if rank == 0 and check:
             for i, t in enumerate(times):
                 if i >= len(times) - S and t == 0.0:
                     got = frame[i % S].cpu().numpy().view(np.uint32)
@@ -80,8 +80,8 @@ def main():
         raise AssertionError("rmdf_comm_verify_deal accepted different deals")
     except rmdf_amd.RmdfError as e:
         assert e.code == -8 and "different tile deals" in str(e), str(e)
-    # ... and the exchange falls back to whole fixed-size slots: sizes on the wire still agree (the frame is whatever the mixed deals give)
-    frames([0.0], "unverified deals: whole slots")
+    # ... and the exchange itself still runs to the end: the sizes on the wire never depend on the deal (the frame is whatever the mixed deals give)
+    frames([0.0], "mixed deals", check=False)
     # 4. back to one deal everywhere; verified again; a frame at another time in between
     sr.set_shard_costs(cost)
     sr.comm_verify_deal()

@@ -177,7 +177,7 @@ def test_tile_jobs_issued_ahead_belong_to_one_environment(rmdf, env_faces):
         r.close()
 
 
-@pytest.mark.parametrize("bands,mirror", [(0, 0), (1, 0), (3, 0), (16, 0), (0, 1), (5, 1)])
+@pytest.mark.parametrize("bands,mirror", [(0, 0), (1, 0), (16, 0), (5, 1)])
 def test_whole_frame_host_call_in_row_bands(rmdf, env_faces, bands, mirror):
     """Round 5: rmdf_render_tile(tile_idx = -1, pageable pointer) -- the reference viewer's per-frame call (Main.hs:67, App.hs:154-166) --
     renders the frame as row bands on streams of their own and moves each band to the caller through the page-locked shadow while the
@@ -188,7 +188,7 @@ def test_whole_frame_host_call_in_row_bands(rmdf, env_faces, bands, mirror):
     try:
         for slot, k in ((rmdf.ENV_REFLECTION, "refl"), (rmdf.ENV_COS_1, "cos1"), (rmdf.ENV_COS_8, "cos8")):
             r.set_env_cube(slot, env_faces[k])
-        for scene, w, h, ms in ((2, 1920, 1080, 64), (0, 1283, 721, 32), (2, 200, 100, 64), (3, 1000, 999, 24)):
+        for scene, w, h, ms in ((2, 1920, 1080, 64), (0, 1283, 721, 32), (2, 200, 100, 64), (3, 600, 599, 24)):
             ref = r.render(scene, w, h, 0.7, max_steps=ms, want_f32=False)["rgba8"]
             for rep in range(2):                             # the second call runs cost-ordered, band by band
                 fb = np.full(w * h + 64, 0xDEADBEEF, np.uint32)

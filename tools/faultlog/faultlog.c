@@ -62,7 +62,28 @@ __attribute__((constructor)) static void init(void)
     struct sigaction sa; memset(&sa, 0, sizeof sa); sa.sa_handler = dump; sigaction(SIGABRT, &sa, NULL); sigaction(SIGSEGV, &sa, NULL); sigaction(SIGBUS, &sa, NULL);
 }
 
-#define NEXT(name) static __typeof__(&name) real; if (!real) real = (__typeof__(&name))dlsym(RTLD_NEXT, #name)
+// The real entry point: from the copy of the library that is ALREADY in the process (python imports torch's bundled ROCm libraries with
+// RTLD_LOCAL: RTLD_NEXT does not see them), first in load order; RTLD_NEXT as the fall-back for plain hosts.
+#include <link.h>
+struct find_lib { const char *part; char path[512]; };
+static int find_lib_cb(struct dl_phdr_info *info, size_t size, void *data)
+{
+    struct find_lib *f = (struct find_lib *)data;
+    (void)size;
+    if (!f->path[0] && info->dlpi_name && strstr(info->dlpi_name, f->part) && !strstr(info->dlpi_name, "libfaultlog")) snprintf(f->path, sizeof f->path, "%s", info->dlpi_name);
+    return 0;
+}
+static void *real_sym(const char *lib_part, const char *name)
+{
+    struct find_lib f; f.part = lib_part; f.path[0] = 0;
+    dl_iterate_phdr(find_lib_cb, &f);
+    void *p = NULL;
+    if (f.path[0]) { void *h = dlopen(f.path, RTLD_NOW | RTLD_NOLOAD); if (h) p = dlsym(h, name); }
+    if (!p) p = dlsym(RTLD_NEXT, name);
+    if (!p) { fprintf(stderr, "faultlog: cannot resolve %s\n", name); abort(); }
+    return p;
+}
+#define NEXT(name) static __typeof__(&name) real; if (!real) real = (__typeof__(&name))real_sym(#name[1] == 's' ? "libhsa-runtime64" : "libamdhip64", #name)
 #define RA __builtin_return_address(0)
 
 hipError_t hipMalloc(void **p, size_t n) { NEXT(hipMalloc); hipError_t e = real(p, n); rec("hipMalloc", p ? (uint64_t)*p : 0, n, e, RA); return e; }
