@@ -82,8 +82,10 @@ typedef struct {
     int device;      /* HIP device ordinal                                              */
     int reserved[7]; /* [0] = RMDF_FLAG_* bits; [1] = host threads that copy frames to the caller, the calling thread included
                         (0 = chosen by core count: 16 on >= 64 cores, 8 on > 8); [2] = row bands a whole-frame call into host
-                        memory keeps in flight (0 = the library's choice, 1 = one launch; at most 16); [3] = 1: those bands reach
-                        the host by the render kernel's own stores instead of a copy behind it; rest zero */
+                        memory keeps in flight (0 = the library's choice, 1 = one launch; at most 16); [3] = how those bands reach the host: 0 = the
+                        library's choice; 1 = one launch per band, the kernel storing the rows into page-locked host memory itself;
+                        2 = ONE launch that does so and flags every completed band; 3 = the same with the strips dispatched band by
+                        band; (0 with [2] given: one launch per band and a copy behind it); rest zero */
 } rmdf_config;
 
 /* ---- lifetime: withShaderRenderer (ShaderRendering.hs:60-110) --------------------- */

@@ -237,7 +237,7 @@ class ShaderRenderer:
         cfg.reserved[0] = flags
         cfg.reserved[1] = copy_threads             # host threads of the frame copies (0 = library default)
         cfg.reserved[2] = frame_bands              # whole-frame host calls: row bands in flight (0 = library default, 1 = one launch)
-        cfg.reserved[3] = frame_mirror             # ... their rows reach the host by the kernel's own stores (1) instead of a copy behind it (0)
+        cfg.reserved[3] = frame_mirror             # ... how their rows reach the host: rmdf.h (0 .. 3)
         err = C.create_string_buffer(1024)
         rc = self._lib.rmdf_create_ex(C.byref(self._ctx), C.byref(cfg), err, 1024)
         if rc != 0:

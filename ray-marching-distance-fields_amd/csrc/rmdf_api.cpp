@@ -47,7 +47,7 @@ struct OrderState {
     hipStream_t stream = nullptr;
     unsigned   *d_cost = nullptr, *d_order = nullptr;
     int         cap = 0, n = 0;
-    int         key[10] = { -1, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    int         key[12] = { -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     bool        used = false, valid = false;
     unsigned    last_use = 0;
 };
@@ -98,11 +98,15 @@ struct rmdf_ctx {
     Staging      staging;              // the page-locked chunks between caller memory and the device (rmdf_host.hpp)
     // whole-frame calls into pageable memory (render_whole_frame_host): row bands on streams of their own
 #define RMDF_WF_MAX_BANDS 16
-#define RMDF_WF_DEFAULT_BANDS 6
+#define RMDF_WF_DEFAULT_BANDS 2
+#define RMDF_WF_DEFAULT_MODE 1
     hipStream_t  wf_stream[RMDF_WF_MAX_BANDS] = { nullptr };
     hipEvent_t   wf_done[RMDF_WF_MAX_BANDS] = { nullptr };
     hipEvent_t   wf_fork = nullptr;
     int          wf_bands = 0, wf_mirror = 0;      // rmdf_config.reserved[2], [3]
+    volatile unsigned *wf_flags = nullptr, *wf_flags_dev = nullptr;       // one-launch hand-over: band k of frame `seq` is in the shadow when wf_flags[k] == seq
+    unsigned    *d_wf_count = nullptr;
+    unsigned     wf_seq = 0;
     unsigned     spec_dropped = 0;     // tile jobs that could not be issued ahead of their call (render_tile_fast)
     unsigned     env_gen = 0;          // bumped whenever a cube-map slot changes: tile jobs rendered ahead belong to ONE environment
     // ... and the tile jobs of that mode: a tile is rendered into a device scratch tile AND, by the kernel's mirror store, into a
@@ -481,7 +485,9 @@ int ensure_gbuf(rmdf_ctx *ctx, int w, int h)
 
 // after_render (optional): queued on `stream` right behind the render kernel, before the sort of next frame's strip order -- what a caller
 // waits for (an event, a copy of the rows) must not wait for that sort too
-int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t stream, const std::function<int()> *after_render = nullptr)
+// order_bands > 0 (with p.band_strip_rows): dispatch order of a whole-frame host call that hands bands over as they complete --
+// the costliest strips first, then band by band from the outside in (k_order_blocks)
+int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t stream, const std::function<int()> *after_render = nullptr, int order_bands = 0)
 {
 #ifdef RMDF_XCHECK
     // librmdf_xcheck.so: the alternative schedule of the same per-ray arithmetic (cross-check tests, A/B measurements).
@@ -535,14 +541,20 @@ int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t str
             HIP_TRY(ctx, dev_malloc((void **)&os->d_order, (size_t)nblk * 4));
             os->cap = nblk;
         }
-        const int key[10] = { scene, p.w, p.h, p.x0, p.y0, p.x1, p.y1, p.max_steps,
-                              p.n_shard_tiles, p.shard_key };
+        const int key[12] = { scene, p.w, p.h, p.x0, p.y0, p.x1, p.y1, p.max_steps,
+                              p.n_shard_tiles, p.shard_key, p.band_flag ? p.band_strip_rows : 0, order_bands };
         const bool same = os->valid && os->n == nblk && memcmp(key, os->key, sizeof key) == 0;
         q.block_cost = os->d_cost;
         q.block_order = same ? os->d_order : nullptr;
         HIP_TRY(ctx, launch_render(scene, q, stream));
         if (after_render) RMDF_TRY((*after_render)());
-        HIP_TRY(ctx, launch_order_blocks(os->d_cost, nblk, os->d_order, stream));
+        if (order_bands > 0) {
+            // (single-rectangle launches only: strip index = column + row * columns)
+            const int gx = (((p.x1 + 1) & ~1) - (p.x0 & ~1) + 31) / 32;
+            HIP_TRY(ctx, launch_order_blocks(os->d_cost, nblk, os->d_order, stream, gx, p.band_strip_rows, order_bands));
+        } else {
+            HIP_TRY(ctx, launch_order_blocks(os->d_cost, nblk, os->d_order, stream));
+        }
         memcpy(os->key, key, sizeof key);
         os->n = nblk; os->valid = true;
     } else {
@@ -1107,6 +1119,69 @@ int render_tile_fast(rmdf_ctx *ctx, int scene, int tile_idx, const FrameParams &
     return RMDF_OK;
 }
 
+// The same hand-over with ONE launch (rmdf_config.reserved[3] = 2, 3): the kernel stores the frame's rows into the page-locked shadow itself
+// (mirror stores) and, band by band, tells the host when all rows of a band have landed (FrameParams::band_flag); the host threads copy
+// each band to the caller while the launch is still running.  No per-band launches, copies or events: a band costs the host nothing
+// until it is complete.  reserved[3] = 3 also dispatches the strips band by band behind the costliest ones, outer bands first, so
+// that the bands do complete one after the other (plain longest-first order finishes all of them at the end).
+int render_whole_frame_one_launch(rmdf_ctx *ctx, int scene, const FrameParams &p, uint32_t *out_rgba8, int nb, int mode)
+{
+    const int w = ctx->w, h = ctx->h;
+    WorkPool &pool = ctx_pool(ctx);
+    const int strip_rows = (h + 7) / 8;
+    int bsr = (strip_rows + nb - 1) / nb;                            // rows of strips per band
+    if (bsr < 1) bsr = 1;
+    nb = (strip_rows + bsr - 1) / bsr;
+    if (!ctx->wf_flags) {
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->wf_flags, RMDF_WF_MAX_BANDS * sizeof(unsigned), hipHostMallocMapped));
+        memset((void *)ctx->wf_flags, 0, RMDF_WF_MAX_BANDS * sizeof(unsigned));
+        HIP_TRY(ctx, hipHostGetDevicePointer((void **)&ctx->wf_flags_dev, (void *)ctx->wf_flags, 0));
+        HIP_TRY(ctx, dev_malloc((void **)&ctx->d_wf_count, RMDF_WF_MAX_BANDS * sizeof(unsigned)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_wf_count, 0, RMDF_WF_MAX_BANDS * sizeof(unsigned), ctx->stream));
+    }
+    const unsigned seq = ++ctx->wf_seq ? ctx->wf_seq : ++ctx->wf_seq;      // never 0: the flags start there
+    FrameParams q = p;
+    q.x0 = 0; q.x1 = w; q.y0 = 0; q.y1 = h;
+    q.rgba8 = ctx->d_rgba8;
+    q.rgba8_mirror = ctx->h_shadow_dev;
+    q.band_count = ctx->d_wf_count; q.band_flag = ctx->wf_flags_dev; q.band_seq = seq; q.band_strip_rows = bsr;
+    int rc = launch_scene(ctx, scene, q, ctx->stream, nullptr, mode >= 3 ? nb : 0);
+    if (rc != RMDF_OK) { (void)hipDeviceSynchronize(); ctx->shadow_valid = false; return rc; }
+    char *sh = (char *)ctx->h_shadow, *dst = (char *)out_rgba8;
+    unsigned pending = nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u);
+    unsigned spins = 0;
+    while (pending) {
+        for (int k = 0; k < nb; k++) {
+            if (!((pending >> k) & 1u)) continue;
+            if (__atomic_load_n(&ctx->wf_flags[k], __ATOMIC_ACQUIRE) != seq) continue;
+            const int y0 = k * bsr * 8, y1 = (k + 1) * bsr * 8 < h ? (k + 1) * bsr * 8 : h;
+            const size_t off = (size_t)y0 * w * 4, bytes = (size_t)(y1 - y0) * w * 4;
+            pool.copy(dst + off, sh + off, bytes);
+            pending &= ~(1u << k);
+        }
+        if (pending) {
+            __builtin_ia32_pause();
+            // a launch that died leaves its flags unset: look at the stream now and then instead of spinning for ever
+            if ((++spins & 0xffffu) == 0u) {
+                const hipError_t e = hipStreamQuery(ctx->stream);
+                if (e != hipSuccess && e != hipErrorNotReady) { ctx->shadow_valid = false; return fail(ctx, RMDF_E_HIP, std::string("whole-frame launch: ") + hipGetErrorString(e)); }
+                if (e == hipSuccess) {
+                    // the stream is idle and a flag is still missing: cannot happen with a healthy launch -- finish from the device frame
+                    bool all = true;
+                    for (int k = 0; k < nb; k++) if (((pending >> k) & 1u) && __atomic_load_n(&ctx->wf_flags[k], __ATOMIC_ACQUIRE) != seq) all = false;
+                    if (!all) {
+                        ctx->shadow_valid = false;
+                        HIP_TRY(ctx, hipMemsetAsync(ctx->d_wf_count, 0, RMDF_WF_MAX_BANDS * sizeof(unsigned), ctx->stream));
+                        return download(ctx, out_rgba8, ctx->d_rgba8, (size_t)w * h * 4, ctx->stream);
+                    }
+                }
+            }
+        }
+    }
+    ctx->shadow_valid = true;
+    return RMDF_OK;
+}
+
 // Whole frame into PAGEABLE caller memory: `rmdf_render_tile(tile_idx = -1, ptr)`, the call the reference's viewer makes every frame
 // (Main.hs:67 starts it with tiling off; App.hs:154-166 -> fillFrameBuffer, FrameBuffer.hs:117-158).  Launch, copy 8.3 MB, return
 // costs 0.59 ms at 1080p against 0.38 ms for the kernel: the copy (and the runtime's page-locking of the caller's pages for it) stands
@@ -1121,10 +1196,13 @@ int render_whole_frame_host(rmdf_ctx *ctx, int scene, const FrameParams &p, uint
     const size_t npx = (size_t)w * h;
     RMDF_TRY(ensure_shadow(ctx, npx));
     WorkPool &pool = ctx_pool(ctx);
+    // the library's choice (neither knob given): RMDF_WF_DEFAULT_* -- measured on the headline frame and the Cornell box, tools/whole_frame_sweep.py
+    const int mode = (ctx->wf_bands == 0 && ctx->wf_mirror == 0) ? RMDF_WF_DEFAULT_MODE : ctx->wf_mirror;
     int nb = ctx->wf_bands > 0 ? ctx->wf_bands : RMDF_WF_DEFAULT_BANDS;
     if (npx * 4 < ((size_t)2 << 20)) nb = 1;                         // small frames: one launch, one copy
     if (nb > h / 64) nb = h / 64 > 0 ? h / 64 : 1;                   // a band is at least 64 rows
-    const bool mirror = ctx->wf_mirror != 0;
+    const bool mirror = mode != 0;
+    if (mode >= 2) return render_whole_frame_one_launch(ctx, scene, p, out_rgba8, nb, mode);
     int ys[RMDF_WF_MAX_BANDS + 1];
     for (int k = 0; k <= nb; k++) ys[k] = k == nb ? h : (int)(((long long)h * k / nb) & ~7ll);
     for (int k = 0; k < nb; k++) {
@@ -1343,9 +1421,9 @@ int rmdf_create(rmdf_ctx **out, const rmdf_config *cfg)
     }
     ctx->wf_bands = cfg ? cfg->reserved[2] : 0;
     ctx->wf_mirror = cfg ? cfg->reserved[3] : 0;
-    if (ctx->wf_bands < 0 || ctx->wf_bands > RMDF_WF_MAX_BANDS || ctx->wf_mirror < 0 || ctx->wf_mirror > 1) {
+    if (ctx->wf_bands < 0 || ctx->wf_bands > RMDF_WF_MAX_BANDS || ctx->wf_mirror < 0 || ctx->wf_mirror > 3) {
         rmdf_destroy(ctx);
-        return fail(nullptr, RMDF_E_INVALID, "rmdf_config.reserved[2] (whole-frame row bands): 0 .. 16; reserved[3] (mirror stores): 0 / 1");
+        return fail(nullptr, RMDF_E_INVALID, "rmdf_config.reserved[2] (whole-frame row bands): 0 .. 16; reserved[3] (how the bands reach the host): 0 .. 3");
     }
     for (int k = 0; k < 4; k++)
         if ((e = hipStreamCreateWithFlags(&ctx->pstream[k], hipStreamNonBlocking)) != hipSuccess ||
@@ -1382,6 +1460,8 @@ void rmdf_destroy(rmdf_ctx *ctx)
         if (ctx->wf_stream[k]) (void)hipStreamDestroy(ctx->wf_stream[k]);
     }
     if (ctx->wf_fork) (void)hipEventDestroy(ctx->wf_fork);
+    if (ctx->wf_flags) (void)hipHostFree((void *)ctx->wf_flags);
+    if (ctx->d_wf_count) (void)dev_free(ctx->d_wf_count);
     for (auto &j : ctx->tile_job) {
         if (j.d_tile) (void)dev_free(j.d_tile);
         if (j.h_tile) (void)hipHostFree(j.h_tile);

@@ -43,6 +43,14 @@ struct FrameParams {
     int merge_stragglers;     // k_render: pool the last rays of a workgroup's four packets in one wave (MERGE variant)
     const unsigned *block_order;
     unsigned *block_cost;
+    // whole-frame calls into host memory (rmdf_api.cpp: render_whole_frame_host, OUT_MIRROR variant only): the frame's strip rows are
+    // grouped into bands of band_strip_rows rows of strips; the workgroup that completes a band (band_count: device counters, one per
+    // band, left at zero) writes band_seq to band_flag[band] (host-mapped) once every mirror store of the band has landed in host
+    // memory, and the host copies that band to the caller while the rest of the frame is still rendering.  null = no bands.
+    unsigned *band_count;
+    volatile unsigned *band_flag;
+    unsigned band_seq;
+    int band_strip_rows;
 #ifdef RMDF_XCHECK
     // librmdf_xcheck.so only: the alternative schedule (xcheck/rmdf_march.hip) and the measurement aids
     // G-buffer written by k_march_mb8, read by k_shade; indexed px + py*gw over the frame padded to even
@@ -112,7 +120,9 @@ void tile_rect_host(int tile_idx, int w, int h, int *x0, int *y0, int *x1, int *
 // rmdf_render.hip
 hipError_t launch_render(int scene, const FrameParams &p, hipStream_t stream);
 int render_grid_blocks(const FrameParams &p);              // number of 32x8 strips launch_render() uses for p
-hipError_t launch_order_blocks(const unsigned *d_cost, int n, unsigned *d_order, hipStream_t stream);
+// gx / band_strip_rows / nbands: 0, or the band geometry of a whole-frame host call -- the order is then "the strips within a factor two of
+// the costliest first (they are the launch's critical path wherever they lie), the others band by band, outer bands first"
+hipError_t launch_order_blocks(const unsigned *d_cost, int n, unsigned *d_order, hipStream_t stream, int gx = 0, int band_strip_rows = 0, int nbands = 0);
 // rmdf_util.hip
 hipError_t launch_resolve_box2(const uint32_t *d_src, int sw, int sh, uint32_t *d_dst, hipStream_t stream);
 hipError_t launch_selftest_exact_math(unsigned long long *d_counts, const float *d_cornell_tab, hipStream_t stream);

@@ -558,7 +558,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
     const float gr = pow_pinned(color.x, inv_gamma), gg = pow_pinned(color.y, inv_gamma), gb = pow_pinned(color.z, inv_gamma);
     // Stage the 32x8 strip in LDS so that every store instruction writes whole 128-byte lines (a wave's own
     // 8x8 packet would write 32-byte pieces of 8 different rows).  Thread t stores pixel (t % 32, t / 32).
-    __shared__ uint32_t s_rgba8[8][WPB * 8];
+    __shared__ __attribute__((aligned(16))) uint32_t s_rgba8[8][WPB * 8];
     __shared__ float4   s_f32[OUT == OUT_PLANES ? 8 : 1][WPB * 8];
     __shared__ uint32_t s_meta[OUT == OUT_PLANES ? 8 : 1][WPB * 8];
     {
@@ -576,12 +576,44 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
         if (qx >= g.rx0 && qx < g.rx1 && qy >= g.ry0 && qy < g.ry1) {
             const size_t idx = g.obase + (size_t)(qx - g.ox) + (size_t)(qy - g.oy) * (size_t)g.pitch;
             if (OUT != OUT_PLANES || p.rgba8) p.rgba8[idx] = s_rgba8[oy_][ox_];
-            if (OUT == OUT_MIRROR) p.rgba8_mirror[idx] = s_rgba8[oy_][ox_];
             if (OUT == OUT_PLANES) {
                 if (p.rgba_f32) p.rgba_f32[idx] = s_f32[oy_][ox_];
                 const uint32_t m = s_meta[oy_][ox_];
                 if (p.steps) p.steps[idx] = (uint16_t)(m & 0xffffu);
                 if (p.iters) p.iters[idx] = (uint16_t)(m >> 16);
+            }
+        }
+    }
+    if (OUT == OUT_MIRROR && threadIdx.x < 64) {
+        // The same rows into host memory over PCIe (a registered caller buffer, the page-locked shadow frame, a tile job's host tile): ONE
+        // wave, sixteen bytes per lane -- the strip's eight 128-byte rows leave in one store instruction instead of four (round 5: the
+        // mirror variant of the headline kernel took 0.45 ms against 0.38 without the second store).  Groups of four pixels that are
+        // not whole, or not 16-byte aligned in the destination (a caller's buffer may sit anywhere), go out pixel by pixel.
+        const int row = (int)threadIdx.x >> 3, c4 = ((int)threadIdx.x & 7) * 4;
+        const int qx = g.ex0 + g.bx * (WPB * 8) + c4, qy = g.ey0 + g.by * 8 + row;
+        if (qy >= g.ry0 && qy < g.ry1 && qx + 3 >= g.rx0 && qx < g.rx1) {
+            // (qx - g.ox can be -1 .. -3 when the group straddles the rectangle's left edge: signed arithmetic; those elements are not stored)
+            const ptrdiff_t idx = (ptrdiff_t)g.obase + (ptrdiff_t)(qx - g.ox) + (ptrdiff_t)(qy - g.oy) * (ptrdiff_t)g.pitch;
+            uint32_t *dst = p.rgba8_mirror + idx;
+            if (qx >= g.rx0 && qx + 3 < g.rx1 && (((uintptr_t)dst) & 15u) == 0u) {
+                *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(&s_rgba8[row][c4]);
+            } else {
+                for (int k = 0; k < 4; k++)
+                    if (qx + k >= g.rx0 && qx + k < g.rx1) dst[k] = s_rgba8[row][c4 + k];
+            }
+        }
+    }
+    if (OUT == OUT_MIRROR && p.band_flag) {
+        // (wave 0 made the workgroup's stores to host memory; its lane 0 speaks for them)
+        if (threadIdx.x == 0) {
+            __threadfence_system();                                  // the stores above have landed in host memory
+            const int band = g.by / p.band_strip_rows;
+            const int rows = (int)gridDim.y - band * p.band_strip_rows;
+            const unsigned n_band = gridDim.x * (unsigned)(rows < p.band_strip_rows ? rows : p.band_strip_rows);
+            const unsigned before = __hip_atomic_fetch_add(&p.band_count[band], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (before == n_band - 1u) {                             // every other workgroup of the band has passed its own fence
+                p.band_count[band] = 0u;                             // ready for the next frame
+                __hip_atomic_store((unsigned *)&p.band_flag[band], p.band_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
@@ -673,11 +705,12 @@ int render_grid_blocks(const FrameParams &p)
 
 // Counting sort of the strips by descending cost (256 logarithmic-ish bins): order[rank] = strip.
 // One workgroup; ~n/1024 elements per thread.  Longest-processing-time-first dispatch needs no exact order.
-__global__ __launch_bounds__(1024) void k_order_blocks(const unsigned *__restrict__ cost, int n, unsigned *__restrict__ order)
+__global__ __launch_bounds__(1024) void k_order_blocks(const unsigned *__restrict__ cost, int n, unsigned *__restrict__ order, int gx, int band_strip_rows, int nbands)
 {
-    __shared__ unsigned hist[256], base[256];
+    __shared__ unsigned hist[256], base[256], s_maxbin;
     const int tid = threadIdx.x;
     if (tid < 256) hist[tid] = 0u;
+    if (tid == 0) s_maxbin = 0u;
     __syncthreads();
     auto bin_of = [](unsigned c) -> unsigned {
         // 8 sub-bins per power of two: monotone in c, 0..255
@@ -686,19 +719,33 @@ __global__ __launch_bounds__(1024) void k_order_blocks(const unsigned *__restric
         const unsigned b = (unsigned)(e - 2) * 8u + ((c >> (e - 3)) & 7u);
         return b > 255u ? 255u : b;
     };
-    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[bin_of(cost[i])], 1u);
+    if (nbands > 0) {
+        for (int i = tid; i < n; i += 1024) atomicMax(&s_maxbin, bin_of(cost[i]));
+        __syncthreads();
+    }
+    const unsigned long_bin = s_maxbin > 8u ? s_maxbin - 8u : 0u;          // within a factor two of the costliest strip
+    // sort key, descending: plain LPT = the cost bin; with bands: the long strips by cost bin (keys 128 ..), then the bands, outer first
+    auto key_of = [&](int i) -> unsigned {
+        const unsigned b = bin_of(cost[i]);
+        if (nbands <= 0) return b;
+        if (b >= long_bin && s_maxbin > 16u) return 128u + (b >> 1);
+        const int band = (i / gx) / band_strip_rows;
+        const int from_edge = band < nbands - 1 - band ? 2 * band : 2 * (nbands - 1 - band) + 1;        // 0, 1 = the two outer bands, ...
+        return (unsigned)(127 - (from_edge < 127 ? from_edge : 127));
+    };
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[key_of(i)], 1u);
     __syncthreads();
     if (tid == 0) {
         unsigned acc = 0u;
-        for (int b = 255; b >= 0; b--) { base[b] = acc; acc += hist[b]; }   // descending cost
+        for (int b = 255; b >= 0; b--) { base[b] = acc; acc += hist[b]; }   // descending key
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) order[atomicAdd(&base[bin_of(cost[i])], 1u)] = (unsigned)i;
+    for (int i = tid; i < n; i += 1024) order[atomicAdd(&base[key_of(i)], 1u)] = (unsigned)i;
 }
 
-hipError_t launch_order_blocks(const unsigned *d_cost, int n, unsigned *d_order, hipStream_t stream)
+hipError_t launch_order_blocks(const unsigned *d_cost, int n, unsigned *d_order, hipStream_t stream, int gx, int band_strip_rows, int nbands)
 {
-    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, stream, d_cost, n, d_order);
+    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, stream, d_cost, n, d_order, gx, band_strip_rows, nbands);
     return hipGetLastError();
 }
 

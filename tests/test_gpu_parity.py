@@ -177,12 +177,13 @@ def test_tile_jobs_issued_ahead_belong_to_one_environment(rmdf, env_faces):
         r.close()
 
 
-@pytest.mark.parametrize("bands,mirror", [(0, 0), (1, 0), (16, 0), (5, 1)])
+@pytest.mark.parametrize("bands,mirror", [(0, 0), (1, 0), (16, 0), (5, 1), (4, 2), (7, 3), (16, 3)])
 def test_whole_frame_host_call_in_row_bands(rmdf, env_faces, bands, mirror):
     """Round 5: rmdf_render_tile(tile_idx = -1, pageable pointer) -- the reference viewer's per-frame call (Main.hs:67, App.hs:154-166) --
     renders the frame as row bands on streams of their own and moves each band to the caller through the page-locked shadow while the
     others render (rmdf_api.cpp: render_whole_frame_host).  Whatever the band count (rmdf_config.reserved[2]) and whichever way the rows
-    reach the host (reserved[3]), the frame equals the single-launch plane-writing variant; sizes with ragged last strips, a size
+    reach the host (reserved[3]: 0 a copy behind each band's launch, 1 the band kernels' own mirror stores, 2 ONE launch that mirrors and
+    flags completed bands, 3 the same with the strips dispatched band by band), the frame equals the single-launch plane-writing variant; sizes with ragged last strips, a size
     too small for bands; a tiled call afterwards starts from that frame (the shadow is valid)."""
     r = rmdf.ShaderRenderer(0, frame_bands=bands, frame_mirror=mirror)
     try:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """rmdf_render_tile(tile_idx = -1, pageable pointer) -- the reference viewer's per-frame call: ms per call by row-band count
-(rmdf_config.reserved[2]), by the way a band's rows reach the host (reserved[3]: copy behind the kernel / the kernel's mirror store)
+(rmdf_config.reserved[2]), by the way a band's rows reach the host (reserved[3]: 0 copy behind each band's kernel, 1 the band kernels' mirror stores, 2 one launch with mirror stores and band flags, 3 the same dispatched band by band)
 and by host copy threads (reserved[1]).  usage: whole_frame_sweep.py [reps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,8 +23,9 @@ def run(**kw):
     return out
 print("bands mirror threads | headline 1080p: best ms, mean ms, Mpixels/s | Cornell 720p: best ms, mean ms, Mpixels/s")
 for threads in (0, 8, 32):
-    for mirror in (0, 1):
+    for mirror in (0, 1, 2, 3):
         for bands in (1, 2, 3, 4, 6, 8, 12, 16):
-            if threads and bands not in (1, 6, 8): continue
+            if threads and bands not in (1, 4, 8): continue
+            if mirror < 2 and bands > 4: continue
             r = run(frame_bands=bands, frame_mirror=mirror, copy_threads=threads)
             print("%5d %6d %7d | %.4f %.4f %8.1f | %.4f %.4f %8.1f" % (bands, mirror, threads, r[0][0], r[0][1], r[0][2], r[1][0], r[1][1], r[1][2]), flush=True)
