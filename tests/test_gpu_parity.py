@@ -556,6 +556,12 @@ def test_cornell_pruning_is_invisible(rmdf, sr, orc, env_oracle, env_faces):
                 assert np.array_equal(a[k], b[k]), (k, w, h, t)
             assert np.array_equal(a["rgba_f32"].view(np.uint32), b["rgba_f32"].view(np.uint32)), (w, h, t)
         assert_frame_parity(sr.render(0, 250, 130, 9.7, max_steps=64), orc.render(0, 250, 130, 9.7, 64, env_oracle), "cornell t=9.7")
+        # round 5: a wave down to eight live rays marches them eight lanes per ray (de_cornell_box_group8).  The RGBA8-only product variant
+        # (other register budget, same march) against the unpruned planes, with step limits that let the grazing rays run long
+        for (w, h, t, ms) in ((1280, 720, 0.0, 128), (800, 450, 5.1, 256), (333, 187, 8.8, 300), (64, 64, 1.0, 1000)):
+            fb = np.zeros(w * h, np.uint32)
+            sr.draw_shader_tile(0, None, w, h, t, fb, max_steps=ms)
+            assert np.array_equal(fb.reshape(h, w), plain.render(0, w, h, t, max_steps=ms, want_f32=False)["rgba8"]), (w, h, t, ms)
     finally:
         plain.close()
 
@@ -635,6 +641,20 @@ def _run_bench_distributed(nproc, extra_env, args, timeout=900):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout                        # exactly one JSON line on stdout, from rank 0
     return json.loads(lines[0]), r.stderr
+
+
+def test_bench_runs_eight_ranks_on_one_gpu_against_the_rccl_double():
+    """Round 5: `bench.py --gpus 8` end to end on ONE GPU -- eight processes share cuda:0 (RMDF_BENCH_SHARE_GPU=1), the control plane is gloo,
+    and the exchange is the library's own (rmdf_comm_init, the peers' ncclSend, the root's grouped ncclRecv, rmdf_comm_verify_deal, eight
+    frames in flight on one communicator) against the test double of RCCL (RMDF_RCCL_LIB, librmdf_xcheck.so).  The frames the exchange
+    assembles equal the committed digest before anything is timed.  Readiness for the driver's 8-GPU run, not a scaling number."""
+    env = {"RMDF_BENCH_SHARE_GPU": "1", "RMDF_RCCL_LIB": _fake_rccl_lib(), "FAKE_RCCL_TIMEOUT_S": "120", "RMDF_BENCH_MIN_WARM": "0.02"}
+    d, err = _run_bench_distributed(8, env, ["--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-secondary"])
+    assert d["n_gpus"] == 8 and d["config"]["rccl_ranks"] == 8
+    assert "TEST DOUBLE" in d["config"]["exchange"] and d["config"]["exchange"].startswith("librmdf_xcheck")
+    assert d["config"]["exchanged_frames_verified"].startswith("8 exchanged frame(s) in flight == committed sha256"), d["config"]
+    assert d["config"]["tile_deal"].startswith("cost-aware") and "verified by the library" in d["config"]["tile_deal"], d["config"]["tile_deal"]
+    assert "falling back" not in err
 
 
 def test_bench_sharded_path_over_rccl_with_one_rank():

@@ -22,12 +22,13 @@ w=${w:-1280}; h=${h:-720}; ms=${ms:-128}
 libs=("$@"); [ ${#libs[@]} -eq 0 ] && libs=(tools/abtest/*.so)
 [ $DEF = 1 ] && libs=(default "${libs[@]}")
 export RMDF_FLAGS=$FLAGS
+tmp=$(mktemp /tmp/ab.XXXXXX); trap 'rm -f $tmp $tmp.json $tmp.err' EXIT
 for s in $S; do for an in $AN; do for lib in "${libs[@]}"; do
   if [ "$lib" = default ]; then unset RMDF_LIB; else export RMDF_LIB=$PWD/$lib; fi
   if python bench.py --scene $sc --width $w --height $h --max-steps $ms --no-cpu-baseline --no-secondary --no-animated \
-       --streams $s --steps $K --animate $an 2>/tmp/ab.err > /tmp/ab.json; then
-    python tools/show_bench.py /tmp/ab.json | sed "s|/tmp/ab.json|$lib scene=$sc S=$s animate=$an flags=$FLAGS|"
+       --streams $s --steps $K --animate $an 2>$tmp.err > $tmp.json; then
+    python tools/show_bench.py $tmp.json | sed "s|$tmp.json|$lib scene=$sc S=$s animate=$an flags=$FLAGS|"
   else
-    echo "$lib scene=$sc S=$s flags=$FLAGS: bench.py failed:"; tail -3 /tmp/ab.err
+    echo "$lib scene=$sc S=$s flags=$FLAGS: bench.py failed:"; tail -3 $tmp.err
   fi
 done; done; done

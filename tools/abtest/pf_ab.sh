@@ -1,3 +1,5 @@
+#!/bin/bash
+# A/B of prefilter kernel variants (libraries built by build_variant.sh): usage tools/abtest/pf_ab.sh
 for lib in default tools/abtest/e_maxilp.so default; do
   if [ "$lib" = default ]; then unset RMDF_LIB; else export RMDF_LIB=$PWD/$lib; fi
   python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-animated 2>/dev/null | python -c "

@@ -1,3 +1,5 @@
+#!/bin/bash
+# TCP / cache counters of a Cornell rectangle launch (rocprofv3 --pmc): usage tools/cornell_rect_tcp.sh
 export TMPDIR=/tmp
 out=gpurun_out/rect_tcp; rm -rf $out; mkdir -p $out
 i=0
