@@ -64,7 +64,7 @@ __device__ __forceinline__ bool in_core_range(float x)
 // y = v_rsq_f32(x) (<= 1 ulp), s0 = RN(x*y), one correction s0 + (x - s0^2) * (y/2): the correctly rounded root for EVERY
 // x in [2^-100, 2^100] with ONE transcendental instruction (round 2 used v_sqrt_f32 + a neighbour test: 9 instructions; in
 // this kernel's mix a transcendental costs ~4.6 simple issue slots, so sequences that bought fewer instructions with a second
-// transcendental did not pay -- DESIGN.md A.1).  y is handed out: it also seeds the reciprocal of the root (rsqrt_ieee).
+// transcendental did not pay -- NOTEBOOK.md A.1).  y is handed out: it also seeds the reciprocal of the root (rsqrt_ieee).
 __device__ __forceinline__ float sqrt_core_y(float x, float &y)       // x in [2^-100, 2^100]
 {
     y = __builtin_amdgcn_rsqf(x);
@@ -1163,7 +1163,7 @@ __device__ __forceinline__ float cube_texcoord_rcp(float c, float ama, float y, 
 
 // RMDF_AB_NO_TEXEL_FETCH (tools/abtest only, never defined in the product build): every texel read is replaced by a value
 // made from its address -- no memory access at all.  The frame is wrong, of course; the build exists to measure an UPPER
-// BOUND of what any staging of env-map texels (LDS or otherwise) could save: DESIGN.md A.1.
+// BOUND of what any staging of env-map texels (LDS or otherwise) could save: NOTEBOOK.md A.1.
 #ifdef RMDF_AB_NO_TEXEL_FETCH
 #define RMDF_TEXEL(ptr) make_uint2((unsigned)(size_t)(ptr) & 0x3bff3bffu, 0x3c00u)
 #else

@@ -380,7 +380,7 @@ __device__ __forceinline__ void f4_sum_group(const float (&rr)[NR], const float4
 // operations in the reference's order.  The sample count n is an integer (see k_prefilter), so the producers count.  Two kernels are
 // built this way: k_prefilter_fused4 (the reference's four powers at once) and k_prefilter_chan (one power).  The first kernel of
 // the kind (k_prefilter_split: two summing waves + six producers per workgroup, cosine table in LDS, packed (r, g) sums on broadcast
-// row reads: 0.54 / 0.62 / 0.72 / 0.82 ms per power) is in the history of this file; DESIGN.md A.3 has its measurements.
+// row reads: 0.54 / 0.62 / 0.72 / 0.82 ms per power) is in the history of this file; NOTEBOOK.md A.3 has its measurements.
 
 // Round 3, third form: the reference's FOUR powers (1, 8, 64, 512: buildPreConvolvedHDREnvMapCache, ShaderRendering.hs:131-149) in one
 // launch.  The four maps differ only in the exponent, and the binary64 squaring chains nest: c^8 is three squarings, c^64 three more

@@ -5,7 +5,7 @@
 // the fly (hsa_amd_memory_lock: a userptr mapping of those pages into the GPU's address space, created and torn down per call, the
 // queue drained around it).  The library does not want the driver to build GPU mappings of memory it does not own -- a numpy array, a
 // Haskell storable vector, a std::vector of its own that is freed a line later: the intermittent GPU memory fault of round 4 was first
-// caught under exactly such a call -- and it does not want to pay for them: 0.59 ms for a 1080p frame into pageable memory
+// caught under exactly such a call (NOTEBOOK.md A.5) -- and it does not want to pay for them: 0.59 ms for a 1080p frame into pageable memory
 // against 0.38 ms for the kernel.  So the runtime only ever sees device memory and memory the library page-locked itself, once:
 //   upload():   caller -> staging (host threads) -> device (async: the call may return before the DMA ends, the caller's memory is
 //               not read after return);

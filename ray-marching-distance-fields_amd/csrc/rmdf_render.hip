@@ -644,7 +644,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
 template <int SCENE, bool MERGE, int OUT>
 __global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : ((SCENE == 0 && OUT != OUT_PLANES) ? 6 : 1)) void k_render(const FrameParams p) { render_body<SCENE, MERGE, OUT>(p); }
 
-// One source, one object -- or five (csrc/Makefile, `make SPLIT=1`: the build the GPU-memory-fault hunt of rounds 4 and 5 needs).
+// One source, one object -- or five (csrc/Makefile, `make SPLIT=1`: the build the GPU-memory-fault hunt of rounds 4 and 5 needs, NOTEBOOK.md A.5).
 // Compiled with -DRMDF_RENDER_SCENE=N this file yields the kernels of FragmentShader N and their launcher launch_render_scene_N, with
 // -DRMDF_RENDER_SPLIT the host side they share (grid, strip order, dispatch); with neither, everything.  Same kernels byte for byte.
 #define RMDF_CAT2(a, b) a##b

@@ -1,4 +1,4 @@
-// faultlog.c -- LD_PRELOAD recorder for the hunt of the intermittent GPU memory fault.
+// faultlog.c -- LD_PRELOAD recorder for the hunt of the intermittent GPU memory fault (NOTEBOOK.md A.5).
 // Keeps a ring of every device / pinned-host allocation, free, page lock and large copy the PROCESS makes through the HIP and HSA entry
 // points (librmdf, RCCL, torch and the HIP runtime's own calls into libhsa-runtime64 alike), and when the ROCr fault handler abort()s
 // writes the ring, the call that was running and /proc/self/maps to $RMDF_FAULTLOG_DIR/fault_<pid>.txt.  ROCr prints the faulting
