@@ -1150,6 +1150,7 @@ int render_whole_frame_one_launch(rmdf_ctx *ctx, int scene, const FrameParams &p
     char *sh = (char *)ctx->h_shadow, *dst = (char *)out_rgba8;
     unsigned pending = nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u);
     unsigned spins = 0;
+    pool.prime(2000);                                                  // the copy threads spin from now until the last band is through
     while (pending) {
         for (int k = 0; k < nb; k++) {
             if (!((pending >> k) & 1u)) continue;
@@ -1178,6 +1179,7 @@ int render_whole_frame_one_launch(rmdf_ctx *ctx, int scene, const FrameParams &p
             }
         }
     }
+    pool.relax();
     ctx->shadow_valid = true;
     return RMDF_OK;
 }
@@ -1238,6 +1240,7 @@ int render_whole_frame_host(rmdf_ctx *ctx, int scene, const FrameParams &p, uint
     if (rc != RMDF_OK) { (void)hipDeviceSynchronize(); ctx->shadow_valid = false; return rc; }   // bands already issued still write frame and shadow
     // the bands to the caller as they land
     unsigned pending = nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u);
+    pool.prime(2000);
     while (pending) {
         for (int k = 0; k < nb; k++) {
             if (!((pending >> k) & 1u)) continue;
@@ -1250,6 +1253,7 @@ int render_whole_frame_host(rmdf_ctx *ctx, int scene, const FrameParams &p, uint
         }
         if (pending) __builtin_ia32_pause();
     }
+    pool.relax();
     ctx->shadow_valid = true;                                          // (every band is over: the device frame is complete as well)
     return RMDF_OK;
 }

@@ -39,17 +39,24 @@ class WorkPool {
     std::atomic<unsigned> gen_{ 0 };
     std::atomic<bool> stop_{ false };
     std::atomic<int> pending_{ 0 };
+    std::atomic<long long> prime_until_{ 0 };
+    std::atomic<unsigned> prime_gen_{ 0 };
     int parts_ = 1;
     bool open_ = false;
 
+    static long long now_us()
+    {
+        return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
     void worker(int idx)
     {
-        using clock = std::chrono::steady_clock;
-        unsigned seen = 0;
-        clock::time_point hot_until = clock::now();
+        unsigned seen = 0, seen_prime = 0;
+        long long hot_until = now_us();
         for (;;) {
             bool got = false;
-            while (clock::now() < hot_until) {
+            for (;;) {
+                const long long t = now_us(), prime = prime_until_.load(std::memory_order_relaxed);
+                if (t >= hot_until && t >= prime) break;
                 if (gen_.load(std::memory_order_acquire) != seen || stop_.load(std::memory_order_relaxed)) { got = true; break; }
                 __builtin_ia32_pause();
             }
@@ -57,13 +64,15 @@ class WorkPool {
             int np;
             {
                 std::unique_lock<std::mutex> lk(m_);
-                if (!got) cv_work_.wait(lk, [&] { return stop_.load() || gen_.load() != seen; });
+                if (!got) cv_work_.wait(lk, [&] { return stop_.load() || gen_.load() != seen || prime_gen_.load() != seen_prime; });
                 if (stop_.load()) return;
+                seen_prime = prime_gen_.load();
+                if (gen_.load() == seen) continue;            // woken to spin (prime()), not for a job
                 seen = gen_.load(); fn = fn_; np = parts_;
             }
             if (idx + 1 < np) fn(idx + 1);
             if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> lk(m_); cv_done_.notify_one(); }
-            hot_until = clock::now() + std::chrono::microseconds(60);
+            hot_until = now_us() + 60;
         }
     }
 
@@ -75,6 +84,16 @@ public:
         try { for (int i = 0; i < n; i++) threads_.emplace_back([this, i] { worker(i); }); } catch (...) { }
     }
     int workers() const { return (int)threads_.size(); }
+    // jobs are about to arrive within the next `us` microseconds (a frame's bands landing one by one): the workers leave their sleep now
+    // and spin that long, so that each job starts within a microsecond instead of a futex wake-up
+    void prime(long long us)
+    {
+        if (threads_.empty()) return;
+        prime_until_.store(now_us() + us, std::memory_order_relaxed);
+        { std::lock_guard<std::mutex> lk(m_); prime_gen_.fetch_add(1, std::memory_order_release); }
+        cv_work_.notify_all();
+    }
+    void relax() { prime_until_.store(0, std::memory_order_relaxed); }     // the frame is through: back to sleep (after the usual 60 us)
     // parts is clamped to workers() + 1
     void begin(int parts, std::function<void(int)> fn)
     {

@@ -25,4 +25,16 @@ for f in glob.glob(sys.argv[1] + "/p*/**/*_counter_collection.csv", recursive=Tr
         c[k] = statistics.median(v.values())
 for k in sorted(c):
     print("%-18s %-26s %16.0f" % (k[0], k[1], c[k]))
+# Which roof?  Per kernel: the share of each unit's cycles that the launch used (256 CUs, 1024 SIMDs, 8 XCDs; GRBM_GUI_ACTIVE is summed over
+# the XCDs).  LDS array: SQ_LDS_IDX_ACTIVE = LDS-array cycles over all CUs (MI355X_MICROARCH.md "LDS": 256 B/clk/CU when every cycle is
+# used); vector issue: one wave64 instruction per SIMD every 2 cycles; scalar issue: one instruction per CU and cycle.
+print()
+print("%-18s %9s %9s %11s %11s %11s %11s" % ("kernel", "ms@2.4GHz", "LDS array", "VALU issue", "SALU issue", "waves wait", "LDS instr"))
+for name in sorted(set(k[0] for k in c)):
+    g = lambda n: c.get((name, n), float("nan"))
+    cyc = g("GRBM_GUI_ACTIVE") / 8.0
+    if not cyc == cyc or cyc <= 0:
+        continue
+    print("%-18s %9.4f %9.3f %11.3f %11.3f %11.3f %11.0f" % (name, cyc / 2.4e6, g("SQ_LDS_IDX_ACTIVE") / (256 * cyc), g("SQ_INSTS_VALU") * 2 / (1024 * cyc),
+          g("SQ_INSTS_SALU") / (256 * cyc), g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES") if g("SQ_WAVE_CYCLES") else float("nan"), g("SQ_INSTS_LDS")))
 PY
