@@ -85,7 +85,8 @@ typedef struct {
                         memory keeps in flight (0 = the library's choice, 1 = one launch; at most 16); [3] = how those bands reach the host: 0 = the
                         library's choice; 1 = one launch per band, the kernel storing the rows into page-locked host memory itself;
                         2 = ONE launch that does so and flags every completed band; 3 = the same with the strips dispatched band by
-                        band; (0 with [2] given: one launch per band and a copy behind it); rest zero */
+                        band (2 and 3: written after GPU access closed in round 5 -- compiled, reviewed, NOT yet run on hardware);
+                        (0 with [2] given: one launch per band and a copy behind it); rest zero */
 } rmdf_config;
 
 /* ---- lifetime: withShaderRenderer (ShaderRendering.hs:60-110) --------------------- */

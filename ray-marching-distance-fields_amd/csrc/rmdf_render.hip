@@ -576,6 +576,9 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
         if (qx >= g.rx0 && qx < g.rx1 && qy >= g.ry0 && qy < g.ry1) {
             const size_t idx = g.obase + (size_t)(qx - g.ox) + (size_t)(qy - g.oy) * (size_t)g.pitch;
             if (OUT != OUT_PLANES || p.rgba8) p.rgba8[idx] = s_rgba8[oy_][ox_];
+#ifndef RMDF_AB_MIRROR16
+            if (OUT == OUT_MIRROR) p.rgba8_mirror[idx] = s_rgba8[oy_][ox_];
+#endif
             if (OUT == OUT_PLANES) {
                 if (p.rgba_f32) p.rgba_f32[idx] = s_f32[oy_][ox_];
                 const uint32_t m = s_meta[oy_][ox_];
@@ -584,6 +587,8 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
             }
         }
     }
+#ifdef RMDF_AB_MIRROR16
+    // (A/B build only -- written after GPU access closed in round 5, NOT yet run on hardware: NOTEBOOK.md A.5 "whole-frame host calls")
     if (OUT == OUT_MIRROR && threadIdx.x < 64) {
         // The same rows into host memory over PCIe (a registered caller buffer, the page-locked shadow frame, a tile job's host tile): ONE
         // wave, sixteen bytes per lane -- the strip's eight 128-byte rows leave in one store instruction instead of four (round 5: the
@@ -603,6 +608,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
             }
         }
     }
+#endif
     if (OUT == OUT_MIRROR && p.band_flag) {
         // (wave 0 made the workgroup's stores to host memory; its lane 0 speaks for them)
         if (threadIdx.x == 0) {

@@ -350,3 +350,17 @@ def test_copy_pool_and_deal_fingerprint_symbols(rmdf):
     assert lib.rmdf_comm_verify_deal(None, None) == -1
     assert lib.rmdf_get_cornell_vertices(None) == -1
     assert lib.rmdf_get_shader_constants(None, None, 0) >= 40
+
+
+def test_worker_pool_of_the_ctx(tmp_path):
+    """csrc/rmdf_host.hpp: WorkPool -- the ctx's host threads (frame copies, staging copies, table builders) -- exercised without a GPU
+    (tests/host_pool_test.cpp): every part of every job exactly once for pools of 0 .. 15 workers, begin / finish with work in between,
+    prime() / relax() around jobs, the spin hand-over and the condition-variable hand-over, copy() and segments(); plain and under
+    ThreadSanitizer."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "host_pool_test.cpp")
+    for tag, flags in (("plain", ["-O2"]), ("tsan", ["-O1", "-g", "-fsanitize=thread"])):
+        exe = str(tmp_path / ("host_pool_test_" + tag))
+        subprocess.check_call(["g++", "-std=c++17", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + flags + [src, "-o", exe])
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "pool ok" in r.stdout and "ThreadSanitizer" not in r.stderr, (tag, r.stdout[-500:], r.stderr[-2000:])
