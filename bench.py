@@ -776,20 +776,10 @@ def main():
                     sr.render_supersampled(scene, w, h, L, a.time, max_steps=ms)
             blocks.append((time.perf_counter() - t1) / reps)
         d2h_rate = mpix / sorted(blocks)[1]
+        # (rounds 2-4 also timed the call into a buffer registered with rmdf_register_host_buffer -- hipHostRegister on the caller's pages,
+        # written by the render kernel directly: 4050-4310 Mpixels/s.  Round 5 retired that mapping with the GPU memory fault it was part
+        # of (NOTEBOOK.md A.5); registration is bookkeeping now and every buffer takes the path timed above.)
         d2h_registered = None
-        if L == 0:
-            # the same hand-over into a buffer the caller registered once (rmdf_register_host_buffer): the render kernel
-            # writes it over PCIe while it renders
-            sr.register_host_buffer(host)
-            sr.draw_shader_tile(scene, None, w, h, a.time, host, max_steps=ms)
-            blocks = []
-            for _ in range(3):
-                t1 = time.perf_counter()
-                for _ in range(reps):
-                    sr.draw_shader_tile(scene, None, w, h, a.time, host, max_steps=ms)
-                blocks.append((time.perf_counter() - t1) / reps)
-            d2h_registered = mpix / sorted(blocks)[1]
-            sr.unregister_host_buffer(host)
 
         env_bytes = 6 * 172 * 172 * 8 + 2 * 6 * 87 * 87 * 8               # padded RGB16F cube maps read once
         px_this_launch = rw * rh if not sharded else len(sr.shard_tiles(rank, world)) * (rw // 8) * (rh // 8)

@@ -302,13 +302,13 @@ int rmdf_selftest_shading_math(rmdf_ctx *ctx, uint64_t mismatches[5]);
  * a lone frame rendered from idle runs at the lower clock.  Blocks until the probe has finished. */
 int rmdf_probe_shader_clock(rmdf_ctx *ctx, double spin_us, double *mhz);
 
-/* Optional: pin a host buffer the caller reuses from frame to frame (page-locks it and maps it into the GPU's address
- * space).  A whole-frame rmdf_render_tile (tile_idx = -1) whose out_rgba8 lies inside a registered range is then
- * written by the render kernel itself, row by row while it renders, instead of being copied after the launch: the PCIe
- * transfer hides behind the frame.  Everything else about the call is unchanged (it still blocks until the buffer is
- * complete; the library's accumulating frame is updated too).  The buffer must stay valid until it is unregistered or
- * the ctx is destroyed.  A viewer whose frame-buffer pointer changes every frame (an orphaned PBO, FrameBuffer.hs:129)
- * simply does not register. */
+/* Optional, and since round 5 a hint only: declare a host buffer the caller reuses from frame to frame.  Rounds 2-4 page-locked the
+ * range and mapped it into the GPU's address space (hipHostRegister) so that the render kernel could store a whole frame into it
+ * directly.  Round 5 found every GPU memory fault of its hunt on heap ranges that such a registration had covered earlier (the
+ * ROCm user-mode stack kept resolving addresses inside them to the old, shorter mapping: NOTEBOOK.md A.5), so the library no longer
+ * creates GPU mappings of memory it does not own: the call records the range, rmdf_unregister_host_buffer forgets it, and a whole-
+ * frame rmdf_render_tile into it takes the same path as into any other pointer (row bands through page-locked staging, rmdf_api.cpp).
+ * Same results, same blocking behaviour; registering twice is harmless; unregistering an unknown pointer is RMDF_E_INVALID. */
 int rmdf_register_host_buffer(rmdf_ctx *ctx, void *ptr, size_t bytes);
 int rmdf_unregister_host_buffer(rmdf_ctx *ctx, void *ptr);
 

@@ -355,8 +355,8 @@ class ShaderRenderer:
                                                                d_gathered or None, d_frame or None, stream or None))
 
     def register_host_buffer(self, arr):
-        """Pin + GPU-map a numpy frame buffer that is reused from frame to frame: whole-frame draw_shader_tile calls into
-        it are then written by the render kernel directly (the PCIe copy hides behind the frame)."""
+        """Declare a numpy frame buffer that is reused from frame to frame.  A hint only since round 5 (rmdf.h): the library no longer maps
+        caller memory into the GPU's address space; every buffer takes the staged whole-frame path."""
         self._check(self._lib.rmdf_register_host_buffer(self._ctx, arr.ctypes.data, arr.nbytes))
 
     def unregister_host_buffer(self, arr):

@@ -126,8 +126,8 @@ struct rmdf_ctx {
         unsigned  env_gen = 0;
     };
     TileJob      tile_job[RMDF_TILE_JOBS];
-    // host buffers registered for direct GPU writes (rmdf_register_host_buffer)
-    struct HostReg { char *host; size_t bytes; char *dev; };
+    // host buffers the caller declared with rmdf_register_host_buffer (bookkeeping only since round 5)
+    struct HostReg { char *host; size_t bytes; };
     std::vector<HostReg> host_regs;
     // per-tile costs that steer the deal of tiles to ranks (rmdf_set_shard_costs); unset = static deal
     float        shard_cost[64];
@@ -1289,21 +1289,11 @@ int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double t
     p.rgba8 = ctx->d_rgba8;
     if (planes) { p.rgba_f32 = ctx->d_rgba_f32; p.steps = ctx->d_steps; p.iters = ctx->d_iters; }
     const size_t npx = (size_t)ctx->w * ctx->h;
-    // Whole-frame call into a registered host buffer: the render kernel stores the RGBA8 rows into it directly (next to
-    // the library's own accumulating frame), so the PCIe transfer overlaps the render instead of following it.
-    bool direct = false;
-    if (whole && out_rgba8 && !planes
-#ifdef RMDF_XCHECK
-        && !(ctx->flags & RMDF_FLAG_FLAT_MARCH)
-#endif
-    ) {
-        for (auto &r : ctx->host_regs)
-            if ((char *)out_rgba8 >= r.host && (char *)out_rgba8 + npx * 4 <= r.host + r.bytes) {
-                p.rgba8_mirror = (uint32_t *)(r.dev + ((char *)out_rgba8 - r.host));
-                direct = true;
-                break;
-            }
-    }
+    // (Until round 5 a whole-frame call into a buffer registered with rmdf_register_host_buffer was written by the render kernel directly:
+    // hipHostRegister on the caller's pages.  Every GPU memory fault of the round-4 / round-5 hunt fell on a heap range that such a
+    // registration had covered -- registered, used, unregistered, and minutes later part of a larger buffer the HIP runtime page-locked
+    // for one of its own copies (NOTEBOOK.md A.5, profiles/r05_fault_hunt.txt).  The library no longer asks the driver for a GPU mapping
+    // of memory it does not own: registration is bookkeeping, every buffer takes the staged path.)
     // Tile mode hands back the WHOLE accumulating frame on every call (the reference maps a freshly orphaned PBO each time:
     // FrameBuffer.hs:129,207-213), 64 times per frame, and every call has to wait for its tile's kernel -- whose run time is its
     // longest ray's, not 1/64 of the frame's.  What the call does instead of `launch, copy 8.3 MB over PCIe, wait`:
@@ -1321,7 +1311,7 @@ int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double t
     )
         return render_tile_fast(ctx, scene, tile_idx, p, out_rgba8);
     // whole frame into caller memory that is not registered: row bands through the page-locked shadow (render_whole_frame_host)
-    if (whole && out_rgba8 && !planes && !direct && npx * 4 <= ((size_t)1 << 30)
+    if (whole && out_rgba8 && !planes && npx * 4 <= ((size_t)1 << 30)
 #ifdef RMDF_XCHECK
         && !(ctx->flags & RMDF_FLAG_FLAT_MARCH)
 #endif
@@ -1332,7 +1322,7 @@ int render_common(rmdf_ctx *ctx, int scene, int tile_idx, int w, int h, double t
     // (every other case -- the test planes, frames too large for a page-locked shadow, the cross-check schedule, no output at all --
     // copies what was asked for behind the launch, through the staging chunks)
     ctx->shadow_valid = false;                               // the device frame moves on without the shadow
-    if (out_rgba8 && !direct) RMDF_TRY(download(ctx, out_rgba8, ctx->d_rgba8, npx * 4, ctx->stream));
+    if (out_rgba8) RMDF_TRY(download(ctx, out_rgba8, ctx->d_rgba8, npx * 4, ctx->stream));
     if (out_rgba_f32) RMDF_TRY(download(ctx, out_rgba_f32, ctx->d_rgba_f32, npx * 16, ctx->stream));
     if (out_steps) RMDF_TRY(download(ctx, out_steps, ctx->d_steps, npx * 2, ctx->stream));
     if (out_iters) RMDF_TRY(download(ctx, out_iters, ctx->d_iters, npx * 2, ctx->stream));
@@ -1482,7 +1472,6 @@ void rmdf_destroy(rmdf_ctx *ctx)
     if (ctx->d_work_counter) (void)dev_free(ctx->d_work_counter);
     if (ctx->d_dbg) (void)dev_free(ctx->d_dbg);
 #endif
-    for (auto &r : ctx->host_regs) (void)hipHostUnregister(r.host);
     for (auto &o : ctx->orders) {
         if (o.d_cost) (void)dev_free(o.d_cost);
         if (o.d_order) (void)dev_free(o.d_order);
@@ -2273,19 +2262,14 @@ int rmdf_save_png(const char *path, const uint32_t *fb_rgba8, int w, int h)
 
 int rmdf_register_host_buffer(rmdf_ctx *ctx, void *ptr, size_t bytes)
 {
+    // Kept for hosts built against the round-2 .. round-4 header.  It used to hipHostRegister the range so that the render kernel could
+    // store into it; since round 5 it only remembers the range (the library creates no GPU mapping of caller memory: render_common), and
+    // a whole-frame call into it takes the same staged path as any other pointer.
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
     if (!ptr || bytes == 0) return fail(ctx, RMDF_E_INVALID, "rmdf_register_host_buffer: bad argument");
     RMDF_GUARD_BEGIN
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (auto &r : ctx->host_regs) if (r.host == (char *)ptr && r.bytes == bytes) return RMDF_OK;
-    HIP_TRY(ctx, hipHostRegister(ptr, bytes, hipHostRegisterMapped));
-    void *dev = nullptr;
-    hipError_t e = hipHostGetDevicePointer(&dev, ptr, 0);
-    if (e != hipSuccess) {
-        (void)hipHostUnregister(ptr);
-        return fail(ctx, RMDF_E_HIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));
-    }
-    ctx->host_regs.push_back(rmdf_ctx::HostReg{ (char *)ptr, bytes, (char *)dev });
+    ctx->host_regs.push_back(rmdf_ctx::HostReg{ (char *)ptr, bytes });
     return RMDF_OK;
     RMDF_GUARD_END(ctx)
 }
@@ -2295,9 +2279,6 @@ int rmdf_unregister_host_buffer(rmdf_ctx *ctx, void *ptr)
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");
     for (size_t i = 0; i < ctx->host_regs.size(); i++)
         if (ctx->host_regs[i].host == (char *)ptr) {
-            HIP_TRY(ctx, hipSetDevice(ctx->device));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            HIP_TRY(ctx, hipHostUnregister(ptr));
             ctx->host_regs.erase(ctx->host_regs.begin() + (long)i);
             return RMDF_OK;
         }

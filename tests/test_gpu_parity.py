@@ -757,9 +757,9 @@ def test_two_gpus_if_present():
 
 
 def test_registered_host_buffer(sr, rmdf):
-    """rmdf_register_host_buffer: whole-frame calls into a registered buffer are written by the render kernel directly;
-    same pixels as the copying path, the accumulating frame stays in step (a later tiled call returns it), buffers that are
-    not registered (or only partly inside a registration) take the copy."""
+    """rmdf_register_host_buffer (bookkeeping only since round 5: the library creates no GPU mapping of caller memory any more): whole-frame
+    calls into a registered buffer give the same pixels as into any other, nothing outside the frame is touched, the accumulating frame
+    stays in step (a later tiled call returns it), registering twice is harmless, unregistering twice is an error."""
     w, h, ms = 640, 360, 256
     ref = sr.render(2, w, h, 0.0, max_steps=ms)["rgba8"]
     big = np.zeros(w * h + 4096, np.uint32)
