@@ -610,9 +610,10 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
     }
 #endif
     if (OUT == OUT_MIRROR && p.band_flag) {
-        // (wave 0 made the workgroup's stores to host memory; its lane 0 speaks for them)
+        // every wave waits until ITS stores have landed in host memory; behind the barrier lane 0 speaks for the workgroup
+        __threadfence_system();
+        __syncthreads();
         if (threadIdx.x == 0) {
-            __threadfence_system();                                  // the stores above have landed in host memory
             const int band = g.by / p.band_strip_rows;
             const int rows = (int)gridDim.y - band * p.band_strip_rows;
             const unsigned n_band = gridDim.x * (unsigned)(rows < p.band_strip_rows ? rows : p.band_strip_rows);
