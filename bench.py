@@ -233,6 +233,9 @@ def sha256_file(path):
     return h.hexdigest()
 
 
+_PMC_OTHER_BUILD = {}       # the committed counter passes when they belong to ANOTHER build of the library (reported apart, labelled)
+
+
 def pmc_record(lib_path, workload):
     """PMC figures of the dominant kernel from the committed counter passes (profiles/pmc_traffic.json, written by
     tools/pmc_summary.py on the GPU box).  They are measurements of ONE build: used only when the file names this very
@@ -248,6 +251,7 @@ def pmc_record(lib_path, workload):
         return None, "profiles/pmc_traffic.json is for workload %s" % t.get("workload")
     have = sha256_file(lib_path)
     if t.get("lib_sha256") != have:
+        _PMC_OTHER_BUILD["record"] = t
         return None, "profiles/pmc_traffic.json was collected with another build of librmdf.so (%s..., this is %s...)" % (
             str(t.get("lib_sha256"))[:12], have[:12])
     return t, "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this build, librmdf.so sha256 %s...)" % have[:12]
@@ -865,6 +869,17 @@ def main():
                                   "note": "binding roof = FP32 vector-ALU issue (SURVEY 8d): as-written IEEE operations (sqrt, 1/sqrt, "
                                           "log, pow, / each 1; no FMA contraction by the parity contract) per second against 256 CU x "
                                           "4 SIMD x 32 lanes x 2.4 GHz; HBM side in hbm_roofline"}
+            if not pmc and _PMC_OTHER_BUILD.get("record"):
+                # no counter passes exist for THIS build (round 5: GPU access closed before the round's profiling run).  The committed ones
+                # are round 4's; that build's k_render<2, true, 0> has the same march loop instruction for instruction (only the shading
+                # tail lost 21 instructions: exp's scaling became one v_ldexp_f32), so they are printed -- apart from `traffic`, which stays
+                # null because it would not be a measurement of this library.
+                o = _PMC_OTHER_BUILD["record"]
+                result["roofline"]["counters_of_previous_build"] = {
+                    "lib_sha256": o.get("lib_sha256"), "hbm_bytes_per_launch": o.get("hbm_bytes_per_launch"),
+                    "valu_instructions_per_launch": (o.get("valu") or {}).get("SQ_INSTS_VALU_per_launch"),
+                    "lane_utilisation": (o.get("valu") or {}).get("lane_utilisation"),
+                    "note": "rocprofv3 --pmc passes of the round-4 library (profiles/pmc_traffic.json); not of the library this run timed"}
             valu_instr = None if not pmc else (pmc.get("valu") or {}).get("SQ_INSTS_VALU_per_launch")
             if valu_instr:
                 simds = cus * 4
@@ -941,11 +956,16 @@ def main():
     return result
 
 
-def scene_pmc(name):
+def scene_pmc(name, lib_path=None):
     """VALU instruction count of a secondary scene from the committed counter pass (profiles/scene_pmc.json, written by tools/prof_scene.sh),
-    or None."""
+    or None -- also None when the pass does not name THIS build of librmdf.so (round 5 rewrote the kernels of scenes 1 and 3: round 4's
+    instruction counts over the new kernels' times would be a figure of nothing)."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "scene_pmc.json"))).get(name, {}).get("SQ_INSTS_VALU_per_launch")
+        rec = json.load(open(os.path.join(ROOT, "profiles", "scene_pmc.json"))).get(name, {})
+        import rmdf_amd
+        if rec.get("lib_sha256") != sha256_file(lib_path or os.environ.get("RMDF_LIB", rmdf_amd.LIB_PATH)):
+            return None
+        return rec.get("SQ_INSTS_VALU_per_launch")
     except Exception:                                           # noqa: BLE001
         return None
 

@@ -22,13 +22,15 @@ for d in ("p1", "p2"):
             c[k] = statistics.median(v.values())
 ms = c["GRBM_GUI_ACTIVE"] / 8 / 2.4e6
 import json, os
-name = {"1": "scene1_detest_1280x720_m128", "3": "scene3_mbgeneral_1280x720_m128"}.get(sc)
+name = {"0": "config2_cornell_1280x720_m128", "1": "scene1_detest_1280x720_m128", "3": "scene3_mbgeneral_1280x720_m128"}.get(sc)
+import hashlib
+lib_sha = hashlib.sha256(open("ray-marching-distance-fields_amd/librmdf.so", "rb").read()).hexdigest()
 if name:
     # bench.py reads the instruction count of the secondary scenes from here (profiles/scene_pmc.json after copying)
     fn = "gpurun_out/scene_pmc.json"
     d = json.load(open(fn)) if os.path.exists(fn) else {}
     d[name] = {"SQ_INSTS_VALU_per_launch": c["SQ_INSTS_VALU"], "lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"] / 64 / c["SQ_ACTIVE_INST_VALU"], 3),
-               "kernel_ms_from_GRBM_GUI_ACTIVE": round(ms, 4), "source": "tools/prof_scene.sh %s (rocprofv3 --pmc, median per launch)" % sc}
+               "kernel_ms_from_GRBM_GUI_ACTIVE": round(ms, 4), "lib_sha256": lib_sha, "source": "tools/prof_scene.sh %s (rocprofv3 --pmc, median per launch)" % sc}
     json.dump(d, open(fn, "w"), indent=1, sort_keys=True)
 print("scene %s: kernel ~%.3f ms; VALU instr %.1f M -> %.2f G/s/SIMD (0.93 = issue peak); lane utilisation %.2f; waves waiting %.0f %% of their cycles; SALU %.1f M, SMEM %.2f M, VMEM reads %.2f M, LDS %.2f M" %
       (sc, ms, c["SQ_INSTS_VALU"] / 1e6, c["SQ_INSTS_VALU"] / 1024 / (ms * 1e-3) / 1e9, c["SQ_THREAD_CYCLES_VALU"] / 64 / c["SQ_ACTIVE_INST_VALU"],
