@@ -1200,7 +1200,9 @@ int render_whole_frame_host(rmdf_ctx *ctx, int scene, const FrameParams &p, uint
     WorkPool &pool = ctx_pool(ctx);
     // the library's choice (neither knob given): RMDF_WF_DEFAULT_* -- measured on the headline frame and the Cornell box, tools/whole_frame_sweep.py
     const int mode = (ctx->wf_bands == 0 && ctx->wf_mirror == 0) ? RMDF_WF_DEFAULT_MODE : ctx->wf_mirror;
-    int nb = ctx->wf_bands > 0 ? ctx->wf_bands : RMDF_WF_DEFAULT_BANDS;
+    // (the library's choice: two bands from 6 MB of frame on -- 1920x1080: 0.516 ms against 0.552 with one; the 3.7 MB Cornell frame of
+    // config 2 is faster in one piece, 0.249 against 0.273 ms)
+    int nb = ctx->wf_bands > 0 ? ctx->wf_bands : (npx * 4 >= ((size_t)6 << 20) ? RMDF_WF_DEFAULT_BANDS : 1);
     if (npx * 4 < ((size_t)2 << 20)) nb = 1;                         // small frames: one launch, one copy
     if (nb > h / 64) nb = h / 64 > 0 ? h / 64 : 1;                   // a band is at least 64 rows
     const bool mirror = mode != 0;
