@@ -24,6 +24,12 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#ifdef FAKE_RCCL_NO_GPU
+/* CPU-tier self-test of the double itself (tests/test_host_logic.py): "device" buffers are host memory, streams do not exist */
+#define hipStreamSynchronize(s) ((void)(s), hipSuccess)
+#define hipMemcpy(d, s, n, k) (memcpy((d), (s), (n)), hipSuccess)
+#endif
+
 struct ncclComm {
     char uid[33];
     int rank, nranks;

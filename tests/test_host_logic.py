@@ -364,3 +364,98 @@ def test_worker_pool_of_the_ctx(tmp_path):
         subprocess.check_call(["g++", "-std=c++17", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + flags + [src, "-o", exe])
         r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "pool ok" in r.stdout and "ThreadSanitizer" not in r.stderr, (tag, r.stdout[-500:], r.stderr[-2000:])
+
+
+def _fake_rccl_rank(so, uid_hex, rank, n, q):
+    """one rank of test_the_rccl_double_itself (module level: multiprocessing pickles it)"""
+    import ctypes as C
+    try:
+        L = C.CDLL(so)
+
+        class Uid(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        uid = Uid()
+        uid.internal = uid_hex.encode()
+        comm = C.c_void_p()
+        L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+        for f in (L.ncclSend, L.ncclRecv):
+            f.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ncclGetErrorString.restype = C.c_char_p
+        assert L.ncclCommInitRank(C.byref(comm), n, uid, rank) == 0
+        ncclChar = 0
+        out = {}
+        words = 1000 + 17 * rank
+        mine = (np.arange(words, dtype=np.uint32) * 2654435761 + rank).astype(np.uint32)
+        if rank == 0:
+            # the gather's shape: a grouped fan-in of n - 1 receives of DIFFERENT sizes, twice (sequence numbers per ordered pair)
+            for rnd in range(2):
+                bufs = [np.zeros(1000 + 17 * r, np.uint32) for r in range(n)]
+                assert L.ncclGroupStart() == 0
+                for r in range(1, n):
+                    assert L.ncclRecv(bufs[r].ctypes.data, bufs[r].nbytes, ncclChar, r, comm, None) == 0
+                assert L.ncclGroupEnd() == 0
+                for r in range(1, n):
+                    assert np.array_equal(bufs[r], (np.arange(1000 + 17 * r, dtype=np.uint32) * 2654435761 + r).astype(np.uint32) + rnd), (rnd, r)
+            # a receive whose size differs from the send fails instead of hanging; one nobody answers times out
+            small = np.zeros(5, np.uint32)
+            rc = L.ncclRecv(small.ctypes.data, small.nbytes, ncclChar, 1, comm, None)
+            out["mismatch"] = (rc, L.ncclGetErrorString(rc).decode())
+            rc = L.ncclRecv(small.ctypes.data, small.nbytes, ncclChar, n - 1, comm, None)
+            out["timeout"] = (rc, L.ncclGetErrorString(rc).decode())
+            # to self, grouped: the loopback self-test's shape
+            back = np.zeros(words, np.uint32)
+            assert L.ncclGroupStart() == 0
+            assert L.ncclRecv(back.ctypes.data, back.nbytes, ncclChar, 0, comm, None) == 0
+            assert L.ncclSend(mine.ctypes.data, mine.nbytes, ncclChar, 0, comm, None) == 0
+            assert L.ncclGroupEnd() == 0
+            assert np.array_equal(back, mine)
+        else:
+            for rnd in range(2):
+                data = (mine + rnd).astype(np.uint32)
+                assert L.ncclSend(data.ctypes.data, data.nbytes, ncclChar, 0, comm, None) == 0
+            if rank == 1:
+                assert L.ncclSend(mine.ctypes.data, 64, ncclChar, 0, comm, None) == 0          # 64 bytes where rank 0 expects 20
+            if rank == 2:
+                assert L.ncclSend(mine.ctypes.data, 8, ncclChar, 0, comm, None) == 0           # never received: CommDestroy of rank 0 removes it
+        if rank == 0:
+            import time
+            time.sleep(0.3)
+        assert L.ncclCommDestroy(comm) == 0
+        q.put((rank, "ok", out))
+    except Exception as e:                                      # noqa: BLE001
+        import traceback
+        q.put((rank, "failed: %s\n%s" % (e, traceback.format_exc()), {}))
+
+
+def test_the_rccl_double_itself(tmp_path):
+    """tests/fake_rccl.c is what the N > 1 exchange tests of the GPU tier stand on, so it is tested itself -- on the CPU tier, built with
+    FAKE_RCCL_NO_GPU ("device" buffers are host memory): four processes; a grouped fan-in of receives of different sizes, twice (ordering per
+    pair); a receive whose size differs from its send fails with ncclInvalidArgument instead of hanging; a receive nobody answers fails with
+    ncclSystemError after FAKE_RCCL_TIMEOUT_S; grouped send + receive to self; nothing is left in /dev/shm."""
+    import multiprocessing as mp
+    import subprocess
+    so = str(tmp_path / "libfake_rccl_cpu.so")
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-DFAKE_RCCL_NO_GPU", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "fake_rccl.c"), "-o", so])
+    uid = "%032x" % int.from_bytes(os.urandom(16), "big")
+    os.environ["FAKE_RCCL_TIMEOUT_S"] = "1"
+    try:
+        ctx = mp.get_context("fork")
+        q = ctx.Queue()
+        n = 4
+        ps = [ctx.Process(target=_fake_rccl_rank, args=(so, uid, r, n, q)) for r in range(n)]
+        for p in ps:
+            p.start()
+        res = {}
+        for _ in range(n):
+            rank, status, out = q.get(timeout=120)
+            res[rank] = (status, out)
+        for p in ps:
+            p.join(30)
+        assert all(res[r][0] == "ok" for r in range(n)), res
+        out = res[0][1]
+        assert out["mismatch"][0] != 0 and "expects 20 bytes" in out["mismatch"][1] and "sent 64" in out["mismatch"][1], out
+        assert out["timeout"][0] != 0 and "waited" in out["timeout"][1], out
+        assert not [f for f in os.listdir("/dev/shm") if f.startswith("fakerccl_" + uid)]
+    finally:
+        os.environ.pop("FAKE_RCCL_TIMEOUT_S", None)
