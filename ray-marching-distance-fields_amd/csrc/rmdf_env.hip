@@ -715,6 +715,200 @@ __global__ __launch_bounds__(64 * (3 + CH_PROD), 6) void k_prefilter_chan(const 
     }
 }
 
+// Round 5, fifth form (A/B only: RMDF_PREFILTER_RING=1; written after GPU access closed, NOT yet run on hardware).  k_prefilter_chan's
+// counters say no unit is busy -- LDS array 0.31, vector issue 0.34, scalar issue 0.37 of their peaks -- and its waves wait 53 % of their
+// cycles: producers and summing waves meet at one s_barrier per 64 source texels, 513 times per workgroup, and whoever arrives first waits.
+// Here they never meet.  The factors go through a ring of RING_SLOTS chunk buffers with two counters per slot in LDS: a producer wave adds
+// one to `filled` when its part of a chunk is written (all eight do, every chunk), a summing wave adds one to `drained` when it has read
+// the chunk out; chunk s lives in slot s % RING_SLOTS, is readable when filled == (s / RING_SLOTS + 1) * producers and writable when the
+// chunk RING_SLOTS before it is drained by all three summing waves.  So the producers run up to three chunks ahead and the stalls of one
+// side are absorbed by the ring instead of being handed to the other.  Same factors, same order of sums per destination texel and channel:
+// the arithmetic is k_prefilter_chan's line for line.  32-texel chunks (four slots fit the LDS budget of two workgroups per CU); needs at
+// least RING_SLOTS chunks per source row (w >= 128), so that a staged source row is never overwritten while a summing wave still reads it.
+#define RING_PROD 8
+#define RING_CHUNK 32
+#define RING_STRIDE 36
+#define RING_SLOTS 4
+#define RING_MAXCH 8                  // chunks per source row at most (w <= 256)
+template <int G, int CH, int NR>
+__device__ __forceinline__ void ring_sum_group(const float (&rr)[NR], const float4 &f, float &a)
+{
+    const float p0 = mul_row_bcast<(12 * G + CH) % 16>(rr[(12 * G + CH) / 16], f.x);
+    const float p1 = mul_row_bcast<(12 * G + 3 + CH) % 16>(rr[(12 * G + 3 + CH) / 16], f.y);
+    const float p2 = mul_row_bcast<(12 * G + 6 + CH) % 16>(rr[(12 * G + 6 + CH) / 16], f.z);
+    const float p3 = mul_row_bcast<(12 * G + 9 + CH) % 16>(rr[(12 * G + 9 + CH) / 16], f.w);
+    a = a + p0; a = a + p1; a = a + p2; a = a + p3;
+}
+template <int CH, int NR>
+__device__ __forceinline__ void ring_sum_chunk(const float (&rr)[NR], const float4 (&f)[RING_CHUNK / 4], unsigned live, float &a)
+{
+    if (live & 1u)   ring_sum_group<0, CH>(rr, f[0], a);
+    if (live & 2u)   ring_sum_group<1, CH>(rr, f[1], a);
+    if (live & 4u)   ring_sum_group<2, CH>(rr, f[2], a);
+    if (live & 8u)   ring_sum_group<3, CH>(rr, f[3], a);
+    if (live & 16u)  ring_sum_group<4, CH>(rr, f[4], a);
+    if (live & 32u)  ring_sum_group<5, CH>(rr, f[5], a);
+    if (live & 64u)  ring_sum_group<6, CH>(rr, f[6], a);
+    if (live & 128u) ring_sum_group<7, CH>(rr, f[7], a);
+}
+__device__ __forceinline__ void ring_wait_at_least(unsigned *counter, unsigned target)
+{
+    // the whole wave waits on one LDS word (wave-uniform address: a broadcast read); s_sleep keeps the spinning wave off the issue ports
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+}
+
+template <int LOG2P>
+__global__ __launch_bounds__(64 * (3 + RING_PROD), 6) void k_prefilter_ring(const float *__restrict__ src, int w, int h,
+        const float *__restrict__ lutT, const float2 *__restrict__ tcs, float *__restrict__ out)
+{
+    extern __shared__ float lds_dyn[];
+    const int nch = (w + RING_CHUNK - 1) / RING_CHUNK;                   // chunks per source row, >= RING_SLOTS (launcher)
+    const int row_stride = nch * RING_CHUNK * 3;                          // floats per staged row, zero beyond w * 3
+    float *lds_row = lds_dyn;                                             // [2][row_stride]
+    float *lds_ring = lds_row + 2 * row_stride;                           // [RING_SLOTS][64][RING_STRIDE]
+    unsigned *lds_flag = (unsigned *)(lds_ring + RING_SLOTS * 64 * RING_STRIDE);     // [RING_SLOTS][8]: live groups of the chunk in the slot
+    unsigned *lds_filled = lds_flag + RING_SLOTS * 8;                     // [RING_SLOTS]
+    unsigned *lds_drained = lds_filled + RING_SLOTS;                      // [RING_SLOTS]
+    unsigned *lds_cnt = lds_drained + RING_SLOTS;                         // [RING_PROD][64]: the producers' sample counts, at the end
+    const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool consumer = g < 3;                                          // summing wave g = channel g
+    const int pidx = consumer ? 0 : g - 3;
+    const int blk = blockIdx.x, dy = blockIdx.y;
+    const int dx = blk * 64 + lane;
+    const float *glut = lutT + (size_t)blk * w * 64;
+    constexpr int NT = 64 * (3 + RING_PROD), NP = 64 * RING_PROD, NPF = 2;
+    for (int i = threadIdx.x; i < 2 * row_stride; i += NT) lds_row[i] = 0.0f;
+    if (threadIdx.x < 2 * RING_SLOTS) lds_filled[threadIdx.x] = 0u;       // filled[] and drained[] are adjacent
+    const int ptid = (int)threadIdx.x - 64 * 3;
+    const int nrow = w * 3;
+    float pf[NPF] = { 0.0f, 0.0f };
+    float lutreg[RING_MAXCH][4];
+    if (!consumer) {
+#pragma unroll
+        for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; pf[k] = i < nrow ? src[i] : 0.0f; }
+#pragma unroll
+        for (int j = 0; j < RING_MAXCH; j++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) { const int x = j * RING_CHUNK + 4 * pidx + t; lutreg[j][t] = x < w ? glut[x * 64 + lane] : 0.0f; }
+    }
+    typedef const float __attribute__((address_space(4))) cfloat;
+    const float lc = ((cfloat *)tcs)[2 * dy], ls = ((cfloat *)tcs)[2 * dy + 1];
+    float acc = 0.0f;
+    unsigned ni = 0u;
+    __syncthreads();                                                      // the only barrier before the end: rows zeroed, counters zeroed
+    const unsigned total = (unsigned)h * (unsigned)nch;                   // chunks of this workgroup
+    if (!consumer) {
+        unsigned s = 0u;
+        for (int y = 0; y < h; y++) {
+            const float pc = ((cfloat *)tcs)[2 * y], ps = ((cfloat *)tcs)[2 * y + 1];
+            const float lcpc = lc * pc, lsps = ls * ps;
+#pragma unroll
+            for (int j = 0; j < RING_MAXCH; j++) {
+                if (j >= nch) continue;
+                const unsigned slot = s % RING_SLOTS, round = s / RING_SLOTS;
+                // the slot's previous chunk (s - RING_SLOTS) has been read out by all three summing waves.  That also covers the staged row:
+                // row y goes into buffer y & 1 at j == 0, which row y - 2 used; its last chunk is s - nch - 1 <= s - RING_SLOTS - 1
+                if (round > 0u) ring_wait_at_least(&lds_drained[slot], 3u * round);
+                if (j == 0) {
+                    float *rb = lds_row + (y & 1) * row_stride;
+#pragma unroll
+                    for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; if (i < nrow) rb[i] = pf[k]; }
+                    if (y + 1 < h) {
+                        const float *nsrc = src + (size_t)(y + 1) * nrow;
+#pragma unroll
+                        for (int k = 0; k < NPF; k++) { const int i = ptid + k * NP; pf[k] = i < nrow ? nsrc[i] : 0.0f; }
+                    }
+                }
+                const int x0 = j * RING_CHUNK;
+                const int ng = ((w - x0 < RING_CHUNK ? w - x0 : RING_CHUNK) + 3) >> 2;
+                if (pidx < ng) {
+                    float c0[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const float cos_angle = lcpc + lsps * lutreg[j][t];
+                        unsigned ind;
+                        asm("v_med3_i32 %0, %1, 0, 1" : "=v"(ind) : "v"(__float_as_int(cos_angle)));
+                        ni += ind;
+                        c0[t] = __builtin_fmaxf(cos_angle, 0.0f);
+                    }
+                    const bool live = __ballot(__builtin_fmaxf(__builtin_fmaxf(c0[0], c0[1]), __builtin_fmaxf(c0[2], c0[3])) > 0.0f) != 0ull;
+                    if (lane == 0) lds_flag[slot * 8 + pidx] = live ? 1u : 0u;
+                    if (live) {
+                        float fac[4];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            float cp = c0[t];
+                            if (LOG2P > 0) {
+                                double cd = (double)c0[t];
+#pragma unroll
+                                for (int q = 0; q < LOG2P; q++) cd = cd * cd;
+                                cp = (float)cd;
+                            }
+                            fac[t] = ps * cp;
+                        }
+                        *(float4 *)(lds_ring + slot * 64 * RING_STRIDE + lane * RING_STRIDE + 4 * pidx) = make_float4(fac[0], fac[1], fac[2], fac[3]);
+                    }
+                } else if (lane == 0 && pidx < 8) {
+                    lds_flag[slot * 8 + pidx] = 0u;                       // a group past the row's end
+                }
+                // this wave's part of chunk s (row floats, flag, factors) is in LDS: count it in
+                if (lane == 0) __hip_atomic_fetch_add(&lds_filled[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                s++;
+            }
+        }
+    } else {
+        unsigned s = 0u;
+        for (int y = 0; y < h; y++) {
+#pragma unroll
+            for (int j = 0; j < RING_MAXCH; j++) {
+                if (j >= nch) continue;
+                const unsigned slot = s % RING_SLOTS, round = s / RING_SLOTS;
+                ring_wait_at_least(&lds_filled[slot], (unsigned)RING_PROD * (round + 1u));
+                const int x0 = j * RING_CHUNK;
+                const int ng = ((w - x0 < RING_CHUNK ? w - x0 : RING_CHUNK) + 3) >> 2;
+                const float *fsrc = lds_ring + slot * 64 * RING_STRIDE + lane * RING_STRIDE;
+                const float *rrow = lds_row + (y & 1) * row_stride + x0 * 3 + (lane & 15);
+                float rr[RING_CHUNK * 3 / 16];
+                float4 f[RING_CHUNK / 4];
+                const unsigned fl = lds_flag[slot * 8 + (lane & 7)];
+                const unsigned live = (unsigned)__ballot(fl != 0u) & ((ng >= 8) ? 0xffu : ((1u << ng) - 1u));
+#pragma unroll
+                for (int m = 0; m < RING_CHUNK * 3 / 16; m++) rr[m] = rrow[16 * m];
+#pragma unroll
+                for (int k = 0; k < RING_CHUNK / 4; k++) f[k] = *(const float4 *)(fsrc + 4 * k);      // (dead groups: stale, unused)
+                // everything this wave needs of the slot is in registers (the compiler waits for the reads before their first use; the
+                // release below is ordered behind them): hand the slot back before the sums
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(&lds_drained[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (g == 0)      ring_sum_chunk<0>(rr, f, live, acc);
+                else if (g == 1) ring_sum_chunk<1>(rr, f, live, acc);
+                else             ring_sum_chunk<2>(rr, f, live, acc);
+                s++;
+            }
+        }
+    }
+    (void)total;
+    if (!consumer) lds_cnt[pidx * 64 + lane] = ni;
+    __syncthreads();
+    if (consumer) {
+        unsigned nt = 0u;
+#pragma unroll
+        for (int k = 0; k < RING_PROD; k++) nt += lds_cnt[k * 64 + lane];
+        const float n = (float)(nt < 16777216u ? nt : 16777216u);        // a Float counter: n + 1 == n from 2^24 on
+        if (dx < w) out[((size_t)dx + (size_t)dy * w) * 3 + g] = acc / n;
+    }
+}
+
+template <int LOG2P>
+static hipError_t launch_prefilter_ring_t(const float *d_src, int w, int h, const float *d_lutT, const float2 *d_tcs, float *d_out, hipStream_t stream)
+{
+    const int nch = (w + RING_CHUNK - 1) / RING_CHUNK;
+    const size_t lds = (2 * (size_t)nch * RING_CHUNK * 3 + (size_t)RING_SLOTS * 64 * RING_STRIDE) * sizeof(float) +
+                       ((size_t)RING_SLOTS * 8 + 2 * RING_SLOTS + (size_t)RING_PROD * 64) * sizeof(unsigned);
+    hipLaunchKernelGGL((k_prefilter_ring<LOG2P>), dim3((w + 63) / 64, h), dim3(64 * (3 + RING_PROD)), lds, stream, d_src, w, h, d_lutT, d_tcs, d_out);
+    return hipGetLastError();
+}
+
 template <int LOG2P>
 static hipError_t launch_prefilter_chan_t(const float *d_src, int w, int h, const float *d_lutT, const float2 *d_tcs, float *d_out, hipStream_t stream)
 {
@@ -752,6 +946,9 @@ static hipError_t launch_prefilter_t(const float *d_src, int w, int h, float pow
                                      float *d_out, hipStream_t stream, bool split_ok)
 {
     static const bool one_wave = getenv("RMDF_PREFILTER_ONE_WAVE") != nullptr;          // A/B switch (tools/, tests): the one-wave kernel at every size
+    static const bool ring = getenv("RMDF_PREFILTER_RING") != nullptr;                  // A/B switch: the barrier-free ring form (not yet run on hardware)
+    if (LOG2P >= 0 && ring && w >= RING_SLOTS * RING_CHUNK && w <= 256 && w % 4 == 0 && split_ok && !one_wave)
+        return launch_prefilter_ring_t<(LOG2P >= 0 ? LOG2P : 0)>(d_src, w, h, d_lutT, d_tcs, d_out, stream);
     if (LOG2P >= 0 && w <= 256 && w % 4 == 0 && split_ok && !one_wave)                  // the reference's size: factor and sum on different waves
         return launch_prefilter_chan_t<(LOG2P >= 0 ? LOG2P : 0)>(d_src, w, h, d_lutT, d_tcs, d_out, stream);
     const dim3 grid((w + 63) / 64, (h + PREFILTER_WAVES - 1) / PREFILTER_WAVES), block(64 * PREFILTER_WAVES);

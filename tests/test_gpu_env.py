@@ -12,7 +12,7 @@ import shutil
 import numpy as np
 import pytest
 
-from conftest import ENV_CACHE, rel_err
+from conftest import unverified, ENV_CACHE, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -58,6 +58,30 @@ def test_latlong_to_cube_is_bit_exact(rmdf, orc, env_latlongs):
             assert np.array_equal(got, ref), (slot, int((got != ref).sum()))
     finally:
         fresh.close()
+
+
+@unverified
+@pytest.mark.gpu
+def test_the_barrier_free_ring_form_of_the_prefilter_is_bit_exact(orc, env_latlongs, tmp_path):
+    """k_prefilter_ring (RMDF_PREFILTER_RING=1, read once per process: a child process): a power alone at 256x128, 128x64 and 252x5 == the
+    default kernel's maps == the oracle's, bit for bit.  Written after GPU access closed in round 5: never run on hardware."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import rmdf_amd\n"
+            "z = np.load(sys.argv[1]); sr = rmdf_amd.ShaderRenderer(0)\n"
+            "np.savez(sys.argv[2], **{k + '_' + str(int(p)): sr.prefilter_env(z[k], p) for k in z.files for p in (1.0, 8.0, 64.0, 512.0)})\n" % ROOT)
+    srcs = {"a": orc.resize_hdr(env_latlongs["refl"], 256), "b": orc.resize_hdr(env_latlongs["refl"], 128), "c": synthetic_latlong(252, 5, 7)}
+    np.savez(str(tmp_path / "in.npz"), **srcs)
+    for tag, env in (("ring", dict(os.environ, RMDF_PREFILTER_RING="1")), ("default", dict(os.environ))):
+        env.pop("RMDF_PREFILTER_RING", None) if tag == "default" else None
+        r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "in.npz"), str(tmp_path / (tag + ".npz"))], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+    ring, dflt = np.load(str(tmp_path / "ring.npz")), np.load(str(tmp_path / "default.npz"))
+    for k in ring.files:
+        assert np.array_equal(ring[k].view(np.uint32), dflt[k].view(np.uint32)), k
+    for p in (1.0, 512.0):
+        assert np.array_equal(ring["b_%d" % int(p)].view(np.uint32), orc.cosine_convolve(srcs["b"], p, pow_mode=1).view(np.uint32)), p
 
 
 @pytest.mark.parametrize("w,h", [(32, 16), (128, 64), (256, 128), (100, 37), (8, 3), (4, 2), (252, 5)])
