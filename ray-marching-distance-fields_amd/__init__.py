@@ -343,7 +343,7 @@ class ShaderRenderer:
 
     def comm_verify_deal(self, stream=0):
         """COLLECTIVE: every rank of the communicator calls it after its last set_shard_costs / set_shard_root_handicap; raises on
-        every rank if the ranks hold different deals (the exchange then keeps whole fixed-size slots)."""
+        every rank if the ranks hold different deals (frames would be assembled from the wrong tiles; the sizes on the wire never depend on the deal)."""
         self._check(self._lib.rmdf_comm_verify_deal(self._ctx, stream or None))
 
     def gather_shards_device(self, w, h, d_shard, d_gathered=0, stream=0):

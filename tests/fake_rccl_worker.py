@@ -69,7 +69,7 @@ def main():
     sr.comm_verify_deal()
     mine = sr.shard_tiles(rank, n)
     assert 0 < len(mine) <= slots
-    frames([0.0] * S, "verified cost-aware deal (exact tile counts on the wire)")
+    frames([0.0] * S, "verified cost-aware deal")
     # 3. ONE rank holds other costs: every rank gets RMDF_E_COMM from the check, nobody hangs
     bad = np.array(cost, np.float32).copy()
     if rank == n - 1:
