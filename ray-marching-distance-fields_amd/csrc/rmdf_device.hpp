@@ -1009,9 +1009,20 @@ __device__ __forceinline__ float group8_min(float v)
     v = (o < v) ? o : v;
     return v;
 }
+__device__ __forceinline__ float group4_min(float v)       // min over the four lanes of a quad, result in all of them
+{
+    float o;
+    o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]
+    v = (o < v) ? o : v;
+    o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
+    v = (o < v) ? o : v;
+    return v;
+}
 // One estimate for the ray of this lane's group; EVERY lane of the wave calls it (live = the group has a ray; the others ignore the result).  sub = lane & 7.  prev: the candidates measured speculatively (in/out: this step's mask for the next step).
+template <int G = 8>        // lanes per ray: 8 (the product), or 4 (A/B: -DRMDF_AB_XL_G=4 -- sixteen rays per wave, two DPP steps; not yet run on hardware)
 __device__ __forceinline__ float de_cornell_box_group8(bool live, v3 pos, const float *rows, const unsigned *fine, int sub, unsigned &prev)
 {
+    static_assert(G == 8 || G == 4, "groups of eight or four lanes");
     // (a group without a ray measures nothing: empty masks)
     const unsigned m = live ? cornell_cell_mask_fast<CORNELL_FINE_N>(pos, fine) : 0u;      // in flight while the previous candidates are measured
     if (!live) prev = 0u;
@@ -1021,7 +1032,7 @@ __device__ __forceinline__ float de_cornell_box_group8(bool live, v3 pos, const 
     for (int round = 0; round < 2; round++) {
         // this lane's triangles of `set`: ranks sub, sub + 8, ...
         int n = __builtin_popcount(set);
-        for (int k = sub; __ballot(k < n) != 0ull; k += 8) {
+        for (int k = sub; __ballot(k < n) != 0ull; k += G) {
             if (k < n) {
                 const int i = nth_set_bit32(set, k);
                 const float x = cornell_tri_dist2(pos, rows + i * CORNELL_STRIDE);
@@ -1032,7 +1043,7 @@ __device__ __forceinline__ float de_cornell_box_group8(bool live, v3 pos, const 
         if (round == 0 && __ballot(set != 0u) == 0ull) break;
     }
     prev = m == 0xffffffffu ? 0u : m;          // (a point outside the grid measures all 32: nothing to carry over)
-    return sqrt_rn(group8_min(best));
+    return sqrt_rn(G == 8 ? group8_min(best) : group4_min(best));
 }
 
 __device__ __forceinline__ float de_cornell_box_table(v3 pos, const float *__restrict__ tab, int prune, int &hint, const unsigned *grid = nullptr)

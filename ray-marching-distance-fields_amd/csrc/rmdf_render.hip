@@ -91,6 +91,9 @@ enum { OUT_RGBA8 = 0, OUT_MIRROR = 1, OUT_PLANES = 2 };
 #else
 #define XL_TAIL true
 #endif
+#ifndef RMDF_AB_XL_G                // lanes per ray of that tail: 8 (a wave takes it up at <= 8 live rays); A/B: 4 (at <= 16; not yet run on hardware)
+#define RMDF_AB_XL_G 8
+#endif
 
 // Everything a lane derives from (strip, thread id): the rectangle of its launch / shard slot, its pixel, its primary ray.
 // (Deriving it a second time after the march from laundered inputs, so that none of it occupies registers across the march
@@ -195,9 +198,9 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
         for (;;) {
             const unsigned long long am = __ballot(act);
             if (am == 0ull) break;
-            if (cgrid && __popcll(am) <= 8) {
+            if (cgrid && __popcll(am) <= 64 / RMDF_AB_XL_G) {
                 // group gi = the gi-th live lane's ray: every lane of the group takes a copy of its state
-                const int gi = lane >> 3, sub = lane & 7;
+                const int gi = lane / RMDF_AB_XL_G, sub = lane & (RMDF_AB_XL_G - 1);
                 unsigned long long mm = am;
                 for (int i = 0; i < gi; i++) mm &= mm - 1ull;
                 const bool gact0 = mm != 0ull;
@@ -210,7 +213,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
                 unsigned prev = 0u;
                 while (__ballot(gact) != 0ull) {
                     const v3 pos = mk3(origin.x + xt * xdx, origin.y + xt * xdy, origin.z + xt * xdz);
-                    const float dist = de_cornell_box_group8(gact, pos, s_ctab, cgrid, sub, prev);
+                    const float dist = de_cornell_box_group8<RMDF_AB_XL_G>(gact, pos, s_ctab, cgrid, sub, prev);
                     if (gact) {
                         xt += dist;
                         const bool out = xt > xtmax;
