@@ -54,3 +54,35 @@ def test_shader_constants_equal_reference(side, orc, rmdf):
     assert set(have) == set(want), (sorted(set(have) ^ set(want)))
     for name, v in want.items():
         assert np.float32(have[name]) == np.float32(v), (side, name, have[name], v)
+
+
+def test_the_viewer_patch_applies_to_the_reference(tmp_path):
+    """INTEGRATION.md section 3 is prose about three of the reference's files; hs/apply_viewer_patch.py is the same change as anchored edits.
+    Where the reference checkout is present (this container, not the GPU box) the script must apply cleanly -- every anchor found exactly as
+    often as stated -- and leave exactly the described differences.  (Compiling the result needs GHC, which the image does not have.)"""
+    import subprocess
+    import sys
+    ref = "/root/reference"
+    if not os.path.exists(os.path.join(ref, "App.hs")):
+        pytest.skip("no reference checkout here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "patched")
+    r = subprocess.run([sys.executable, os.path.join(root, "ray-marching-distance-fields_amd", "hs", "apply_viewer_patch.py"), ref, out],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    import difflib
+    delta = {}
+    for name in ("App.hs", "Main.hs", "rmdf.cabal"):
+        a = open(os.path.join(ref, name)).read().splitlines()
+        b = open(os.path.join(out, name)).read().splitlines()
+        d = [l for l in difflib.unified_diff(a, b, lineterm="", n=0) if l[:1] in "+-" and l[:3] not in ("+++", "---")]
+        delta[name] = (sum(1 for l in d if l[0] == "-"), sum(1 for l in d if l[0] == "+"), d)
+    assert delta["App.hs"][:2] == (4, 7) and delta["Main.hs"][:2] == (1, 2) and delta["rmdf.cabal"][:2] == (1, 3), {k: v[:2] for k, v in delta.items()}
+    added = "\n".join(l[1:] for l in delta["App.hs"][2] if l[0] == "+")
+    assert added.count("hipShader FS") == 4 and "import RmdfFFI" in added and "_aeHR" in added and "drawHipTile _aeHR" in added
+    assert "withHipRenderer reflMapFn $ \\_aeHR -> do" in "\n".join(delta["Main.hs"][2])
+    assert os.path.exists(os.path.join(out, "RmdfFFI.hs"))
+    # the script refuses to write the reference's source into this repository
+    r = subprocess.run([sys.executable, os.path.join(root, "ray-marching-distance-fields_amd", "hs", "apply_viewer_patch.py"), ref, os.path.join(root, "gpurun_out", "x")],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "outside this repository" in r.stderr
