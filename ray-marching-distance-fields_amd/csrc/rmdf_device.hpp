@@ -930,14 +930,21 @@ __device__ __forceinline__ unsigned wave_or_active(unsigned m)
 // The candidates come from the fine grid in global memory (`fine`, CORNELL_FINE_N^3 masks); the hinted triangle is evaluated whether or
 // not it is a candidate of the cell -- the minimum over a superset of the candidates is the same minimum -- so the mask is not
 // needed before ~140 instructions have run, and its latency hides.
-__device__ __forceinline__ float de_cornell_box_lanes(v3 pos, const float *rows, const unsigned *fine, int &hint)
+// keep (A/B only, -DRMDF_AB_SHARED_BOUNDS; not yet run on hardware): if non-null, the bound tests use a margin wider by 2e-5 and the lane's
+// survivors are handed out -- de_cornell_box_lanes_kept then serves any point within 1e-5 of `pos` (the normal's other three sample points)
+// without a pass of bound tests of its own.  Why that is the same minimum: the point-triangle distance is 1-Lipschitz, so for a point p'
+// with |p' - pos| <= e every triangle has d'(t) >= d(t) - e and the hinted one d'(g) <= d(g) + e; a triangle whose lower bound exceeds
+// d(g) + 2e (+ the usual margin) therefore cannot undercut d'(g).  The cell's mask covers p' as well: the grid's masks hold for every point
+// within 1e-4 of the cell (rmdf_api.cpp: cornell_grid).
+__device__ __forceinline__ float de_cornell_box_lanes(v3 pos, const float *rows, const unsigned *fine, int &hint, unsigned *keep = nullptr)
 {
     const unsigned m = cornell_cell_mask_fast<CORNELL_FINE_N>(pos, fine);
     int g = hint & 31;
     float best = cornell_tri_dist2(pos, rows + g * CORNELL_STRIDE);
     // dmax^2 for dmax = 1.001 sqrt(best) + 1e-5 (the margin of de_cornell_box_table) without the root:
     // (1.001 r + 1e-5)^2 = 1.002001 b + 2.002e-5 r + 1e-10 <= 1.0031 b + 1.02e-7  (2 r <= b / 0.01 + 0.01)
-    const float dmax2 = __builtin_fmaf(best, 1.0031f, 1.02e-7f);
+    // with the margin widened to 3e-5 (keep): (1.001 r + 3e-5)^2 = 1.002001 b + 6.006e-5 r + 9e-10 <= 1.0031 b + 8.3e-7  (6.006e-5 r <= 0.0011 b + 8.2e-7)
+    const float dmax2 = __builtin_fmaf(best, 1.0031f, keep ? 8.3e-7f : 1.02e-7f);
     unsigned my = m & ~(1u << g), surv = 0u;
     while (__ballot(my != 0u) != 0ull) {
         if (my != 0u) {
@@ -958,6 +965,7 @@ __device__ __forceinline__ float de_cornell_box_lanes(v3 pos, const float *rows,
             if (!(bound2 > dmax2)) surv |= 1u << i;
         }
     }
+    if (keep) *keep = surv | (1u << g);
     while (__ballot(surv != 0u) != 0ull) {
         if (surv != 0u) {
             const int i = (int)__builtin_ctz(surv);
@@ -967,6 +975,20 @@ __device__ __forceinline__ float de_cornell_box_lanes(v3 pos, const float *rows,
         }
     }
     hint = g;
+    return sqrt_rn(best);
+}
+// the estimate of a point within 1e-5 of the one `kept` was made for: the kept triangles measured, nothing else (see above)
+__device__ __forceinline__ float de_cornell_box_lanes_kept(v3 pos, const float *rows, unsigned kept)
+{
+    float best = 998001.0f;
+    while (__ballot(kept != 0u) != 0ull) {
+        if (kept != 0u) {
+            const int i = (int)__builtin_ctz(kept);
+            kept &= kept - 1u;
+            const float x = cornell_tri_dist2(pos, rows + i * CORNELL_STRIDE);
+            best = (x < best) ? x : best;
+        }
+    }
     return sqrt_rn(best);
 }
 

@@ -394,6 +394,9 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
         const v3 np = mk3(isec.x - dir.x * shk::isec_step_back, isec.y - dir.y * shk::isec_step_back, isec.z - dir.z * shk::isec_step_back);
         const float eps = shk::normal_eps;
         float d0 = 0.0f, ddx = 0.0f, ddy = 0.0f, ddz = 0.0f, occl = 0.0f;
+#ifdef RMDF_AB_SHARED_BOUNDS
+        unsigned kept_tris = 0u;
+#endif
 #pragma unroll 1
         for (int k = 0; k < 8; k++) {
             if (k == 4) n = normalize3(mk3(ddx, ddy, ddz));
@@ -401,7 +404,16 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
             const float wtk = k == 4 ? shk::cornell_ao_w0 : (k == 5 ? shk::cornell_ao_w1 : (k == 6 ? shk::cornell_ao_w2 : shk::cornell_ao_w3));
             const v3 pos = k < 4 ? mk3(np.x - (k == 1 ? eps : 0.0f), np.y - (k == 2 ? eps : 0.0f), np.z - (k == 3 ? eps : 0.0f))
                                  : mk3(isec.x + n.x * dlk, isec.y + n.y * dlk, isec.z + n.z * dlk);
+#ifdef RMDF_AB_SHARED_BOUNDS
+            // (A/B only, not yet run on hardware: the normal's four sample points lie within 1e-5 of each other -- one pass of bound tests,
+            // its margin widened accordingly, serves all four: rmdf_device.hpp de_cornell_box_lanes `keep`)
+            float d;
+            if (cgrid && k == 0)      d = de_cornell_box_lanes(pos, s_ctab, cgrid, tri_hint, &kept_tris);
+            else if (cgrid && k < 4)  d = de_cornell_box_lanes_kept(pos, s_ctab, kept_tris);
+            else                      d = distance_estimator<SCENE>(pos, p, iters, tri_hint, cgrid, s_ctab);
+#else
             const float d = distance_estimator<SCENE>(pos, p, iters, tri_hint, cgrid, s_ctab);
+#endif
             if (k == 0) d0 = d;
             else if (k == 1) ddx = d0 - d;
             else if (k == 2) ddy = d0 - d;

@@ -283,6 +283,89 @@ def test_cornell_pruning_planes_are_lower_bounds_of_the_distance():
     assert worst > -1.0                                                                   # (ran)
 
 
+def test_cornell_kept_set_of_one_sample_point_serves_its_neighbours():
+    """-DRMDF_AB_SHARED_BOUNDS (rmdf_device.hpp: de_cornell_box_lanes `keep`, de_cornell_box_lanes_kept; an A/B variant, not the
+    product default): the normal's four sample points lie within 1e-5 of each other, so the first one's pass of bound tests, its margin
+    widened to 3e-5, is to serve the other three, which then measure only the kept triangles.  Host arithmetic, no GPU: for 200 000
+    points p (random and near the triangles) and every hint g, each triangle NOT kept at p -- outside the cell's mask, or with
+    bound^2 > 1.0031 d(p, g)^2 + 8.3e-7 -- is farther from p - 1e-5 e_k than the nearest triangle by more than 5e-6, i.e. by far more than
+    the float rounding of the distance formulas, so it cannot be the minimum there."""
+    import ctypes as C
+    import rmdf_amd
+    L = rmdf_amd.load_library(xcheck=True)
+    stride, bounds = C.c_int(), C.c_int()
+    assert L.rmdf_debug_cornell_table(None, C.byref(stride), C.byref(bounds)) == 0
+    S, B = stride.value, bounds.value
+    tab = np.zeros((32, S), np.float32)
+    assert L.rmdf_debug_cornell_table(tab.ctypes.data, None, None) == 0
+    N = 64
+    grid = np.zeros(N ** 3, np.uint32)
+    assert L.rmdf_debug_cornell_masks(N, 0, grid.ctypes.data) == 0
+    tri = tab[:, :9].astype(np.float64).reshape(32, 3, 3)
+    planes = tab[:, B:B + 16].reshape(32, 4, 4)
+
+    def true_dist(p):                                       # closest point by clamped projection onto plane / edges, float64: [n, 3] -> [n, 32]
+        a, b, c = tri[None, :, 0], tri[None, :, 1], tri[None, :, 2]
+        P = p[:, None, :]
+        def seg(u, v):
+            e = v - u
+            t = np.clip(((P - u) * e).sum(-1) / (e * e).sum(-1), 0.0, 1.0)
+            return np.sqrt(((P - (u + t[..., None] * e)) ** 2).sum(-1))
+        n = np.cross(b - a, c - a)
+        n = n / np.linalg.norm(n, axis=-1, keepdims=True)
+        pd = ((P - a) * n).sum(-1)
+        q = P - pd[..., None] * n
+        inside = np.ones(pd.shape, bool)
+        for u, v in ((a, b), (b, c), (c, a)):
+            inside &= (np.cross(v - u, q - u) * n).sum(-1) >= 0.0
+        edge = np.minimum(np.minimum(seg(a, b), seg(b, c)), seg(c, a))
+        return np.where(inside, np.abs(pd), edge)
+
+    def kernel_bound2(p32):
+        x, y, z = (p32[:, None, None, k] for k in range(3))
+        pl = planes[None]
+        f32 = np.float32
+        dots = (f32(pl[..., 2] * z) + f32(f32(pl[..., 1] * y) + f32(pl[..., 0] * x))) - pl[..., 3]
+        pd, sm = dots[..., 0], np.maximum(dots[..., 1:].max(axis=-1), f32(0.0))
+        return sm * sm + pd * pd
+
+    def cell_mask(p32):
+        s = np.float32(N / 2.2)
+        idx = np.floor(p32 * s + np.float32(1.1) * s).astype(np.int64)
+        ok = ((idx >= 0) & (idx < N)).all(axis=1)
+        idx = np.clip(idx, 0, N - 1)
+        m = grid[(idx[:, 2] * N + idx[:, 1]) * N + idx[:, 0]]
+        return np.where(ok, m, np.uint32(0xffffffff))
+
+    rng = np.random.default_rng(11)
+    w = rng.dirichlet((1.0, 1.0, 1.0), (32, 1500))
+    on = np.einsum("tnk,tkc->tnc", w, tri).reshape(-1, 3)
+    pts = np.concatenate([rng.uniform(-1.05, 1.05, (100000, 3)), on + rng.normal(0.0, 2e-3, on.shape), on + rng.normal(0.0, 3e-5, on.shape),
+                          np.repeat(tri.reshape(-1, 3), 40, axis=0) + rng.normal(0.0, 1e-3, (96 * 40, 3))])
+    bits = (np.uint32(1) << np.arange(32, dtype=np.uint32))[None, :]
+    kept_counts = []
+    for lo in range(0, len(pts), 20000):
+        p = pts[lo:lo + 20000]
+        p32 = p.astype(np.float32)
+        d0 = true_dist(p32.astype(np.float64))
+        b2 = kernel_bound2(p32)
+        in_cell = (cell_mask(p32)[:, None] & bits) != 0
+        # hints: the nearest triangle (what the march hands over almost always) and a random one (nothing relies on the hint being good)
+        for g in (d0.argmin(axis=1), rng.integers(0, 32, len(p))):
+            best = (d0[np.arange(len(p)), g] ** 2).astype(np.float32)
+            thr = np.float32(1.0031) * best + np.float32(8.3e-7)
+            kept = (in_cell & (b2 <= thr[:, None])) | (np.arange(32)[None, :] == g[:, None])
+            kept_counts.append(kept.sum(axis=1).mean())
+            for k in range(3):
+                q = p32.astype(np.float64)
+                q[:, k] -= 1e-5
+                d = true_dist(q)
+                gap = np.where(kept, np.inf, d - d.min(axis=1, keepdims=True))
+                assert gap.min() > 5e-6, (float(gap.min()), k)
+    print("mean kept triangles per point (nearest hint, random hint) per block:", [round(float(x), 2) for x in kept_counts])
+    assert 1.0 <= min(kept_counts) and kept_counts[0] < 4.0, kept_counts       # with a good hint the kept set is small
+
+
 def test_dpp_products_of_the_prefilter_have_no_read_after_write_hazard(tmp_path):
     """k_prefilter_chan / k_prefilter_fused4 multiply source texels through `v_mul_f32_dpp ... row_newbcast` written as inline asm
     (hipcc does not fold update_dpp into the multiply).  The compiler's hazard recogniser does not look inside inline asm, and gfx9

@@ -12,7 +12,7 @@ timeout 900 python -m pytest tests -m gpu -x -q > $o/tier.txt 2>&1; tail -3 $o/t
 step "2. bench.py, default"
 timeout 600 python bench.py > $o/bench_default.json 2> $o/bench_default.err; python tools/show_bench.py $o/bench_default.json 2>/dev/null | head -30
 step "3. scene kernels: default / without the eight-lane Cornell tail / four lanes per ray / round-4 library"
-for l in default tools/abtest/noxl.so tools/abtest/xl4.so tools/abtest/r04.so; do if [ $l = default ]; then unset RMDF_LIB; else export RMDF_LIB=$PWD/$l; fi; timeout 200 python tools/scene_times.py 60; done > $o/scene_times.txt 2>&1; unset RMDF_LIB; cat $o/scene_times.txt
+for l in default tools/abtest/noxl.so tools/abtest/xl4.so tools/abtest/sharedb.so tools/abtest/r04.so; do if [ $l = default ]; then unset RMDF_LIB; else export RMDF_LIB=$PWD/$l; fi; timeout 200 python tools/scene_times.py 60; done > $o/scene_times.txt 2>&1; unset RMDF_LIB; cat $o/scene_times.txt
 step "4. whole-frame host call: every band count and hand-over mode; the 16-byte mirror stores"
 timeout 500 python tools/whole_frame_sweep.py 40 > $o/wf_sweep.txt 2>&1; cat $o/wf_sweep.txt
 RMDF_LIB=$PWD/tools/abtest/mirror16.so timeout 500 python tools/whole_frame_sweep.py 40 > $o/wf_sweep_mirror16.txt 2>&1; cat $o/wf_sweep_mirror16.txt
