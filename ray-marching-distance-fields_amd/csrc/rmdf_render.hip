@@ -407,10 +407,15 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
 #ifdef RMDF_AB_SHARED_BOUNDS
             // (A/B only, not yet run on hardware: the normal's four sample points lie within 1e-5 of each other -- one pass of bound tests,
             // its margin widened accordingly, serves all four: rmdf_device.hpp de_cornell_box_lanes `keep`)
+            // (one inlined copy of each form: the AO samples take the wider margin too -- a superset of survivors, the same minimum)
             float d;
-            if (cgrid && k == 0)      d = de_cornell_box_lanes(pos, s_ctab, cgrid, tri_hint, &kept_tris);
-            else if (cgrid && k < 4)  d = de_cornell_box_lanes_kept(pos, s_ctab, kept_tris);
-            else                      d = distance_estimator<SCENE>(pos, p, iters, tri_hint, cgrid, s_ctab);
+            if (cgrid) {
+                unsigned kept_now = 0u;
+                if (k == 0 || k >= 4) d = de_cornell_box_lanes(pos, s_ctab, cgrid, tri_hint, &kept_now);
+                else                  d = de_cornell_box_lanes_kept(pos, s_ctab, kept_tris);
+                if (k == 0) kept_tris = kept_now;
+            } else
+                d = distance_estimator<SCENE>(pos, p, iters, tri_hint, cgrid, s_ctab);
 #else
             const float d = distance_estimator<SCENE>(pos, p, iters, tri_hint, cgrid, s_ctab);
 #endif
