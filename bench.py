@@ -916,7 +916,12 @@ def main():
                                   "note": "operation counters are only known for the headline workload (or after the "
                                           "cpu_baseline leg counted them)"}
         if not a.no_secondary and world == 1 and not sharded and L == 0:
-            result["secondary"] = secondary_workloads(sr, torch, dev, stream, cus, streams)
+            # (the extra workloads never cost the headline line: a failure in them is reported in the line instead)
+            try:
+                result["secondary"] = secondary_workloads(sr, torch, dev, stream, cus, streams)
+            except Exception as e:                                  # noqa: BLE001
+                result["secondary"] = None
+                result["secondary_error"] = "%s: %s" % (type(e).__name__, e)
         if ref is not None:
             from oracle import orc
             # the reference's own CPU paths (BASELINE.json north_star: "timed on the same box's host cores ... as the
