@@ -557,8 +557,20 @@ def test_cornell_pruning_is_invisible(rmdf, sr, orc, env_oracle, env_faces):
                 assert np.array_equal(a[k], b[k]), (k, w, h, t)
             assert np.array_equal(a["rgba_f32"].view(np.uint32), b["rgba_f32"].view(np.uint32)), (w, h, t)
         assert_frame_parity(sr.render(0, 250, 130, 9.7, max_steps=64), orc.render(0, 250, 130, 9.7, 64, env_oracle), "cornell t=9.7")
-        # round 5: a wave down to eight live rays marches them eight lanes per ray (de_cornell_box_group8).  The RGBA8-only product variant
-        # (other register budget, same march) against the unpruned planes, with step limits that let the grazing rays run long
+    finally:
+        plain.close()
+
+
+@unverified
+def test_cornell_eight_lane_tail_with_long_step_limits(rmdf, sr, env_faces):
+    """Round 5: a wave down to eight live rays marches them eight lanes per ray (rmdf_device.hpp: de_cornell_box_group8).  The RGBA8-only
+    product variant (other register budget, same march) against the unpruned planes, with step limits that let the grazing rays run long.
+    (The views of the test above already go through that tail and have passed on hardware; these inputs were written after GPU access
+    closed and have not run.)"""
+    plain = rmdf.ShaderRenderer(0, flags=rmdf.FLAG_NO_PRUNE)
+    try:
+        for slot, k in ((rmdf.ENV_REFLECTION, "refl"), (rmdf.ENV_COS_1, "cos1"), (rmdf.ENV_COS_8, "cos8")):
+            plain.set_env_cube(slot, env_faces[k])
         for (w, h, t, ms) in ((1280, 720, 0.0, 128), (800, 450, 5.1, 256), (333, 187, 8.8, 300), (64, 64, 1.0, 1000)):
             fb = np.zeros(w * h, np.uint32)
             sr.draw_shader_tile(0, None, w, h, t, fb, max_steps=ms)
