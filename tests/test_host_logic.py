@@ -366,6 +366,53 @@ def test_cornell_kept_set_of_one_sample_point_serves_its_neighbours():
     assert 1.0 <= min(kept_counts) and kept_counts[0] < 4.0, kept_counts       # with a good hint the kept set is small
 
 
+def test_product_kernels_keep_their_register_budgets(tmp_path):
+    """Occupancy is part of the measured figures (eight waves per SIMD for the headline kernel, six for the Cornell
+    box, no private segment in either) and nothing else in the CPU tier would notice a compiler, flag or source change that costs a
+    wave or starts spilling in a hot kernel.  The kernel descriptors of the BUILT librmdf.so (llvm-objdump --offloading, llvm-readelf
+    --notes; no GPU): register counts, private segment, LDS of the product variants, and the same table as profiles/r05_kernel_resources.txt
+    holds for the round's sources."""
+    import re
+    import shutil
+    import subprocess
+    import rmdf_amd
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("no llvm-objdump / llvm-readelf")
+    lib = str(tmp_path / "librmdf.so")
+    shutil.copy(rmdf_amd.LIB_PATH, lib)                                   # (--offloading extracts next to its input)
+    subprocess.run([objdump, "--offloading", lib], check=True, capture_output=True, cwd=str(tmp_path), timeout=120)
+    kernels = {}
+    for f in sorted(os.listdir(str(tmp_path))):
+        if "amdgcn" not in f:
+            continue
+        notes = subprocess.run([readelf, "--notes", str(tmp_path / f)], check=True, capture_output=True, text=True, timeout=120).stdout
+        for blk in notes.split("- .agpr_count:")[1:]:
+            g = lambda key: re.search(r"\.%s:\s+(\S+)" % key, blk).group(1)
+            kernels[g("name")] = {"vgpr": int(g("vgpr_count")), "sgpr": int(g("sgpr_count")), "scratch": int(g("private_segment_fixed_size")),
+                                  "lds": int(g("group_segment_fixed_size")), "wg": int(g("max_flat_workgroup_size"))}
+    k = lambda scene, merge, out: kernels["_ZN4rmdf8k_renderILi%dELb%dELi%dEEEvNS_11FrameParamsE" % (scene, merge, out)]
+    assert len([n for n in kernels if "k_render" in n]) == 24, sorted(kernels)
+    # waves per SIMD = 512 // (VGPRs rounded up to 8): the headline kernel and its mirror-store variant at eight, no private segment
+    for out in (0, 1):
+        h = k(2, 1, out)
+        assert h["vgpr"] <= 64 and h["scratch"] == 0 and h["wg"] == 256, h
+        assert h["lds"] <= 20 * 1024, h                                  # eight workgroups of four waves per CU: 8 x LDS <= 160 KB
+    # the Cornell box as the product launches it (no pooling): six waves, no private segment
+    for out in (0, 1):
+        c = k(0, 0, out)
+        assert c["vgpr"] <= 80 and c["scratch"] == 0, c
+    # test scene and general-power Mandelbulb (pooled): seven waves or better, no private segment since round 5 (no calls left)
+    for scene in (1, 3):
+        for out in (0, 1):
+            t = k(scene, 1, out)
+            assert t["vgpr"] <= 72 and t["scratch"] == 0, (scene, t)
+    # the lobe prefilter's producer / summing-wave kernels are launched with 11 and 12 waves per workgroup: they must fit 80 VGPRs
+    for n, d in kernels.items():
+        if "k_prefilter_chan" in n or "k_prefilter_fused4" in n or "k_prefilter_ring" in n:
+            assert d["vgpr"] <= 80, (n, d)
+
+
 def test_dpp_products_of_the_prefilter_have_no_read_after_write_hazard(tmp_path):
     """k_prefilter_chan / k_prefilter_fused4 multiply source texels through `v_mul_f32_dpp ... row_newbcast` written as inline asm
     (hipcc does not fold update_dpp into the multiply).  The compiler's hazard recogniser does not look inside inline asm, and gfx9
