@@ -42,6 +42,17 @@ int rmdf_debug_cornell_masks(int n, int brute_force, uint32_t *out);
  * (either may be NULL) receive the two offsets.  tests/test_host_logic.py holds every plane to "a lower bound of the distance". */
 int rmdf_debug_cornell_table(float *out, int *stride, int *bounds);
 
+/* Host-only check aids: the tables the env-map kernels only gather through, as the library builds them on the host with glibc's
+ * acosf / atanf / cosf / sinf (the functions GHC's Float instances call in the reference).
+ * rmdf_debug_cube_uv_table: the environment (u, v) of every texel of the six cw x cw cube faces (cubeMapPixelToDir ->
+ * worldToLocal -> cartesianToSpherical -> sphericalToEnvironmentUV, HDREnvMap.hs:76-87,139-147, CoordTransf.hs:35-70);
+ * out: 6 * cw * cw * 2 floats, face-major, rows, columns.
+ * rmdf_debug_lobe_tables: cosineConvolveHDREnvMap's cos|phi_L - phi_x| per (destination column, source column) and cos / sin theta
+ * per row (HDREnvMap.hs:222-239); lutT: ceil(w / 64) * w * 64 floats indexed (block * w + x) * 64 + lane, destination column =
+ * min(block * 64 + lane, w - 1); tcs: 2 * h floats.  tests/test_host_logic.py holds both to the oracle / to the formulas. */
+int rmdf_debug_cube_uv_table(int cw, float *out);
+int rmdf_debug_lobe_tables(int w, int h, float *lutT, float *tcs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,7 +57,8 @@ ABI_SYMBOLS = (
     "rmdf_copy_to_host", "rmdf_probe_shader_clock", "rmdf_comm_selftest_loopback", "rmdf_get_cornell_vertices",
     "rmdf_get_shader_constants",
 )
-XCHECK_SYMBOLS = ("rmdf_debug_march_stats", "rmdf_debug_cornell_masks", "rmdf_debug_cornell_table")      # include/rmdf_xcheck.h
+XCHECK_SYMBOLS = ("rmdf_debug_march_stats", "rmdf_debug_cornell_masks", "rmdf_debug_cornell_table", "rmdf_debug_cube_uv_table",
+                  "rmdf_debug_lobe_tables")      # include/rmdf_xcheck.h
 
 
 class RmdfError(RuntimeError):
@@ -207,6 +208,8 @@ def load_library(xcheck=False):
         L.rmdf_debug_march_stats.argtypes = [vp, C.c_int, vp, C.c_int]
         L.rmdf_debug_cornell_masks.argtypes = [C.c_int, C.c_int, vp]
         L.rmdf_debug_cornell_table.argtypes = [vp, vp, vp]
+        L.rmdf_debug_cube_uv_table.argtypes = [C.c_int, vp]
+        L.rmdf_debug_lobe_tables.argtypes = [C.c_int, C.c_int, vp, vp]
     L.rmdf_selftest_exact_math.argtypes = [vp, vp]
     L.rmdf_selftest_pinned_math.argtypes = [vp, vp]
     L.rmdf_selftest_shading_math.argtypes = [vp, vp]

@@ -2201,6 +2201,33 @@ int rmdf_debug_cornell_table(float *out, int *stride, int *bounds)
     return RMDF_OK;
 }
 
+int rmdf_debug_cube_uv_table(int cw, float *out)
+{
+    // host-only: the table k_latlong_to_cube gathers through (cube_uv_table_host), 6 * cw * cw (u, v) pairs
+    if (!out || cw < 1 || cw > 4096) return RMDF_E_INVALID;
+    try {
+        WorkPool none;                                         // no workers: evaluated on the calling thread
+        std::vector<float> uv;
+        cube_uv_table_host(none, cw, uv);
+        memcpy(out, uv.data(), uv.size() * sizeof(float));
+    } catch (...) { return RMDF_E_NOMEM; }
+    return RMDF_OK;
+}
+
+int rmdf_debug_lobe_tables(int w, int h, float *lutT, float *tcs)
+{
+    // host-only: the cosine tables the lobe prefilter kernels read (lobe_tables_host): ceil(w / 64) * w * 64 and 2 * h floats
+    if (!lutT || !tcs || w < 2 || h < 2 || w > 8192 || h > 4096) return RMDF_E_INVALID;
+    try {
+        WorkPool none;
+        std::vector<float> a, b;
+        lobe_tables_host(none, w, h, a, b);
+        memcpy(lutT, a.data(), a.size() * sizeof(float));
+        memcpy(tcs, b.data(), b.size() * sizeof(float));
+    } catch (...) { return RMDF_E_NOMEM; }
+    return RMDF_OK;
+}
+
 int rmdf_debug_march_stats(rmdf_ctx *ctx, int enable, uint64_t *out, int max_waves)
 {
     if (!ctx) return fail(nullptr, RMDF_E_INVALID, "null ctx");

@@ -366,6 +366,53 @@ def test_cornell_kept_set_of_one_sample_point_serves_its_neighbours():
     assert 1.0 <= min(kept_counts) and kept_counts[0] < 4.0, kept_counts       # with a good hint the kept set is small
 
 
+def test_host_built_env_tables_against_the_oracle():
+    """The env-map kernels only GATHER through tables the library builds on the host (rmdf_api.cpp: cube_uv_table_host, lobe_tables_host);
+    the arithmetic the reference does per texel -- cubeMapPixelToDir, worldToLocal, cartesianToSpherical, sphericalToEnvironmentUV
+    (HDREnvMap.hs:76-87, CoordTransf.hs:35-70), pxToTheta / pxToPhi and the cosine tables of cosineConvolveHDREnvMap (HDREnvMap.hs:222-239)
+    -- happens there.  No GPU: (1) the oracle's latLongHDREnvMapToCubeMap of a random image must be the oracle's pixelAtBilinear at
+    the PRODUCT's (u, v) of every texel, for three face sizes (a wrong u or v picks other texels of a random image); (2) the lobe tables
+    equal the formulas restated in numpy float32 with the process's own libm cosf / sinf, for a 256-wide, a ragged and a tiny map."""
+    import ctypes as C
+    import rmdf_amd
+    from oracle import orc
+    L = rmdf_amd.load_library(xcheck=True)
+    rng = np.random.default_rng(5)
+    for (lw, lh) in ((96, 48), (51, 25), (512, 256)):
+        cw = lw // 3
+        latlong = rng.uniform(0.0, 5.0, (lh, lw, 3)).astype(np.float32)
+        uv = np.zeros((6, cw, cw, 2), np.float32)
+        assert L.rmdf_debug_cube_uv_table(cw, uv.ctypes.data) == 0
+        assert (uv >= 0.0).all() and (uv <= 1.0).all()
+        faces = orc.latlong_to_cube(latlong)
+        assert faces.shape == (6, cw, cw, 3)
+        step = 1 if cw <= 32 else 7                                       # (every texel of the small faces, a lattice of the large one)
+        for f in range(6):
+            for y in range(0, cw, step):
+                for x in range(0, cw, step):
+                    got = orc.pixel_at_bilinear(latlong, float(uv[f, y, x, 0]), float(uv[f, y, x, 1]))
+                    assert np.array_equal(np.asarray(got, np.float32).view(np.uint32), faces[f, y, x].view(np.uint32)), (lw, f, y, x)
+    assert L.rmdf_debug_cube_uv_table(0, uv.ctypes.data) != 0
+    libm = C.CDLL("libm.so.6")
+    libm.cosf.restype = libm.sinf.restype = C.c_float
+    libm.cosf.argtypes = libm.sinf.argtypes = [C.c_float]
+    f32 = np.float32
+    pi = f32(3.14159265358979323846)
+    for (w, h) in ((256, 128), (100, 37), (4, 2)):
+        nblk = (w + 63) // 64
+        lut, tcs = np.zeros((nblk, w, 64), np.float32), np.zeros((h, 2), np.float32)
+        assert L.rmdf_debug_lobe_tables(w, h, lut.ctypes.data, tcs.ctypes.data) == 0
+        phi = (np.arange(w, dtype=np.float32) / f32(w - 1) * f32(2.0) * pi).astype(np.float32)        # pxToPhi, HDREnvMap.hs:226
+        th = (np.arange(h, dtype=np.float32) / f32(h - 1) * pi).astype(np.float32)                    # pxToTheta, :225
+        for y in range(h):
+            assert tcs[y, 0] == f32(libm.cosf(float(th[y]))) and tcs[y, 1] == f32(libm.sinf(float(th[y]))), (w, h, y)
+        for dx in sorted(set(list(range(0, w, max(1, w // 9))) + [w - 1])):
+            want = np.array([libm.cosf(float(np.abs(f32(phi[dx] - phi[x])))) for x in range(w)], np.float32)   # absPhiDiffCosLookup, :231
+            assert np.array_equal(lut[dx // 64, :, dx % 64], want), (w, h, dx)
+        if w % 64:                                                        # lanes past the last column repeat it (they are never stored)
+            assert np.array_equal(lut[nblk - 1, :, 63], lut[nblk - 1, :, (w - 1) % 64])
+
+
 def test_product_kernels_keep_their_register_budgets(tmp_path):
     """Occupancy is part of the measured figures (eight waves per SIMD for the headline kernel, six for the Cornell
     box, no private segment in either) and nothing else in the CPU tier would notice a compiler, flag or source change that costs a
