@@ -51,6 +51,9 @@ int rmdf_debug_cornell_table(float *out, int *stride, int *bounds);
  * per row (HDREnvMap.hs:222-239); lutT: ceil(w / 64) * w * 64 floats indexed (block * w + x) * 64 + lane, destination column =
  * min(block * 64 + lane, w - 1); tcs: 2 * h floats.  tests/test_host_logic.py holds both to the oracle / to the formulas. */
 int rmdf_debug_cube_uv_table(int cw, float *out);
+/* ... and the camera block of main() + lookat (fragment.shd:829-838, 883-902), which the library evaluates once per frame on the host
+ * (host libm sinf / cosf / tanf) instead of once per pixel: xaxis, yaxis, zaxis, eye (12 floats) and tan(hfov / 2). */
+int rmdf_debug_camera(int scene, float time, float cam[12], float *fov_xs);
 int rmdf_debug_lobe_tables(int w, int h, float *lutT, float *tcs);
 
 #ifdef __cplusplus

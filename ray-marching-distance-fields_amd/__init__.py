@@ -58,7 +58,7 @@ ABI_SYMBOLS = (
     "rmdf_get_shader_constants",
 )
 XCHECK_SYMBOLS = ("rmdf_debug_march_stats", "rmdf_debug_cornell_masks", "rmdf_debug_cornell_table", "rmdf_debug_cube_uv_table",
-                  "rmdf_debug_lobe_tables")      # include/rmdf_xcheck.h
+                  "rmdf_debug_lobe_tables", "rmdf_debug_camera")      # include/rmdf_xcheck.h
 
 
 class RmdfError(RuntimeError):
@@ -210,6 +210,7 @@ def load_library(xcheck=False):
         L.rmdf_debug_cornell_table.argtypes = [vp, vp, vp]
         L.rmdf_debug_cube_uv_table.argtypes = [C.c_int, vp]
         L.rmdf_debug_lobe_tables.argtypes = [C.c_int, C.c_int, vp, vp]
+        L.rmdf_debug_camera.argtypes = [C.c_int, C.c_float, vp, vp]
     L.rmdf_selftest_exact_math.argtypes = [vp, vp]
     L.rmdf_selftest_pinned_math.argtypes = [vp, vp]
     L.rmdf_selftest_shading_math.argtypes = [vp, vp]

@@ -2201,6 +2201,15 @@ int rmdf_debug_cornell_table(float *out, int *stride, int *bounds)
     return RMDF_OK;
 }
 
+int rmdf_debug_camera(int scene, float time, float cam[12], float *fov_xs)
+{
+    // host-only: the camera block every frame's kernel arguments carry (host_camera, host_fov_xs)
+    if (!cam || scene < RMDF_FS_DE_CORNELL_BOX || scene > RMDF_FS_MB_GENERAL) return RMDF_E_INVALID;
+    host_camera(scene, time, cam);
+    if (fov_xs) *fov_xs = host_fov_xs();
+    return RMDF_OK;
+}
+
 int rmdf_debug_cube_uv_table(int cw, float *out)
 {
     // host-only: the table k_latlong_to_cube gathers through (cube_uv_table_host), 6 * cw * cw (u, v) pairs

@@ -413,6 +413,27 @@ def test_host_built_env_tables_against_the_oracle():
             assert np.array_equal(lut[nblk - 1, :, 63], lut[nblk - 1, :, (w - 1) % 64])
 
 
+def test_host_camera_equals_the_oracles_at_many_times():
+    """a1: the camera block of main() and lookat (fragment.shd:829-838, 883-902) is evaluated once per frame on the host
+    (rmdf_api.cpp: host_camera) -- the GPU tier compares it with the oracle at four times per scene; here, without a GPU, at 3000
+    times per FragmentShader value (the orbit's period and far beyond, negative times, huge times), bit for bit, with tan(hfov / 2)."""
+    import ctypes as C
+    import rmdf_amd
+    from oracle import orc
+    L = rmdf_amd.load_library(xcheck=True)
+    rng = np.random.default_rng(3)
+    times = np.concatenate([np.linspace(0.0, 4.0 * np.pi * 6.0, 1500), rng.uniform(-1e3, 1e3, 1000), rng.uniform(-1e7, 1e7, 496),
+                            [0.0, -0.0, 1e-30, 3.0e9]]).astype(np.float32)
+    cam, fov = np.zeros(12, np.float32), C.c_float()
+    for scene in range(4):
+        for t in times:
+            assert L.rmdf_debug_camera(scene, float(t), cam.ctypes.data, C.byref(fov)) == 0
+            want = np.asarray(orc.camera(scene, float(t)), np.float32).ravel()
+            assert np.array_equal(cam.view(np.uint32), want.view(np.uint32)), (scene, float(t), cam, want)
+        assert np.float32(fov.value) == np.float32(orc.fov_xs())
+    assert L.rmdf_debug_camera(4, 0.0, cam.ctypes.data, None) != 0
+
+
 def test_product_kernels_keep_their_register_budgets(tmp_path):
     """Occupancy is part of the measured figures (eight waves per SIMD for the headline kernel, six for the Cornell
     box, no private segment in either) and nothing else in the CPU tier would notice a compiler, flag or source change that costs a
