@@ -54,6 +54,13 @@ int rmdf_debug_cube_uv_table(int cw, float *out);
 /* ... and the camera block of main() + lookat (fragment.shd:829-838, 883-902), which the library evaluates once per frame on the host
  * (host libm sinf / cosf / tanf) instead of once per pixel: xaxis, yaxis, zaxis, eye (12 floats) and tan(hfov / 2). */
 int rmdf_debug_camera(int scene, float time, float cam[12], float *fov_xs);
+/* ... and the Radiance (.hdr) reader and writer behind rmdf_load_env_hdr -- loadHDRImage (HDREnvMap.hs:31-52) and JP.saveRadianceImage
+ * (ShaderRendering.hs:147): flat and new-style run-length coded scanlines, JuicyPixels' RGBE <-> Float arithmetic.  The reader parses
+ * bytes from disk; tests/test_host_logic.py compares both with the oracle's and feeds the reader truncated and corrupted files.
+ * rmdf_debug_hdr_decode: out may be NULL (size query: *w, *h); cap_floats >= 3 * w * h.  rmdf_debug_hdr_encode returns the file
+ * image's length (header + 4 bytes per texel), or a negative RMDF_E_* code. */
+int  rmdf_debug_hdr_decode(const uint8_t *file, size_t len, int *w, int *h, float *out, size_t cap_floats);
+long rmdf_debug_hdr_encode(const float *rgb, int w, int h, uint8_t *out, size_t cap);
 int rmdf_debug_lobe_tables(int w, int h, float *lutT, float *tcs);
 
 #ifdef __cplusplus

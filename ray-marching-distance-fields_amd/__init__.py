@@ -58,7 +58,7 @@ ABI_SYMBOLS = (
     "rmdf_get_shader_constants",
 )
 XCHECK_SYMBOLS = ("rmdf_debug_march_stats", "rmdf_debug_cornell_masks", "rmdf_debug_cornell_table", "rmdf_debug_cube_uv_table",
-                  "rmdf_debug_lobe_tables", "rmdf_debug_camera")      # include/rmdf_xcheck.h
+                  "rmdf_debug_lobe_tables", "rmdf_debug_camera", "rmdf_debug_hdr_decode", "rmdf_debug_hdr_encode")      # include/rmdf_xcheck.h
 
 
 class RmdfError(RuntimeError):
@@ -211,6 +211,9 @@ def load_library(xcheck=False):
         L.rmdf_debug_cube_uv_table.argtypes = [C.c_int, vp]
         L.rmdf_debug_lobe_tables.argtypes = [C.c_int, C.c_int, vp, vp]
         L.rmdf_debug_camera.argtypes = [C.c_int, C.c_float, vp, vp]
+        L.rmdf_debug_hdr_decode.argtypes = [vp, C.c_size_t, vp, vp, vp, C.c_size_t]
+        L.rmdf_debug_hdr_encode.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
+        L.rmdf_debug_hdr_encode.restype = C.c_long
     L.rmdf_selftest_exact_math.argtypes = [vp, vp]
     L.rmdf_selftest_pinned_math.argtypes = [vp, vp]
     L.rmdf_selftest_shading_math.argtypes = [vp, vp]

@@ -2210,6 +2210,36 @@ int rmdf_debug_camera(int scene, float time, float cam[12], float *fov_xs)
     return RMDF_OK;
 }
 
+int rmdf_debug_hdr_decode(const uint8_t *file, size_t len, int *w, int *h, float *out, size_t cap_floats)
+{
+    // host-only: the Radiance reader behind rmdf_load_env_hdr (decode_hdr).  out may be null (size query).
+    if (!file || !w || !h) return RMDF_E_INVALID;
+    try {
+        std::vector<float> rgb;
+        std::string why;
+        if (!decode_hdr(file, len, *w, *h, rgb, why)) return RMDF_E_IO;
+        if (out) {
+            if (cap_floats < rgb.size()) return RMDF_E_INVALID;
+            memcpy(out, rgb.data(), rgb.size() * sizeof(float));
+        }
+    } catch (...) { return RMDF_E_NOMEM; }
+    return RMDF_OK;
+}
+
+long rmdf_debug_hdr_encode(const float *rgb, int w, int h, uint8_t *out, size_t cap)
+{
+    // host-only: the cache-file image rmdf_load_env_hdr writes (encode_hdr); returns its length, or a negative error code
+    if (!rgb || !out || w <= 0 || h <= 0) return RMDF_E_INVALID;
+    try {
+        std::vector<float> v(rgb, rgb + (size_t)w * h * 3);
+        std::vector<uint8_t> file;
+        encode_hdr(v, w, h, file);
+        if (file.size() > cap) return RMDF_E_INVALID;
+        memcpy(out, file.data(), file.size());
+        return (long)file.size();
+    } catch (...) { return RMDF_E_NOMEM; }
+}
+
 int rmdf_debug_cube_uv_table(int cw, float *out)
 {
     // host-only: the table k_latlong_to_cube gathers through (cube_uv_table_host), 6 * cw * cw (u, v) pairs

@@ -434,6 +434,98 @@ def test_host_camera_equals_the_oracles_at_many_times():
     assert L.rmdf_debug_camera(4, 0.0, cam.ctypes.data, None) != 0
 
 
+def test_host_radiance_reader_and_writer_against_the_oracle():
+    """rmdf_load_env_hdr reads the light probe and reads / writes the *_cache_pow_*.hdr files with host code of the library's own
+    (rmdf_api.cpp: decode_hdr, encode_hdr: loadHDRImage HDREnvMap.hs:31-52, JP.saveRadianceImage ShaderRendering.hs:147).  No GPU:
+    the shipped light probe and a run-length coded file decode to the oracle's floats bit for bit; random images -- zeros, denormals, huge
+    values, negative channels, one dominant channel -- encode to the oracle's bytes; and the reader, which parses bytes from disk, gets
+    3000 truncated and corrupted files: it must agree with the oracle's reader on accept / reject and on every float, and never crash."""
+    import ctypes as C
+    import rmdf_amd
+    from oracle import orc
+    L = rmdf_amd.load_library(xcheck=True)
+
+    def decode(data):
+        buf = np.frombuffer(data, np.uint8) if len(data) else np.zeros(1, np.uint8)
+        w, h = C.c_int(), C.c_int()
+        if L.rmdf_debug_hdr_decode(buf.ctypes.data, len(data), C.byref(w), C.byref(h), None, 0) != 0:
+            return None
+        out = np.empty((h.value, w.value, 3), np.float32)
+        assert L.rmdf_debug_hdr_decode(buf.ctypes.data, len(data), C.byref(w), C.byref(h), out.ctypes.data, out.size) == 0
+        return out
+
+    def oracle_decode(data):
+        try:
+            return orc.hdr_decode(data)
+        except ValueError:
+            return None
+
+    same = lambda a, b: (a is None and b is None) or (a is not None and b is not None and a.shape == b.shape
+                                                       and np.array_equal(a.view(np.uint32), b.view(np.uint32)))
+    probe = open(rmdf_amd.DEFAULT_ENV_HDR, "rb").read()
+    a = decode(probe)
+    assert a is not None and a.shape == (256, 512, 3) and same(a, orc.hdr_decode(probe))
+    # writer: random images of every kind the cache files can hold
+    rng = np.random.default_rng(9)
+    imgs = [rng.uniform(0.0, 4.0, (7, 13, 3)), np.zeros((2, 8, 3)), rng.uniform(0.0, 1e-36, (3, 9, 3)), rng.uniform(0.0, 3e38, (3, 9, 3)),
+            rng.normal(0.0, 1.0, (5, 8, 3)), np.exp(rng.uniform(-80.0, 80.0, (16, 16, 3))), rng.uniform(0.0, 1.0, (4, 8, 3)) * [1e6, 1.0, 1e-6]]
+    for img in imgs:
+        img = img.astype(np.float32)
+        h, w, _ = img.shape
+        out = np.zeros(128 + 4 * w * h, np.uint8)
+        n = L.rmdf_debug_hdr_encode(img.ctypes.data, w, h, out.ctypes.data, out.size)
+        assert n > 0 and out[:n].tobytes() == orc.hdr_encode(img), img.shape
+        assert same(decode(out[:n].tobytes()), orc.hdr_decode(out[:n].tobytes()))
+    assert L.rmdf_debug_hdr_encode(imgs[0].astype(np.float32).ctypes.data, 13, 7, out.ctypes.data, 10) < 0          # no room
+    # a run-length coded file (runs, literals, a run of 127) and its flat twin
+    w, h = 200, 4
+    rgbe = rng.integers(0, 255, (h, w, 4)).astype(np.uint8)
+    rgbe[1, 10:170] = rgbe[1, 10]
+    rgbe[2, :, 3] = 130
+    header = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w)
+    rle = bytearray(header)
+    for y in range(h):
+        rle += bytes([2, 2, w >> 8, w & 255])
+        for ch in range(4):
+            row, x = rgbe[y, :, ch], 0
+            while x < w:
+                run = 1
+                while x + run < w and run < 127 and row[x + run] == row[x]:
+                    run += 1
+                if run >= 3:
+                    rle += bytes([128 + run, int(row[x])]); x += run
+                else:
+                    lit = min(w - x, 5)
+                    rle += bytes([lit]) + row[x:x + lit].tobytes(); x += lit
+    flat = header + rgbe.tobytes()
+    assert same(decode(flat), orc.hdr_decode(flat)) and same(decode(bytes(rle)), decode(flat)) and same(decode(bytes(rle)), orc.hdr_decode(bytes(rle)))
+    # corrupted and truncated files: same verdict, same floats, no crash
+    accepted = 0
+    for base in (flat, bytes(rle)):
+        for i in range(1500):
+            m = bytearray(base)
+            kind = i % 5
+            if kind == 0:
+                m = m[:rng.integers(0, len(m))]
+            elif kind == 1:
+                for _ in range(rng.integers(1, 4)):
+                    m[rng.integers(0, len(m))] = rng.integers(0, 256)
+            elif kind == 2:                                              # damage in the header / resolution line
+                m[rng.integers(0, len(header))] = rng.integers(0, 256)
+            elif kind == 3:
+                pos = rng.integers(len(header), len(m))
+                m[pos:pos] = bytes(rng.integers(0, 256, rng.integers(1, 9)).astype(np.uint8))
+            else:
+                pos = rng.integers(len(header), len(m) - 8)
+                del m[pos:pos + rng.integers(1, 8)]
+            got, want = decode(bytes(m)), oracle_decode(bytes(m))
+            assert same(got, want), (i, kind, None if got is None else got.shape, None if want is None else want.shape)
+            accepted += got is not None
+    assert 100 < accepted < 2900, accepted                               # both verdicts occur
+    for junk in (b"", b"\n", b"#?RADIANCE\n\n-Y 0 +X 0\n", b"#?RADIANCE\n\n-Y 70000 +X 70000\n" + b"x" * 64, b"#?RADIANCE\n\n+X 4 -Y 4\n" + b"x" * 64):
+        assert same(decode(junk), oracle_decode(junk)), junk
+
+
 def test_product_kernels_keep_their_register_budgets(tmp_path):
     """Occupancy is part of the measured figures (eight waves per SIMD for the headline kernel, six for the Cornell
     box, no private segment in either) and nothing else in the CPU tier would notice a compiler, flag or source change that costs a
