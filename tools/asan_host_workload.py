@@ -63,3 +63,34 @@ st,bo=C.c_int(),C.c_int(); L.rmdf_debug_cornell_table(None,C.byref(st),C.byref(b
 img=rng.uniform(0,4,(7,13,3)).astype(np.float32); out=np.zeros(64+4*7*13,np.uint8)
 print("encode", L.rmdf_debug_hdr_encode(img.ctypes.data,13,7,out.ctypes.data,out.size))
 print("host-only builders clean")
+# the remaining entry points that need no device: the static deal, the constant tables, the PNG writer, the camera
+import tempfile
+L.rmdf_shard_tiles.argtypes = [C.c_int, C.c_int, vp]
+for n in list(range(1, 65)) + [0, -1, 65, 1000]:
+    seen = []
+    for r in range(max(n, 1)):
+        t = (C.c_int * 64)()
+        k = L.rmdf_shard_tiles(r, n, t)
+        if 1 <= n <= 64:
+            assert 0 <= k <= (64 + n - 1) // n
+            seen += list(t[:k])
+        else:
+            assert k <= 0
+    if 1 <= n <= 64: assert sorted(seen) == list(range(64)), n
+L.rmdf_get_cornell_vertices.argtypes = [vp]
+v = np.zeros(96 * 3, np.float32); assert L.rmdf_get_cornell_vertices(v.ctypes.data) == 0
+names = (C.c_char_p * 128)(); vals = np.zeros(128, np.float32)
+L.rmdf_get_shader_constants.argtypes = [vp, vp, C.c_int]
+k = L.rmdf_get_shader_constants(names, vals.ctypes.data, 128); assert k > 40
+L.rmdf_save_png.argtypes = [C.c_char_p, vp, C.c_int, C.c_int]
+with tempfile.TemporaryDirectory() as d:
+    for (pw, ph) in ((1, 1), (7, 3), (640, 360)):
+        fb = rng.integers(0, 2**32, pw * ph, dtype=np.uint64).astype(np.uint32)
+        assert L.rmdf_save_png(os.path.join(d, "a.png").encode(), fb.ctypes.data, pw, ph) == 0
+    assert L.rmdf_save_png(os.path.join(d, "no", "dir.png").encode(), fb.ctypes.data, 640, 360) != 0
+L.rmdf_debug_camera.argtypes = [C.c_int, C.c_float, vp, vp]
+cam = np.zeros(12, np.float32)
+for sc in range(4):
+    for t in (0.0, 1.5, -7.0, 1e9, float("inf"), float("nan")):
+        assert L.rmdf_debug_camera(sc, t, cam.ctypes.data, None) == 0
+print("deal, tables, PNG writer, camera clean")
