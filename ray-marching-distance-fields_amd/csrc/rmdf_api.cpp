@@ -1,6 +1,7 @@
 // rmdf_api.cpp -- the C ABI of librmdf.so (include/rmdf.h): host-side counterpart of
 // ShaderRendering.hs (withShaderRenderer / drawShaderTile) for the HIP renderer.
 // No CPU rendering path exists here: every pixel comes from the gfx950 kernels.
+#include <sys/stat.h>
 #include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
@@ -626,10 +627,13 @@ bool read_file(const char *path, std::vector<uint8_t> &out)
 {
     FILE *f = fopen(path, "rb");
     if (!f) return false;
+    // a regular file of a sane size: fopen() opens a directory too, and ftell() on one answers LONG_MAX (found by tools/asan_host.sh)
+    struct stat sb;
+    if (fstat(fileno(f), &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 0 || sb.st_size > ((off_t)1 << 31)) { fclose(f); return false; }
     fseek(f, 0, SEEK_END);
     long n = ftell(f);
     fseek(f, 0, SEEK_SET);
-    if (n < 0) { fclose(f); return false; }
+    if (n < 0 || n > ((long)1 << 31)) { fclose(f); return false; }
     out.resize((size_t)n);
     size_t got = n ? fread(out.data(), 1, (size_t)n, f) : 0;
     fclose(f);

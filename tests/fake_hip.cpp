@@ -1,0 +1,348 @@
+// fake_hip.cpp -- a TEST DOUBLE of the HIP runtime entry points librmdf imports, for running the library's HOST code -- context set-up,
+// staging, whole-frame bands, tile jobs, shard gather / assembly, env-map pipeline and cache files, error paths -- on a box WITHOUT a GPU,
+// under AddressSanitizer if wanted (tools/asan_host.sh).  Test infrastructure only: it is LD_PRELOADed into a test's child process
+// (tests/test_host_logic.py: test_host_paths_against_the_hip_double, tests/fake_hip_workload.py); the product never loads it, and
+// librmdf without a real HIP runtime and device fails in rmdf_create as before.
+//
+// What it is: "device memory" is malloc'd host memory (so every copy between caller memory, staging and device buffers is bounds-checked
+// by the allocator's red zones under ASan, and a device pointer can be read by the checks below); streams and events are tokens and every
+// operation completes before its call returns; kernels are NOT run -- each launch is replaced by a small host routine that writes what
+// the kernel's CONTRACT says where the kernel would write it (k_render: a pixel value that is a hash of everything that must
+// distinguish one pixel from another -- position, frame size, scene, camera, step limit, the contents of the three cube maps -- into the
+// frame, the mirror, the planes, the shard slots; k_assemble_shards, k_resolve_box2, k_fill_u32, k_order_blocks exactly; the env-map
+// kernels as nearest-texel stand-ins that read and write every element the real ones do).  What it is NOT: evidence about any kernel,
+// about asynchrony (nothing overlaps here), about the driver.  The pixels it produces mean nothing; that two paths produce the SAME
+// pixels, that nothing outside a buffer is touched and that nothing leaks is what the tests look at.
+//
+// Build (hipcc for the structure definitions of rmdf_internal.hpp; host code only):
+//   hipcc -O1 -g -std=c++17 -fPIC --cuda-host-only -x hip -I ray-marching-distance-fields_amd/csrc -shared tests/fake_hip.cpp -o tests/libfake_hip.so
+#include <hip/hip_runtime_api.h>
+#include <algorithm>
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <set>
+#include <string>
+#include <vector>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rmdf_internal.hpp"
+
+using rmdf::FrameParams;
+
+namespace {
+
+std::mutex g_mu;
+std::map<const void *, std::string> g_kernels;          // host stub address -> device name
+std::set<void *> g_dev, g_host, g_streams, g_events;
+std::atomic<long long> g_launches{ 0 }, g_unknown{ 0 }, g_copied{ 0 }, g_fail_malloc_in{ 0 };
+std::string g_last_unknown;
+struct CallCfg { dim3 grid, block; size_t shmem; hipStream_t stream; };
+thread_local std::vector<CallCfg> t_cfg;
+
+uint32_t mix(uint32_t h, uint32_t v) { h ^= v + 0x9e3779b9u + (h << 6) + (h >> 2); h *= 0x85ebca6bu; h ^= h >> 13; return h; }
+uint32_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+void tile_rect(int idx, int w, int h, int &x0, int &y0, int &x1, int &y1)
+{
+    const int tx = (idx % 64) % 8, ty = (idx % 64) / 8;          // ShaderRendering.hs:183-193 as rmdf_api.cpp: tile_rect_host states it
+    x0 = (2 * tx * w + 7) / 16; x1 = (2 * (tx + 1) * w + 7) / 16; y0 = (2 * ty * h + 7) / 16; y1 = (2 * (ty + 1) * h + 7) / 16;
+}
+
+// ---- k_render<SCENE, MERGE, OUT> ------------------------------------------------------------------------------------------------------
+void fake_render(const std::string &name, const FrameParams &p, dim3 grid)
+{
+    int scene = 0, merge = 0, out = 0;
+    const size_t at = name.find("k_renderILi");
+    if (at == std::string::npos || sscanf(name.c_str() + at, "k_renderILi%dELb%dELi%dE", &scene, &merge, &out) != 3) abort();
+    // what distinguishes one frame from another: everything the kernel's arguments carry that reaches a pixel
+    uint32_t base = mix(0x1234567u, (uint32_t)scene);
+    for (int k = 0; k < 12; k++) base = mix(base, fbits(p.cam[k]));
+    base = mix(mix(mix(base, (uint32_t)p.w), (uint32_t)p.h), (uint32_t)p.max_steps);
+    base = mix(base, fbits(p.power) * (scene == 3 ? 1u : 0u));
+    for (const rmdf::CubeDev *c : { &p.env_refl, &p.env_cos1, &p.env_cos8 }) {
+        const size_t n = (size_t)6 * (c->W + 2) * (c->W + 2);
+        uint32_t t = (uint32_t)c->W;
+        for (size_t i = 0; i < n; i += (n / 61 + 1)) t = mix(mix(t, c->texels[i].x), c->texels[i].y);   // reads first .. last texel
+        t = mix(mix(t, c->texels[n - 1].x), c->texels[n - 1].y);
+        base = mix(base, t);
+    }
+    const size_t nblk = (size_t)grid.x * grid.y * grid.z;
+    if (p.block_order) {                                       // must be a permutation of the launch's strips
+        std::vector<char> seen(nblk, 0);
+        for (size_t i = 0; i < nblk; i++) { const unsigned s = p.block_order[i]; if (s >= nblk || seen[s]) { fprintf(stderr, "fake_hip: block_order is not a permutation\n"); abort(); } seen[s] = 1; }
+    }
+    auto put = [&](size_t idx, int px, int py) {
+        const uint32_t h = mix(mix(base, (uint32_t)px), (uint32_t)py);
+        const uint32_t v = h | 0xff000000u;
+        if (out != 2 || p.rgba8) p.rgba8[idx] = v;
+        if (out == 1) p.rgba8_mirror[idx] = v;
+        if (out == 2) {
+            if (p.rgba_f32) p.rgba_f32[idx] = make_float4((float)(v & 255u) / 255.0f, (float)((v >> 8) & 255u) / 255.0f, (float)((v >> 16) & 255u) / 255.0f, 1.0f);
+            const unsigned steps = (h >> 3) % (unsigned)(p.max_steps > 0 ? p.max_steps : 1), hit = (h >> 1) & 1u;
+            if (p.steps) p.steps[idx] = (uint16_t)(steps | (hit << 15));
+            if (p.iters) p.iters[idx] = (uint16_t)((h >> 9) & 0x3ffu);
+        }
+    };
+    if (p.n_shard_tiles > 0) {
+        if ((int)grid.z != p.n_shard_tiles) abort();
+        for (int slot = 0; slot < p.n_shard_tiles; slot++) {
+            int x0, y0, x1, y1;
+            tile_rect(p.shard_tile[slot], p.w, p.h, x0, y0, x1, y1);
+            const size_t obase = (size_t)slot * (size_t)(p.w / 8) * (size_t)(p.h / 8);
+            for (int py = y0; py < y1; py++)
+                for (int px = x0; px < x1; px++) put(obase + (size_t)(px - x0) + (size_t)(py - y0) * (size_t)(x1 - x0), px, py);
+        }
+    } else {
+        for (int py = p.y0; py < p.y1; py++)
+            for (int px = p.x0; px < p.x1; px++) put((size_t)px + (size_t)py * (size_t)p.w, px, py);
+    }
+    if (p.block_cost)
+        for (size_t i = 0; i < nblk; i++) p.block_cost[i] = 1u + (mix(base, (uint32_t)i) >> 20);
+    if (out == 1 && p.band_flag) {
+        const int nb = ((int)grid.y + p.band_strip_rows - 1) / p.band_strip_rows;
+        for (int b = 0; b < nb; b++) { if (p.band_count[b] != 0u) abort(); __atomic_store_n((unsigned *)&p.band_flag[b], p.band_seq, __ATOMIC_RELEASE); }
+    }
+}
+
+template <typename T> T arg(void **args, int i) { T v; memcpy(&v, args[i], sizeof v); return v; }
+
+float src_checksum(const float *src, size_t n)                  // reads every element
+{
+    float s = 0.0f;
+    for (size_t i = 0; i < n; i++) s += src[i] * (float)((i % 7) + 1);
+    return s;
+}
+
+void fake_launch(const std::string &name, dim3 grid, dim3 block, void **args)
+{
+    (void)block;
+    auto has = [&](const char *s) { return name.find(s) != std::string::npos; };
+    if (has("k_renderILi")) { fake_render(name, *(const FrameParams *)args[0], grid); return; }
+    if (has("k_order_blocks")) {
+        const unsigned *cost = arg<const unsigned *>(args, 0); const int n = arg<int>(args, 1); unsigned *order = arg<unsigned *>(args, 2);
+        std::vector<unsigned> idx((size_t)n);
+        for (int i = 0; i < n; i++) idx[(size_t)i] = (unsigned)i;
+        std::stable_sort(idx.begin(), idx.end(), [&](unsigned a, unsigned b) { return cost[a] > cost[b]; });
+        for (int i = 0; i < n; i++) order[i] = idx[(size_t)i];
+        return;
+    }
+    if (has("k_fill_u32")) {
+        uint32_t *dst = arg<uint32_t *>(args, 0); const uint32_t v = arg<uint32_t>(args, 1); const size_t n = arg<size_t>(args, 2);
+        for (size_t i = 0; i < n; i++) dst[i] = v;
+        return;
+    }
+    if (has("k_assemble_shards")) {                               // both forms: the same mapping (rmdf_util.hip)
+        const uint32_t *gathered = arg<const uint32_t *>(args, 0); uint32_t *frame = arg<uint32_t *>(args, 1);
+        const int w = arg<int>(args, 2), h = arg<int>(args, 3), nranks = arg<int>(args, 4);
+        const rmdf::ShardWhere where = arg<rmdf::ShardWhere>(args, 5);
+        const int tw = w / 8, th = h / 8, slots = (64 + nranks - 1) / nranks;
+        for (int py = 0; py < h; py++)
+            for (int px = 0; px < w; px++) {
+                const int tx = px / tw, ty = py / th, rs = where.v[tx + ty * 8];
+                frame[(size_t)py * w + px] = gathered[((size_t)(rs >> 8) * slots + (rs & 255)) * (size_t)tw * th + (size_t)(px - tx * tw) + (size_t)(py - ty * th) * tw];
+            }
+        return;
+    }
+    if (has("k_resolve_box2")) {
+        const uint32_t *src = arg<const uint32_t *>(args, 0); const int dw = arg<int>(args, 1), dh = arg<int>(args, 2); uint32_t *dst = arg<uint32_t *>(args, 3);
+        for (int y = 0; y < dh; y++)
+            for (int x = 0; x < dw; x++) {
+                uint32_t o = 0;
+                for (int c = 0; c < 4; c++) {
+                    unsigned s = 2;
+                    for (int k = 0; k < 4; k++) s += (src[(size_t)(2 * y + (k >> 1)) * (2 * dw) + 2 * x + (k & 1)] >> (8 * c)) & 255u;
+                    o |= ((s >> 2) & 255u) << (8 * c);
+                }
+                dst[(size_t)y * dw + x] = o;
+            }
+        return;
+    }
+    if (has("k_cube_upload")) {                                   // stand-in: clamped copy as four 16-bit quantities per texel
+        const float *faces = arg<const float *>(args, 0); const int W = arg<int>(args, 1); uint2 *padded = arg<uint2 *>(args, 2);
+        const int P = W + 2;
+        for (int f = 0; f < 6; f++)
+            for (int Y = 0; Y < P; Y++)
+                for (int X = 0; X < P; X++) {
+                    const int x = std::min(std::max(X - 1, 0), W - 1), y = std::min(std::max(Y - 1, 0), W - 1);
+                    const float *t = &faces[(((size_t)f * W + y) * W + x) * 3];
+                    uint2 o;
+                    o.x = (fbits(t[0]) >> 16) | (fbits(t[1]) & 0xffff0000u);
+                    o.y = fbits(t[2]) >> 16;
+                    padded[((size_t)f * P + Y) * P + X] = o;
+                }
+        return;
+    }
+    if (has("k_latlong_to_cube")) {                               // stand-in: nearest texel at the table's (u, v)
+        const float *ll = arg<const float *>(args, 0); const int w = arg<int>(args, 1), h = arg<int>(args, 2), cw = arg<int>(args, 3);
+        const float2 *uv = arg<const float2 *>(args, 4); float *faces = arg<float *>(args, 5);
+        for (size_t i = 0; i < (size_t)6 * cw * cw; i++) {
+            const int x = std::min(w - 1, std::max(0, (int)(uv[i].x * (float)(w - 1)))), y = std::min(h - 1, std::max(0, (int)(uv[i].y * (float)(h - 1))));
+            for (int k = 0; k < 3; k++) faces[i * 3 + k] = ll[((size_t)y * w + x) * 3 + k];
+        }
+        return;
+    }
+    if (has("k_resize_latlong")) {                                // stand-in: nearest texel
+        const float *src = arg<const float *>(args, 0); const int sw = arg<int>(args, 1), sh = arg<int>(args, 2), dw = arg<int>(args, 3), dh = arg<int>(args, 4);
+        float *out = arg<float *>(args, 5);
+        for (int y = 0; y < dh; y++)
+            for (int x = 0; x < dw; x++)
+                for (int k = 0; k < 3; k++) out[((size_t)y * dw + x) * 3 + k] = src[((size_t)std::min(sh - 1, y * sh / dh) * sw + std::min(sw - 1, x * sw / dw)) * 3 + k];
+        return;
+    }
+    if (has("k_prefilter")) {                                     // stand-in: source scaled by a function of the power; reads both tables end to end
+        const float *src = arg<const float *>(args, 0); const int w = arg<int>(args, 1), h = arg<int>(args, 2);
+        const size_t n = (size_t)w * h * 3;
+        const float cs = src_checksum(src, n);
+        auto tables = [&](const float *lutT, const float2 *tcs) { const size_t nl = (size_t)((w + 63) / 64) * w * 64; return lutT[0] + lutT[nl - 1] + tcs[0].x + tcs[h - 1].y; };
+        auto fill = [&](float *out, float power, float tb) { if (out) for (size_t i = 0; i < n; i++) out[i] = src[i] / (1.0f + power) + 0.0f * (cs + tb); };
+        if (has("k_prefilter_fused4")) {
+            const float tb = tables(arg<const float *>(args, 3), arg<const float2 *>(args, 4));
+            const float pw[4] = { 1.0f, 8.0f, 64.0f, 512.0f };
+            for (int k = 0; k < 4; k++) fill(arg<float *>(args, 5 + k), pw[k], tb);
+        } else if (has("k_prefilter_chan") || has("k_prefilter_ring")) {
+            int l2 = 0;
+            sscanf(name.c_str() + name.find("ILi") + 3, "%d", &l2);
+            fill(arg<float *>(args, 5), (float)(1 << l2), tables(arg<const float *>(args, 3), arg<const float2 *>(args, 4)));
+        } else {                                                  // k_prefilter<LOG2P, LUT_IN_LDS>(src, w, h, power, lutT, tcs, out, ..)
+            fill(arg<float *>(args, 6), arg<float>(args, 3), tables(arg<const float *>(args, 4), arg<const float2 *>(args, 5)));
+        }
+        return;
+    }
+    if (has("k_selftest") || has("k_clock_probe")) return;        // their result buffers were cleared by the host: "no mismatch"
+    g_unknown++;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_last_unknown = name;
+}
+
+void *take(std::set<void *> &s, size_t bytes)
+{
+    void *p = malloc(bytes ? bytes : 1);
+    if (!p) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    s.insert(p);
+    return p;
+}
+bool give(std::set<void *> &s, void *p)
+{
+    { std::lock_guard<std::mutex> lk(g_mu); if (!s.erase(p)) return false; }
+    free(p);
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- test hooks ---------------------------------------------------------------------------------------------------------------------------
+// out[0..7]: live device allocations, live page-locked allocations, live streams, live events, launches, launches of kernels the double
+// does not know, bytes moved by memcpy calls, registered kernels
+void fake_hip_counters(long long out[8])
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    out[0] = (long long)g_dev.size(); out[1] = (long long)g_host.size(); out[2] = (long long)g_streams.size(); out[3] = (long long)g_events.size();
+    out[4] = g_launches; out[5] = g_unknown; out[6] = g_copied; out[7] = (long long)g_kernels.size();
+}
+int fake_hip_last_unknown(char *buf, int cap)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    snprintf(buf, (size_t)cap, "%s", g_last_unknown.c_str());
+    return (int)g_last_unknown.size();
+}
+void fake_hip_fail_malloc_in(long long n) { g_fail_malloc_in = n; }       // the n-th device / page-locked allocation from now fails (0 = none)
+
+// ---- registration and launch ---------------------------------------------------------------------------------------------------------------
+void **__hipRegisterFatBinary(const void *) { static void *token[1]; return token; }
+void __hipUnregisterFatBinary(void **) { }
+void __hipRegisterFunction(void **, const void *host_fn, char *, const char *device_name, unsigned, void *, void *, void *, void *, int *)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_kernels[host_fn] = device_name;
+}
+hipError_t __hipPushCallConfiguration(dim3 grid, dim3 block, size_t shmem, hipStream_t stream) { t_cfg.push_back(CallCfg{ grid, block, shmem, stream }); return hipSuccess; }
+hipError_t __hipPopCallConfiguration(dim3 *grid, dim3 *block, size_t *shmem, hipStream_t *stream)
+{
+    if (t_cfg.empty()) return hipErrorInvalidValue;
+    const CallCfg c = t_cfg.back(); t_cfg.pop_back();
+    *grid = c.grid; *block = c.block; *shmem = c.shmem; *stream = c.stream;
+    return hipSuccess;
+}
+hipError_t hipLaunchKernel(const void *fn, dim3 grid, dim3 block, void **args, size_t, hipStream_t)
+{
+    std::string name;
+    { std::lock_guard<std::mutex> lk(g_mu); auto it = g_kernels.find(fn); if (it == g_kernels.end()) return hipErrorInvalidDeviceFunction; name = it->second; }
+    g_launches++;
+    if (grid.x == 0 || grid.y == 0 || grid.z == 0 || block.x == 0) return hipErrorInvalidConfiguration;
+    fake_launch(name, grid, block, args);
+    return hipSuccess;
+}
+hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+
+// ---- device, streams, events -----------------------------------------------------------------------------------------------------------------
+hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
+hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+hipError_t hipGetDeviceProperties(hipDeviceProp_t *prop, int d)
+{
+    if (d != 0) return hipErrorInvalidDevice;
+    memset(prop, 0, sizeof *prop);
+    snprintf(prop->name, sizeof prop->name, "no GPU: tests/fake_hip.cpp");
+    snprintf(prop->gcnArchName, sizeof prop->gcnArchName, "gfx950:fake");
+    prop->multiProcessorCount = 256;
+    prop->totalGlobalMem = (size_t)8 << 30;
+    prop->warpSize = 64;
+    return hipSuccess;
+}
+hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 0; *greatest = -1; return hipSuccess; }
+hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+hipError_t hipGetLastError(void) { return hipSuccess; }
+const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : (e == hipErrorOutOfMemory ? "out of memory (fake_hip)" : "error (fake_hip)"); }
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)take(g_streams, 8); return *s ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned f, int) { return hipStreamCreateWithFlags(s, f); }
+hipError_t hipStreamDestroy(hipStream_t s) { return give(g_streams, s) ? hipSuccess : hipErrorInvalidHandle; }
+hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (hipEvent_t)take(g_events, 8); return *e ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipEventDestroy(hipEvent_t e) { return give(g_events, e) ? hipSuccess : hipErrorInvalidHandle; }
+hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+
+// ---- memory ---------------------------------------------------------------------------------------------------------------------------------
+static bool failing()
+{
+    long long n = g_fail_malloc_in.load();
+    while (n > 0 && !g_fail_malloc_in.compare_exchange_weak(n, n - 1)) { }
+    return n == 1;
+}
+hipError_t hipMalloc(void **p, size_t bytes) { if (failing()) { *p = nullptr; return hipErrorOutOfMemory; } *p = take(g_dev, bytes); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipFree(void *p) { if (!p) return hipSuccess; return give(g_dev, p) ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { if (failing()) { *p = nullptr; return hipErrorOutOfMemory; } *p = take(g_host, bytes); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void *p) { if (!p) return hipSuccess; return give(g_host, p) ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return hipSuccess; }
+hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind, hipStream_t) { memmove(dst, src, n); g_copied += (long long)n; return hipSuccess; }
+hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind) { memmove(dst, src, n); g_copied += (long long)n; return hipSuccess; }   // (tests/fake_rccl.c uses it)
+hipError_t hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t)
+{
+    if (width > dpitch || width > spitch) return hipErrorInvalidPitchValue;
+    for (size_t y = 0; y < height; y++) memmove((char *)dst + y * dpitch, (const char *)src + y * spitch, width);
+    g_copied += (long long)(width * height);
+    return hipSuccess;
+}
+hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+// (the virtual-memory calls of the cross-check build's electric-fence allocator: not offered here -- the allocator's red zones do that job)
+hipError_t hipMemGetAllocationGranularity(size_t *, const hipMemAllocationProp *, hipMemAllocationGranularity_flags) { return hipErrorNotSupported; }
+hipError_t hipMemCreate(hipMemGenericAllocationHandle_t *, size_t, const hipMemAllocationProp *, unsigned long long) { return hipErrorNotSupported; }
+hipError_t hipMemRelease(hipMemGenericAllocationHandle_t) { return hipErrorNotSupported; }
+hipError_t hipMemAddressReserve(void **, size_t, size_t, void *, unsigned long long) { return hipErrorNotSupported; }
+hipError_t hipMemAddressFree(void *, size_t) { return hipErrorNotSupported; }
+hipError_t hipMemMap(void *, size_t, size_t, hipMemGenericAllocationHandle_t, unsigned long long) { return hipErrorNotSupported; }
+hipError_t hipMemUnmap(void *, size_t) { return hipErrorNotSupported; }
+hipError_t hipMemSetAccess(void *, size_t, const hipMemAccessDesc *, size_t) { return hipErrorNotSupported; }
+
+}  // extern "C"

@@ -1,0 +1,369 @@
+#!/usr/bin/env python3
+"""The library's host paths against the HIP test double (tests/fake_hip.cpp) -- no GPU.  Run in a child process with
+LD_PRELOAD=tests/libfake_hip.so (tests/test_host_logic.py: test_host_paths_against_the_hip_double; tools/asan_host.sh adds the
+AddressSanitizer build).  The double's "kernels" write a hash of (pixel, frame, scene, camera, step limit, cube-map contents) where the
+real kernels write colours, so what is checked here is the HOST's work: that every way of asking for a frame hands back the same
+frame, in the right place, touching nothing else; that tiles, bands, shards and cache files end up where they belong; that error paths
+return errors; that nothing leaks.  Nothing here says anything about a kernel.
+usage: fake_hip_workload.py [xcheck] [quick]"""
+import ctypes as C
+import os
+import shutil
+import sys
+import tempfile
+import threading
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import rmdf_amd as rmdf                                      # noqa: E402
+
+if os.environ.get("FAKE_HIP_WORKLOAD_XCHECK_LIB"):             # tools/asan_host.sh: the sanitizer build of the cross-check library
+    rmdf.XCHECK_LIB_PATH = os.environ["FAKE_HIP_WORKLOAD_XCHECK_LIB"]
+XCHECK = "xcheck" in sys.argv[1:]
+QUICK = "quick" in sys.argv[1:]
+FAKE = C.CDLL(os.environ.get("FAKE_HIP_LIB", os.path.join(ROOT, "tests", "libfake_hip.so")))  # (already in the process: LD_PRELOAD)
+FAKE.fake_hip_counters.argtypes = [C.c_void_p]
+FAKE.fake_hip_fail_malloc_in.argtypes = [C.c_longlong]
+CANARY = 0xDEADBEEF
+
+
+def counters():
+    a = (C.c_longlong * 8)()
+    FAKE.fake_hip_counters(a)
+    return dict(zip(("dev", "host", "streams", "events", "launches", "unknown", "copied", "kernels"), a))
+
+
+def set_env(sr, seed, sizes=(16, 8, 8)):
+    rng = np.random.default_rng(seed)
+    for slot, W in zip((rmdf.ENV_REFLECTION, rmdf.ENV_COS_1, rmdf.ENV_COS_8), sizes):
+        sr.set_env_cube(slot, rng.uniform(0.0, 2.0, (6, W, W, 3)).astype(np.float32))
+
+
+def whole(sr, scene, w, h, t, ms, pad=32):
+    fb = np.full(w * h + 2 * pad, CANARY, np.uint32)
+    sr.draw_shader_tile(scene, None, w, h, t, fb[pad:pad + w * h], max_steps=ms)
+    assert (fb[:pad] == CANARY).all() and (fb[pad + w * h:] == CANARY).all(), "whole-frame call wrote outside the frame"
+    return fb[pad:pad + w * h].reshape(h, w).copy()
+
+
+def section_whole_frame_paths():
+    sizes = [(2, 1920, 1080, 64), (0, 1283, 721, 32), (2, 200, 100, 64), (3, 600, 599, 24), (1, 33, 17, 16), (2, 8, 8, 8), (2, 1, 1, 4)]
+    if QUICK:
+        sizes = sizes[1:]
+    ref = {}
+    for bands, mode in [(0, 0), (1, 0), (16, 0), (5, 1), (2, 1), (1, 2), (4, 2), (7, 3), (16, 3)]:
+        sr = rmdf.ShaderRenderer(0, xcheck=XCHECK, frame_bands=bands, frame_mirror=mode)
+        set_env(sr, 1)
+        for key in sizes:
+            scene, w, h, ms = key
+            planes = sr.render(scene, w, h, 0.7, max_steps=ms)
+            ref.setdefault(key, planes["rgba8"].copy())
+            assert np.array_equal(planes["rgba8"], ref[key]), (bands, mode, key)
+            assert (planes["rgba8"] >> 24 == 0xFF).all() and (planes["steps"] & 0x7fff < ms).all()
+            for rep in range(3):                              # (from the second call on the strips are dispatched in cost order)
+                assert np.array_equal(whole(sr, scene, w, h, 0.7, ms), ref[key]), (bands, mode, key, rep)
+            tiled = np.zeros(w * h, np.uint32)
+            sr.draw_shader_tile(scene, 9, w, h, 0.7, tiled, max_steps=ms)       # not tile 0: keeps the latched frame
+            assert np.array_equal(tiled.reshape(h, w), ref[key]), (bands, mode, key, "tile after whole frame")
+            other = whole(sr, scene, w, h, 1.9, ms)           # another camera: another frame
+            assert w * h < 64 or not np.array_equal(other, ref[key])
+        sr.close()
+    for bad in (dict(frame_bands=17), dict(frame_bands=-1), dict(frame_mirror=4), dict(copy_threads=65)):
+        try:
+            rmdf.ShaderRenderer(0, xcheck=XCHECK, **bad)
+            raise AssertionError("accepted %r" % bad)
+        except rmdf.RmdfError:
+            pass
+    print("ok whole-frame paths (%d configurations x %d frames)" % (9, len(sizes)), flush=True)
+
+
+def section_tile_mode():
+    for threads in (1, 3, 0, 64):
+        sr = rmdf.ShaderRenderer(0, xcheck=XCHECK, copy_threads=threads)
+        set_env(sr, 2)
+        for (scene, w, h, ms) in ((2, 640, 480, 64), (0, 333, 187, 32), (2, 40, 24, 16), (3, 1920, 1080, 32)):
+            if QUICK and w > 1000:
+                continue
+            full = whole(sr, scene, w, h, 1.5, ms)
+            fb = np.full(w * h + 64, CANARY, np.uint32)
+            for idx in range(64):
+                sr.draw_shader_tile(scene, idx, w, h, 1.5 if idx == 0 else 99.0 + idx, fb[32:32 + w * h], max_steps=ms)   # time latches on tile 0
+                assert (fb[:32] == CANARY).all() and (fb[32 + w * h:] == CANARY).all()
+            assert np.array_equal(fb[32:32 + w * h].reshape(h, w), full), (threads, scene, w, h)
+            # tiles in another order, with jumps: every call returns the accumulated frame
+            order = list(np.random.default_rng(w).permutation(64))
+            order.remove(0)
+            fb[:] = 0
+            sr.draw_shader_tile(scene, 0, w, h, 2.5, fb[32:32 + w * h], max_steps=ms)
+            for idx in order:
+                sr.draw_shader_tile(scene, int(idx), w, h, 0.0, fb[32:32 + w * h], max_steps=ms)
+            assert np.array_equal(fb[32:32 + w * h].reshape(h, w), whole(sr, scene, w, h, 2.5, ms)), (threads, scene, w, h, "permuted")
+        sr.close()
+    # the environment changes between two tile calls of one frame: tiles issued ahead of their calls must not show the old one
+    sr = rmdf.ShaderRenderer(0, xcheck=XCHECK)
+    w, h, ms = 640, 360, 32
+    set_env(sr, 3)
+    a = whole(sr, 2, w, h, 0.3, ms)
+    set_env(sr, 4)
+    b = whole(sr, 2, w, h, 0.3, ms)
+    assert not np.array_equal(a, b)
+    for swap_at in (1, 20, 62, 63):
+        set_env(sr, 3)
+        fb = np.zeros(w * h, np.uint32)
+        want = np.zeros((h, w), np.uint32)
+        for idx in range(64):
+            if idx == swap_at:
+                set_env(sr, 4)
+            sr.draw_shader_tile(2, idx, w, h, 0.3, fb, max_steps=ms)
+            x0, y0, x1, y1 = rmdf.tile_rect(idx, w, h)
+            want[y0:y1, x0:x1] = (a if idx < swap_at else b)[y0:y1, x0:x1]
+            assert np.array_equal(fb.reshape(h, w)[y0:y1, x0:x1], want[y0:y1, x0:x1]), (swap_at, idx)
+        assert np.array_equal(fb.reshape(h, w), want), swap_at
+    # a registered buffer (bookkeeping only since round 5) behaves like any other; unregistering twice is an error
+    big = np.zeros(w * h + 4096, np.uint32)
+    sr.register_host_buffer(big)
+    sr.register_host_buffer(big)
+    view = big[1024:1024 + w * h]
+    sr.draw_shader_tile(2, None, w, h, 0.3, view, max_steps=ms)
+    assert np.array_equal(view.reshape(h, w), b) and (big[:1024] == 0).all() and (big[1024 + w * h:] == 0).all()
+    sr.unregister_host_buffer(big)
+    try:
+        sr.unregister_host_buffer(big)
+        raise AssertionError("second unregister accepted")
+    except rmdf.RmdfError:
+        pass
+    sr.close()
+    print("ok tile mode, environment swap, registered buffer", flush=True)
+
+
+def section_shards():
+    sr = rmdf.ShaderRenderer(0, xcheck=XCHECK)
+    set_env(sr, 5)
+    for (w, h, ms) in ((640, 360, 32), (1920, 1080, 32), (64, 64, 8)):
+        if QUICK and w > 1000:
+            continue
+        full = whole(sr, 2, w, h, 0.0, ms)
+        for costs in (None, sr.probe_tile_costs(2, w, h, 0.0, ms)):
+            sr.set_shard_costs(costs)
+            sr.set_shard_root_handicap(0.0 if costs is None else 0.25)
+            for n in (1, 2, 3, 8, 64):
+                slots = rmdf.shard_slots(n)
+                gathered = np.full((n, slots, h // 8, w // 8), CANARY, np.uint32)
+                seen = []
+                for r in range(n):
+                    seen += list(sr.shard_tiles(r, n))
+                    sr.render_shard_device(2, w, h, 0.0, ms, r, n, gathered[r].ctypes.data)
+                assert sorted(seen) == list(range(64)), (n, seen)
+                frame = np.full(w * h + 64, CANARY, np.uint32)
+                sr.assemble_shards_device(w, h, n, gathered.ctypes.data, frame[32:].ctypes.data)
+                sr.synchronize()
+                assert np.array_equal(frame[32:32 + w * h].reshape(h, w), full), (w, h, n, costs is not None)
+                assert (frame[:32] == CANARY).all() and (frame[32 + w * h:] == CANARY).all()
+        sr.set_shard_costs(None)
+        sr.set_shard_root_handicap(0.0)
+    # supersampling: 2x2 rays per pixel, one mip level
+    for (w, h) in ((320, 180), (64, 40)):
+        got = sr.render_supersampled(2, w, h, 1, 0.0, max_steps=16)
+        hi = whole(sr, 2, 2 * w, 2 * h, 0.0, 16).view(np.uint8).reshape(2 * h, 2 * w, 4).astype(np.uint32)
+        want = ((hi[0::2, 0::2] + hi[0::2, 1::2] + hi[1::2, 0::2] + hi[1::2, 1::2] + 2) >> 2).astype(np.uint8).view(np.uint32).reshape(h, w)
+        assert np.array_equal(got, want), (w, h)
+    sr.close()
+    print("ok shards (static and cost-aware deal; 1, 2, 3, 8, 64 ranks), supersampling", flush=True)
+
+
+def section_env_pipeline():
+    sr = rmdf.ShaderRenderer(0, xcheck=XCHECK)
+    rng = np.random.default_rng(6)
+    for (lw, lh) in ((96, 48), (51, 25), (512, 256)):
+        ll = rng.uniform(0.0, 3.0, (lh, lw, 3)).astype(np.float32)
+        sr.set_env_latlong(rmdf.ENV_REFLECTION, ll)
+        padded = sr.get_env_cube_padded(rmdf.ENV_REFLECTION)
+        assert padded.shape[0] == 6 and padded.shape[1] == padded.shape[2] == lw // 3 + 2, padded.shape
+        small = sr.resize_latlong(ll, 24)
+        assert small.shape[1] == 24 and small.shape[2] == 3
+    for (w, h) in ((256, 128), (100, 37), (8, 3), (300, 150)):
+        src = rng.uniform(0.0, 3.0, (h, w, 3)).astype(np.float32)
+        outs = sr.prefilter_env_powers(src, (1.0, 8.0, 64.0, 512.0))
+        assert len(outs) == 4 and all(o.shape == (h, w, 3) for o in outs)
+        for p, o in zip((1.0, 8.0, 64.0, 512.0), outs):
+            assert np.array_equal(sr.prefilter_env(src, p), o), (w, h, p)       # one power alone: another kernel, the same (stand-in) map
+        assert sr.prefilter_env(src, 3.5).shape == (h, w, 3)
+        assert len(sr.prefilter_env_powers(src, (8.0, 512.0))) == 2
+    # the cache files of withShaderRenderer's pipeline: built on the first load (private name + rename), read on the second
+    with tempfile.TemporaryDirectory() as d:
+        hdr = os.path.join(d, "probe.hdr")
+        shutil.copy(rmdf.DEFAULT_ENV_HDR, hdr)
+        before = counters()["launches"]
+        sr.load_env_hdr(hdr)
+        first = counters()["launches"] - before
+        files = sorted(os.listdir(d))
+        assert len(files) == 5 and not [f for f in files if ".tmp" in f], files
+        a = whole(sr, 2, 200, 100, 0.0, 16)
+        sizes = {f: os.path.getsize(os.path.join(d, f)) for f in files}
+        before = counters()["launches"]
+        sr.load_env_hdr(hdr)
+        second = counters()["launches"] - before
+        assert second < first, (first, second)               # no prefilter launches the second time
+        assert np.array_equal(whole(sr, 2, 200, 100, 0.0, 16), a)
+        assert sizes == {f: os.path.getsize(os.path.join(d, f)) for f in sorted(os.listdir(d))}
+        # a damaged cache file is an error the caller sees, not a crash
+        victim = [f for f in files if "cache" in f][0]
+        open(os.path.join(d, victim), "wb").write(b"#?RADIANCE\n\n-Y 128 +X 256\n" + b"\x02\x02\x01\x00" + b"\xff" * 40)
+        try:
+            sr.load_env_hdr(hdr)
+            damaged = "accepted (rebuilt)"
+        except rmdf.RmdfError as e:
+            damaged = "error %d" % e.code
+        for missing in (os.path.join(d, "nope.hdr"), d):
+            try:
+                sr.load_env_hdr(missing)
+                raise AssertionError("loaded %s" % missing)
+            except rmdf.RmdfError:
+                pass
+    sr.close()
+    # a renderer without an environment refuses to render
+    sr = rmdf.ShaderRenderer(0, xcheck=XCHECK)
+    try:
+        sr.render(2, 64, 64, 0.0)
+        raise AssertionError("rendered without an environment")
+    except rmdf.RmdfError as e:
+        assert "environment" in str(e)
+    for bad in ((7, 64, 64, 16), (2, 0, 64, 16), (2, 64, 40000, 16), (2, 64, 64, 40000)):
+        set_env(sr, 1)
+        try:
+            sr.render(bad[0], bad[1], bad[2], 0.0, max_steps=bad[3])
+            raise AssertionError("accepted %r" % (bad,))
+        except (rmdf.RmdfError, ValueError):
+            pass
+    sr.close()
+    print("ok env pipeline, cache files (damaged cache: %s), argument errors" % damaged, flush=True)
+
+
+def section_leaks_and_failed_allocations():
+    assert counters()["dev"] == 0 and counters()["host"] == 0 and counters()["streams"] == 0 and counters()["events"] == 0, counters()
+    for _ in range(3):
+        sr = rmdf.ShaderRenderer(0, xcheck=XCHECK)
+        set_env(sr, 7)
+        whole(sr, 2, 640, 360, 0.0, 16)
+        sr.close()
+        c = counters()
+        assert c["dev"] == 0 and c["host"] == 0 and c["streams"] == 0 and c["events"] == 0, c
+    # the n-th allocation fails: an error, not a crash; and everything is given back
+    failed = 0
+    for n in range(1, 60 if not QUICK else 25):
+        FAKE.fake_hip_fail_malloc_in(n)
+        sr = None
+        try:
+            sr = rmdf.ShaderRenderer(0, xcheck=XCHECK)
+            set_env(sr, 7)
+            sr.render(0, 200, 100, 0.0, max_steps=8)
+            whole(sr, 2, 1920, 1080, 0.0, 8)
+            fb = np.zeros(200 * 100, np.uint32)
+            for idx in range(6):
+                sr.draw_shader_tile(2, idx, 200, 100, 0.0, fb, max_steps=8)
+            sr.prefilter_env(np.ones((16, 32, 3), np.float32), 8.0)
+        except rmdf.RmdfError as e:
+            failed += 1
+            assert e.code in (-2, -7, -3), (n, e.code, str(e))
+        finally:
+            FAKE.fake_hip_fail_malloc_in(0)
+            if sr is not None:
+                sr.close()
+        c = counters()
+        assert c["dev"] == 0 and c["host"] == 0 and c["streams"] == 0 and c["events"] == 0, (n, c)
+    assert failed >= 10, failed
+    print("ok no leaks over create / destroy; %d injected allocation failures: an error each, nothing left behind" % failed, flush=True)
+
+
+def section_exchange():
+    """N ranks as N threads of this process, each with its own renderer and its own rank of one communicator of the RCCL double
+    (tests/fake_rccl.c, honoured by the cross-check library only)."""
+    if not XCHECK or not os.environ.get("RMDF_RCCL_LIB"):
+        print("skip exchange (needs the cross-check library and RMDF_RCCL_LIB)", flush=True)
+        return
+    w, h, ms, S = 640, 360, 16, 3
+    for n in (2, 3, 8):
+        uid = rmdf.comm_get_unique_id(xcheck=True)
+        errors, results = [], {}
+
+        def rank_main(rank):
+            try:
+                sr = rmdf.ShaderRenderer(0, xcheck=True)
+                set_env(sr, 8)
+                sr.comm_init(uid, rank, n)
+                assert sr.comm_info() == (rank, n)
+                slots = rmdf.shard_slots(n)
+                gath = [np.zeros((n, slots, h // 8, w // 8), np.uint32) if rank == 0 else None for _ in range(S)]
+                shard = [gath[k][0] if rank == 0 else np.zeros((slots, h // 8, w // 8), np.uint32) for k in range(S)]
+                frame = [np.zeros((h, w), np.uint32) if rank == 0 else None for _ in range(S)]
+                single = sr.render(2, w, h, 0.0, max_steps=ms, want_f32=False)["rgba8"].copy() if rank == 0 else None
+
+                def frames(times, tag, check=True):
+                    for i, t in enumerate(times):
+                        k = i % S
+                        sr.render_frame_sharded_device(2, w, h, t, ms, shard[k].ctypes.data, gath[k].ctypes.data if rank == 0 else 0,
+                                                       frame[k].ctypes.data if rank == 0 else 0)
+                    sr.synchronize()
+                    if rank == 0 and check:
+                        for i, t in enumerate(times):
+                            if i >= len(times) - S and t == 0.0:
+                                assert np.array_equal(frame[i % S], single), "%s: frame %d differs from the single launch" % (tag, i)
+
+                frames([0.0] * (2 * S), "static deal")
+                cost = sr.probe_tile_costs(2, w, h, 0.0, ms)
+                sr.set_shard_costs(cost)
+                sr.set_shard_root_handicap(0.25)
+                sr.comm_verify_deal()
+                frames([0.0] * S, "verified cost-aware deal")
+                bad = np.array(cost, np.float32).copy()
+                if rank == n - 1:
+                    bad[::3] *= 7.0
+                sr.set_shard_costs(bad)
+                try:
+                    sr.comm_verify_deal()
+                    raise AssertionError("rmdf_comm_verify_deal accepted different deals")
+                except rmdf.RmdfError as e:
+                    assert e.code == -8, str(e)
+                frames([0.0], "mixed deals", check=False)
+                sr.set_shard_costs(cost)
+                sr.comm_verify_deal()
+                frames([2.5] + [0.0] * S, "second verified deal")
+                sr.comm_destroy()
+                sr.close()
+                results[rank] = True
+            except BaseException as e:                          # noqa: BLE001
+                import traceback
+                errors.append((rank, traceback.format_exc()))
+
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(300)
+        assert not errors and len(results) == n, errors[:2]
+    c = counters()
+    assert c["dev"] == 0 and c["host"] == 0 and c["streams"] == 0 and c["events"] == 0, c
+    print("ok exchange with 2, 3 and 8 ranks against the RCCL double (deal check equal / unequal, frames in flight)", flush=True)
+
+
+def main():
+    assert os.environ.get("LD_PRELOAD", "").find("libfake_hip") >= 0, "run with LD_PRELOAD=tests/libfake_hip.so"
+    sr = rmdf.ShaderRenderer(0, xcheck=XCHECK)
+    assert "fake_hip" in sr.device_info()[0], sr.device_info()
+    sr.close()
+    section_whole_frame_paths()
+    section_tile_mode()
+    section_shards()
+    section_env_pipeline()
+    section_leaks_and_failed_allocations()
+    section_exchange()
+    c = counters()
+    assert c["unknown"] == 0 or XCHECK, c
+    print("done: %d launches through the double, %.1f MB moved by its copy calls, %d kernels registered, %d launches of kernels it has no stand-in for"
+          % (c["launches"], c["copied"] / 1e6, c["kernels"], c["unknown"]), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -526,6 +526,72 @@ def test_host_radiance_reader_and_writer_against_the_oracle():
         assert same(decode(junk), oracle_decode(junk)), junk
 
 
+def _fake_hip_lib():
+    """tests/libfake_hip.so, built from tests/fake_hip.cpp when missing or older than its sources (hipcc, host code only)."""
+    import subprocess
+    from conftest import ROOT
+    so, src = os.path.join(ROOT, "tests", "libfake_hip.so"), os.path.join(ROOT, "tests", "fake_hip.cpp")
+    csrc = os.path.join(ROOT, "ray-marching-distance-fields_amd", "csrc")
+    deps = [src] + [os.path.join(csrc, f) for f in ("rmdf_internal.hpp", "rmdf_device.hpp")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-g", "-std=c++17", "-fPIC", "--cuda-host-only", "--offload-arch=gfx950", "-x", "hip",
+                               "-I", csrc, "-shared", src, "-o", so])
+    return so
+
+
+@pytest.mark.parametrize("which", ["product", "xcheck"])
+def test_host_paths_against_the_hip_double(which):
+    """Everything librmdf does on the HOST behind a ctx, run on this box without a GPU: the HIP runtime is replaced by a test double
+    (tests/fake_hip.cpp, LD_PRELOADed into a child process) whose "device memory" is malloc'd memory and whose "kernels" write a hash
+    of (pixel, frame, scene, camera, step limit, cube-map contents) where the real kernels write colours.  tests/fake_hip_workload.py then
+    asks for frames in every way the ABI offers and checks the host's work: all four whole-frame hand-overs x band counts == the
+    plane-writing single launch, canaries around caller buffers intact; 64 tiles in order and permuted == the frame; an environment
+    swapped between two tile calls shows from that tile on (tiles issued ahead never show the old one); shards of 1, 2, 3, 8, 64 ranks,
+    static and cost-aware deal, assembled == the frame; supersampling == a numpy box filter; the env pipeline's shapes and its cache
+    files (written once, read the second time, a damaged one is an error); argument errors; no device / page-locked allocation,
+    stream or event left after rmdf_destroy; an error -- never a crash, never a leak -- when the n-th allocation fails, for n = 1..59;
+    and, with the cross-check library, the N-rank exchange (2, 3, 8 ranks as threads, the RCCL double) with equal and unequal deals.
+    The SHIPPED librmdf.so's host code is what runs ("product"); tools/asan_host.sh runs the same under AddressSanitizer + UBSan.
+    Nothing here is evidence about a kernel -- the double says so at length."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, LD_PRELOAD=_fake_hip_lib(), FAKE_RCCL_TIMEOUT_S="120", OMP_NUM_THREADS="1")
+    env.pop("RMDF_LIB", None)
+    args = [sys.executable, os.path.join(ROOT, "tests", "fake_hip_workload.py")]
+    if which == "xcheck":
+        fake_rccl = os.path.join(ROOT, "tests", "libfake_rccl.so")
+        if not os.path.exists(fake_rccl) or os.path.getmtime(fake_rccl) < os.path.getmtime(os.path.join(ROOT, "tests", "fake_rccl.c")):
+            subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "fake_rccl.c"),
+                                   "-o", fake_rccl, "-L/opt/rocm/lib", "-lamdhip64"])
+        env["RMDF_RCCL_LIB"] = fake_rccl
+        args.append("xcheck")
+    r = subprocess.run(args, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    oks = [l for l in r.stdout.splitlines() if l.startswith("ok ")]
+    assert len(oks) == (6 if which == "xcheck" else 5) and r.stdout.strip().splitlines()[-1].startswith("done:"), r.stdout[-1500:]
+    assert " 0 launches of kernels it has no stand-in for" in r.stdout
+
+
+def test_the_library_without_a_device_still_fails_loudly():
+    """... and without the double nothing has changed: on a box without a GPU rmdf_create fails with RMDF_E_NO_DEVICE and a message --
+    there is no CPU rendering path, and the HIP double is not something the library can find by itself."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    code = ("import sys; sys.path.insert(0, %r); import rmdf_amd\n"
+            "try:\n    rmdf_amd.ShaderRenderer(0)\n    print('created')\n"
+            "except rmdf_amd.RmdfError as e:\n    print('error', e.code, e)\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():
+        assert "created" in r.stdout
+    else:
+        assert r.stdout.startswith("error") and "no HIP device" in r.stdout, (r.stdout, r.stderr[-500:])
+
+
 def test_product_kernels_keep_their_register_budgets(tmp_path):
     """Occupancy is part of the measured figures (eight waves per SIMD for the headline kernel, six for the Cornell
     box, no private segment in either) and nothing else in the CPU tier would notice a compiler, flag or source change that costs a

@@ -12,3 +12,11 @@ cd "$here/../ray-marching-distance-fields_amd/csrc"
   -o "$tmp/librmdf_asan.so" -lz -ldl
 rt="$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)"
 LD_PRELOAD="$rt" ASAN_OPTIONS=detect_leaks=0 python3 "$here/asan_host_workload.py" "$tmp/librmdf_asan.so"
+# ... and everything behind a ctx -- staging, whole-frame bands (all four hand-overs), tile jobs, shards, the env pipeline and its cache
+# files, injected allocation failures, the N-rank exchange against the RCCL double -- with the HIP runtime replaced by tests/fake_hip.cpp
+# ("device memory" = malloc'd memory: every copy in or out of it is checked by the sanitizer's red zones)
+/opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --cuda-host-only --offload-arch=gfx950 -x hip -I . -fsanitize=address,undefined -fno-sanitize=vptr \
+  -shared "$here/../tests/fake_hip.cpp" -o "$tmp/libfake_hip.so"
+gcc -O1 -g -fPIC -shared -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include "$here/../tests/fake_rccl.c" -o "$tmp/libfake_rccl.so" -L/opt/rocm/lib -lamdhip64
+LD_PRELOAD="$rt $tmp/libfake_hip.so" ASAN_OPTIONS=detect_leaks=0 FAKE_HIP_WORKLOAD_XCHECK_LIB="$tmp/librmdf_asan.so" FAKE_HIP_LIB="$tmp/libfake_hip.so" \
+  RMDF_RCCL_LIB="$tmp/libfake_rccl.so" FAKE_RCCL_TIMEOUT_S=120 python3 "$here/../tests/fake_hip_workload.py" xcheck
