@@ -5,13 +5,21 @@
 // librmdf without a real HIP runtime and device fails in rmdf_create as before.
 //
 // What it is: "device memory" is malloc'd host memory (so every copy between caller memory, staging and device buffers is bounds-checked
-// by the allocator's red zones under ASan, and a device pointer can be read by the checks below); streams and events are tokens and every
-// operation completes before its call returns; kernels are NOT run -- each launch is replaced by a small host routine that writes what
+// by the allocator's red zones under ASan, and a device pointer can be read by the checks below); kernels are NOT run -- each launch is
+// replaced by a small host routine that writes what
 // the kernel's CONTRACT says where the kernel would write it (k_render: a pixel value that is a hash of everything that must
 // distinguish one pixel from another -- position, frame size, scene, camera, step limit, the contents of the three cube maps -- into the
 // frame, the mirror, the planes, the shard slots; k_assemble_shards, k_resolve_box2, k_fill_u32, k_order_blocks exactly; the env-map
-// kernels as nearest-texel stand-ins that read and write every element the real ones do).  What it is NOT: evidence about any kernel,
-// about asynchrony (nothing overlaps here), about the driver.  The pixels it produces mean nothing; that two paths produce the SAME
+// kernels as nearest-texel stand-ins that read and write every element the real ones do).
+// Two modes.  Default: streams and events are tokens and every operation completes before its call returns.  FAKE_HIP_ASYNC=1: every
+// stream is a worker thread with an in-order queue -- launches, hipMemcpyAsync between device and page-locked memory, hipMemsetAsync and
+// event records are queued and return at once; hipStreamWaitEvent makes a stream wait for the record it saw; hipEventQuery /
+// hipStreamQuery answer hipErrorNotReady while work is pending; hipFree / hipHostFree / hipDeviceSynchronize drain every stream first, as
+// the real runtime does; a copy that touches PAGEABLE memory (neither hipMalloc'ed nor hipHostMalloc'ed) drains its stream and runs in
+// the caller's thread.  FAKE_HIP_JITTER_US=n delays every queued operation by a random 0..n microseconds.  In this mode a host that
+// reads a buffer before the event that guards it, or re-uses a staging chunk before its DMA has run, computes with stale data -- the
+// workload's comparisons fail -- and ThreadSanitizer (tools/asan_host.sh tsan) sees the two accesses without a happens-before edge.
+// What it is NOT: evidence about any kernel or about the driver.  The pixels it produces mean nothing; that two paths produce the SAME
 // pixels, that nothing outside a buffer is touched and that nothing leaks is what the tests look at.
 //
 // Build (hipcc for the structure definitions of rmdf_internal.hpp; host code only):
@@ -19,7 +27,15 @@
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <random>
+#include <thread>
+#include <unistd.h>
+#include <malloc.h>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <set>
 #include <string>
@@ -37,7 +53,7 @@ namespace {
 
 std::mutex g_mu;
 std::map<const void *, std::string> g_kernels;          // host stub address -> device name
-std::set<void *> g_dev, g_host, g_streams, g_events;
+std::set<void *> g_dev, g_host;
 std::atomic<long long> g_launches{ 0 }, g_unknown{ 0 }, g_copied{ 0 }, g_fail_malloc_in{ 0 };
 std::string g_last_unknown;
 struct CallCfg { dim3 grid, block; size_t shmem; hipStream_t stream; };
@@ -117,38 +133,41 @@ float src_checksum(const float *src, size_t n)                  // reads every e
     return s;
 }
 
-void fake_launch(const std::string &name, dim3 grid, dim3 block, void **args)
+// the arguments are decoded NOW (the args array belongs to the caller's stack frame); what is returned runs when the stream gets to it
+std::function<void()> make_task(const std::string &name, dim3 grid, dim3 block, void **args)
 {
     (void)block;
     auto has = [&](const char *s) { return name.find(s) != std::string::npos; };
-    if (has("k_renderILi")) { fake_render(name, *(const FrameParams *)args[0], grid); return; }
+    if (has("k_renderILi")) { const FrameParams p = *(const FrameParams *)args[0]; return [=] { fake_render(name, p, grid); }; }
     if (has("k_order_blocks")) {
         const unsigned *cost = arg<const unsigned *>(args, 0); const int n = arg<int>(args, 1); unsigned *order = arg<unsigned *>(args, 2);
+        return [=] {
         std::vector<unsigned> idx((size_t)n);
         for (int i = 0; i < n; i++) idx[(size_t)i] = (unsigned)i;
         std::stable_sort(idx.begin(), idx.end(), [&](unsigned a, unsigned b) { return cost[a] > cost[b]; });
         for (int i = 0; i < n; i++) order[i] = idx[(size_t)i];
-        return;
+        };
     }
     if (has("k_fill_u32")) {
         uint32_t *dst = arg<uint32_t *>(args, 0); const uint32_t v = arg<uint32_t>(args, 1); const size_t n = arg<size_t>(args, 2);
-        for (size_t i = 0; i < n; i++) dst[i] = v;
-        return;
+        return [=] { for (size_t i = 0; i < n; i++) dst[i] = v; };
     }
     if (has("k_assemble_shards")) {                               // both forms: the same mapping (rmdf_util.hip)
         const uint32_t *gathered = arg<const uint32_t *>(args, 0); uint32_t *frame = arg<uint32_t *>(args, 1);
         const int w = arg<int>(args, 2), h = arg<int>(args, 3), nranks = arg<int>(args, 4);
         const rmdf::ShardWhere where = arg<rmdf::ShardWhere>(args, 5);
+        return [=] {
         const int tw = w / 8, th = h / 8, slots = (64 + nranks - 1) / nranks;
         for (int py = 0; py < h; py++)
             for (int px = 0; px < w; px++) {
                 const int tx = px / tw, ty = py / th, rs = where.v[tx + ty * 8];
                 frame[(size_t)py * w + px] = gathered[((size_t)(rs >> 8) * slots + (rs & 255)) * (size_t)tw * th + (size_t)(px - tx * tw) + (size_t)(py - ty * th) * tw];
             }
-        return;
+        };
     }
     if (has("k_resolve_box2")) {
         const uint32_t *src = arg<const uint32_t *>(args, 0); const int dw = arg<int>(args, 1), dh = arg<int>(args, 2); uint32_t *dst = arg<uint32_t *>(args, 3);
+        return [=] {
         for (int y = 0; y < dh; y++)
             for (int x = 0; x < dw; x++) {
                 uint32_t o = 0;
@@ -159,10 +178,11 @@ void fake_launch(const std::string &name, dim3 grid, dim3 block, void **args)
                 }
                 dst[(size_t)y * dw + x] = o;
             }
-        return;
+        };
     }
     if (has("k_cube_upload")) {                                   // stand-in: clamped copy as four 16-bit quantities per texel
         const float *faces = arg<const float *>(args, 0); const int W = arg<int>(args, 1); uint2 *padded = arg<uint2 *>(args, 2);
+        return [=] {
         const int P = W + 2;
         for (int f = 0; f < 6; f++)
             for (int Y = 0; Y < P; Y++)
@@ -174,48 +194,134 @@ void fake_launch(const std::string &name, dim3 grid, dim3 block, void **args)
                     o.y = fbits(t[2]) >> 16;
                     padded[((size_t)f * P + Y) * P + X] = o;
                 }
-        return;
+        };
     }
     if (has("k_latlong_to_cube")) {                               // stand-in: nearest texel at the table's (u, v)
         const float *ll = arg<const float *>(args, 0); const int w = arg<int>(args, 1), h = arg<int>(args, 2), cw = arg<int>(args, 3);
         const float2 *uv = arg<const float2 *>(args, 4); float *faces = arg<float *>(args, 5);
+        return [=] {
         for (size_t i = 0; i < (size_t)6 * cw * cw; i++) {
             const int x = std::min(w - 1, std::max(0, (int)(uv[i].x * (float)(w - 1)))), y = std::min(h - 1, std::max(0, (int)(uv[i].y * (float)(h - 1))));
             for (int k = 0; k < 3; k++) faces[i * 3 + k] = ll[((size_t)y * w + x) * 3 + k];
         }
-        return;
+        };
     }
     if (has("k_resize_latlong")) {                                // stand-in: nearest texel
         const float *src = arg<const float *>(args, 0); const int sw = arg<int>(args, 1), sh = arg<int>(args, 2), dw = arg<int>(args, 3), dh = arg<int>(args, 4);
         float *out = arg<float *>(args, 5);
+        return [=] {
         for (int y = 0; y < dh; y++)
             for (int x = 0; x < dw; x++)
                 for (int k = 0; k < 3; k++) out[((size_t)y * dw + x) * 3 + k] = src[((size_t)std::min(sh - 1, y * sh / dh) * sw + std::min(sw - 1, x * sw / dw)) * 3 + k];
-        return;
+        };
     }
     if (has("k_prefilter")) {                                     // stand-in: source scaled by a function of the power; reads both tables end to end
         const float *src = arg<const float *>(args, 0); const int w = arg<int>(args, 1), h = arg<int>(args, 2);
-        const size_t n = (size_t)w * h * 3;
-        const float cs = src_checksum(src, n);
-        auto tables = [&](const float *lutT, const float2 *tcs) { const size_t nl = (size_t)((w + 63) / 64) * w * 64; return lutT[0] + lutT[nl - 1] + tcs[0].x + tcs[h - 1].y; };
-        auto fill = [&](float *out, float power, float tb) { if (out) for (size_t i = 0; i < n; i++) out[i] = src[i] / (1.0f + power) + 0.0f * (cs + tb); };
+        struct Out { float *p; float power; };
+        std::vector<Out> outs;
+        const float *lutT; const float2 *tcs;
         if (has("k_prefilter_fused4")) {
-            const float tb = tables(arg<const float *>(args, 3), arg<const float2 *>(args, 4));
+            lutT = arg<const float *>(args, 3); tcs = arg<const float2 *>(args, 4);
             const float pw[4] = { 1.0f, 8.0f, 64.0f, 512.0f };
-            for (int k = 0; k < 4; k++) fill(arg<float *>(args, 5 + k), pw[k], tb);
+            for (int k = 0; k < 4; k++) outs.push_back(Out{ arg<float *>(args, 5 + k), pw[k] });
         } else if (has("k_prefilter_chan") || has("k_prefilter_ring")) {
             int l2 = 0;
             sscanf(name.c_str() + name.find("ILi") + 3, "%d", &l2);
-            fill(arg<float *>(args, 5), (float)(1 << l2), tables(arg<const float *>(args, 3), arg<const float2 *>(args, 4)));
+            lutT = arg<const float *>(args, 3); tcs = arg<const float2 *>(args, 4);
+            outs.push_back(Out{ arg<float *>(args, 5), (float)(1 << l2) });
         } else {                                                  // k_prefilter<LOG2P, LUT_IN_LDS>(src, w, h, power, lutT, tcs, out, ..)
-            fill(arg<float *>(args, 6), arg<float>(args, 3), tables(arg<const float *>(args, 4), arg<const float2 *>(args, 5)));
+            lutT = arg<const float *>(args, 4); tcs = arg<const float2 *>(args, 5);
+            outs.push_back(Out{ arg<float *>(args, 6), arg<float>(args, 3) });
         }
-        return;
+        return [=] {
+            const size_t n = (size_t)w * h * 3, nl = (size_t)((w + 63) / 64) * w * 64;
+            const float cs = src_checksum(src, n), tb = lutT[0] + lutT[nl - 1] + tcs[0].x + tcs[h - 1].y;
+            for (const Out &o : outs)
+                if (o.p) for (size_t i = 0; i < n; i++) o.p[i] = src[i] / (1.0f + o.power) + 0.0f * (cs + tb);
+        };
     }
-    if (has("k_selftest") || has("k_clock_probe")) return;        // their result buffers were cleared by the host: "no mismatch"
+    if (has("k_selftest") || has("k_clock_probe")) return [] { };  // their result buffers were cleared by the host: "no mismatch"
     g_unknown++;
     std::lock_guard<std::mutex> lk(g_mu);
     g_last_unknown = name;
+    return [] { };
+}
+
+// ---- streams and events ------------------------------------------------------------------------------------------------------------------------
+const bool g_async = getenv("FAKE_HIP_ASYNC") && atoi(getenv("FAKE_HIP_ASYNC")) != 0;
+const int g_jitter_us = getenv("FAKE_HIP_JITTER_US") ? atoi(getenv("FAKE_HIP_JITTER_US")) : 0;
+// FAKE_HIP_SABOTAGE=events: hipEventQuery / hipEventSynchronize claim completion at once -- what a host that forgot to wait would see.
+// For the test of the tests: with it the asynchronous workload must FAIL (tests/test_host_logic.py).
+const bool g_sabotage_events = getenv("FAKE_HIP_SABOTAGE") && strstr(getenv("FAKE_HIP_SABOTAGE"), "events");
+
+struct Stream {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_idle;
+    std::deque<std::function<void()>> q;
+    bool busy = false, stop = false;
+    std::thread th;
+    std::minstd_rand rng{ 12345u };
+    void start() { th = std::thread([this] { run(); }); }
+    void run()
+    {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                f = std::move(q.front()); q.pop_front(); busy = true;
+            }
+            if (g_jitter_us > 0) usleep((useconds_t)(rng() % (unsigned)(g_jitter_us + 1)));
+            f();
+            { std::lock_guard<std::mutex> lk(mu); busy = false; if (q.empty()) cv_idle.notify_all(); }
+        }
+    }
+    void push(std::function<void()> f) { { std::lock_guard<std::mutex> lk(mu); q.push_back(std::move(f)); } cv_work.notify_one(); }
+    void drain() { std::unique_lock<std::mutex> lk(mu); cv_idle.wait(lk, [&] { return q.empty() && !busy; }); }
+    bool idle() { std::lock_guard<std::mutex> lk(mu); return q.empty() && !busy; }
+    void finish() { drain(); { std::lock_guard<std::mutex> lk(mu); stop = true; } cv_work.notify_one(); if (th.joinable()) th.join(); }
+};
+struct Event {
+    std::mutex mu;
+    std::condition_variable cv;
+    unsigned long long recorded = 0, completed = 0;       // generations: a record is complete when completed >= its generation
+};
+std::map<Stream *, std::shared_ptr<Stream>> g_streams;   // (drain_all holds references while it waits: another thread may destroy a stream meanwhile)
+std::map<Event *, std::shared_ptr<Event>> g_events;      // queued operations hold a reference: an event may be destroyed while they are pending
+std::shared_ptr<Stream> g_null_stream;                      // the legacy default stream (hipMemset, stream 0)
+
+std::shared_ptr<Stream> stream_of(hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (s) { auto it = g_streams.find((Stream *)s); return it == g_streams.end() ? nullptr : it->second; }
+    if (!g_null_stream) { g_null_stream = std::make_shared<Stream>(); if (g_async) g_null_stream->start(); }
+    return g_null_stream;
+}
+void submit(hipStream_t s, std::function<void()> f)
+{
+    if (!g_async) { f(); return; }
+    auto st = stream_of(s);
+    if (!st) { fprintf(stderr, "fake_hip: work submitted to a stream that does not exist\n"); abort(); }
+    st->push(std::move(f));
+}
+void drain_all()
+{
+    if (!g_async) return;
+    std::vector<std::shared_ptr<Stream>> all;
+    { std::lock_guard<std::mutex> lk(g_mu); for (auto &kv : g_streams) all.push_back(kv.second); if (g_null_stream) all.push_back(g_null_stream); }
+    for (auto &st : all) st->drain();
+}
+bool library_owned(const void *p)                          // inside a hipMalloc / hipHostMalloc block?  (pageable memory is not)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (const std::set<void *> *set : { &g_dev, &g_host }) {
+        auto it = set->upper_bound((void *)p);
+        if (it == set->begin()) continue;
+        --it;
+        if ((const char *)p < (const char *)*it + malloc_usable_size(*it)) return true;
+    }
+    return false;
 }
 
 void *take(std::set<void *> &s, size_t bytes)
@@ -270,13 +376,13 @@ hipError_t __hipPopCallConfiguration(dim3 *grid, dim3 *block, size_t *shmem, hip
     *grid = c.grid; *block = c.block; *shmem = c.shmem; *stream = c.stream;
     return hipSuccess;
 }
-hipError_t hipLaunchKernel(const void *fn, dim3 grid, dim3 block, void **args, size_t, hipStream_t)
+hipError_t hipLaunchKernel(const void *fn, dim3 grid, dim3 block, void **args, size_t, hipStream_t stream)
 {
     std::string name;
     { std::lock_guard<std::mutex> lk(g_mu); auto it = g_kernels.find(fn); if (it == g_kernels.end()) return hipErrorInvalidDeviceFunction; name = it->second; }
     g_launches++;
     if (grid.x == 0 || grid.y == 0 || grid.z == 0 || block.x == 0) return hipErrorInvalidConfiguration;
-    fake_launch(name, grid, block, args);
+    submit(stream, make_task(name, grid, block, args));
     return hipSuccess;
 }
 hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
@@ -297,20 +403,79 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t *prop, int d)
     return hipSuccess;
 }
 hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 0; *greatest = -1; return hipSuccess; }
-hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+hipError_t hipDeviceSynchronize(void) { drain_all(); return hipSuccess; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
-const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : (e == hipErrorOutOfMemory ? "out of memory (fake_hip)" : "error (fake_hip)"); }
-hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)take(g_streams, 8); return *s ? hipSuccess : hipErrorOutOfMemory; }
+const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : (e == hipErrorOutOfMemory ? "out of memory (fake_hip)" : (e == hipErrorNotReady ? "not ready" : "error (fake_hip)")); }
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned)
+{
+    auto st = std::make_shared<Stream>();
+    if (g_async) st->start();
+    { std::lock_guard<std::mutex> lk(g_mu); g_streams[st.get()] = st; }
+    *s = (hipStream_t)st.get();
+    return hipSuccess;
+}
 hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned f, int) { return hipStreamCreateWithFlags(s, f); }
-hipError_t hipStreamDestroy(hipStream_t s) { return give(g_streams, s) ? hipSuccess : hipErrorInvalidHandle; }
-hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (hipEvent_t)take(g_events, 8); return *e ? hipSuccess : hipErrorOutOfMemory; }
-hipError_t hipEventDestroy(hipEvent_t e) { return give(g_events, e) ? hipSuccess : hipErrorInvalidHandle; }
-hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
-hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
-hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s)
+{
+    std::shared_ptr<Stream> st;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_streams.find((Stream *)s);
+        if (it == g_streams.end()) return hipErrorInvalidHandle;
+        st = it->second;
+        g_streams.erase(it);
+    }
+    if (g_async) st->finish();                                // (the object goes when the last drain_all that saw it lets go)
+    return hipSuccess;
+}
+hipError_t hipStreamQuery(hipStream_t s) { auto st = stream_of(s); if (!st) return hipErrorInvalidHandle; return !g_async || st->idle() ? hipSuccess : hipErrorNotReady; }
+hipError_t hipStreamSynchronize(hipStream_t s) { auto st = stream_of(s); if (!st) return hipErrorInvalidHandle; if (g_async) st->drain(); return hipSuccess; }
+static std::shared_ptr<Event> event_of(hipEvent_t e)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_events.find((Event *)e);
+    return it == g_events.end() ? nullptr : it->second;
+}
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned)
+{
+    auto ev = std::make_shared<Event>();
+    { std::lock_guard<std::mutex> lk(g_mu); g_events[ev.get()] = ev; }
+    *e = (hipEvent_t)ev.get();
+    return hipSuccess;
+}
+hipError_t hipEventDestroy(hipEvent_t e)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_events.erase((Event *)e) ? hipSuccess : hipErrorInvalidHandle;
+}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s)
+{
+    auto ev = event_of(e);
+    if (!ev) return hipErrorInvalidHandle;
+    unsigned long long gen;
+    { std::lock_guard<std::mutex> lk(ev->mu); gen = ++ev->recorded; }
+    submit(s, [ev, gen] { { std::lock_guard<std::mutex> lk(ev->mu); if (ev->completed < gen) ev->completed = gen; } ev->cv.notify_all(); });
+    return hipSuccess;
+}
+hipError_t hipEventQuery(hipEvent_t e) { auto ev = event_of(e); if (!ev) return hipErrorInvalidHandle; if (g_sabotage_events) return hipSuccess; std::lock_guard<std::mutex> lk(ev->mu); return ev->completed >= ev->recorded ? hipSuccess : hipErrorNotReady; }
+hipError_t hipEventSynchronize(hipEvent_t e)
+{
+    auto ev = event_of(e);
+    if (!ev) return hipErrorInvalidHandle;
+    if (g_sabotage_events) return hipSuccess;
+    std::unique_lock<std::mutex> lk(ev->mu);
+    ev->cv.wait(lk, [&] { return ev->completed >= ev->recorded; });
+    return hipSuccess;
+}
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned)
+{
+    auto ev = event_of(e);
+    if (!ev) return hipErrorInvalidHandle;
+    unsigned long long gen;
+    { std::lock_guard<std::mutex> lk(ev->mu); gen = ev->recorded; }      // the record the call saw (none: nothing to wait for)
+    submit(s, [ev, gen] { std::unique_lock<std::mutex> lk(ev->mu); ev->cv.wait(lk, [&] { return ev->completed >= gen; }); });
+    return hipSuccess;
+}
 
 // ---- memory ---------------------------------------------------------------------------------------------------------------------------------
 static bool failing()
@@ -320,21 +485,31 @@ static bool failing()
     return n == 1;
 }
 hipError_t hipMalloc(void **p, size_t bytes) { if (failing()) { *p = nullptr; return hipErrorOutOfMemory; } *p = take(g_dev, bytes); return *p ? hipSuccess : hipErrorOutOfMemory; }
-hipError_t hipFree(void *p) { if (!p) return hipSuccess; return give(g_dev, p) ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipFree(void *p) { if (!p) return hipSuccess; drain_all(); return give(g_dev, p) ? hipSuccess : hipErrorInvalidValue; }
 hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { if (failing()) { *p = nullptr; return hipErrorOutOfMemory; } *p = take(g_host, bytes); return *p ? hipSuccess : hipErrorOutOfMemory; }
-hipError_t hipHostFree(void *p) { if (!p) return hipSuccess; return give(g_host, p) ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipHostFree(void *p) { if (!p) return hipSuccess; drain_all(); return give(g_host, p) ? hipSuccess : hipErrorInvalidValue; }
 hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return hipSuccess; }
-hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind, hipStream_t) { memmove(dst, src, n); g_copied += (long long)n; return hipSuccess; }
-hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind) { memmove(dst, src, n); g_copied += (long long)n; return hipSuccess; }   // (tests/fake_rccl.c uses it)
-hipError_t hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t)
+hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind, hipStream_t s)
 {
-    if (width > dpitch || width > spitch) return hipErrorInvalidPitchValue;
-    for (size_t y = 0; y < height; y++) memmove((char *)dst + y * dpitch, (const char *)src + y * spitch, width);
-    g_copied += (long long)(width * height);
+    g_copied += (long long)n;
+    if (g_async && library_owned(dst) && library_owned(src)) { submit(s, [=] { memmove(dst, src, n); }); return hipSuccess; }
+    if (g_async) { auto st = stream_of(s); if (st) st->drain(); }   // pageable memory: behind the stream's work, in the caller's thread
+    memmove(dst, src, n);
     return hipSuccess;
 }
-hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
-hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind) { drain_all(); memmove(dst, src, n); g_copied += (long long)n; return hipSuccess; }   // (tests/fake_rccl.c uses it)
+hipError_t hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t s)
+{
+    if (width > dpitch || width > spitch) return hipErrorInvalidPitchValue;
+    g_copied += (long long)(width * height);
+    auto run = [=] { for (size_t y = 0; y < height; y++) memmove((char *)dst + y * dpitch, (const char *)src + y * spitch, width); };
+    if (g_async && library_owned(dst) && library_owned(src)) { submit(s, run); return hipSuccess; }
+    if (g_async) { auto st = stream_of(s); if (st) st->drain(); }
+    run();
+    return hipSuccess;
+}
+hipError_t hipMemset(void *p, int v, size_t n) { drain_all(); memset(p, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t s) { submit(s, [=] { memset(p, v, n); }); return hipSuccess; }
 // (the virtual-memory calls of the cross-check build's electric-fence allocator: not offered here -- the allocator's red zones do that job)
 hipError_t hipMemGetAllocationGranularity(size_t *, const hipMemAllocationProp *, hipMemAllocationGranularity_flags) { return hipErrorNotSupported; }
 hipError_t hipMemCreate(hipMemGenericAllocationHandle_t *, size_t, const hipMemAllocationProp *, unsigned long long) { return hipErrorNotSupported; }

@@ -5,7 +5,7 @@ AddressSanitizer build).  The double's "kernels" write a hash of (pixel, frame, 
 real kernels write colours, so what is checked here is the HOST's work: that every way of asking for a frame hands back the same
 frame, in the right place, touching nothing else; that tiles, bands, shards and cache files end up where they belong; that error paths
 return errors; that nothing leaks.  Nothing here says anything about a kernel.
-usage: fake_hip_workload.py [xcheck] [quick]"""
+usage: fake_hip_workload.py [xcheck] [quick] [only=whole|tiles|shards|env|leaks|exchange ...]"""
 import ctypes as C
 import os
 import shutil
@@ -350,15 +350,17 @@ def section_exchange():
 
 def main():
     assert os.environ.get("LD_PRELOAD", "").find("libfake_hip") >= 0, "run with LD_PRELOAD=tests/libfake_hip.so"
+    if os.environ.get("FAKE_HIP_WORKLOAD_WATCHDOG_S"):          # a hang: say where every thread stands, then give up
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["FAKE_HIP_WORKLOAD_WATCHDOG_S"]), exit=True)
     sr = rmdf.ShaderRenderer(0, xcheck=XCHECK)
     assert "fake_hip" in sr.device_info()[0], sr.device_info()
     sr.close()
-    section_whole_frame_paths()
-    section_tile_mode()
-    section_shards()
-    section_env_pipeline()
-    section_leaks_and_failed_allocations()
-    section_exchange()
+    only = [a[5:] for a in sys.argv[1:] if a.startswith("only=")]
+    for name, fn in (("whole", section_whole_frame_paths), ("tiles", section_tile_mode), ("shards", section_shards), ("env", section_env_pipeline),
+                     ("leaks", section_leaks_and_failed_allocations), ("exchange", section_exchange)):
+        if not only or name in only:
+            fn()
     c = counters()
     assert c["unknown"] == 0 or XCHECK, c
     print("done: %d launches through the double, %.1f MB moved by its copy calls, %d kernels registered, %d launches of kernels it has no stand-in for"

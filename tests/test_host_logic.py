@@ -539,7 +539,7 @@ def _fake_hip_lib():
     return so
 
 
-@pytest.mark.parametrize("which", ["product", "xcheck"])
+@pytest.mark.parametrize("which", ["product", "xcheck", "xcheck-async"])
 def test_host_paths_against_the_hip_double(which):
     """Everything librmdf does on the HOST behind a ctx, run on this box without a GPU: the HIP runtime is replaced by a test double
     (tests/fake_hip.cpp, LD_PRELOADed into a child process) whose "device memory" is malloc'd memory and whose "kernels" write a hash
@@ -551,7 +551,11 @@ def test_host_paths_against_the_hip_double(which):
     files (written once, read the second time, a damaged one is an error); argument errors; no device / page-locked allocation,
     stream or event left after rmdf_destroy; an error -- never a crash, never a leak -- when the n-th allocation fails, for n = 1..59;
     and, with the cross-check library, the N-rank exchange (2, 3, 8 ranks as threads, the RCCL double) with equal and unequal deals.
-    The SHIPPED librmdf.so's host code is what runs ("product"); tools/asan_host.sh runs the same under AddressSanitizer + UBSan.
+    The SHIPPED librmdf.so's host code is what runs ("product"); tools/asan_host.sh runs the same under AddressSanitizer + UBSan and
+    under ThreadSanitizer.  "xcheck-async": the double's asynchronous mode -- every stream a worker thread with an in-order queue, events
+    with generations, hipErrorNotReady while work is pending, every queued operation delayed by a random 0..150 us -- in which a host
+    that reads a buffer before the event guarding it computes with stale data and fails the comparisons
+    (test_the_hip_double_notices_a_host_that_does_not_wait shows that it does).
     Nothing here is evidence about a kernel -- the double says so at length."""
     import subprocess
     import sys
@@ -559,7 +563,9 @@ def test_host_paths_against_the_hip_double(which):
     env = dict(os.environ, LD_PRELOAD=_fake_hip_lib(), FAKE_RCCL_TIMEOUT_S="120", OMP_NUM_THREADS="1")
     env.pop("RMDF_LIB", None)
     args = [sys.executable, os.path.join(ROOT, "tests", "fake_hip_workload.py")]
-    if which == "xcheck":
+    if which == "xcheck-async":
+        env.update(FAKE_HIP_ASYNC="1", FAKE_HIP_JITTER_US="150", FAKE_HIP_WORKLOAD_WATCHDOG_S="600")
+    if which.startswith("xcheck"):
         fake_rccl = os.path.join(ROOT, "tests", "libfake_rccl.so")
         if not os.path.exists(fake_rccl) or os.path.getmtime(fake_rccl) < os.path.getmtime(os.path.join(ROOT, "tests", "fake_rccl.c")):
             subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "fake_rccl.c"),
@@ -569,8 +575,24 @@ def test_host_paths_against_the_hip_double(which):
     r = subprocess.run(args, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     oks = [l for l in r.stdout.splitlines() if l.startswith("ok ")]
-    assert len(oks) == (6 if which == "xcheck" else 5) and r.stdout.strip().splitlines()[-1].startswith("done:"), r.stdout[-1500:]
+    assert len(oks) == (6 if which.startswith("xcheck") else 5) and r.stdout.strip().splitlines()[-1].startswith("done:"), r.stdout[-1500:]
     assert " 0 launches of kernels it has no stand-in for" in r.stdout
+
+
+def test_the_hip_double_notices_a_host_that_does_not_wait():
+    """The test of the test above: with FAKE_HIP_SABOTAGE=events the double's hipEventQuery / hipEventSynchronize claim completion at
+    once -- what a host that forgot to wait for its band, tile or staging event would see -- and the asynchronous workload must FAIL
+    (stale rows reach the caller's frame), where the same run without the sabotage passes."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    base = dict(os.environ, LD_PRELOAD=_fake_hip_lib(), FAKE_HIP_ASYNC="1", FAKE_HIP_JITTER_US="200", FAKE_HIP_WORKLOAD_WATCHDOG_S="300", OMP_NUM_THREADS="1")
+    base.pop("RMDF_LIB", None)
+    args = [sys.executable, os.path.join(ROOT, "tests", "fake_hip_workload.py"), "quick", "only=whole", "only=tiles"]
+    good = subprocess.run(args, env=base, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert good.returncode == 0 and good.stdout.count("\nok ") + good.stdout.startswith("ok ") == 2, (good.stdout[-800:], good.stderr[-2000:])
+    bad = subprocess.run(args, env=dict(base, FAKE_HIP_SABOTAGE="events"), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert bad.returncode != 0 and "AssertionError" in bad.stderr, (bad.stdout[-800:], bad.stderr[-2000:])
 
 
 def test_the_library_without_a_device_still_fails_loudly():
