@@ -51,11 +51,21 @@ using rmdf::FrameParams;
 
 namespace {
 
-std::mutex g_mu;
-std::map<const void *, std::string> g_kernels;          // host stub address -> device name
-std::set<void *> g_dev, g_host;
+// (the globals are built on first use and never torn down: librmdf.so's static constructors register its kernels, and in a program that
+// links librmdf directly they may run before this library's own)
+struct Globals {
+    std::mutex mu;
+    std::map<const void *, std::string> kernels;        // host stub address -> device name
+    std::set<void *> dev, host;
+    std::string last_unknown;
+};
+Globals &G() { static Globals *g = new Globals; return *g; }
+#define g_mu (G().mu)
+#define g_kernels (G().kernels)
+#define g_dev (G().dev)
+#define g_host (G().host)
+#define g_last_unknown (G().last_unknown)
 std::atomic<long long> g_launches{ 0 }, g_unknown{ 0 }, g_copied{ 0 }, g_fail_malloc_in{ 0 };
-std::string g_last_unknown;
 struct CallCfg { dim3 grid, block; size_t shmem; hipStream_t stream; };
 thread_local std::vector<CallCfg> t_cfg;
 
@@ -248,11 +258,14 @@ std::function<void()> make_task(const std::string &name, dim3 grid, dim3 block, 
 }
 
 // ---- streams and events ------------------------------------------------------------------------------------------------------------------------
-const bool g_async = getenv("FAKE_HIP_ASYNC") && atoi(getenv("FAKE_HIP_ASYNC")) != 0;
-const int g_jitter_us = getenv("FAKE_HIP_JITTER_US") ? atoi(getenv("FAKE_HIP_JITTER_US")) : 0;
+bool async_mode() { static const bool v = getenv("FAKE_HIP_ASYNC") && atoi(getenv("FAKE_HIP_ASYNC")) != 0; return v; }
+int jitter_us() { static const int v = getenv("FAKE_HIP_JITTER_US") ? atoi(getenv("FAKE_HIP_JITTER_US")) : 0; return v; }
+#define g_async (async_mode())
+#define g_jitter_us (jitter_us())
 // FAKE_HIP_SABOTAGE=events: hipEventQuery / hipEventSynchronize claim completion at once -- what a host that forgot to wait would see.
 // For the test of the tests: with it the asynchronous workload must FAIL (tests/test_host_logic.py).
-const bool g_sabotage_events = getenv("FAKE_HIP_SABOTAGE") && strstr(getenv("FAKE_HIP_SABOTAGE"), "events");
+bool sabotage_events() { static const bool v = getenv("FAKE_HIP_SABOTAGE") && strstr(getenv("FAKE_HIP_SABOTAGE"), "events"); return v; }
+#define g_sabotage_events (sabotage_events())
 
 struct Stream {
     std::mutex mu;
@@ -287,9 +300,15 @@ struct Event {
     std::condition_variable cv;
     unsigned long long recorded = 0, completed = 0;       // generations: a record is complete when completed >= its generation
 };
-std::map<Stream *, std::shared_ptr<Stream>> g_streams;   // (drain_all holds references while it waits: another thread may destroy a stream meanwhile)
-std::map<Event *, std::shared_ptr<Event>> g_events;      // queued operations hold a reference: an event may be destroyed while they are pending
-std::shared_ptr<Stream> g_null_stream;                      // the legacy default stream (hipMemset, stream 0)
+struct Handles {
+    std::map<Stream *, std::shared_ptr<Stream>> streams;  // (drain_all holds references while it waits: another thread may destroy a stream meanwhile)
+    std::map<struct Event *, std::shared_ptr<struct Event>> events;   // queued operations hold a reference: an event may be destroyed while they are pending
+    std::shared_ptr<Stream> null_stream;                  // the legacy default stream (hipMemset, stream 0)
+};
+Handles &H() { static Handles *h = new Handles; return *h; }
+#define g_streams (H().streams)
+#define g_events (H().events)
+#define g_null_stream (H().null_stream)
 
 std::shared_ptr<Stream> stream_of(hipStream_t s)
 {

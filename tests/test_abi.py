@@ -158,6 +158,35 @@ def test_c_host_compiles_against_the_header(tmp_path):
     assert os.path.exists(_build_c_host(tmp_path, "c_host_multi"))
 
 
+def test_c_host_runs_against_the_hip_double(tmp_path):
+    """The plain-C host without a GPU: its HIP runtime is the test double (tests/fake_hip.cpp, LD_PRELOAD), so its pixels mean
+    nothing -- but the C program's own check `64 tiles == untiled` holds, it exits 0, the env pipeline writes its four cache files next to
+    the (copied) light probe, and the PNG it writes decodes to the frame the Python mirror gets from the same double and the same
+    files: the ABI as a C compiler sees it, the tile loop, the screenshot path, end to end on the CPU tier."""
+    import shutil
+    import subprocess
+    import sys
+    import rmdf_amd
+    from test_host_logic import _fake_hip_lib
+    exe = _build_c_host(tmp_path)
+    hdr = str(tmp_path / "probe.hdr")
+    shutil.copy(rmdf_amd.DEFAULT_ENV_HDR, hdr)                     # (the double's prefilter is a stand-in: its cache files must not land in the tree)
+    png = str(tmp_path / "c_host.png")
+    env = dict(os.environ, LD_PRELOAD=_fake_hip_lib())
+    out = subprocess.run([exe, hdr, png, "2", "320", "184"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "64 tiles == untiled: yes" in out.stdout
+    assert len([f for f in os.listdir(str(tmp_path)) if "_cache_pow_" in f]) == 4
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import rmdf_amd\n"
+            "from PIL import Image\n"
+            "with rmdf_amd.with_shader_renderer(%r) as sr:\n"
+            "    fb = rmdf_amd.FrameBuffer(320, 184)\n"
+            "    sr.draw_shader_tile(2, None, 320, 184, 1.5, fb.vec, max_steps=256)\n"
+            "print('same' if np.array_equal(np.asarray(Image.open(%r)), fb.to_image_rows_top_down()) else 'differs')\n" % (ROOT, hdr, png))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip() == "same", (r.stdout, r.stderr[-2000:])
+
+
 @pytest.mark.gpu
 def test_c_host_runs(tmp_path):
     """The C host on the GPU: 64 tiled calls accumulate the untiled frame (it checks that itself) and the PNG it writes
