@@ -5,7 +5,7 @@ AddressSanitizer build).  The double's "kernels" write a hash of (pixel, frame, 
 real kernels write colours, so what is checked here is the HOST's work: that every way of asking for a frame hands back the same
 frame, in the right place, touching nothing else; that tiles, bands, shards and cache files end up where they belong; that error paths
 return errors; that nothing leaks.  Nothing here says anything about a kernel.
-usage: fake_hip_workload.py [xcheck] [quick] [only=whole|tiles|shards|env|leaks|exchange ...]"""
+usage: fake_hip_workload.py [xcheck] [quick] [only=whole|tiles|shards|env|random|leaks|exchange ...]"""
 import ctypes as C
 import os
 import shutil
@@ -241,6 +241,77 @@ def section_env_pipeline():
     print("ok env pipeline, cache files (damaged cache: %s), argument errors" % damaged, flush=True)
 
 
+def section_random_call_sequences():
+    """A model of what the boundary promises (ShaderRendering.hs:162-193 as include/rmdf.h states it: time, step limit and size latch on tile 0
+    or a whole-frame call; a new size clears the accumulating frame; the shader value and the environment are those of the call; every
+    call hands back the whole accumulating frame) against the library, over random call sequences: tiles in any order and repeated, whole
+    frames through the fast path and through the plane-writing path, size changes, environment changes, shader changes -- with tile jobs
+    issued ahead, band hand-overs and the shadow frame all in play.  The expected pixels come from a second renderer that only ever
+    renders whole frames through the plain path."""
+    rng = np.random.default_rng(11)
+    ref = rmdf.ShaderRenderer(0, xcheck=XCHECK, frame_bands=1, frame_mirror=0)
+    cache = {}
+
+    def want_frame(scene, w, h, t, ms, seed):
+        key = (scene, w, h, t, ms, seed)
+        if key not in cache:
+            if cache.get("seed") != seed:
+                set_env(ref, seed)
+                cache["seed"] = seed
+            cache[key] = ref.render(scene, w, h, t, max_steps=ms, want_f32=False)["rgba8"].copy()
+        return cache[key]
+
+    sizes = [(128, 72), (64, 40), (200, 100), (33, 17), (640, 360)]
+    nops = 0
+    for trial in range(6 if QUICK else 16):
+        cfg = dict(frame_bands=int(rng.integers(0, 6)), frame_mirror=int(rng.integers(0, 4)), copy_threads=int(rng.choice([0, 1, 3])))
+        sr = rmdf.ShaderRenderer(0, xcheck=XCHECK, **cfg)
+        seed = int(rng.integers(100, 104))
+        set_env(sr, seed)
+        cur, lt, lms, model = None, None, None, None
+        for step in range(60 if QUICK else 120):
+            op = rng.choice(["tile", "tile", "tile", "tile", "next", "whole", "planes", "planes_tile", "env", "size"])
+            scene = int(rng.integers(0, 4))
+            t = float(rng.choice([0.0, 1.0, 2.5, 7.0]))
+            ms = int(rng.choice([8, 16, 33]))
+            w, h = cur if cur and op != "size" else sizes[int(rng.integers(0, len(sizes)))]
+            if op == "env":
+                seed = int(rng.integers(100, 104))
+                set_env(sr, seed)
+                continue
+            if op == "size":
+                op = "tile"
+            if op == "next":                                   # the tile after the last one: the pattern the jobs issued ahead are made for
+                op, idx = "tile", (locals().get("last_idx", -1) + 1) % 128
+            else:
+                idx = int(rng.integers(0, 128))
+            whole_call = op in ("whole", "planes")
+            first = whole_call or idx % 64 == 0
+            if first or cur is None or (w, h) != cur:
+                if cur is None or (w, h) != cur:
+                    model = np.full((h, w), 0xFF000000, np.uint32)
+                cur, lt, lms = (w, h), t, ms
+            src = want_frame(scene, w, h, lt, lms, seed)
+            if whole_call:
+                model[:] = src
+            else:
+                x0, y0, x1, y1 = rmdf.tile_rect(idx, w, h)
+                model[y0:y1, x0:x1] = src[y0:y1, x0:x1]
+                last_idx = idx
+            if op in ("tile", "whole"):
+                fb = np.full(w * h + 16, CANARY, np.uint32)
+                sr.draw_shader_tile(scene, None if whole_call else idx, w, h, t, fb[8:8 + w * h], max_steps=ms)
+                assert (fb[:8] == CANARY).all() and (fb[8 + w * h:] == CANARY).all()
+                got = fb[8:8 + w * h].reshape(h, w)
+            else:
+                got = sr.render(scene, w, h, t, max_steps=ms, tile_idx=None if whole_call else idx, want_f32=bool(rng.integers(0, 2)))["rgba8"]
+            assert np.array_equal(got, model), (trial, step, op, scene, idx, (w, h), t, ms, cfg)
+            nops += 1
+        sr.close()
+    ref.close()
+    print("ok %d random calls against the model of the boundary (tiles / whole frames / planes, size, shader and environment changes)" % nops, flush=True)
+
+
 def section_leaks_and_failed_allocations():
     assert counters()["dev"] == 0 and counters()["host"] == 0 and counters()["streams"] == 0 and counters()["events"] == 0, counters()
     for _ in range(3):
@@ -358,7 +429,7 @@ def main():
     sr.close()
     only = [a[5:] for a in sys.argv[1:] if a.startswith("only=")]
     for name, fn in (("whole", section_whole_frame_paths), ("tiles", section_tile_mode), ("shards", section_shards), ("env", section_env_pipeline),
-                     ("leaks", section_leaks_and_failed_allocations), ("exchange", section_exchange)):
+                     ("random", section_random_call_sequences), ("leaks", section_leaks_and_failed_allocations), ("exchange", section_exchange)):
         if not only or name in only:
             fn()
     c = counters()
