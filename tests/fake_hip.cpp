@@ -362,7 +362,24 @@ bool give(std::set<void *> &s, void *p)
 
 extern "C" {
 
+// per-entry-point call counts (fake_hip_calls): what a frame costs the host in runtime calls is a figure of its own -- each is microseconds
+struct Calls { std::mutex mu; std::map<std::string, long long> n; };
+static Calls &CALLS() { static Calls *c = new Calls; return *c; }
+static void count_call(const char *name) { Calls &c = CALLS(); std::lock_guard<std::mutex> lk(c.mu); c.n[name]++; }
+#define COUNT() count_call(__func__)
+
 // ---- test hooks ---------------------------------------------------------------------------------------------------------------------------
+// "name=count;name=count;..." of every runtime entry point called since the last reset (reset != 0: clear after reading)
+int fake_hip_calls(char *buf, int cap, int reset)
+{
+    Calls &c = CALLS();
+    std::lock_guard<std::mutex> lk(c.mu);
+    std::string out;
+    for (auto &kv : c.n) out += kv.first + "=" + std::to_string(kv.second) + ";";
+    if (reset) c.n.clear();
+    snprintf(buf, (size_t)cap, "%s", out.c_str());
+    return (int)out.size();
+}
 // out[0..7]: live device allocations, live page-locked allocations, live streams, live events, launches, launches of kernels the double
 // does not know, bytes moved by memcpy calls, registered kernels
 void fake_hip_counters(long long out[8])
@@ -396,7 +413,7 @@ hipError_t __hipPopCallConfiguration(dim3 *grid, dim3 *block, size_t *shmem, hip
     return hipSuccess;
 }
 hipError_t hipLaunchKernel(const void *fn, dim3 grid, dim3 block, void **args, size_t, hipStream_t stream)
-{
+{ COUNT();
     std::string name;
     { std::lock_guard<std::mutex> lk(g_mu); auto it = g_kernels.find(fn); if (it == g_kernels.end()) return hipErrorInvalidDeviceFunction; name = it->second; }
     g_launches++;
@@ -408,7 +425,7 @@ hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hip
 
 // ---- device, streams, events -----------------------------------------------------------------------------------------------------------------
 hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
+hipError_t hipSetDevice(int d) { COUNT(); return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
 hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t *prop, int d)
 {
@@ -422,11 +439,11 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t *prop, int d)
     return hipSuccess;
 }
 hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 0; *greatest = -1; return hipSuccess; }
-hipError_t hipDeviceSynchronize(void) { drain_all(); return hipSuccess; }
-hipError_t hipGetLastError(void) { return hipSuccess; }
+hipError_t hipDeviceSynchronize(void) { COUNT(); drain_all(); return hipSuccess; }
+hipError_t hipGetLastError(void) { COUNT(); return hipSuccess; }
 const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : (e == hipErrorOutOfMemory ? "out of memory (fake_hip)" : (e == hipErrorNotReady ? "not ready" : "error (fake_hip)")); }
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned)
-{
+{ COUNT();
     auto st = std::make_shared<Stream>();
     if (g_async) st->start();
     { std::lock_guard<std::mutex> lk(g_mu); g_streams[st.get()] = st; }
@@ -447,8 +464,8 @@ hipError_t hipStreamDestroy(hipStream_t s)
     if (g_async) st->finish();                                // (the object goes when the last drain_all that saw it lets go)
     return hipSuccess;
 }
-hipError_t hipStreamQuery(hipStream_t s) { auto st = stream_of(s); if (!st) return hipErrorInvalidHandle; return !g_async || st->idle() ? hipSuccess : hipErrorNotReady; }
-hipError_t hipStreamSynchronize(hipStream_t s) { auto st = stream_of(s); if (!st) return hipErrorInvalidHandle; if (g_async) st->drain(); return hipSuccess; }
+hipError_t hipStreamQuery(hipStream_t s) { COUNT(); auto st = stream_of(s); if (!st) return hipErrorInvalidHandle; return !g_async || st->idle() ? hipSuccess : hipErrorNotReady; }
+hipError_t hipStreamSynchronize(hipStream_t s) { COUNT(); auto st = stream_of(s); if (!st) return hipErrorInvalidHandle; if (g_async) st->drain(); return hipSuccess; }
 static std::shared_ptr<Event> event_of(hipEvent_t e)
 {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -456,7 +473,7 @@ static std::shared_ptr<Event> event_of(hipEvent_t e)
     return it == g_events.end() ? nullptr : it->second;
 }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned)
-{
+{ COUNT();
     auto ev = std::make_shared<Event>();
     { std::lock_guard<std::mutex> lk(g_mu); g_events[ev.get()] = ev; }
     *e = (hipEvent_t)ev.get();
@@ -468,7 +485,7 @@ hipError_t hipEventDestroy(hipEvent_t e)
     return g_events.erase((Event *)e) ? hipSuccess : hipErrorInvalidHandle;
 }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s)
-{
+{ COUNT();
     auto ev = event_of(e);
     if (!ev) return hipErrorInvalidHandle;
     unsigned long long gen;
@@ -476,9 +493,9 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s)
     submit(s, [ev, gen] { { std::lock_guard<std::mutex> lk(ev->mu); if (ev->completed < gen) ev->completed = gen; } ev->cv.notify_all(); });
     return hipSuccess;
 }
-hipError_t hipEventQuery(hipEvent_t e) { auto ev = event_of(e); if (!ev) return hipErrorInvalidHandle; if (g_sabotage_events) return hipSuccess; std::lock_guard<std::mutex> lk(ev->mu); return ev->completed >= ev->recorded ? hipSuccess : hipErrorNotReady; }
+hipError_t hipEventQuery(hipEvent_t e) { COUNT(); auto ev = event_of(e); if (!ev) return hipErrorInvalidHandle; if (g_sabotage_events) return hipSuccess; std::lock_guard<std::mutex> lk(ev->mu); return ev->completed >= ev->recorded ? hipSuccess : hipErrorNotReady; }
 hipError_t hipEventSynchronize(hipEvent_t e)
-{
+{ COUNT();
     auto ev = event_of(e);
     if (!ev) return hipErrorInvalidHandle;
     if (g_sabotage_events) return hipSuccess;
@@ -487,7 +504,7 @@ hipError_t hipEventSynchronize(hipEvent_t e)
     return hipSuccess;
 }
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned)
-{
+{ COUNT();
     auto ev = event_of(e);
     if (!ev) return hipErrorInvalidHandle;
     unsigned long long gen;
@@ -503,13 +520,13 @@ static bool failing()
     while (n > 0 && !g_fail_malloc_in.compare_exchange_weak(n, n - 1)) { }
     return n == 1;
 }
-hipError_t hipMalloc(void **p, size_t bytes) { if (failing()) { *p = nullptr; return hipErrorOutOfMemory; } *p = take(g_dev, bytes); return *p ? hipSuccess : hipErrorOutOfMemory; }
-hipError_t hipFree(void *p) { if (!p) return hipSuccess; drain_all(); return give(g_dev, p) ? hipSuccess : hipErrorInvalidValue; }
-hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { if (failing()) { *p = nullptr; return hipErrorOutOfMemory; } *p = take(g_host, bytes); return *p ? hipSuccess : hipErrorOutOfMemory; }
-hipError_t hipHostFree(void *p) { if (!p) return hipSuccess; drain_all(); return give(g_host, p) ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipMalloc(void **p, size_t bytes) { COUNT(); if (failing()) { *p = nullptr; return hipErrorOutOfMemory; } *p = take(g_dev, bytes); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipFree(void *p) { COUNT(); if (!p) return hipSuccess; drain_all(); return give(g_dev, p) ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { COUNT(); if (failing()) { *p = nullptr; return hipErrorOutOfMemory; } *p = take(g_host, bytes); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void *p) { COUNT(); if (!p) return hipSuccess; drain_all(); return give(g_host, p) ? hipSuccess : hipErrorInvalidValue; }
 hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return hipSuccess; }
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind, hipStream_t s)
-{
+{ COUNT();
     g_copied += (long long)n;
     if (g_async && library_owned(dst) && library_owned(src)) { submit(s, [=] { memmove(dst, src, n); }); return hipSuccess; }
     if (g_async) { auto st = stream_of(s); if (st) st->drain(); }   // pageable memory: behind the stream's work, in the caller's thread
@@ -518,7 +535,7 @@ hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind, h
 }
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind) { drain_all(); memmove(dst, src, n); g_copied += (long long)n; return hipSuccess; }   // (tests/fake_rccl.c uses it)
 hipError_t hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t s)
-{
+{ COUNT();
     if (width > dpitch || width > spitch) return hipErrorInvalidPitchValue;
     g_copied += (long long)(width * height);
     auto run = [=] { for (size_t y = 0; y < height; y++) memmove((char *)dst + y * dpitch, (const char *)src + y * spitch, width); };
@@ -527,8 +544,8 @@ hipError_t hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t sp
     run();
     return hipSuccess;
 }
-hipError_t hipMemset(void *p, int v, size_t n) { drain_all(); memset(p, v, n); return hipSuccess; }
-hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t s) { submit(s, [=] { memset(p, v, n); }); return hipSuccess; }
+hipError_t hipMemset(void *p, int v, size_t n) { COUNT(); drain_all(); memset(p, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t s) { COUNT(); submit(s, [=] { memset(p, v, n); }); return hipSuccess; }
 // (the virtual-memory calls of the cross-check build's electric-fence allocator: not offered here -- the allocator's red zones do that job)
 hipError_t hipMemGetAllocationGranularity(size_t *, const hipMemAllocationProp *, hipMemAllocationGranularity_flags) { return hipErrorNotSupported; }
 hipError_t hipMemCreate(hipMemGenericAllocationHandle_t *, size_t, const hipMemAllocationProp *, unsigned long long) { return hipErrorNotSupported; }

@@ -5,7 +5,7 @@ AddressSanitizer build).  The double's "kernels" write a hash of (pixel, frame, 
 real kernels write colours, so what is checked here is the HOST's work: that every way of asking for a frame hands back the same
 frame, in the right place, touching nothing else; that tiles, bands, shards and cache files end up where they belong; that error paths
 return errors; that nothing leaks.  Nothing here says anything about a kernel.
-usage: fake_hip_workload.py [xcheck] [quick] [only=whole|tiles|shards|env|random|leaks|exchange ...]"""
+usage: fake_hip_workload.py [xcheck] [quick] [only=whole|tiles|shards|env|random|calls|leaks|exchange ...]"""
 import ctypes as C
 import os
 import shutil
@@ -312,6 +312,44 @@ def section_random_call_sequences():
     print("ok %d random calls against the model of the boundary (tiles / whole frames / planes, size, shader and environment changes)" % nops, flush=True)
 
 
+def section_runtime_calls_per_frame():
+    """What a frame costs the host in HIP runtime calls (each is microseconds of host time; the band sweep of round 5 lost to them): counted
+    by the double, held to a budget so that a change that adds calls to the per-frame paths shows up on the CPU tier."""
+    FAKE.fake_hip_calls.argtypes = [C.c_char_p, C.c_int, C.c_int]
+
+    def calls():
+        b = C.create_string_buffer(16384)
+        FAKE.fake_hip_calls(b, 16384, 1)
+        d = {k: int(v) for k, v in (kv.split("=") for kv in b.value.decode().split(";") if kv)}
+        return sum(v for k, v in d.items() if k not in ("hipEventQuery", "hipStreamQuery")), d      # (polls depend on timing)
+
+    w, h, n = 1920, 1080, 10
+    fb = np.zeros(w * h, np.uint32)
+    rows = []
+    for name, cfg, budget in (("default (two mirror bands)", dict(), 14), ("one mirror band", dict(frame_bands=1, frame_mirror=1), 8),
+                              ("two bands, copies behind the launches", dict(frame_bands=2, frame_mirror=0), 16),
+                              ("eight mirror bands", dict(frame_bands=8, frame_mirror=1), 34), ("one launch, eight flagged bands", dict(frame_bands=8, frame_mirror=2), 5)):
+        sr = rmdf.ShaderRenderer(0, xcheck=XCHECK, **cfg)
+        set_env(sr, 1)
+        for _ in range(3):
+            sr.draw_shader_tile(2, None, w, h, 0.0, fb, max_steps=8)
+        calls()
+        for _ in range(n):
+            sr.draw_shader_tile(2, None, w, h, 0.0, fb, max_steps=8)
+        per_frame, d = calls()
+        assert per_frame <= budget * n, (name, per_frame / n, d)
+        rows.append("%s %.1f" % (name, per_frame / n))
+        if not cfg:
+            for rep in range(2):
+                for idx in range(64):
+                    sr.draw_shader_tile(2, idx, w, h, 0.0, fb, max_steps=8)
+                per_tile, d = calls()
+            assert per_tile <= 8 * 64, (per_tile / 64.0, d)
+            rows.append("tile call %.1f" % (per_tile / 64.0))
+        sr.close()
+    print("ok runtime calls per 1080p frame: " + "; ".join(rows), flush=True)
+
+
 def section_leaks_and_failed_allocations():
     assert counters()["dev"] == 0 and counters()["host"] == 0 and counters()["streams"] == 0 and counters()["events"] == 0, counters()
     for _ in range(3):
@@ -429,7 +467,8 @@ def main():
     sr.close()
     only = [a[5:] for a in sys.argv[1:] if a.startswith("only=")]
     for name, fn in (("whole", section_whole_frame_paths), ("tiles", section_tile_mode), ("shards", section_shards), ("env", section_env_pipeline),
-                     ("random", section_random_call_sequences), ("leaks", section_leaks_and_failed_allocations), ("exchange", section_exchange)):
+                     ("random", section_random_call_sequences), ("calls", section_runtime_calls_per_frame),
+                     ("leaks", section_leaks_and_failed_allocations), ("exchange", section_exchange)):
         if not only or name in only:
             fn()
     c = counters()

@@ -577,7 +577,7 @@ def test_host_paths_against_the_hip_double(which):
     r = subprocess.run(args, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     oks = [l for l in r.stdout.splitlines() if l.startswith("ok ")]
-    assert len(oks) == (7 if which.startswith("xcheck") else 6) and r.stdout.strip().splitlines()[-1].startswith("done:"), r.stdout[-1500:]
+    assert len(oks) == (8 if which.startswith("xcheck") else 7) and r.stdout.strip().splitlines()[-1].startswith("done:"), r.stdout[-1500:]
     assert " 0 launches of kernels it has no stand-in for" in r.stdout
 
 
