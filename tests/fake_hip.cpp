@@ -424,12 +424,15 @@ hipError_t hipLaunchKernel(const void *fn, dim3 grid, dim3 block, void **args, s
 hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 
 // ---- device, streams, events -----------------------------------------------------------------------------------------------------------------
-hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-hipError_t hipSetDevice(int d) { COUNT(); return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
-hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+// FAKE_HIP_DEVICES=n: n identical devices (one process per "GPU" hosts, examples/c_host_multi.c); all of them share the double's one heap
+static int device_count() { static const int v = getenv("FAKE_HIP_DEVICES") && atoi(getenv("FAKE_HIP_DEVICES")) > 0 ? atoi(getenv("FAKE_HIP_DEVICES")) : 1; return v; }
+static thread_local int t_device = 0;
+hipError_t hipGetDeviceCount(int *n) { *n = device_count(); return hipSuccess; }
+hipError_t hipSetDevice(int d) { COUNT(); if (d < 0 || d >= device_count()) return hipErrorInvalidDevice; t_device = d; return hipSuccess; }
+hipError_t hipGetDevice(int *d) { *d = t_device; return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t *prop, int d)
 {
-    if (d != 0) return hipErrorInvalidDevice;
+    if (d < 0 || d >= device_count()) return hipErrorInvalidDevice;
     memset(prop, 0, sizeof *prop);
     snprintf(prop->name, sizeof prop->name, "no GPU: tests/fake_hip.cpp");
     snprintf(prop->gcnArchName, sizeof prop->gcnArchName, "gfx950:fake");

@@ -187,6 +187,47 @@ def test_c_host_runs_against_the_hip_double(tmp_path):
     assert r.returncode == 0 and r.stdout.strip() == "same", (r.stdout, r.stderr[-2000:])
 
 
+@pytest.mark.parametrize("nranks", [2, 8])
+def test_c_host_multi_runs_against_the_doubles(tmp_path, nranks):
+    """examples/c_host_multi.c -- one forked process per GPU, the unique id through a shared page, rmdf_comm_init, the cost-aware deal,
+    one rmdf_render_frame_sharded_device per frame -- with N > 1 ranks and no GPU: N devices of the HIP double (FAKE_HIP_DEVICES), the
+    RCCL double between the processes (files in /dev/shm), the program linked against the cross-check library (the only one that honours
+    RMDF_RCCL_LIB).  All ranks load the same light probe at once and build its four cache files concurrently (private name + rename:
+    exactly four files afterwards, none temporary); the program's own check `sharded == single launch` holds and its PNG decodes to
+    the frame a single renderer gets from the same double and the same files."""
+    import shutil
+    import subprocess
+    import sys
+    import rmdf_amd
+    from test_host_logic import _fake_hip_lib
+    rmdf_amd.build()
+    libdir = os.path.dirname(rmdf_amd.XCHECK_LIB_PATH)
+    exe = str(tmp_path / "c_host_multi")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-std=c99", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_host_multi.c"),
+                           "-o", exe, "-L", libdir, "-lrmdf_xcheck", "-Wl,-rpath," + libdir])
+    fake_rccl = os.path.join(ROOT, "tests", "libfake_rccl.so")
+    if not os.path.exists(fake_rccl) or os.path.getmtime(fake_rccl) < os.path.getmtime(os.path.join(ROOT, "tests", "fake_rccl.c")):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "fake_rccl.c"),
+                               "-o", fake_rccl, "-L/opt/rocm/lib", "-lamdhip64"])
+    hdr = str(tmp_path / "probe.hdr")
+    shutil.copy(rmdf_amd.DEFAULT_ENV_HDR, hdr)
+    png = str(tmp_path / "multi.png")
+    env = dict(os.environ, LD_PRELOAD=_fake_hip_lib(), FAKE_HIP_DEVICES=str(nranks), RMDF_RCCL_LIB=fake_rccl, FAKE_RCCL_TIMEOUT_S="120")
+    out = subprocess.run([exe, hdr, png, str(nranks), "640", "360", "5"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "sharded == single launch: yes" in out.stdout and ("rank 0 of %d" % nranks) in out.stdout, out.stdout
+    files = sorted(os.listdir(str(tmp_path)))
+    assert len([f for f in files if "_cache_pow_" in f]) == 4 and not [f for f in files if ".tmp" in f], files
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import rmdf_amd\n"
+            "from PIL import Image\n"
+            "with rmdf_amd.with_shader_renderer(%r) as sr:\n"
+            "    fb = rmdf_amd.FrameBuffer(640, 360)\n"
+            "    sr.draw_shader_tile(2, None, 640, 360, 0.0, fb.vec, max_steps=256)\n"
+            "print('same' if np.array_equal(np.asarray(Image.open(%r)), fb.to_image_rows_top_down()) else 'differs')\n" % (ROOT, hdr, png))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, LD_PRELOAD=_fake_hip_lib()))
+    assert r.returncode == 0 and r.stdout.strip() == "same", (r.stdout, r.stderr[-2000:])
+
+
 @pytest.mark.gpu
 def test_c_host_runs(tmp_path):
     """The C host on the GPU: 64 tiled calls accumulate the untiled frame (it checks that itself) and the PNG it writes
