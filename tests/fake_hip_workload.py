@@ -5,7 +5,7 @@ AddressSanitizer build).  The double's "kernels" write a hash of (pixel, frame, 
 real kernels write colours, so what is checked here is the HOST's work: that every way of asking for a frame hands back the same
 frame, in the right place, touching nothing else; that tiles, bands, shards and cache files end up where they belong; that error paths
 return errors; that nothing leaks.  Nothing here says anything about a kernel.
-usage: fake_hip_workload.py [xcheck] [quick] [only=whole|tiles|shards|env|random|calls|leaks|exchange ...]"""
+usage: fake_hip_workload.py [xcheck] [quick] [only=whole|tiles|shards|env|random|calls|args|leaks|exchange ...]"""
 import ctypes as C
 import os
 import shutil
@@ -350,6 +350,54 @@ def section_runtime_calls_per_frame():
     print("ok runtime calls per 1080p frame: " + "; ".join(rows), flush=True)
 
 
+def section_argument_sweep():
+    """Every entry point of the ABI whose first parameter is the ctx, with a valid ctx and null pointers / empty or unusable paths / zero,
+    one, negative and large scalars for everything else (four variants each): an error code or a harmless success -- never a crash, never
+    a write through a null pointer -- and the renderer still works afterwards.  (Entry points without a ctx get all-zero arguments.)"""
+    L = rmdf.load_library(xcheck=XCHECK)
+    names = list(rmdf.ABI_SYMBOLS) + (list(rmdf.XCHECK_SYMBOLS) if XCHECK else [])
+    no_ctx = {"rmdf_create", "rmdf_create_ex", "rmdf_get_cornell_vertices", "rmdf_get_shader_constants", "rmdf_debug_cornell_table", "rmdf_debug_hdr_decode",
+              "rmdf_debug_hdr_encode", "rmdf_comm_get_unique_id", "rmdf_shard_tiles", "rmdf_save_png", "rmdf_debug_cornell_masks", "rmdf_debug_cube_uv_table",
+              "rmdf_debug_lobe_tables", "rmdf_debug_camera", "rmdf_is_tile_idx_first_tile", "rmdf_is_tile_idx_last_tile"}
+    is_ptr = lambda t: t is C.c_void_p or t is C.c_char_p or (isinstance(t, type) and issubclass(t, C._Pointer))
+    sr = rmdf.ShaderRenderer(0, xcheck=XCHECK)
+    set_env(sr, 1)
+    calls = 0
+    for n in names:
+        f = getattr(L, n)
+        if n in ("rmdf_destroy", "rmdf_last_error") or f.argtypes is None:
+            continue
+        if n in no_ctx:
+            if n in ("rmdf_comm_get_unique_id",) and not os.environ.get("RMDF_RCCL_LIB"):
+                continue                                        # (would load the real RCCL)
+            f(*[(0.0 if t in (C.c_double, C.c_float) else (None if is_ptr(t) else 0)) for t in f.argtypes])
+            calls += 1
+            continue
+        if n.startswith("rmdf_comm_") and not os.environ.get("RMDF_RCCL_LIB"):
+            continue
+        assert f.argtypes[0] is C.c_void_p, n
+        for variant in range(4):
+            args = [sr._ctx]
+            for t in f.argtypes[1:]:
+                if t in (C.c_double, C.c_float):
+                    args.append([0.0, 1.0, -1.0, 1e30][variant])
+                elif t is C.c_char_p:
+                    args.append([None, b"", b"/nonexistent/x", b"/"][variant])
+                elif is_ptr(t):
+                    args.append(None)
+                elif t is C.c_size_t:
+                    args.append([0, 1, 64, 4096][variant])
+                else:
+                    args.append([0, 1, -1, 64][variant])
+            f(*args)
+            calls += 1
+    fb = np.zeros(200 * 100, np.uint32)
+    sr.draw_shader_tile(2, None, 200, 100, 0.0, fb, max_steps=8)
+    assert (fb >> 24 == 0xFF).all()
+    sr.close()
+    print("ok %d calls with null pointers and out-of-range scalars: errors, no crash" % calls, flush=True)
+
+
 def section_leaks_and_failed_allocations():
     assert counters()["dev"] == 0 and counters()["host"] == 0 and counters()["streams"] == 0 and counters()["events"] == 0, counters()
     for _ in range(3):
@@ -468,7 +516,7 @@ def main():
     only = [a[5:] for a in sys.argv[1:] if a.startswith("only=")]
     for name, fn in (("whole", section_whole_frame_paths), ("tiles", section_tile_mode), ("shards", section_shards), ("env", section_env_pipeline),
                      ("random", section_random_call_sequences), ("calls", section_runtime_calls_per_frame),
-                     ("leaks", section_leaks_and_failed_allocations), ("exchange", section_exchange)):
+                     ("args", section_argument_sweep), ("leaks", section_leaks_and_failed_allocations), ("exchange", section_exchange)):
         if not only or name in only:
             fn()
     c = counters()

@@ -550,7 +550,8 @@ def test_host_paths_against_the_hip_double(which):
     static and cost-aware deal, assembled == the frame; supersampling == a numpy box filter; the env pipeline's shapes and its cache
     files (written once, read the second time, a damaged one is an error); argument errors; 1700 random calls -- tiles in any order,
     whole frames, plane-writing calls, size / shader / environment changes -- against a model of what the boundary promises
-    (latching, accumulation, clearing); no device / page-locked allocation,
+    (latching, accumulation, clearing); every ctx entry point with null pointers, unusable paths and out-of-range scalars (errors, no
+    crash); no device / page-locked allocation,
     stream or event left after rmdf_destroy; an error -- never a crash, never a leak -- when the n-th allocation fails, for n = 1..59;
     and, with the cross-check library, the N-rank exchange (2, 3, 8 ranks as threads, the RCCL double) with equal and unequal deals.
     The SHIPPED librmdf.so's host code is what runs ("product"); tools/asan_host.sh runs the same under AddressSanitizer + UBSan and
@@ -577,7 +578,7 @@ def test_host_paths_against_the_hip_double(which):
     r = subprocess.run(args, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     oks = [l for l in r.stdout.splitlines() if l.startswith("ok ")]
-    assert len(oks) == (8 if which.startswith("xcheck") else 7) and r.stdout.strip().splitlines()[-1].startswith("done:"), r.stdout[-1500:]
+    assert len(oks) == (9 if which.startswith("xcheck") else 8) and r.stdout.strip().splitlines()[-1].startswith("done:"), r.stdout[-1500:]
     assert " 0 launches of kernels it has no stand-in for" in r.stdout
 
 
