@@ -34,6 +34,7 @@
 #include <thread>
 #include <unistd.h>
 #include <malloc.h>
+#include <sys/mman.h>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -549,14 +550,32 @@ hipError_t hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t sp
 }
 hipError_t hipMemset(void *p, int v, size_t n) { COUNT(); drain_all(); memset(p, v, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t s) { COUNT(); submit(s, [=] { memset(p, v, n); }); return hipSuccess; }
-// (the virtual-memory calls of the cross-check build's electric-fence allocator: not offered here -- the allocator's red zones do that job)
-hipError_t hipMemGetAllocationGranularity(size_t *, const hipMemAllocationProp *, hipMemAllocationGranularity_flags) { return hipErrorNotSupported; }
-hipError_t hipMemCreate(hipMemGenericAllocationHandle_t *, size_t, const hipMemAllocationProp *, unsigned long long) { return hipErrorNotSupported; }
-hipError_t hipMemRelease(hipMemGenericAllocationHandle_t) { return hipErrorNotSupported; }
-hipError_t hipMemAddressReserve(void **, size_t, size_t, void *, unsigned long long) { return hipErrorNotSupported; }
-hipError_t hipMemAddressFree(void *, size_t) { return hipErrorNotSupported; }
-hipError_t hipMemMap(void *, size_t, size_t, hipMemGenericAllocationHandle_t, unsigned long long) { return hipErrorNotSupported; }
-hipError_t hipMemUnmap(void *, size_t) { return hipErrorNotSupported; }
-hipError_t hipMemSetAccess(void *, size_t, const hipMemAccessDesc *, size_t) { return hipErrorNotSupported; }
+// The virtual-memory calls of the cross-check build's electric-fence allocator (rmdf_host.hpp: GuardAlloc): an address range is an
+// mmap(PROT_NONE), mapping a handle into it makes that part readable and writable, everything else stays a fence -- with 4 KiB pages where
+// the GPU has 2 MiB ones.  A stand-in "kernel" (or a host copy) that steps outside a guarded buffer dies of SIGSEGV here.
+struct VmHandle { size_t bytes; };
+hipError_t hipMemGetAllocationGranularity(size_t *g, const hipMemAllocationProp *, hipMemAllocationGranularity_flags) { *g = 4096; return hipSuccess; }
+hipError_t hipMemCreate(hipMemGenericAllocationHandle_t *h, size_t bytes, const hipMemAllocationProp *, unsigned long long)
+{
+    if (failing()) return hipErrorOutOfMemory;
+    *h = (hipMemGenericAllocationHandle_t) new VmHandle{ bytes };
+    return hipSuccess;
+}
+hipError_t hipMemRelease(hipMemGenericAllocationHandle_t h) { delete (VmHandle *)h; return hipSuccess; }
+hipError_t hipMemAddressReserve(void **p, size_t bytes, size_t, void *, unsigned long long)
+{
+    void *m = mmap(nullptr, bytes, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (m == MAP_FAILED) return hipErrorOutOfMemory;
+    *p = m;
+    return hipSuccess;
+}
+hipError_t hipMemAddressFree(void *p, size_t bytes) { return munmap(p, bytes) == 0 ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipMemMap(void *p, size_t bytes, size_t, hipMemGenericAllocationHandle_t h, unsigned long long)
+{
+    if (!h || ((VmHandle *)h)->bytes < bytes) return hipErrorInvalidValue;
+    return mprotect(p, bytes, PROT_READ | PROT_WRITE) == 0 ? hipSuccess : hipErrorInvalidValue;
+}
+hipError_t hipMemUnmap(void *p, size_t bytes) { drain_all(); return mprotect(p, bytes, PROT_NONE) == 0 && madvise(p, bytes, MADV_DONTNEED) == 0 ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipMemSetAccess(void *, size_t, const hipMemAccessDesc *, size_t) { return hipSuccess; }
 
 }  // extern "C"

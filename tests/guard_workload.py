@@ -16,10 +16,31 @@ import rmdf_amd                                             # noqa: E402
 
 def main():
     assert os.environ.get("RMDF_GUARD_ALLOC") in ("end", "start")
+    # On the CPU tier the same workload runs against the HIP test double (tests/fake_hip.cpp, LD_PRELOAD): its virtual-memory calls are
+    # mmap / mprotect, so the fence is real there too -- it then checks the HOST's buffer sizes against what the kernels' stand-ins write
+    # and read, and the allocator's own bookkeeping (tests/test_host_logic.py: test_guarded_allocations_against_the_hip_double).
+    double = "libfake_hip" in os.environ.get("LD_PRELOAD", "")
+    import ctypes as C
+    import shutil
+    import tempfile
+    tmpdir = tempfile.mkdtemp() if double else None
+    hdr = rmdf_amd.DEFAULT_ENV_HDR
+    if double:                                               # (the double's prefilter is a stand-in: its cache files must not land in the tree)
+        hdr = os.path.join(tmpdir, "probe.hdr")
+        shutil.copy(rmdf_amd.DEFAULT_ENV_HDR, hdr)
     rng = np.random.RandomState(7)
     sr = rmdf_amd.ShaderRenderer(0, xcheck=True)
+    L = rmdf_amd.load_library(True)
+    held = []
+
+    def dmalloc(nbytes):
+        """device memory from the library's own allocator (rmdf_device_malloc -> dev_malloc: fenced like everything else)"""
+        p = C.c_void_p()
+        assert L.rmdf_device_malloc(sr.handle, nbytes, C.byref(p)) == 0
+        held.append(p)
+        return p.value
     # the whole env pipeline: decode, resize (k_resize_latlong), the fused four-power prefilter, RGBE caches, k_latlong_to_cube, k_cube_upload
-    sr.load_env_hdr(rmdf_amd.DEFAULT_ENV_HDR)
+    sr.load_env_hdr(hdr)
     # prefilter kernels: the channel-split form, the one-wave form (odd width, wide map reading its table through L2), other powers
     for (w, h) in ((256, 128), (100, 37), (252, 5), (8, 3), (260, 20), (1100, 6)):
         src = rng.uniform(0.0, 4.0, (h, w, 3)).astype(np.float32)
@@ -57,31 +78,34 @@ def main():
     sr.draw_shader_tile(2, None, 640, 360, 0.0, big[1024:1024 + 640 * 360], max_steps=32)
     sr.unregister_host_buffer(big)
     # the alternative schedule of the cross-check build (its G-buffer and work counter)
-    alt = rmdf_amd.ShaderRenderer(0, flags=rmdf_amd.FLAG_FLAT_MARCH)
-    alt.load_env_hdr(rmdf_amd.DEFAULT_ENV_HDR)
+    alt = rmdf_amd.ShaderRenderer(0, flags=rmdf_amd.FLAG_FLAT_MARCH, xcheck=True)
+    alt.load_env_hdr(hdr)
     for (w, h) in ((333, 187), (33, 17)):
         alt.render(2, w, h, 0.4, max_steps=64)
     alt.close()
     # shards, the assembly, the resolve, the supersampled frame, the cost probe, frames on caller streams
-    import torch
-    dev = torch.device("cuda", 0)
     w, h = 640, 360
     for n in (1, 3, 8):
         slots = rmdf_amd.shard_slots(n)
-        gath = torch.zeros((n, slots, h // 8, w // 8), dtype=torch.int32, device=dev)
-        frame = torch.zeros((h, w), dtype=torch.int32, device=dev)
+        tile = (h // 8) * (w // 8) * 4
+        gath = dmalloc(n * slots * tile)
+        frame = dmalloc(w * h * 4)
         for r in range(n):
-            sr.render_shard_device(2, w, h, 0.0, 48, r, n, gath[r].data_ptr())
-        sr.assemble_shards_device(w, h, n, gath.data_ptr(), frame.data_ptr())
+            sr.render_shard_device(2, w, h, 0.0, 48, r, n, gath + r * slots * tile)
+        sr.assemble_shards_device(w, h, n, gath, frame)
         sr.synchronize()
     sr.render_supersampled(2, 160, 90, 2, 0.0, max_steps=32)
     sr.probe_tile_costs(2, 1920, 1080, 0.0, 64)
-    rect = torch.zeros((187, 333), dtype=torch.int32, device=dev)
-    sr.render_rect_device(0, 333, 187, 0.0, 32, (5, 3, 301, 180), d_rgba8=rect.data_ptr())
+    rect = dmalloc(187 * 333 * 4)
+    sr.render_rect_device(0, 333, 187, 0.0, 32, (5, 3, 301, 180), d_rgba8=rect)
     sr.synchronize()
     # the self-tests' kernels (their own cube map, the Cornell table)
     assert sum(sr.selftest_shading_math()) == 0
+    for p in held:
+        assert L.rmdf_device_free(sr.handle, p) == 0
     sr.close()
+    if tmpdir:
+        shutil.rmtree(tmpdir, ignore_errors=True)
     print("guard workload ok")
 
 

@@ -598,6 +598,41 @@ def test_the_hip_double_notices_a_host_that_does_not_wait():
     assert bad.returncode != 0 and "AssertionError" in bad.stderr, (bad.stdout[-800:], bad.stderr[-2000:])
 
 
+@pytest.mark.parametrize("mode", ["end", "start"])
+def test_guarded_allocations_against_the_hip_double(mode):
+    """The cross-check build's electric-fence device allocator (rmdf_host.hpp: GuardAlloc, RMDF_GUARD_ALLOC=end|start; written in round 5
+    and not yet run on hardware) on the HIP double, whose virtual-memory calls are mmap / mprotect: every device allocation of the library
+    ends (or starts) at an inaccessible page.  tests/guard_workload.py -- every kernel of the library at sizes that round to nothing
+    convenient -- then checks the HOST's buffer sizes against what the kernels' stand-ins read and write (one element outside is
+    SIGSEGV), and the allocator's own bookkeeping over hundreds of allocations and frees."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, LD_PRELOAD=_fake_hip_lib(), RMDF_GUARD_ALLOC=mode)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "guard_workload.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "guard workload ok" in r.stdout, (r.returncode, r.stdout[-800:], r.stderr[-3000:])
+
+
+def test_the_fence_of_the_hip_double_does_catch_an_overrun():
+    """... and the fence is real: the library's resolve kernel (its exact stand-in), told that the source frame is two rows taller than
+    the guarded buffer it is given, kills the child; with the true height it survives."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import os, sys; sys.path.insert(0, %r); import rmdf_amd, ctypes as C\n"
+            "sr = rmdf_amd.ShaderRenderer(0, xcheck=True)\n"
+            "L = rmdf_amd.load_library(True); p = C.c_void_p(); q = C.c_void_p()\n"
+            "assert L.rmdf_device_malloc(sr.handle, 256 * 64 * 4, C.byref(p)) == 0 and L.rmdf_device_malloc(sr.handle, 128 * 33 * 4, C.byref(q)) == 0\n"
+            "sr.resolve_box2_device(p.value, 256, 64, q.value); sr.synchronize(); print('before', flush=True)\n"
+            "sr.resolve_box2_device(p.value, 256, int(sys.argv[1]), q.value)\n"
+            "sr.synchronize(); print('survived', flush=True)\n" % ROOT)
+    env = dict(os.environ, LD_PRELOAD=_fake_hip_lib(), RMDF_GUARD_ALLOC="end")
+    ok = subprocess.run([sys.executable, "-c", code, "64"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0 and "survived" in ok.stdout, (ok.returncode, ok.stdout, ok.stderr[-1500:])
+    r = subprocess.run([sys.executable, "-c", code, "66"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert "before" in r.stdout and "survived" not in r.stdout and r.returncode < 0, (r.returncode, r.stdout, r.stderr[-1500:])
+
+
 def test_the_library_without_a_device_still_fails_loudly():
     """... and without the double nothing has changed: on a box without a GPU rmdf_create fails with RMDF_E_NO_DEVICE and a message --
     there is no CPU rendering path, and the HIP double is not something the library can find by itself."""
