@@ -129,6 +129,9 @@ def test_product_never_touches_the_oracle(rmdf):
             if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", ".hs", ".c")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in text and "rmdf_oracle" not in text and "from oracle" not in text, f
+                # ... nor know of the test doubles: the HIP double reaches a process by LD_PRELOAD only, the RCCL double by RMDF_RCCL_LIB
+                # (cross-check build only); nothing the product ships names either
+                assert "fake_hip" not in text and "libfake" not in text and "fake_rccl" not in text.replace("tests/fake_rccl.c", ""), f
     for lib_path in (rmdf.LIB_PATH, rmdf.XCHECK_LIB_PATH):
         deps = os.popen("ldd %s" % lib_path).read()
         assert "oracle" not in deps and "amdhip64" in deps
