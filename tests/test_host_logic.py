@@ -633,6 +633,21 @@ def test_the_fence_of_the_hip_double_does_catch_an_overrun():
     assert "before" in r.stdout and "survived" not in r.stdout and r.returncode < 0, (r.returncode, r.stdout, r.stderr[-1500:])
 
 
+def test_the_hip_double_covers_every_runtime_symbol_the_libraries_import():
+    """A HIP call the double does not define would fall through to the real runtime in the middle of a doubled process: every
+    `hip*` / `__hip*` symbol librmdf.so, librmdf_xcheck.so and the RCCL double import must be defined by tests/libfake_hip.so."""
+    import subprocess
+    import rmdf_amd
+    from conftest import ROOT
+    have = {l.split()[-1].split("@")[0] for l in subprocess.run(["nm", "-D", "--defined-only", _fake_hip_lib()], capture_output=True, text=True, check=True).stdout.splitlines() if l.strip()}
+    for lib in (rmdf_amd.LIB_PATH, rmdf_amd.XCHECK_LIB_PATH, os.path.join(ROOT, "tests", "libfake_rccl.so")):
+        if not os.path.exists(lib):
+            continue
+        need = {l.split()[-1].split("@")[0] for l in subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True, check=True).stdout.splitlines()
+                if l.strip() and l.split()[-1].startswith(("hip", "__hip"))}
+        assert need and not (need - have), (lib, sorted(need - have))
+
+
 def test_the_library_without_a_device_still_fails_loudly():
     """... and without the double nothing has changed: on a box without a GPU rmdf_create fails with RMDF_E_NO_DEVICE and a message --
     there is no CPU rendering path, and the HIP double is not something the library can find by itself."""
