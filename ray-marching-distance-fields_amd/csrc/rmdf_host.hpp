@@ -12,6 +12,9 @@
 //   download(): device -> staging -> caller (host threads), chunk by chunk, the copy of chunk i overlapping the DMA of chunk i + 1.
 #pragma once
 
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#endif
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
@@ -132,12 +135,46 @@ public:
     {
         if (bytes < ((size_t)1 << 20) || workers() == 0) { memcpy(dst, src, bytes); return; }
         const int parts = workers() + 1;
+        // RMDF_COPY_NT=1 (A/B knob, read once; written after GPU access closed in round 5, not yet measured): the slices with streaming
+        // stores -- a slice is below glibc's non-temporal threshold, so plain memcpy reads every destination line before overwriting it
+        static const bool stream = copy_stream_wanted();
         run(parts, [=](int part) {
             size_t lo, hi;
             slice(bytes, part, parts, 4096, lo, hi);
-            if (hi > lo) memcpy((char *)dst + lo, (const char *)src + lo, hi - lo);
+            if (hi <= lo) return;
+            if (stream) copy_stream((char *)dst + lo, (const char *)src + lo, hi - lo);
+            else memcpy((char *)dst + lo, (const char *)src + lo, hi - lo);
         });
     }
+    static bool copy_stream_wanted()
+    {
+        const char *v = getenv("RMDF_COPY_NT");
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+        return v && v[0] == '1' && __builtin_cpu_supports("avx2");
+#else
+        return (void)v, false;
+#endif
+    }
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    __attribute__((target("avx2"))) static void copy_stream(char *dst, const char *src, size_t n)
+    {
+        size_t head = (32 - ((uintptr_t)dst & 31)) & 31;               // streaming stores want 32-byte aligned destinations
+        if (head > n) head = n;
+        memcpy(dst, src, head);
+        dst += head; src += head; n -= head;
+        const size_t blocks = n / 128;
+        for (size_t i = 0; i < blocks; i++) {
+            const __m256i a = _mm256_loadu_si256((const __m256i *)(src + 128 * i)), b = _mm256_loadu_si256((const __m256i *)(src + 128 * i + 32));
+            const __m256i c = _mm256_loadu_si256((const __m256i *)(src + 128 * i + 64)), d = _mm256_loadu_si256((const __m256i *)(src + 128 * i + 96));
+            _mm256_stream_si256((__m256i *)(dst + 128 * i), a); _mm256_stream_si256((__m256i *)(dst + 128 * i + 32), b);
+            _mm256_stream_si256((__m256i *)(dst + 128 * i + 64), c); _mm256_stream_si256((__m256i *)(dst + 128 * i + 96), d);
+        }
+        memcpy(dst + 128 * blocks, src + 128 * blocks, n - 128 * blocks);
+        _mm_sfence();                                                   // the streamed lines are globally visible before the job counts as done
+    }
+#else
+    static void copy_stream(char *dst, const char *src, size_t n) { memcpy(dst, src, n); }
+#endif
     // fn(lo, hi) over [0, n) in row segments (forSegmentsConcurrently, ConcurrentSegments.hs:14-28)
     template <typename F>
     void segments(int n, F fn)

@@ -793,8 +793,9 @@ def test_worker_pool_of_the_ctx(tmp_path):
     for tag, flags in (("plain", ["-O2"]), ("tsan", ["-O1", "-g", "-fsanitize=thread"])):
         exe = str(tmp_path / ("host_pool_test_" + tag))
         subprocess.check_call(["g++", "-std=c++17", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + flags + [src, "-o", exe])
-        r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0 and "pool ok" in r.stdout and "ThreadSanitizer" not in r.stderr, (tag, r.stdout[-500:], r.stderr[-2000:])
+        for nt in ("0", "1"):                                 # RMDF_COPY_NT=1: copy()'s slices with streaming stores (A/B knob of round 5)
+            r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, RMDF_COPY_NT=nt))
+            assert r.returncode == 0 and "pool ok" in r.stdout and "ThreadSanitizer" not in r.stderr, (tag, nt, r.stdout[-500:], r.stderr[-2000:])
 
 
 def _fake_rccl_rank(so, uid_hex, rank, n, q):

@@ -16,6 +16,7 @@ for l in default tools/abtest/noxl.so tools/abtest/xl4.so tools/abtest/sharedb.s
 step "4. whole-frame host call: every band count and hand-over mode; the 16-byte mirror stores"
 timeout 500 python tools/whole_frame_sweep.py 40 > $o/wf_sweep.txt 2>&1; cat $o/wf_sweep.txt
 RMDF_LIB=$PWD/tools/abtest/mirror16.so timeout 500 python tools/whole_frame_sweep.py 40 > $o/wf_sweep_mirror16.txt 2>&1; cat $o/wf_sweep_mirror16.txt
+RMDF_COPY_NT=1 timeout 500 python tools/whole_frame_sweep.py 40 > $o/wf_sweep_copy_nt.txt 2>&1; cat $o/wf_sweep_copy_nt.txt
 step "5. the tests that have never run (electric fence incl. ONE deliberate fault, 8-rank bench against the RCCL double, one-launch bands)"
 RMDF_TEST_UNVERIFIED=1 timeout 1200 python -m pytest tests -m gpu -q -k "guard or eight_ranks or whole_frame_host_call or ring_form" > $o/unverified.txt 2>&1; tail -15 $o/unverified.txt
 [ "${1:-}" = quick ] && exit 0
