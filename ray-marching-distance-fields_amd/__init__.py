@@ -30,7 +30,9 @@ LIB_PATH = os.path.join(_HERE, "librmdf.so")
 XCHECK_LIB_PATH = os.path.join(_HERE, "librmdf_xcheck.so")     # cross-check build: product sources + alternative schedules
 CSRC = os.path.join(_HERE, "csrc")
 DATA_DIR = os.path.join(_HERE, "data")
-DEFAULT_ENV_HDR = os.path.join(DATA_DIR, "latlong_envmaps", "uffizi_512.hdr")
+# (RMDF_ENV_HDR: another light probe -- or, for the CPU tier's runs against the HIP test double, a private copy of the shipped one, so that
+# the stand-in cache files of those runs never sit next to it)
+DEFAULT_ENV_HDR = os.environ.get("RMDF_ENV_HDR") or os.path.join(DATA_DIR, "latlong_envmaps", "uffizi_512.hdr")
 
 TILES_X, TILES_Y, N_TILES = 8, 8, 64          # ShaderRendering.hs:49-52
 ENV_REFLECTION, ENV_COS_1, ENV_COS_8, ENV_COS_64, ENV_COS_512 = range(5)
@@ -478,11 +480,17 @@ class ShaderRenderer:
         self._check(self._lib.rmdf_synchronize(self._ctx, stream or None))
 
 
+_SHIPPED_PROBE = object()
+
+
 @contextmanager
-def with_shader_renderer(refl_map_fn=DEFAULT_ENV_HDR, device=0):
+def with_shader_renderer(refl_map_fn=_SHIPPED_PROBE, device=0):
     """withShaderRenderer shdFn reflMapFn (ShaderRendering.hs:60-110) as a bracket.  There is no
-    shader file: the kernels are compiled ahead of time for gfx950.  refl_map_fn=None skips the
-    env-map load (set the cube maps yourself)."""
+    shader file: the kernels are compiled ahead of time for gfx950.  Default: the shipped light probe
+    (DEFAULT_ENV_HDR as it stands when the call is made); refl_map_fn=None skips the env-map load (set
+    the cube maps yourself)."""
+    if refl_map_fn is _SHIPPED_PROBE:
+        refl_map_fn = DEFAULT_ENV_HDR
     sr = ShaderRenderer(device)
     try:
         if refl_map_fn is not None:

@@ -139,6 +139,13 @@ def test_product_never_touches_the_oracle(rmdf):
     # (cache files the product built at a first load may sit next to it; they are git-ignored)
     tracked = os.popen("git -C %s ls-files %s" % (ROOT, os.path.join(rmdf.DATA_DIR, "latlong_envmaps"))).read().split()
     assert [os.path.basename(t) for t in tracked] == ["uffizi_512.hdr"], tracked
+    # ... and if cache files do sit there, they are what the real kernels build -- byte for byte the oracle's committed ones -- never the
+    # stand-in maps of a run against the HIP test double (those runs load a private copy of the probe: tests/conftest.py)
+    from conftest import ENV_CACHE
+    d = os.path.join(rmdf.DATA_DIR, "latlong_envmaps")
+    for f in os.listdir(d):
+        if "_cache_pow_" in f:
+            assert open(os.path.join(d, f), "rb").read() == open(os.path.join(ENV_CACHE, f), "rb").read(), f
 
 
 def _build_c_host(tmp_path, name="c_host"):

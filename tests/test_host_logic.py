@@ -648,6 +648,30 @@ def test_the_hip_double_covers_every_runtime_symbol_the_libraries_import():
         assert need and not (need - have), (lib, sorted(need - have))
 
 
+def test_gpu_tier_tests_that_need_no_oracle_run_against_the_hip_double():
+    """Seventeen tests of the GPU tier compare the library with ITSELF -- tiles with the full frame, band hand-overs with the plane-writing
+    launch, tiles issued ahead with what was asked for, a swapped environment, a registered buffer, the error convention, 3000 random boundary calls
+    against tools/tile_mode_fuzz.py's model -- and so hold against the HIP double as well.  Running them here, on the CPU tier, checks the HOST paths they cover AND the
+    tests' own code before it meets a GPU (including the band-test parameters for the one-launch hand-over, which have not run on
+    hardware).  The shipped light probe is loaded from a private copy (tests/conftest.py), no stand-in cache file reaches the tree."""
+    import subprocess
+    import sys
+    import rmdf_amd
+    from conftest import ROOT
+    names = ("test_tiled_frame_equals_full_frame or test_tile_jobs_issued_ahead_never_show or test_tile_jobs_issued_ahead_belong_to_one_environment "
+             "or test_whole_frame_host_call_in_row_bands or test_tile_mode_copy_thread_counts or test_tile_mode_fuzz or test_determinism "
+             "or test_error_convention or test_fresh_frame_is_cleared_to_opaque_black or test_registered_host_buffer")
+    env = dict(os.environ, LD_PRELOAD=_fake_hip_lib(), RMDF_TEST_UNVERIFIED="1")
+    env.pop("RMDF_LIB", None)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k", names],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    tail = r.stdout.strip().splitlines()[-1]
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, (r.stdout[-3000:], r.stderr[-1000:])
+    assert int(tail.split(" passed")[0].split()[-1]) >= 18, tail
+    data = os.path.dirname(rmdf_amd.DEFAULT_ENV_HDR)
+    assert not [f for f in os.listdir(data) if "_cache_pow_" in f], "stand-in cache files next to the shipped light probe"
+
+
 def test_the_library_without_a_device_still_fails_loudly():
     """... and without the double nothing has changed: on a box without a GPU rmdf_create fails with RMDF_E_NO_DEVICE and a message --
     there is no CPU rendering path, and the HIP double is not something the library can find by itself."""
