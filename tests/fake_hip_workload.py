@@ -163,6 +163,37 @@ def section_shards():
                 assert (frame[:32] == CANARY).all() and (frame[32 + w * h:] == CANARY).all()
         sr.set_shard_costs(None)
         sr.set_shard_root_handicap(0.0)
+    # frames in flight on CALLER streams (bench.py's schedule; the strip-order tables are per stream, the least recently used set is
+    # recycled beyond 32 streams): rectangles and shards on 5, then 40 streams, interleaved, every result == the frame
+    FAKE.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    FAKE.hipStreamDestroy.argtypes = [C.c_void_p]
+    FAKE.hipStreamSynchronize.argtypes = [C.c_void_p]
+    w, h, ms = 640, 360, 16
+    full = {t: whole(sr, 2, w, h, t, ms) for t in (0.0, 1.0, 2.5)}
+    for nstreams in (5, 40):
+        streams = []
+        for _ in range(nstreams):
+            st = C.c_void_p()
+            assert FAKE.hipStreamCreateWithFlags(C.byref(st), 1) == 0
+            streams.append(st)
+        n = 8
+        slots = rmdf.shard_slots(n)
+        bufs = [np.zeros((h, w), np.uint32) for _ in streams]
+        shards = [np.zeros((slots, h // 8, w // 8), np.uint32) for _ in streams]
+        for rep in range(3):                                   # (from the second round on: cost-ordered dispatch from each stream's own table)
+            for k, st in enumerate(streams):
+                t = (0.0, 1.0, 2.5)[k % 3]
+                sr.render_rect_device(2, w, h, t, ms, (0, 0, w, h), d_rgba8=bufs[k].ctypes.data, stream=st.value)
+                sr.render_shard_device(2, w, h, t, ms, k % n, n, shards[k].ctypes.data, stream=st.value)
+            for k, st in enumerate(streams):
+                assert FAKE.hipStreamSynchronize(st) == 0
+                t = (0.0, 1.0, 2.5)[k % 3]
+                assert np.array_equal(bufs[k], full[t]), (nstreams, rep, k)
+                for slot, idx in enumerate(sr.shard_tiles(k % n, n)):
+                    x0, y0, x1, y1 = rmdf.tile_rect(idx, w, h)
+                    assert np.array_equal(shards[k][slot], full[t][y0:y1, x0:x1]), (nstreams, rep, k, slot)
+        for st in streams:
+            assert FAKE.hipStreamDestroy(st) == 0
     # supersampling: 2x2 rays per pixel, one mip level
     for (w, h) in ((320, 180), (64, 40)):
         got = sr.render_supersampled(2, w, h, 1, 0.0, max_steps=16)
@@ -170,7 +201,7 @@ def section_shards():
         want = ((hi[0::2, 0::2] + hi[0::2, 1::2] + hi[1::2, 0::2] + hi[1::2, 1::2] + 2) >> 2).astype(np.uint8).view(np.uint32).reshape(h, w)
         assert np.array_equal(got, want), (w, h)
     sr.close()
-    print("ok shards (static and cost-aware deal; 1, 2, 3, 8, 64 ranks), supersampling", flush=True)
+    print("ok shards (static and cost-aware deal; 1, 2, 3, 8, 64 ranks), frames in flight on 5 and 40 caller streams, supersampling", flush=True)
 
 
 def section_env_pipeline():
