@@ -24,6 +24,13 @@ for async in 0 1; do
     FAKE_HIP_ASYNC=$async FAKE_HIP_JITTER_US=30 FAKE_HIP_WORKLOAD_WATCHDOG_S=1500 \
     RMDF_RCCL_LIB="$tmp/libfake_rccl.so" FAKE_RCCL_TIMEOUT_S=120 python3 "$here/../tests/fake_hip_workload.py" xcheck
 done
+# the PRODUCT flavour of the sources (no -DRMDF_XCHECK: what librmdf.so is built from) under the same sanitizers, asynchronous double
+echo "# AddressSanitizer + UBSan, product flavour (no RMDF_XCHECK), HIP double with FAKE_HIP_ASYNC=1"
+/opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-unused-function -I. \
+  -fsanitize=address,undefined -fno-sanitize=vptr -fno-gpu-sanitize -shared -x hip rmdf_api.cpp rmdf_render.hip rmdf_env.hip rmdf_util.hip \
+  -o "$tmp/librmdf_product_asan.so" -lz -ldl
+LD_PRELOAD="$rt $tmp/libfake_hip.so" ASAN_OPTIONS=detect_leaks=0 RMDF_LIB="$tmp/librmdf_product_asan.so" FAKE_HIP_LIB="$tmp/libfake_hip.so" \
+  FAKE_HIP_ASYNC=1 FAKE_HIP_JITTER_US=30 FAKE_HIP_WORKLOAD_WATCHDOG_S=1500 python3 "$here/../tests/fake_hip_workload.py"
 # ThreadSanitizer: the same host code and the double in its asynchronous mode (streams are threads: a buffer touched by the host and by a
 # queued operation without an event, a stream synchronisation or a flag between them is a reported race)
 echo "# ThreadSanitizer, HIP double with FAKE_HIP_ASYNC=1"
