@@ -780,6 +780,37 @@ def test_dpp_products_of_the_prefilter_have_no_read_after_write_hazard(tmp_path)
     assert n_dpp > 1000                                      # both kernels are there, fully unrolled
 
 
+def test_bench_secondary_rooflines_from_the_committed_counters():
+    """bench.py's roofline objects of the other three FragmentShader values (round 5; they have not run on hardware): the as-written
+    operation formulas applied to the oracle counters committed with the full-size digests, the object's keys, the fraction against
+    78.6 T lane-ops/s, the issue fraction against the 2-cycle spec peak -- with a made-up kernel time, no GPU."""
+    import json
+    import bench
+    from conftest import GOLD
+    d = json.load(open(os.path.join(GOLD, "full_size_digests.json")))
+    for name, scene in (("config2_cornell_1280x720_m128", 0), ("detest_1280x720_t2p5_m128", 1), ("mbgeneral_1280x720_t3p0_m128", 3),
+                        ("config3_mandelbulb8_1920x1080_m256", 2)):
+        c = d[name]["counters"]
+        F = bench.secondary_ops(scene, c)
+        if scene == 0:
+            assert F == 76 * c["tri_inside"] + 161 * (32 * c["de_evals"] - c["tri_inside"]) + 32 * c["de_evals"] + 9 * c["march_steps"] + 170 * c["hit_pixels"] + 30 * c["pixels"]
+            assert 0 < c["tri_inside"] < 32 * c["de_evals"]
+        elif scene == 1:
+            assert F == 126 * c["de_evals"] + 9 * c["march_steps"] + 150 * c["hit_pixels"] + 30 * c["pixels"]
+        elif scene == 3:
+            assert F == 37 * c["triplex_iters"] + 11 * c["de_evals"] + 9 * c["march_steps"] + 150 * c["hit_pixels"] + 30 * c["pixels"]
+        else:
+            assert F == bench.flops_model(c)
+        r = bench.secondary_roofline(name, scene, 0.5, 2.0e8, 256)
+        assert r["bound"] == "valu" and r["unit"] == "T lane-ops/s" and r["peak"] == bench.VALU_PEAK_TLANEOPS and r["traffic"] is None
+        assert r["ops_per_launch"] == F and abs(r["achieved"] - F / 0.5e-3 / 1e12) < 1e-3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+        assert abs(r["issue_g_wave_instr_s_simd"] - 2.0e8 / 1024 / 0.5e-3 / 1e9) < 1e-3
+        assert abs(r["issue_frac_of_spec_peak"] - r["issue_g_wave_instr_s_simd"] / bench.VALU_ISSUE_SPEC) < 2e-3
+        assert r["formula"] == bench.SECONDARY_FORMULA[scene] and json.dumps(r)
+        assert "issue_g_wave_instr_s_simd" not in bench.secondary_roofline(name, scene, 0.5, None, 256)
+    assert bench.secondary_roofline("no such digest", 1, 0.5, None, 256)["frac"] is None
+
+
 def test_bench_self_launcher_without_a_gpu():
     """`python bench.py --gpus N` with no launcher around it becomes the launcher itself (bench.py: self_launch) before anything touches
     the GPU.  On a box that shows fewer than N GPUs (this container shows none) it must say so and exit 2 at once -- no rendezvous, no
