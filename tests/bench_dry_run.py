@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Dry run of bench.py's control flow without a GPU (tests/test_host_logic.py: test_bench_dry_run_against_the_hip_double): the HIP runtime is
+the test double (tests/fake_hip.cpp, LD_PRELOAD, synchronous mode), and the handful of torch.cuda entry points bench.py uses are replaced
+here by stand-ins over it -- "device" tensors are CPU tensors (the double's device memory IS host memory), streams are the double's
+streams, events read the wall clock.  Every number the line then carries is meaningless; what is checked is that the line gets built:
+argument handling, the timed-region bookkeeping, the host-call leg, the secondary workloads and their roofline objects, the JSON.
+usage: bench_dry_run.py <bench.py arguments>"""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+assert "libfake_hip" in os.environ.get("LD_PRELOAD", ""), "run with LD_PRELOAD=tests/libfake_hip.so"
+import torch                                                 # noqa: E402
+
+FAKE = C.CDLL(os.environ.get("FAKE_HIP_LIB", os.path.join(ROOT, "tests", "libfake_hip.so")))
+FAKE.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+FAKE.hipStreamSynchronize.argtypes = [C.c_void_p]
+
+
+class Stream:
+    def __init__(self, device=None, priority=0):
+        h = C.c_void_p()
+        assert FAKE.hipStreamCreateWithFlags(C.byref(h), 1) == 0
+        self.cuda_stream = h.value
+
+    def synchronize(self):
+        FAKE.hipStreamSynchronize(self.cuda_stream)
+
+    def wait_stream(self, other): pass
+    def wait_event(self, ev): pass
+    def query(self): return True
+
+
+class Event:
+    def __init__(self, enable_timing=False): self.t = None
+    def record(self, stream=None): self.t = time.perf_counter()
+    def synchronize(self): pass
+    def query(self): return True
+    def elapsed_time(self, other): return max((other.t - self.t) * 1e3, 1e-3)
+
+
+class _StreamCtx:
+    def __init__(self, s): pass
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+
+
+def _cpu(fn):
+    def f(*a, **k):
+        if k.get("device") is not None and str(k["device"]).startswith("cuda"):
+            k["device"] = "cpu"
+        return fn(*a, **k)
+    return f
+
+
+torch.cuda.is_available = lambda: True
+torch.cuda.device_count = lambda: 1
+torch.cuda.set_device = lambda d: None
+torch.cuda.synchronize = lambda d=None: FAKE.hipDeviceSynchronize()
+torch.cuda.Stream = Stream
+torch.cuda.Event = Event
+torch.cuda.stream = _StreamCtx
+torch.cuda.set_stream = lambda s: None
+for name in ("empty", "zeros", "tensor", "ones", "full"):
+    setattr(torch, name, _cpu(getattr(torch, name)))
+_real_to = torch.Tensor.to
+torch.Tensor.to = lambda self, *a, **k: self if (a and str(a[0]).startswith("cuda")) or str(k.get("device", "")).startswith("cuda") else _real_to(self, *a, **k)
+torch.Tensor.cuda = lambda self, *a, **k: self
+
+sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[1:]
+import bench                                                 # noqa: E402
+
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # N > 1: bench.py refuses to time frames that differ from the committed digest of the headline frame.  Under the double the pixels
+    # are the double's, so the digest it is given is that of the double's own single-launch frame: the check keeps its meaning
+    # (exchanged and assembled == rendered in one piece).
+    import hashlib
+    import json
+    import numpy as np
+    import rmdf_amd
+    opt = lambda name, default: type(default)(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else default
+    w, h, ms, t, scene = opt("--width", 1920), opt("--height", 1080), opt("--max-steps", 256), opt("--time", 0.0), opt("--scene", 2)
+    with rmdf_amd.with_shader_renderer() as sr:
+        fb = np.zeros(w * h, np.uint32)
+        sr.draw_shader_tile(scene, None, w, h, t, fb, max_steps=ms)
+    sha = hashlib.sha256(fb.tobytes()).hexdigest()
+    _load = json.load
+
+    def load(f, *a, **k):
+        d = _load(f, *a, **k)
+        if str(getattr(f, "name", "")).endswith("full_size_digests.json"):
+            d["config3_mandelbulb8_1920x1080_m256"]["sha256"]["rgba8"] = sha
+        return d
+    json.load = load
+bench.main()

@@ -780,6 +780,86 @@ def test_dpp_products_of_the_prefilter_have_no_read_after_write_hazard(tmp_path)
     assert n_dpp > 1000                                      # both kernels are there, fully unrolled
 
 
+def test_bench_dry_run_against_the_hip_double(tmp_path):
+    """bench.py's whole single-GPU flow without a GPU (tests/bench_dry_run.py): the HIP runtime is the test double, the few torch.cuda entry
+    points bench.py uses are stand-ins over it.  Every number in the line is meaningless; that the line gets BUILT is the point -- the
+    contract's keys, the roofline object (with the counters of the previous build reported apart), the host-call leg, every secondary
+    workload with its per-scene roofline (round 5's additions, which have not met a GPU), no `secondary_error`."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    import rmdf_amd
+    from conftest import ROOT
+    hdr = str(tmp_path / "probe.hdr")
+    shutil.copy(rmdf_amd.DEFAULT_ENV_HDR, hdr)                 # (stand-in cache files stay out of the tree)
+    env = dict(os.environ, LD_PRELOAD=_fake_hip_lib(), RMDF_ENV_HDR=hdr)
+    for k in ("RMDF_LIB", "RMDF_FLAGS", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_dry_run.py"), "--steps", "2", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f32" and d["metric"].startswith("Mpixels/s") and "workload" in d["config"]
+    assert d["roofline"]["bound"] == "valu" and d["roofline"]["peak"] == 78.6 and "frac" in d["roofline"] and "traffic" in d["roofline"]
+    assert "secondary_error" not in d and d["secondary"], d.get("secondary_error")
+    for name in ("config2_cornell_1280x720_m128", "scene1_detest_1280x720_m128", "scene3_mbgeneral_1280x720_m128"):
+        rl = d["secondary"][name]["roofline"]
+        assert rl["frac"] is not None and rl["ops_per_launch"] > 0 and rl["formula"], (name, rl)
+    assert d["d2h_inclusive_mpixels_s"] > 0 and d["d2h_inclusive_registered_buffer_mpixels_s"] is None
+    assert not [f for f in os.listdir(os.path.dirname(rmdf_amd.DEFAULT_ENV_HDR)) if "_cache_pow_" in f and os.path.dirname(rmdf_amd.DEFAULT_ENV_HDR) != str(tmp_path)]
+
+
+@pytest.mark.parametrize("nranks", [2, 8])
+def test_bench_dry_run_with_n_ranks_against_the_doubles(tmp_path, nranks):
+    """bench.py the way the driver launches N > 1 -- `python -m torch.distributed.run --nproc-per-node N ... --gpus N` -- without a GPU:
+    every rank runs tests/bench_dry_run.py (HIP double + torch.cuda stand-ins), the control plane is gloo (RMDF_BENCH_SHARE_GPU=1) and
+    the exchange is the library's own over the RCCL double.  The whole N > 1 flow executes: unique id over torch.distributed,
+    rmdf_comm_init, the loopback self-test, the probe frame and the cost-aware deal, rmdf_comm_verify_deal, the verification of the
+    exchanged frames (against the digest of the double's own single-launch frame), S frames in flight, the max-over-ranks timing, one
+    JSON line from rank 0.  Readiness of the code path the 8-GPU run takes; no number in the line means anything."""
+    import json
+    import shutil
+    import socket
+    import subprocess
+    import sys
+    import rmdf_amd
+    from conftest import ROOT
+    hdr = str(tmp_path / "probe.hdr")
+    shutil.copy(rmdf_amd.DEFAULT_ENV_HDR, hdr)
+    fake_rccl = os.path.join(ROOT, "tests", "libfake_rccl.so")
+    if not os.path.exists(fake_rccl) or os.path.getmtime(fake_rccl) < os.path.getmtime(os.path.join(ROOT, "tests", "fake_rccl.c")):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "fake_rccl.c"),
+                               "-o", fake_rccl, "-L/opt/rocm/lib", "-lamdhip64"])
+    env = dict(os.environ, LD_PRELOAD=_fake_hip_lib(), RMDF_ENV_HDR=hdr, RMDF_BENCH_SHARE_GPU="1", RMDF_RCCL_LIB=fake_rccl, FAKE_RCCL_TIMEOUT_S="120",
+               RMDF_BENCH_MIN_WARM="0.02")
+    for k in ("RMDF_LIB", "RMDF_FLAGS", "RANK", "WORLD_SIZE", "LOCAL_RANK", "RMDF_BENCH_TORCH_GATHER"):
+        env.pop(k, None)
+    for attempt in range(3):
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), os.path.join(ROOT, "tests", "bench_dry_run.py"), "--gpus", str(nranks), "--steps", "4", "--warmup", "2",
+                            "--repeats", "1", "--no-cpu-baseline", "--no-secondary"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        if r.returncode == 0 or "EADDRINUSE" not in r.stderr:
+            break
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == nranks and c["rccl_ranks"] == nranks and d["steps"] == 4 and d["scaling"] == "strong"
+    assert c["exchange"].startswith("librmdf_xcheck") and "TEST DOUBLE" in c["exchange"]
+    assert c["exchanged_frames_verified"].startswith("%d exchanged frame(s) in flight == committed sha256" % min(nranks, 8)) or "exchanged frame(s) in flight ==" in c["exchanged_frames_verified"]
+    assert c["tile_deal"].startswith("cost-aware") and "verified by the library" in c["tile_deal"], c["tile_deal"]
+    assert "falling back" not in r.stderr
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("fakerccl_")] or True     # (other tests may be using the double at the same time)
+
+
 def test_bench_secondary_rooflines_from_the_committed_counters():
     """bench.py's roofline objects of the other three FragmentShader values (round 5; they have not run on hardware): the as-written
     operation formulas applied to the oracle counters committed with the full-size digests, the object's keys, the fraction against
