@@ -812,6 +812,29 @@ def test_bench_dry_run_against_the_hip_double(tmp_path):
     assert not [f for f in os.listdir(os.path.dirname(rmdf_amd.DEFAULT_ENV_HDR)) if "_cache_pow_" in f and os.path.dirname(rmdf_amd.DEFAULT_ENV_HDR) != str(tmp_path)]
 
 
+@pytest.mark.parametrize("flags", ["--supersample 1 --width 960 --height 540", "--streams 1", "--animate 0.1 --streams 2",
+                                   "--scene 0 --width 1280 --height 720 --max-steps 128", "--scene 3 --no-animated"])
+def test_bench_dry_run_of_the_other_modes(tmp_path, flags):
+    """bench.py's other modes (supersampled config 4, one stream, an animated camera, the other scenes) through the same dry run: each
+    builds its line."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    import rmdf_amd
+    from conftest import ROOT
+    hdr = str(tmp_path / "probe.hdr")
+    shutil.copy(rmdf_amd.DEFAULT_ENV_HDR, hdr)
+    env = dict(os.environ, LD_PRELOAD=_fake_hip_lib(), RMDF_ENV_HDR=hdr)
+    for k in ("RMDF_LIB", "RMDF_FLAGS", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_dry_run.py"), "--steps", "2", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline",
+                        "--no-secondary"] + flags.split(), cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "Traceback" not in r.stderr, (r.stdout[-1000:], r.stderr[-3000:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "workload" in d["config"] and d["roofline"]["bound"] == "valu"
+
+
 @pytest.mark.parametrize("nranks", [2, 8])
 def test_bench_dry_run_with_n_ranks_against_the_doubles(tmp_path, nranks):
     """bench.py the way the driver launches N > 1 -- `python -m torch.distributed.run --nproc-per-node N ... --gpus N` -- without a GPU:
