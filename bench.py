@@ -459,6 +459,7 @@ def main():
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 return int(flag.item()) == 1
             uid = torch.zeros(rmdf_amd.COMM_ID_BYTES, dtype=torch.uint8, device=cdev)
+            torch.cuda.synchronize()
             try:
                 # The exchange's own calls against this rank itself, BEFORE it joins the job's communicator: the ctx has none yet,
                 # so the library runs its grouped ncclRecv + ncclSend of one shard's size on a private one-rank communicator --

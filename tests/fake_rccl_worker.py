@@ -45,6 +45,7 @@ def main():
     gath = [torch.zeros((n, slots, h // 8, w // 8), **i32) if rank == 0 else None for _ in range(S)]
     shard = [gath[k][0] if rank == 0 else torch.zeros((slots, h // 8, w // 8), **i32) for k in range(S)]
     frame = [torch.zeros((h, w), **i32) if rank == 0 else None for _ in range(S)]
+    torch.cuda.synchronize(dev)     # the fills run on torch's stream; the library's non-blocking streams do not wait for them
     single = sr.render(2, w, h, 0.0, max_steps=ms, want_f32=False)["rgba8"] if rank == 0 else None
 
     def frames(times, tag, check=True):

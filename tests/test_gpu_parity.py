@@ -1073,6 +1073,7 @@ def test_exchange_behind_the_c_abi_world_size_one(sr, rmdf):
         st.synchronize()
         assert np.array_equal(frame.cpu().numpy().view(np.uint32), full)
         frame.zero_()
+        torch.cuda.synchronize()      # the fill runs on torch's stream, the render on `st`: nothing else orders the two
         r.render_frame_sharded_device(2, w, h, 0.0, ms, gathered[0].data_ptr(), gathered.data_ptr(), frame.data_ptr(), stream=st.cuda_stream)
         st.synchronize()
         assert np.array_equal(frame.cpu().numpy().view(np.uint32), full)              # rendered straight into its slot
