@@ -84,9 +84,8 @@ typedef struct {
                         (0 = chosen by core count: 16 on >= 64 cores, 8 on > 8); [2] = row bands a whole-frame call into host
                         memory keeps in flight (0 = the library's choice, 1 = one launch; at most 16); [3] = how those bands reach the host: 0 = the
                         library's choice; 1 = one launch per band, the kernel storing the rows into page-locked host memory itself;
-                        2 = ONE launch that does so and flags every completed band; 3 = the same with the strips dispatched band by
-                        band (2 and 3: written after GPU access closed in round 5 -- compiled, reviewed, NOT yet run on hardware);
-                        (0 with [2] given: one launch per band and a copy behind it); rest zero */
+                        (0 with [2] given: one launch per band and a copy behind it); 2, 3 = ONE launch that flags every completed
+                        band -- librmdf_xcheck.so only (never run on hardware): librmdf.so answers RMDF_E_UNSUPPORTED; rest zero */
 } rmdf_config;
 
 /* ---- lifetime: withShaderRenderer (ShaderRendering.hs:60-110) --------------------- */

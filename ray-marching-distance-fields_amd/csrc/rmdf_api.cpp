@@ -542,8 +542,13 @@ int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t str
             HIP_TRY(ctx, dev_malloc((void **)&os->d_order, (size_t)nblk * 4));
             os->cap = nblk;
         }
+#ifdef RMDF_XCHECK
+        const int band_rows = p.band_flag ? p.band_strip_rows : 0;         // (one-launch band hand-over: librmdf_xcheck.so only)
+#else
+        const int band_rows = 0;
+#endif
         const int key[12] = { scene, p.w, p.h, p.x0, p.y0, p.x1, p.y1, p.max_steps,
-                              p.n_shard_tiles, p.shard_key, p.band_flag ? p.band_strip_rows : 0, order_bands };
+                              p.n_shard_tiles, p.shard_key, band_rows, order_bands };
         const bool same = os->valid && os->n == nblk && memcmp(key, os->key, sizeof key) == 0;
         q.block_cost = os->d_cost;
         q.block_order = same ? os->d_order : nullptr;
@@ -552,7 +557,7 @@ int launch_scene(rmdf_ctx *ctx, int scene, const FrameParams &p, hipStream_t str
         if (order_bands > 0) {
             // (single-rectangle launches only: strip index = column + row * columns)
             const int gx = (((p.x1 + 1) & ~1) - (p.x0 & ~1) + 31) / 32;
-            HIP_TRY(ctx, launch_order_blocks(os->d_cost, nblk, os->d_order, stream, gx, p.band_strip_rows, order_bands));
+            HIP_TRY(ctx, launch_order_blocks(os->d_cost, nblk, os->d_order, stream, gx, band_rows, order_bands));
         } else {
             HIP_TRY(ctx, launch_order_blocks(os->d_cost, nblk, os->d_order, stream));
         }
@@ -916,7 +921,11 @@ int prefilter_powers_device(rmdf_ctx *ctx, const float *d_src, int w, int h, con
     int rc = get_lobe_tables(ctx, w, h, &d_lutT, &d_tcs);
     if (rc != RMDF_OK) return rc;
     // the reference's own job -- powers 1, 8, 64 and 512 of one map -- is one launch (rmdf_env.hip: k_prefilter_fused4)
-    static const bool no_fused = getenv("RMDF_PREFILTER_NO_FUSED") != nullptr;       // A/B switch (tools/)
+#ifdef RMDF_XCHECK
+    static const bool no_fused = getenv("RMDF_PREFILTER_NO_FUSED") != nullptr;       // A/B switch of the cross-check build (tools/)
+#else
+    constexpr bool no_fused = false;
+#endif
     // (two or three of the four too: 0.9 ms for the launch against 1.1 / 1.8 for two / three split launches; the other sums are computed
     // and dropped)
     if (n >= 2 && n <= 4 && w <= 256 && w % 4 == 0 && !no_fused) {
@@ -1123,6 +1132,8 @@ int render_tile_fast(rmdf_ctx *ctx, int scene, int tile_idx, const FrameParams &
     return RMDF_OK;
 }
 
+#ifdef RMDF_XCHECK
+// (librmdf_xcheck.so only: never run on hardware; librmdf.so's rmdf_create answers reserved[3] >= 2 with RMDF_E_UNSUPPORTED)
 // The same hand-over with ONE launch (rmdf_config.reserved[3] = 2, 3): the kernel stores the frame's rows into the page-locked shadow itself
 // (mirror stores) and, band by band, tells the host when all rows of a band have landed (FrameParams::band_flag); the host threads copy
 // each band to the caller while the launch is still running.  No per-band launches, copies or events: a band costs the host nothing
@@ -1187,6 +1198,7 @@ int render_whole_frame_one_launch(rmdf_ctx *ctx, int scene, const FrameParams &p
     ctx->shadow_valid = true;
     return RMDF_OK;
 }
+#endif
 
 // Whole frame into PAGEABLE caller memory: `rmdf_render_tile(tile_idx = -1, ptr)`, the call the reference's viewer makes every frame
 // (Main.hs:67 starts it with tiling off; App.hs:154-166 -> fillFrameBuffer, FrameBuffer.hs:117-158).  Launch, copy 8.3 MB, return
@@ -1210,7 +1222,9 @@ int render_whole_frame_host(rmdf_ctx *ctx, int scene, const FrameParams &p, uint
     if (npx * 4 < ((size_t)2 << 20)) nb = 1;                         // small frames: one launch, one copy
     if (nb > h / 64) nb = h / 64 > 0 ? h / 64 : 1;                   // a band is at least 64 rows
     const bool mirror = mode != 0;
+#ifdef RMDF_XCHECK
     if (mode >= 2) return render_whole_frame_one_launch(ctx, scene, p, out_rgba8, nb, mode);
+#endif
     int ys[RMDF_WF_MAX_BANDS + 1];
     for (int k = 0; k <= nb; k++) ys[k] = k == nb ? h : (int)(((long long)h * k / nb) & ~7ll);
     for (int k = 0; k < nb; k++) {
@@ -1425,6 +1439,13 @@ int rmdf_create(rmdf_ctx **out, const rmdf_config *cfg)
         rmdf_destroy(ctx);
         return fail(nullptr, RMDF_E_INVALID, "rmdf_config.reserved[2] (whole-frame row bands): 0 .. 16; reserved[3] (how the bands reach the host): 0 .. 3");
     }
+#ifndef RMDF_XCHECK
+    if (ctx->wf_mirror >= 2) {
+        // the one-launch hand-over (a host spin on flags the kernel writes) has not had a green run on hardware: not in the product
+        rmdf_destroy(ctx);
+        return fail(nullptr, RMDF_E_UNSUPPORTED, "rmdf_config.reserved[3] = 2, 3 (one-launch band hand-over) lives in librmdf_xcheck.so only");
+    }
+#endif
     for (int k = 0; k < 4; k++)
         if ((e = hipStreamCreateWithFlags(&ctx->pstream[k], hipStreamNonBlocking)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming)) != hipSuccess) {

@@ -715,6 +715,7 @@ __global__ __launch_bounds__(64 * (3 + CH_PROD), 6) void k_prefilter_chan(const 
     }
 }
 
+#ifdef RMDF_XCHECK        // librmdf_xcheck.so only, until it has had a green run on hardware
 // Round 5, fifth form (A/B only: RMDF_PREFILTER_RING=1; written after GPU access closed, NOT yet run on hardware).  k_prefilter_chan's
 // counters say no unit is busy -- LDS array 0.31, vector issue 0.34, scalar issue 0.37 of their peaks -- and its waves wait 53 % of their
 // cycles: producers and summing waves meet at one s_barrier per 64 source texels, 513 times per workgroup, and whoever arrives first waits.
@@ -908,6 +909,7 @@ static hipError_t launch_prefilter_ring_t(const float *d_src, int w, int h, cons
     hipLaunchKernelGGL((k_prefilter_ring<LOG2P>), dim3((w + 63) / 64, h), dim3(64 * (3 + RING_PROD)), lds, stream, d_src, w, h, d_lutT, d_tcs, d_out);
     return hipGetLastError();
 }
+#endif
 
 template <int LOG2P>
 static hipError_t launch_prefilter_chan_t(const float *d_src, int w, int h, const float *d_lutT, const float2 *d_tcs, float *d_out, hipStream_t stream)
@@ -945,10 +947,15 @@ template <int LOG2P>
 static hipError_t launch_prefilter_t(const float *d_src, int w, int h, float power, const float *d_lutT, const float2 *d_tcs,
                                      float *d_out, hipStream_t stream, bool split_ok)
 {
-    static const bool one_wave = getenv("RMDF_PREFILTER_ONE_WAVE") != nullptr;          // A/B switch (tools/, tests): the one-wave kernel at every size
-    static const bool ring = getenv("RMDF_PREFILTER_RING") != nullptr;                  // A/B switch: the barrier-free ring form (not yet run on hardware)
+#ifdef RMDF_XCHECK
+    // A/B switches of the cross-check build (tools/, tests; read once per process).  The product library reads no environment variable.
+    static const bool one_wave = getenv("RMDF_PREFILTER_ONE_WAVE") != nullptr;          // the one-wave kernel at every size
+    static const bool ring = getenv("RMDF_PREFILTER_RING") != nullptr;                  // the barrier-free ring form (not yet run on hardware)
     if (LOG2P >= 0 && ring && w >= RING_SLOTS * RING_CHUNK && w <= 256 && w % 4 == 0 && split_ok && !one_wave)
         return launch_prefilter_ring_t<(LOG2P >= 0 ? LOG2P : 0)>(d_src, w, h, d_lutT, d_tcs, d_out, stream);
+#else
+    constexpr bool one_wave = false;
+#endif
     if (LOG2P >= 0 && w <= 256 && w % 4 == 0 && split_ok && !one_wave)                  // the reference's size: factor and sum on different waves
         return launch_prefilter_chan_t<(LOG2P >= 0 ? LOG2P : 0)>(d_src, w, h, d_lutT, d_tcs, d_out, stream);
     const dim3 grid((w + 63) / 64, (h + PREFILTER_WAVES - 1) / PREFILTER_WAVES), block(64 * PREFILTER_WAVES);

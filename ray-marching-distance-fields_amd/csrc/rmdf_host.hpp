@@ -135,7 +135,7 @@ public:
     {
         if (bytes < ((size_t)1 << 20) || workers() == 0) { memcpy(dst, src, bytes); return; }
         const int parts = workers() + 1;
-        // RMDF_COPY_NT=1 (A/B knob, read once; written after GPU access closed in round 5, not yet measured): the slices with streaming
+        // RMDF_COPY_NT=1 (A/B knob of librmdf_xcheck.so, read once; written after GPU access closed in round 5, not yet measured): the slices with streaming
         // stores -- a slice is below glibc's non-temporal threshold, so plain memcpy reads every destination line before overwriting it
         static const bool stream = copy_stream_wanted();
         run(parts, [=](int part) {
@@ -148,11 +148,12 @@ public:
     }
     static bool copy_stream_wanted()
     {
+        // (the cross-check build and the pool's unit test only: unmeasured, so the product library neither reads the variable nor streams)
+#if (defined(RMDF_XCHECK) || defined(RMDF_HOST_POOL_TEST)) && defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
         const char *v = getenv("RMDF_COPY_NT");
-#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
         return v && v[0] == '1' && __builtin_cpu_supports("avx2");
 #else
-        return (void)v, false;
+        return false;
 #endif
     }
 #if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)

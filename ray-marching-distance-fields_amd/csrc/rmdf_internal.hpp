@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -43,7 +44,10 @@ struct FrameParams {
     int merge_stragglers;     // k_render: pool the last rays of a workgroup's four packets in one wave (MERGE variant)
     const unsigned *block_order;
     unsigned *block_cost;
-    // whole-frame calls into host memory (rmdf_api.cpp: render_whole_frame_host, OUT_MIRROR variant only): the frame's strip rows are
+#ifdef RMDF_XCHECK
+    // librmdf_xcheck.so only -- the one-launch band hand-over (rmdf_config.reserved[3] = 2, 3; never run on hardware, so not part of the
+    // product: the product's FrameParams, and with it every product kernel, stays what the GPU tier last ran).  Whole-frame calls into
+    // host memory (rmdf_api.cpp: render_whole_frame_one_launch, OUT_MIRROR variant only): the frame's strip rows are
     // grouped into bands of band_strip_rows rows of strips; the workgroup that completes a band (band_count: device counters, one per
     // band, left at zero) writes band_seq to band_flag[band] (host-mapped) once every mirror store of the band has landed in host
     // memory, and the host copies that band to the caller while the rest of the frame is still rendering.  null = no bands.
@@ -51,7 +55,6 @@ struct FrameParams {
     volatile unsigned *band_flag;
     unsigned band_seq;
     int band_strip_rows;
-#ifdef RMDF_XCHECK
     // librmdf_xcheck.so only: the alternative schedule (xcheck/rmdf_march.hip) and the measurement aids
     // G-buffer written by k_march_mb8, read by k_shade; indexed px + py*gw over the frame padded to even
     // dimensions (helper pixels of odd sizes)
@@ -65,6 +68,11 @@ struct FrameParams {
     float     fold_min;       // underflow bound of the folded Mandelbulb passes (RMDF_MB8_FOLD_MIN; +inf under RMDF_FLAG_FORCE_WRITTEN)
 #endif
 };
+
+#ifdef RMDF_XCHECK
+// (the CPU tier's stand-in kernels read the band fields as a tail behind the product's FrameParams)
+static_assert(offsetof(FrameParams, band_count) == offsetof(FrameParams, block_cost) + sizeof(unsigned *), "the band fields follow block_cost");
+#endif
 
 // Which of the reference's 64 tiles rank `rank` of `nranks` renders, in slot order; returns how many (<= ceil(64/n)).
 // cost == nullptr: the static deal.  The scenes sit in the middle of the frame (the camera looks at the origin), so the
@@ -120,8 +128,9 @@ void tile_rect_host(int tile_idx, int w, int h, int *x0, int *y0, int *x1, int *
 // rmdf_render.hip
 hipError_t launch_render(int scene, const FrameParams &p, hipStream_t stream);
 int render_grid_blocks(const FrameParams &p);              // number of 32x8 strips launch_render() uses for p
-// gx / band_strip_rows / nbands: 0, or the band geometry of a whole-frame host call -- the order is then "the strips within a factor two of
-// the costliest first (they are the launch's critical path wherever they lie), the others band by band, outer bands first"
+// Longest-processing-time-first order of the strips.  (librmdf_xcheck.so: gx / band_strip_rows / nbands = the band geometry of a one-launch
+// whole-frame host call -- the order is then "the strips within a factor two of the costliest first, the others band by band, outer bands
+// first"; the product library has no such launch and takes the plain order whatever it is handed.)
 hipError_t launch_order_blocks(const unsigned *d_cost, int n, unsigned *d_order, hipStream_t stream, int gx = 0, int band_strip_rows = 0, int nbands = 0);
 // rmdf_util.hip
 hipError_t launch_resolve_box2(const uint32_t *d_src, int sw, int sh, uint32_t *d_dst, hipStream_t stream);

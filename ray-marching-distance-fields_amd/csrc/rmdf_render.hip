@@ -629,6 +629,8 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
         }
     }
 #endif
+#ifdef RMDF_XCHECK
+    // (librmdf_xcheck.so only: the one-launch band hand-over has never run on hardware -- the product's OUT_MIRROR kernels stay the ones the GPU tier ran)
     if (OUT == OUT_MIRROR && p.band_flag) {
         // every wave waits until ITS stores have landed in host memory; behind the barrier lane 0 speaks for the workgroup
         __threadfence_system();
@@ -644,6 +646,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
             }
         }
     }
+#endif
     if (p.block_cost) {
         // cost of the strip = the largest escape-iteration total of one of its pixels (proxy of its longest
         // serial chain); only steers next frame's dispatch order, never the image
@@ -680,12 +683,19 @@ __global__ __launch_bounds__(WPB * 64, (SCENE == 2 && OUT != OUT_PLANES) ? 8 : (
 template <int SCENE>
 static void launch_render_scene(const FrameParams &p, dim3 grid, hipStream_t stream)
 {
-    const bool merge = p.merge_stragglers != 0;
+    // The Cornell box never pools its last rays (rmdf_api.cpp fill_params: measured 6 % slower), so its MERGE kernels are not built: they
+    // would be the only kernels of the library with scratch (8 bytes, two spilled VGPRs).  -DRMDF_AB_CORNELL_MERGE=<threshold> builds bring them back.
+#ifdef RMDF_AB_CORNELL_MERGE
+    constexpr bool has_merge = true;
+#else
+    constexpr bool has_merge = SCENE != 0;
+#endif
+    const bool merge = has_merge && p.merge_stragglers != 0;
     const int out = (p.rgba_f32 || p.steps || p.iters) ? OUT_PLANES : (p.rgba8_mirror ? OUT_MIRROR : OUT_RGBA8);
-#define RMDF_LAUNCH(O)                                                                                       \
-    do {                                                                                                     \
-        if (merge) hipLaunchKernelGGL((k_render<SCENE, true, O>), grid, dim3(WPB * 64), 0, stream, p);       \
-        else       hipLaunchKernelGGL((k_render<SCENE, false, O>), grid, dim3(WPB * 64), 0, stream, p);      \
+#define RMDF_LAUNCH(O)                                                                                                      \
+    do {                                                                                                                    \
+        if (merge) hipLaunchKernelGGL((k_render<SCENE, has_merge, O>), grid, dim3(WPB * 64), 0, stream, p);                  \
+        else       hipLaunchKernelGGL((k_render<SCENE, false, O>), grid, dim3(WPB * 64), 0, stream, p);                      \
     } while (0)
     if (out == OUT_PLANES)      RMDF_LAUNCH(OUT_PLANES);
     else if (out == OUT_MIRROR) RMDF_LAUNCH(OUT_MIRROR);
@@ -732,7 +742,32 @@ int render_grid_blocks(const FrameParams &p)
 
 // Counting sort of the strips by descending cost (256 logarithmic-ish bins): order[rank] = strip.
 // One workgroup; ~n/1024 elements per thread.  Longest-processing-time-first dispatch needs no exact order.
-__global__ __launch_bounds__(1024) void k_order_blocks(const unsigned *__restrict__ cost, int n, unsigned *__restrict__ order, int gx, int band_strip_rows, int nbands)
+__global__ __launch_bounds__(1024) void k_order_blocks(const unsigned *__restrict__ cost, int n, unsigned *__restrict__ order)
+{
+    __shared__ unsigned hist[256], base[256];
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0u;
+    __syncthreads();
+    auto bin_of = [](unsigned c) -> unsigned {
+        // 8 sub-bins per power of two: monotone in c, 0..255
+        if (c < 8u) return c;
+        const int e = 31 - __builtin_clz(c);              // >= 3
+        const unsigned b = (unsigned)(e - 2) * 8u + ((c >> (e - 3)) & 7u);
+        return b > 255u ? 255u : b;
+    };
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[bin_of(cost[i])], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        unsigned acc = 0u;
+        for (int b = 255; b >= 0; b--) { base[b] = acc; acc += hist[b]; }   // descending cost
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) order[atomicAdd(&base[bin_of(cost[i])], 1u)] = (unsigned)i;
+}
+
+#ifdef RMDF_XCHECK
+// (librmdf_xcheck.so only, never run on hardware: the same sort with the band geometry of a one-launch whole-frame host call in the key)
+__global__ __launch_bounds__(1024) void k_order_blocks_bands(const unsigned *__restrict__ cost, int n, unsigned *__restrict__ order, int gx, int band_strip_rows, int nbands)
 {
     __shared__ unsigned hist[256], base[256], s_maxbin;
     const int tid = threadIdx.x;
@@ -769,10 +804,18 @@ __global__ __launch_bounds__(1024) void k_order_blocks(const unsigned *__restric
     __syncthreads();
     for (int i = tid; i < n; i += 1024) order[atomicAdd(&base[key_of(i)], 1u)] = (unsigned)i;
 }
+#endif
 
 hipError_t launch_order_blocks(const unsigned *d_cost, int n, unsigned *d_order, hipStream_t stream, int gx, int band_strip_rows, int nbands)
 {
-    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, stream, d_cost, n, d_order, gx, band_strip_rows, nbands);
+#ifdef RMDF_XCHECK
+    if (nbands > 0) {
+        hipLaunchKernelGGL(k_order_blocks_bands, dim3(1), dim3(1024), 0, stream, d_cost, n, d_order, gx, band_strip_rows, nbands);
+        return hipGetLastError();
+    }
+#endif
+    (void)gx; (void)band_strip_rows; (void)nbands;
+    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, stream, d_cost, n, d_order);
     return hipGetLastError();
 }
 

@@ -41,6 +41,7 @@
 #include <set>
 #include <string>
 #include <vector>
+#include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -80,7 +81,11 @@ void tile_rect(int idx, int w, int h, int &x0, int &y0, int &x1, int &y1)
 }
 
 // ---- k_render<SCENE, MERGE, OUT> ------------------------------------------------------------------------------------------------------
-void fake_render(const std::string &name, const FrameParams &p, dim3 grid)
+// librmdf_xcheck.so's FrameParams continues behind the product's with the one-launch band hand-over (rmdf_internal.hpp: the first fields of
+// its RMDF_XCHECK block); the product library has no such launch and its FrameParams ends where this file's copy of the struct ends
+struct BandTail { unsigned *band_count; volatile unsigned *band_flag; unsigned band_seq; int band_strip_rows; };
+
+void fake_render(const std::string &name, const FrameParams &p, dim3 grid, const BandTail &bt)
 {
     int scene = 0, merge = 0, out = 0;
     const size_t at = name.find("k_renderILi");
@@ -129,9 +134,9 @@ void fake_render(const std::string &name, const FrameParams &p, dim3 grid)
     }
     if (p.block_cost)
         for (size_t i = 0; i < nblk; i++) p.block_cost[i] = 1u + (mix(base, (uint32_t)i) >> 20);
-    if (out == 1 && p.band_flag) {
-        const int nb = ((int)grid.y + p.band_strip_rows - 1) / p.band_strip_rows;
-        for (int b = 0; b < nb; b++) { if (p.band_count[b] != 0u) abort(); __atomic_store_n((unsigned *)&p.band_flag[b], p.band_seq, __ATOMIC_RELEASE); }
+    if (out == 1 && bt.band_flag) {
+        const int nb = ((int)grid.y + bt.band_strip_rows - 1) / bt.band_strip_rows;
+        for (int b = 0; b < nb; b++) { if (bt.band_count[b] != 0u) abort(); __atomic_store_n((unsigned *)&bt.band_flag[b], bt.band_seq, __ATOMIC_RELEASE); }
     }
 }
 
@@ -145,11 +150,16 @@ float src_checksum(const float *src, size_t n)                  // reads every e
 }
 
 // the arguments are decoded NOW (the args array belongs to the caller's stack frame); what is returned runs when the stream gets to it
-std::function<void()> make_task(const std::string &name, dim3 grid, dim3 block, void **args)
+std::function<void()> make_task(const std::string &name, dim3 grid, dim3 block, void **args, bool from_xcheck)
 {
     (void)block;
     auto has = [&](const char *s) { return name.find(s) != std::string::npos; };
-    if (has("k_renderILi")) { const FrameParams p = *(const FrameParams *)args[0]; return [=] { fake_render(name, p, grid); }; }
+    if (has("k_renderILi")) {
+        const FrameParams p = *(const FrameParams *)args[0];
+        BandTail bt = { nullptr, nullptr, 0u, 0 };
+        if (from_xcheck) memcpy(&bt, (const char *)args[0] + sizeof(FrameParams), sizeof bt);
+        return [=] { fake_render(name, p, grid, bt); };
+    }
     if (has("k_order_blocks")) {
         const unsigned *cost = arg<const unsigned *>(args, 0); const int n = arg<int>(args, 1); unsigned *order = arg<unsigned *>(args, 2);
         return [=] {
@@ -419,7 +429,9 @@ hipError_t hipLaunchKernel(const void *fn, dim3 grid, dim3 block, void **args, s
     { std::lock_guard<std::mutex> lk(g_mu); auto it = g_kernels.find(fn); if (it == g_kernels.end()) return hipErrorInvalidDeviceFunction; name = it->second; }
     g_launches++;
     if (grid.x == 0 || grid.y == 0 || grid.z == 0 || block.x == 0) return hipErrorInvalidConfiguration;
-    submit(stream, make_task(name, grid, block, args));
+    Dl_info di;                                   // which build launches: the cross-check library's FrameParams is longer (BandTail)
+    const bool from_xcheck = dladdr(fn, &di) && di.dli_fname && strstr(di.dli_fname, "xcheck");
+    submit(stream, make_task(name, grid, block, args, from_xcheck));
     return hipSuccess;
 }
 hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }

@@ -54,6 +54,14 @@ def section_whole_frame_paths():
         sizes = sizes[1:]
     ref = {}
     for bands, mode in [(0, 0), (1, 0), (16, 0), (5, 1), (2, 1), (1, 2), (4, 2), (7, 3), (16, 3)]:
+        if mode >= 2 and not XCHECK:
+            # the one-launch hand-over has had no green run on hardware: the product library refuses it (RMDF_E_UNSUPPORTED)
+            try:
+                rmdf.ShaderRenderer(0, frame_bands=bands, frame_mirror=mode)
+                raise AssertionError("librmdf.so accepted rmdf_config.reserved[3] = %d" % mode)
+            except rmdf.RmdfError as e:
+                assert e.code == -6, e.code
+            continue
         sr = rmdf.ShaderRenderer(0, xcheck=XCHECK, frame_bands=bands, frame_mirror=mode)
         set_env(sr, 1)
         for key in sizes:
@@ -295,7 +303,7 @@ def section_random_call_sequences():
     sizes = [(128, 72), (64, 40), (200, 100), (33, 17), (640, 360)]
     nops = 0
     for trial in range(6 if QUICK else 16):
-        cfg = dict(frame_bands=int(rng.integers(0, 6)), frame_mirror=int(rng.integers(0, 4)), copy_threads=int(rng.choice([0, 1, 3])))
+        cfg = dict(frame_bands=int(rng.integers(0, 6)), frame_mirror=int(rng.integers(0, 4 if XCHECK else 2)), copy_threads=int(rng.choice([0, 1, 3])))
         sr = rmdf.ShaderRenderer(0, xcheck=XCHECK, **cfg)
         seed = int(rng.integers(100, 104))
         set_env(sr, seed)
@@ -359,7 +367,8 @@ def section_runtime_calls_per_frame():
     rows = []
     for name, cfg, budget in (("default (two mirror bands)", dict(), 14), ("one mirror band", dict(frame_bands=1, frame_mirror=1), 8),
                               ("two bands, copies behind the launches", dict(frame_bands=2, frame_mirror=0), 16),
-                              ("eight mirror bands", dict(frame_bands=8, frame_mirror=1), 34), ("one launch, eight flagged bands", dict(frame_bands=8, frame_mirror=2), 5)):
+                              ("eight mirror bands", dict(frame_bands=8, frame_mirror=1), 34)) + \
+                             ((("one launch, eight flagged bands", dict(frame_bands=8, frame_mirror=2), 5),) if XCHECK else ()):
         sr = rmdf.ShaderRenderer(0, xcheck=XCHECK, **cfg)
         set_env(sr, 1)
         for _ in range(3):

@@ -52,6 +52,37 @@ def test_product_library_holds_no_alternative_schedules_or_debug_knobs(rmdf):
     assert "k_march_mb8" in xsyms and "k_march_stats" in xsyms
 
 
+def test_product_library_reads_no_environment_knob(rmdf):
+    """no getenv knob on any launch path of the product.  Every RMDF_* variable (prefilter forms, streaming copies, RCCL
+    override, guard allocator, statistics) is compiled into librmdf_xcheck.so only; the one variable the product names is the HIP runtime's own
+    GPU_MAX_HW_QUEUES, which rmdf_create sets when the host has not."""
+    names = sorted(set(l for l in os.popen("strings -a %s" % rmdf.LIB_PATH).read().split("\n") if l.startswith("RMDF_")))
+    assert names == [], names
+    xnames = set(l for l in os.popen("strings -a %s" % rmdf.XCHECK_LIB_PATH).read().split("\n") if l.startswith("RMDF_"))
+    assert {"RMDF_PREFILTER_RING", "RMDF_COPY_NT", "RMDF_RCCL_LIB"} <= xnames, xnames
+
+
+def test_every_product_kernel_is_one_the_gpu_tier_has_run(rmdf):
+    """tests/golden/gpu_tested_kernels.json: the instruction stream of every kernel of the last library build a GPU executed (commit and run
+    record inside).  The shipped librmdf.so must consist of those kernels, instruction for instruction -- code that has never met hardware
+    (round 5: the band epilogue, the band-aware strip order, the ring prefilter) belongs in librmdf_xcheck.so until it has -- or name the
+    exceptions in the manifest's `not_yet_run` with the reason, so that the list of unverified product code is never implicit."""
+    import json
+    import sys
+    from conftest import GOLD, ROOT
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang-offload-bundler"):
+        pytest.skip("no clang-offload-bundler")
+    sys.path.insert(0, os.path.join(ROOT, "tools", "isa"))
+    import kernel_diff
+    man = json.load(open(os.path.join(GOLD, "gpu_tested_kernels.json")))
+    have = kernel_diff.kernel_hashes(rmdf.LIB_PATH)
+    assert len([k for k in have if "k_render<" in k]) == 21
+    new = {k: v for k, v in have.items() if man["kernels"].get(k) != v and k not in man["not_yet_run"]}
+    assert not new, "product kernels no GPU has run (move them to librmdf_xcheck.so or list them under not_yet_run): %s" % sorted(new)
+    stale = [k for k in man["not_yet_run"] if man["kernels"].get(k) == have.get(k)]
+    assert not stale, "listed as not yet run but identical to the GPU-tested build: %s" % stale
+
+
 def test_rccl_is_not_a_link_dependency(rmdf):
     """RCCL is dlopen()ed by rmdf_comm_init: a single-GPU C host must not need it at load time."""
     deps = os.popen("ldd %s" % rmdf.LIB_PATH).read()

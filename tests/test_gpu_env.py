@@ -73,7 +73,9 @@ def test_the_barrier_free_ring_form_of_the_prefilter_is_bit_exact(orc, env_latlo
             "np.savez(sys.argv[2], **{k + '_' + str(int(p)): sr.prefilter_env(z[k], p) for k in z.files for p in (1.0, 8.0, 64.0, 512.0)})\n" % ROOT)
     srcs = {"a": orc.resize_hdr(env_latlongs["refl"], 256), "b": orc.resize_hdr(env_latlongs["refl"], 128), "c": synthetic_latlong(252, 5, 7)}
     np.savez(str(tmp_path / "in.npz"), **srcs)
-    for tag, env in (("ring", dict(os.environ, RMDF_PREFILTER_RING="1")), ("default", dict(os.environ))):
+    import rmdf_amd
+    xlib = rmdf_amd.XCHECK_LIB_PATH                      # the switch exists in the cross-check build only
+    for tag, env in (("ring", dict(os.environ, RMDF_PREFILTER_RING="1", RMDF_LIB=xlib)), ("default", dict(os.environ, RMDF_LIB=xlib))):
         env.pop("RMDF_PREFILTER_RING", None) if tag == "default" else None
         r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "in.npz"), str(tmp_path / (tag + ".npz"))], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]

@@ -186,7 +186,12 @@ def test_whole_frame_host_call_in_row_bands(rmdf, env_faces, bands, mirror):
     reach the host (reserved[3]: 0 a copy behind each band's launch, 1 the band kernels' own mirror stores, 2 ONE launch that mirrors and
     flags completed bands, 3 the same with the strips dispatched band by band), the frame equals the single-launch plane-writing variant; sizes with ragged last strips, a size
     too small for bands; a tiled call afterwards starts from that frame (the shadow is valid)."""
-    r = rmdf.ShaderRenderer(0, frame_bands=bands, frame_mirror=mirror)
+    if mirror >= 2:
+        # the one-launch hand-over lives in the cross-check build until it has had a green run on hardware: the product refuses it
+        with pytest.raises(rmdf.RmdfError) as e:
+            rmdf.ShaderRenderer(0, frame_bands=bands, frame_mirror=mirror)
+        assert e.value.code == -6                                                  # RMDF_E_UNSUPPORTED
+    r = rmdf.ShaderRenderer(0, xcheck=mirror >= 2, frame_bands=bands, frame_mirror=mirror)
     try:
         for slot, k in ((rmdf.ENV_REFLECTION, "refl"), (rmdf.ENV_COS_1, "cos1"), (rmdf.ENV_COS_8, "cos8")):
             r.set_env_cube(slot, env_faces[k])

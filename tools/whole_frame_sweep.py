@@ -8,7 +8,8 @@ import numpy as np, rmdf_amd
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 cases = ((2, 1920, 1080, 256), (0, 1280, 720, 128))
 def run(**kw):
-    sr = rmdf_amd.ShaderRenderer(0, **kw); sr.load_env_hdr(rmdf_amd.DEFAULT_ENV_HDR)
+    # (hand-over modes 2 and 3 -- one launch, band flags -- exist in the cross-check build only)
+    sr = rmdf_amd.ShaderRenderer(0, xcheck=kw.get("frame_mirror", 0) >= 2, **kw); sr.load_env_hdr(rmdf_amd.DEFAULT_ENV_HDR)
     out = []
     for scene, w, h, ms in cases:
         hb = np.empty(w * h, np.uint32)
