@@ -10,7 +10,9 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <functional>
 #include <exception>
 #include <mutex>
@@ -108,6 +110,7 @@ struct rmdf_ctx {
     volatile unsigned *wf_flags = nullptr, *wf_flags_dev = nullptr;       // one-launch hand-over: band k of frame `seq` is in the shadow when wf_flags[k] == seq
     unsigned    *d_wf_count = nullptr;
     unsigned     wf_seq = 0;
+    long long    wf_last_us = 0;       // how long the previous whole-frame host call waited for its bands (bounds the copy threads' spin window)
     unsigned     spec_dropped = 0;     // tile jobs that could not be issued ahead of their call (render_tile_fast)
     unsigned     env_gen = 0;          // bumped whenever a cube-map slot changes: tile jobs rendered ahead belong to ONE environment
     // ... and the tile jobs of that mode: a tile is rendered into a device scratch tile AND, by the kernel's mirror store, into a
@@ -181,12 +184,15 @@ int fail(rmdf_ctx *ctx, int code, const std::string &msg)
             return fail(ctx, RMDF_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
     } while (0)
 
-// the ctx's host threads, started on first use: rmdf_config.reserved[1] threads with the caller's, or by core count
-WorkPool &ctx_pool(rmdf_ctx *ctx)
+// the ctx's host threads, started on first use BY WORK THAT CAN USE THEM (a copy of at least 1 MB, a table builder): a ctx that only ever
+// moves a few kilobytes (rmdf_create's tables, shard calls on device pointers) never starts a thread -- an unstarted pool runs every job
+// on the calling thread.  rmdf_config.reserved[1] threads with the caller's, or by the CPUs this process may use (affinity mask and
+// container quota, not the machine's core count: rmdf_host.hpp usable_cpus).
+WorkPool &ctx_pool(rmdf_ctx *ctx, size_t bytes = (size_t)-1)
 {
-    if (ctx->pool.workers() == 0) {
-        const unsigned hc = std::thread::hardware_concurrency();
-        ctx->pool.start(ctx->copy_threads ? ctx->copy_threads - 1 : (hc >= 64 ? 15 : (hc > 8 ? 7 : (hc > 1 ? (int)hc - 1 : 0))));
+    if (ctx->pool.workers() == 0 && bytes >= ((size_t)1 << 20)) {
+        const int hc = usable_cpus();
+        ctx->pool.start(ctx->copy_threads ? ctx->copy_threads - 1 : (hc >= 64 ? 15 : (hc > 8 ? 7 : (hc > 1 ? hc - 1 : 0))));
     }
     return ctx->pool;
 }
@@ -197,13 +203,13 @@ WorkPool &ctx_pool(rmdf_ctx *ctx)
 int upload(rmdf_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, hipStream_t st)
 {
     if (bytes == 0) return RMDF_OK;
-    const hipError_t e = ctx->staging.upload(ctx_pool(ctx), d_dst, h_src, bytes, st);
+    const hipError_t e = ctx->staging.upload(ctx_pool(ctx, bytes), d_dst, h_src, bytes, st);
     return e == hipSuccess ? RMDF_OK : fail(ctx, RMDF_E_HIP, std::string("upload through staging: ") + hipGetErrorString(e));
 }
 int download(rmdf_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, hipStream_t st)
 {
     if (bytes == 0) return RMDF_OK;
-    const hipError_t e = ctx->staging.download(ctx_pool(ctx), h_dst, d_src, bytes, st);
+    const hipError_t e = ctx->staging.download(ctx_pool(ctx, bytes), h_dst, d_src, bytes, st);
     return e == hipSuccess ? RMDF_OK : fail(ctx, RMDF_E_HIP, std::string("download through staging: ") + hipGetErrorString(e));
 }
 #define RMDF_TRY(expr) do { const int rc_ = (expr); if (rc_ != RMDF_OK) return rc_; } while (0)
@@ -1078,7 +1084,9 @@ int render_tile_fast(rmdf_ctx *ctx, int scene, int tile_idx, const FrameParams &
     const size_t npx = (size_t)ctx->w * ctx->h;
     const int midx = tile_idx % 64, b = midx % RMDF_TILE_JOBS;
     RMDF_TRY(ensure_shadow(ctx, npx));
-    WorkPool &pool = ctx_pool(ctx);
+    WorkPool &pool = ctx_pool(ctx, npx * 4);
+    PoolJobGuard job_guard(pool);                       // whatever leaves this function -- an error return between begin() and finish(), an exception
+                                                        // from a string or std::function allocation -- the frame copy is joined first
     // this call's job: the one issued speculatively by the previous call if it is for exactly this tile of this frame, else now
     rmdf_ctx::TileJob &j = ctx->tile_job[b];
     auto is_for = [&](const rmdf_ctx::TileJob &t, int idx) {
@@ -1165,7 +1173,7 @@ int render_whole_frame_one_launch(rmdf_ctx *ctx, int scene, const FrameParams &p
     char *sh = (char *)ctx->h_shadow, *dst = (char *)out_rgba8;
     unsigned pending = nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u);
     unsigned spins = 0;
-    pool.prime(2000);                                                  // the copy threads spin from now until the last band is through
+    PoolPrimeGuard hot(pool, 2000);                                    // the copy threads spin from now until the last band is through (or any other way out)
     while (pending) {
         for (int k = 0; k < nb; k++) {
             if (!((pending >> k) & 1u)) continue;
@@ -1194,7 +1202,6 @@ int render_whole_frame_one_launch(rmdf_ctx *ctx, int scene, const FrameParams &p
             }
         }
     }
-    pool.relax();
     ctx->shadow_valid = true;
     return RMDF_OK;
 }
@@ -1213,7 +1220,7 @@ int render_whole_frame_host(rmdf_ctx *ctx, int scene, const FrameParams &p, uint
     const int w = ctx->w, h = ctx->h;
     const size_t npx = (size_t)w * h;
     RMDF_TRY(ensure_shadow(ctx, npx));
-    WorkPool &pool = ctx_pool(ctx);
+    WorkPool &pool = ctx_pool(ctx, npx * 4);
     // the library's choice (neither knob given): RMDF_WF_DEFAULT_* -- measured on the headline frame and the Cornell box, tools/whole_frame_sweep.py
     const int mode = (ctx->wf_bands == 0 && ctx->wf_mirror == 0) ? RMDF_WF_DEFAULT_MODE : ctx->wf_mirror;
     // (the library's choice: two bands from 6 MB of frame on -- 1920x1080: 0.516 ms against 0.552 with one; the 3.7 MB Cornell frame of
@@ -1260,7 +1267,10 @@ int render_whole_frame_host(rmdf_ctx *ctx, int scene, const FrameParams &p, uint
     if (rc != RMDF_OK) { (void)hipDeviceSynchronize(); ctx->shadow_valid = false; return rc; }   // bands already issued still write frame and shadow
     // the bands to the caller as they land
     unsigned pending = nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u);
-    pool.prime(2000);
+    // the copy threads spin while the bands land: twice the previous frame's measured time, within [200 us, 2 ms]; the guard puts
+    // them back to sleep on every way out of this function
+    const auto t_wait0 = std::chrono::steady_clock::now();
+    PoolPrimeGuard hot(pool, ctx->wf_last_us > 0 ? std::min<long long>(2000, std::max<long long>(200, 2 * ctx->wf_last_us)) : 2000);
     while (pending) {
         for (int k = 0; k < nb; k++) {
             if (!((pending >> k) & 1u)) continue;
@@ -1273,7 +1283,7 @@ int render_whole_frame_host(rmdf_ctx *ctx, int scene, const FrameParams &p, uint
         }
         if (pending) __builtin_ia32_pause();
     }
-    pool.relax();
+    ctx->wf_last_us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_wait0).count();
     ctx->shadow_valid = true;                                          // (every band is over: the device frame is complete as well)
     return RMDF_OK;
 }

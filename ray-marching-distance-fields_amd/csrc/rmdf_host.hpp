@@ -16,6 +16,10 @@
 #include <immintrin.h>
 #endif
 #include <hip/hip_runtime.h>
+#if defined(__linux__)
+#include <sched.h>
+#endif
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -196,6 +200,48 @@ public:
         for (auto &t : threads_) if (t.joinable()) t.join();
     }
 };
+
+// Scope guards of the two states a caller can leave a pool in: an open job (begin() without finish(): the workers may still be copying
+// into the caller's buffer, open_ / pending_ stale for the next job) and primed workers (spinning until relax() or the window ends).
+// Every exit of the scope -- an error return, an exception on its way to the C ABI's catch -- closes them.
+struct PoolJobGuard {
+    WorkPool &pool;
+    explicit PoolJobGuard(WorkPool &p) : pool(p) { }
+    ~PoolJobGuard() { pool.finish(); }                  // idempotent: nothing to do after an explicit finish()
+    PoolJobGuard(const PoolJobGuard &) = delete;
+    PoolJobGuard &operator=(const PoolJobGuard &) = delete;
+};
+struct PoolPrimeGuard {
+    WorkPool &pool;
+    PoolPrimeGuard(WorkPool &p, long long us) : pool(p) { pool.prime(us); }
+    ~PoolPrimeGuard() { pool.relax(); }
+    PoolPrimeGuard(const PoolPrimeGuard &) = delete;
+    PoolPrimeGuard &operator=(const PoolPrimeGuard &) = delete;
+};
+
+// CPUs this process may actually use: hardware_concurrency() counts the machine's, not the affinity mask's and not a container's CFS
+// quota (cgroup v2 cpu.max / v1 cpu.cfs_quota_us) -- with several ranks per node or a CPU-limited container, threads sized by the
+// machine would spin against the very thread they are meant to serve.
+inline int usable_cpus()
+{
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+#if defined(__linux__) && !defined(__HIP_DEVICE_COMPILE__)
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int a = CPU_COUNT(&set); if (a >= 1 && a < n) n = a; }
+    long long quota = -1, period = -1;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = { 0 };
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else {
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = -1; fclose(g); }
+    }
+    if (quota > 0 && period > 0) { const int c = (int)((quota + period - 1) / period); if (c >= 1 && c < n) n = c; }
+#endif
+    return n;
+}
 
 // Two page-locked chunks and their events.  Not a cache of anything: a chunk is reused as soon as the DMA that read or wrote it is over.
 struct Staging {

@@ -28,13 +28,31 @@
 /* CPU-tier self-test of the double itself (tests/test_host_logic.py): "device" buffers are host memory, streams do not exist */
 #define hipStreamSynchronize(s) ((void)(s), hipSuccess)
 #define hipMemcpy(d, s, n, k) (memcpy((d), (s), (n)), hipSuccess)
+#define hipHostMalloc(pp, n, f) ((*(pp) = malloc(n)) ? hipSuccess : hipErrorOutOfMemory)
+#define hipHostFree(p) (free(p), hipSuccess)
 #endif
 
 struct ncclComm {
     char uid[33];
     int rank, nranks;
     unsigned long long seq_out[64], seq_in[64];
+    /* ONE page-locked staging buffer per communicator, grown on demand, freed by ncclCommDestroy: the double never hands pageable
+     * memory to the HIP runtime (a short-lived malloc()ed block copied with hipMemcpy is page-locked on the fly by the runtime -- the
+     * pattern round 5's GPU memory fault was traced to, NOTEBOOK.md A.5) */
+    void *stage;
+    size_t stage_cap;
 };
+
+static void *stage_of(struct ncclComm *c, size_t bytes)
+{
+    if (bytes <= c->stage_cap && c->stage) return c->stage;
+    if (c->stage) { (void)hipHostFree(c->stage); c->stage = NULL; c->stage_cap = 0; }
+    size_t cap = bytes < 4096 ? 4096 : bytes;
+    void *p = NULL;
+    if (hipHostMalloc(&p, cap, 0) != hipSuccess || !p) return NULL;
+    c->stage = p; c->stage_cap = cap;
+    return p;
+}
 
 enum { OP_SEND, OP_RECV };
 struct op { int kind; void *buf; size_t bytes; int peer; struct ncclComm *comm; hipStream_t stream; };
@@ -63,18 +81,18 @@ static ncclResult_t do_send(const struct op *o)
 {
     struct ncclComm *c = o->comm;
     if (hipStreamSynchronize(o->stream) != hipSuccess) { snprintf(g_err, sizeof g_err, "fake ncclSend: stream synchronize failed"); return ncclUnhandledCudaError; }
-    void *host = malloc(o->bytes ? o->bytes : 1);
-    if (!host) return ncclSystemError;
-    if (o->bytes && hipMemcpy(host, o->buf, o->bytes, hipMemcpyDeviceToHost) != hipSuccess) { free(host); snprintf(g_err, sizeof g_err, "fake ncclSend: device read failed"); return ncclUnhandledCudaError; }
+    void *host = stage_of(c, o->bytes);
+    if (!host) { snprintf(g_err, sizeof g_err, "fake ncclSend: no page-locked staging buffer of %zu bytes", o->bytes); return ncclSystemError; }
+    if (o->bytes && hipMemcpy(host, o->buf, o->bytes, hipMemcpyDeviceToHost) != hipSuccess) { snprintf(g_err, sizeof g_err, "fake ncclSend: device read failed"); return ncclUnhandledCudaError; }
     char tmp[256], msg[256];
     const unsigned long long q = c->seq_out[o->peer]++;
     path_of(tmp, sizeof tmp, c, c->rank, o->peer, q, "tmp");
     path_of(msg, sizeof msg, c, c->rank, o->peer, q, "msg");
     const int fd = open(tmp, O_WRONLY | O_CREAT | O_TRUNC, 0600);
-    if (fd < 0) { free(host); snprintf(g_err, sizeof g_err, "fake ncclSend: cannot create %s", tmp); return ncclSystemError; }
+    if (fd < 0) { snprintf(g_err, sizeof g_err, "fake ncclSend: cannot create %s", tmp); return ncclSystemError; }
     size_t done = 0;
     while (done < o->bytes) { const ssize_t w = write(fd, (char *)host + done, o->bytes - done); if (w <= 0) break; done += (size_t)w; }
-    close(fd); free(host);
+    close(fd);
     if (done != o->bytes || rename(tmp, msg) != 0) { unlink(tmp); snprintf(g_err, sizeof g_err, "fake ncclSend: short write to %s", tmp); return ncclSystemError; }
     return ncclSuccess;
 }
@@ -104,8 +122,8 @@ static ncclResult_t do_recv(const struct op *o)
         snprintf(g_err, sizeof g_err, "fake ncclRecv: rank %d expects %zu bytes from rank %d, which sent %zu", c->rank, o->bytes, o->peer, (size_t)sb.st_size);
         return ncclInvalidArgument;
     }
-    void *host = malloc(o->bytes ? o->bytes : 1);
-    if (!host) return ncclSystemError;
+    void *host = stage_of(c, o->bytes);
+    if (!host) { unlink(msg); snprintf(g_err, sizeof g_err, "fake ncclRecv: no page-locked staging buffer of %zu bytes", o->bytes); return ncclSystemError; }
     const int fd = open(msg, O_RDONLY);
     size_t done = 0;
     while (fd >= 0 && done < o->bytes) { const ssize_t r = read(fd, (char *)host + done, o->bytes - done); if (r <= 0) break; done += (size_t)r; }
@@ -116,7 +134,6 @@ static ncclResult_t do_recv(const struct op *o)
     else if (hipStreamSynchronize(o->stream) != hipSuccess || (o->bytes && hipMemcpy(o->buf, host, o->bytes, hipMemcpyHostToDevice) != hipSuccess)) {
         snprintf(g_err, sizeof g_err, "fake ncclRecv: device write failed"); res = ncclUnhandledCudaError;
     }
-    free(host);
     return res;
 }
 
@@ -166,6 +183,7 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
             path_of(msg, sizeof msg, comm, src, comm->rank, q, "msg");
             if (unlink(msg) != 0) break;
         }
+    if (comm->stage) (void)hipHostFree(comm->stage);
     free(comm);
     return ncclSuccess;
 }

@@ -55,10 +55,38 @@ static int check_pool(int nworkers)
     return 0;
 }
 
+// the scope guards (round 6): a job left open by an exception is joined -- every part exactly once -- and the pool takes the next job;
+// primed workers are relaxed on the way out; usable_cpus() stays within [1, hardware_concurrency]
+static int check_guards(int nworkers)
+{
+    WorkPool pool;
+    pool.start(nworkers);
+    std::vector<std::atomic<int>> hits(16);
+    for (int round = 0; round < 200; round++) {
+        for (auto &h : hits) h.store(0);
+        const int parts = 1 + round % (nworkers + 1);
+        try {
+            rmdf::PoolPrimeGuard hot(pool, 500);
+            rmdf::PoolJobGuard guard(pool);
+            pool.begin(parts, [&](int part) { hits[(size_t)part].fetch_add(1); });
+            if (round % 3 == 0) throw std::bad_alloc();
+            pool.finish();
+        } catch (const std::bad_alloc &) { }
+        for (int p = 0; p < 16; p++)
+            if (hits[(size_t)p].load() != (p < parts ? 1 : 0)) { printf("guard, pool of %d, round %d: part %d ran %d times\n", nworkers, round, p, hits[(size_t)p].load()); return 1; }
+        int ran = 0;
+        pool.run(parts, [&](int) { __atomic_fetch_add(&ran, 1, __ATOMIC_RELAXED); });
+        if (ran != parts) { printf("guard, pool of %d, round %d: the job after the guard ran %d of %d parts\n", nworkers, round, ran, parts); return 1; }
+    }
+    const int c = rmdf::usable_cpus();
+    if (c < 1 || c > (int)std::thread::hardware_concurrency()) { printf("usable_cpus() = %d\n", c); return 1; }
+    return 0;
+}
+
 int main()
 {
     for (int n : { 0, 1, 3, 15 })
-        if (check_pool(n)) return 1;
+        if (check_pool(n) || check_guards(n)) return 1;
     { WorkPool idle; idle.prime(10); idle.relax(); idle.copy(nullptr, nullptr, 0); }      // no workers at all
     printf("pool ok\n");
     return 0;
