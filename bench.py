@@ -236,6 +236,17 @@ def sha256_file(path):
 _PMC_OTHER_BUILD = {}       # the committed counter passes when they belong to ANOTHER build of the library (reported apart, labelled)
 
 
+def achievable_issue_roof():
+    """profiles/r06_march_loop_classes.json: the headline kernel's ISA priced in vector-port issue slots (tools/isa/march_loop_classes.py,
+    CPU-only), or None"""
+    fn = os.path.join(ROOT, "profiles", "r06_march_loop_classes.json")
+    try:
+        d = json.load(open(fn))
+        return d if all(k in d for k in ("t_spec_ms", "t_sust_ms", "vslots", "pass_instr", "full_slots")) else None
+    except Exception:                                           # noqa: BLE001
+        return None
+
+
 def pmc_record(lib_path, workload):
     """PMC figures of the dominant kernel from the committed counter passes (profiles/pmc_traffic.json, written by
     tools/pmc_summary.py on the GPU box).  They are measurements of ONE build: used only when the file names this very
@@ -870,6 +881,18 @@ def main():
                                   "note": "binding roof = FP32 vector-ALU issue (SURVEY 8d): as-written IEEE operations (sqrt, 1/sqrt, "
                                           "log, pow, / each 1; no FMA contraction by the parity contract) per second against 256 CU x "
                                           "4 SIMD x 32 lanes x 2.4 GHz; HBM side in hbm_roofline"}
+            ach_roof = achievable_issue_roof()
+            if headline and ach_roof:
+                # (B) of profiles/r06_march_loop_classes.txt: the instruction stream this kernel has to issue -- its ISA priced in issue slots
+                # with the per-form costs measured on MI355X -- on 64 live lanes, against the as-written roof (A) above
+                result["roofline"]["achievable_issue"] = {
+                    "ms_at_spec_issue_rate": round(ach_roof["t_spec_ms"], 4), "ms_at_sustained_v_mul_rate": round(ach_roof["t_sust_ms"], 4),
+                    "frac_of_spec": round(ach_roof["t_spec_ms"] / kern_ms, 4), "frac_of_sustained": round(ach_roof["t_sust_ms"] / kern_ms, 4),
+                    "vector_slots_per_iteration_pass": ach_roof["vslots"], "vector_instructions_per_iteration_pass": ach_roof["pass_instr"],
+                    "as_written_ops_per_iteration_pass": 79, "wave_slots_at_full_lanes": round(ach_roof["full_slots"]),
+                    "source": "profiles/r06_march_loop_classes.json (tools/isa/march_loop_classes.py)",
+                    "note": "what is left between `frac_of_sustained` and 1 is lane utilisation (rays that have ended while their packet "
+                            "marches on); between this roof and `peak` the exact roots, guards and the pinned log of the parity contract"}
             if not pmc and _PMC_OTHER_BUILD.get("record"):
                 # no counter passes exist for THIS build (round 5: GPU access closed before the round's profiling run).  The committed ones
                 # are round 4's; that build's k_render<2, true, 0> has the same march loop instruction for instruction (only the shading

@@ -807,6 +807,8 @@ def test_bench_dry_run_against_the_hip_double(tmp_path):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f32" and d["metric"].startswith("Mpixels/s") and "workload" in d["config"]
     assert d["roofline"]["bound"] == "valu" and d["roofline"]["peak"] == 78.6 and "frac" in d["roofline"] and "traffic" in d["roofline"]
+    ai = d["roofline"]["achievable_issue"]                    # round 6: the kernel's ISA priced in issue slots, beside the as-written roof
+    assert ai["vector_instructions_per_iteration_pass"] == 87 and 95 < ai["vector_slots_per_iteration_pass"] < 102 and ai["frac_of_spec"] > 0
     assert "secondary_error" not in d and d["secondary"], d.get("secondary_error")
     for name in ("config2_cornell_1280x720_m128", "scene1_detest_1280x720_m128", "scene3_mbgeneral_1280x720_m128"):
         rl = d["secondary"][name]["roofline"]
@@ -1052,3 +1054,24 @@ def test_the_rccl_double_itself(tmp_path):
         assert not [f for f in os.listdir("/dev/shm") if f.startswith("fakerccl_" + uid)]
     finally:
         os.environ.pop("FAKE_RCCL_TIMEOUT_S", None)
+
+
+def test_march_loop_classes_of_the_shipped_sources(tmp_path):
+    """tools/isa/march_loop_classes.py (round 6): the headline kernel compiled to assembly with the product's flags, the
+    march's iteration pass found in the code generator's loop annotations, its instructions by class.  Pins what DESIGN.md section 6 says about
+    the pass -- 87 vector instructions for 79 as-written operations, two of them transcendental, no v_cndmask, no scratch -- and that the committed
+    profiles/r06_march_loop_classes.json is what the tool derives from the sources as they are."""
+    import json
+    import shutil
+    import sys
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    sys.path.insert(0, os.path.join(ROOT, "tools", "isa"))
+    import march_loop_classes as m
+    text, d = m.report()
+    assert d["pass_instr"] == 87 and abs(d["vslots"] - 98.2) < 1e-9
+    assert "v_cndmask (selects)" not in text.split("## the step loop")[0]          # (the class's row name: the pass has none)
+    committed = json.load(open(os.path.join(ROOT, "profiles", "r06_march_loop_classes.json")))
+    for k in ("pass_instr", "vslots", "full_slots", "t_spec_ms", "t_sust_ms", "ops"):
+        assert abs(committed[k] - d[k]) <= 1e-9 * abs(d[k]), k
+    assert 0.55 < d["t_as_written_ms"] / d["t_spec_ms"] < 0.65          # (B) = 0.59 of (A)
