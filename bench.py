@@ -143,19 +143,26 @@ class Watchdog:
         t = threading.Thread(target=self._run, daemon=True)
         t.start()
 
-    def arm(self, what, seconds=None):
+    def arm(self, what, seconds=None, on_timeout=None):
+        """on_timeout (optional): called instead of the exit when the countdown runs out -- for legs behind the timed region whose loss must
+        not cost the line (it should write the line and end the process itself)"""
         with self.lock:
-            self.what, self.deadline = what, time.monotonic() + (seconds or self.seconds)
+            self.what, self.deadline, self.on_timeout = what, time.monotonic() + (seconds or self.seconds), on_timeout
 
     def disarm(self):
         with self.lock:
-            self.what, self.deadline = None, None
+            self.what, self.deadline, self.on_timeout = None, None, None
 
     def _run(self):
         while True:
             time.sleep(0.5)
             with self.lock:
-                what, dl = self.what, self.deadline
+                what, dl, cb = self.what, self.deadline, getattr(self, "on_timeout", None)
+            if dl is not None and time.monotonic() > dl and cb is not None:
+                sys.stderr.write("bench.py watchdog: rank %d has been stuck in %r -- the line goes out without that leg\n" % (self.rank, what))
+                sys.stderr.flush()
+                cb()
+                os._exit(0)
             if dl is not None and time.monotonic() > dl:
                 sys.stderr.write("bench.py watchdog: rank %d has been stuck in %r for more than %.0f s -- giving up (exit 3)\n" % (self.rank, what, self.seconds))
                 sys.stderr.flush()
@@ -599,7 +606,10 @@ def main():
         tt = torch.tensor([t_render, t_exch if rank == 0 else 0.0], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         mean_render, root_exchange = float(tt[0].item()) / world, float(tt[1].item())
+        mm = torch.tensor([t_render, -t_render], dtype=torch.float64, device=cdev)
+        dist.all_reduce(mm, op=dist.ReduceOp.MAX)
         shard_split = {"shard_render_ms_mean_over_ranks": round(mean_render, 4), "exchange_plus_assemble_ms_rank0": round(root_exchange, 4),
+                       "shard_render_ms_min_over_ranks": round(-float(mm[1].item()), 4), "shard_render_ms_max_over_ranks": round(float(mm[0].item()), 4),
                        "note": "measured before the timed region, one frame at a time on stream 0: every rank's shard render (HIP events), and on "
                                "rank 0 the gather + assembly alone while all peers send at once"}
         measured = min(0.5, root_exchange / max(mean_render, 1e-6))
@@ -825,6 +835,8 @@ def main():
                        "exchange": exchange, "rccl_ranks": rccl_ranks,
                        "exchange_ms": None if shard_split is None else shard_split["exchange_plus_assemble_ms_rank0"],
                        "shard_render_ms": None if shard_split is None else shard_split["shard_render_ms_mean_over_ranks"],
+                       "shard_render_ms_min": None if shard_split is None else shard_split["shard_render_ms_min_over_ranks"],
+                       "shard_render_ms_max": None if shard_split is None else shard_split["shard_render_ms_max_over_ranks"],
                        "frames_in_flight": S, "exchanged_frames_verified": frames_verified, "tile_deal": deal, "animate_dt": a.animate,
                        "device": dev_name, "compute_units": cus},
             "repeats": len(blocks), "ms_per_step_blocks": [round(b / a.steps * 1e3, 4) for b in blocks],
@@ -976,6 +988,21 @@ def main():
             if a.check:
                 result["check_rgba8_equal"] = all(bool(np.array_equal(f.cpu().numpy().view(np.uint32), ref["rgba8"]))
                                                   for f in frames)
+        if not a.no_secondary and world == 1 and not sharded and L == 0 and w % 8 == 0 and h % 8 == 0:
+            # N = 1 carries the N > 1 line's exchange fields too (rccl_ranks, shard_render_ms min / max, exchange_ms), so that the driver's
+            # N = 1 SCALE line can be read field by field beside the others: the same library calls -- shard render of all 64 tiles, gather
+            # (the root's own part, in its slot), assembly -- on a ONE-rank RCCL communicator.  LAST, behind everything else the line holds,
+            # and never fatal: an error is reported in the line, and should RCCL hang, the watchdog writes the line without this leg.
+            def line_without_the_leg():
+                result["config"]["one_rank_exchange_error"] = "timed out (60 s): the leg was abandoned, everything else in this line was complete"
+                os.write(json_fd, (json.dumps(result) + "\n").encode())
+            dog.arm("the one-rank exchange leg (after the timed region)", 60, on_timeout=line_without_the_leg)
+            try:
+                result["config"].update(one_rank_exchange_leg(sr, torch, dev, stream, event_ms, scene, w, h, ms, a.time,
+                                                              frames[0] if a.animate == 0.0 else None, None, xcheck=rccl_double))
+            except Exception as e:                                  # noqa: BLE001
+                result["config"]["one_rank_exchange_error"] = "%s: %s" % (type(e).__name__, e)
+            dog.disarm()
         os.write(json_fd, (json.dumps(result) + "\n").encode())
 
     if sharded:
@@ -997,6 +1024,46 @@ def scene_pmc(name, lib_path=None):
         return rec.get("SQ_INSTS_VALU_per_launch")
     except Exception:                                           # noqa: BLE001
         return None
+
+
+def one_rank_exchange_leg(sr, torch, dev, stream, event_ms, scene, w, h, ms, t, plain_frame, dog=None, xcheck=False):
+    """The sharded frame path with a communicator of ONE rank (all one GPU can hold), timed one frame at a time with HIP events on the
+    launch stream; the assembled frame must equal the plain launch's.  Returns the exchange fields of the N > 1 line for N = 1."""
+    import rmdf_amd
+    i32 = dict(dtype=torch.int32, device=dev)
+    slots = rmdf_amd.shard_slots(1)
+    gathered = torch.zeros((1, slots, h // 8, w // 8), **i32)
+    frame = torch.zeros((h, w), **i32)
+    torch.cuda.synchronize(dev)                                  # the fills ran on torch's stream; the library's calls below do not wait for it
+    sp = stream.cuda_stream
+    own = sr.comm_info()[1] == 0
+    if own:
+        if dog: dog.arm("rmdf_comm_init (one-rank communicator, N = 1 exchange leg)")
+        sr.comm_init(rmdf_amd.comm_get_unique_id(xcheck=xcheck), 0, 1)
+        if dog: dog.disarm()
+    try:
+        shard = gathered[0]                                      # the root renders straight into its slot, as at N > 1
+        render = lambda: sr.render_shard_device(scene, w, h, t, ms, 0, 1, shard.data_ptr(), stream=sp)
+
+        def exch():
+            sr.gather_shards_device(w, h, shard.data_ptr(), gathered.data_ptr(), stream=sp)
+            sr.assemble_shards_device(w, h, 1, gathered.data_ptr(), frame.data_ptr(), stream=sp)
+        whole = lambda: sr.render_frame_sharded_device(scene, w, h, t, ms, shard.data_ptr(), gathered.data_ptr(), frame.data_ptr(), stream=sp)
+        for _ in range(3):
+            whole()
+        torch.cuda.synchronize(dev)
+        same = None if plain_frame is None else bool(torch.equal(frame, plain_frame))
+        t_r = event_ms(render, 10)
+        t_x = event_ms(exch, 10)
+        t_w = event_ms(whole, 10)
+        return {"rccl_ranks": sr.comm_info()[1], "exchange_ms": round(t_x[0], 4), "shard_render_ms": round(t_r[0], 4),
+                "shard_render_ms_min": round(t_r[0], 4), "shard_render_ms_max": round(t_r[0], 4),
+                "sharded_frame_ms": round(t_w[0], 4), "sharded_frame_equals_plain_frame": same,
+                "exchange_fields_note": "N = 1: measured AFTER the timed region on a one-rank RCCL communicator (rmdf_render_frame_sharded_device: all 64 "
+                                        "tiles as one shard, the root's own part gathered in its slot, k_assemble_shards); `value` is the plain launch"}
+    finally:
+        if own:
+            sr.comm_destroy()
 
 
 def secondary_workloads(sr, torch, dev, stream, cus, streams=()):

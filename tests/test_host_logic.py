@@ -817,6 +817,33 @@ def test_bench_dry_run_against_the_hip_double(tmp_path):
     assert not [f for f in os.listdir(os.path.dirname(rmdf_amd.DEFAULT_ENV_HDR)) if "_cache_pow_" in f and os.path.dirname(rmdf_amd.DEFAULT_ENV_HDR) != str(tmp_path)]
 
 
+def test_bench_n1_line_carries_the_exchange_fields(tmp_path):
+    """Round 6: the N = 1 line carries the N > 1 line's exchange fields -- rccl_ranks, shard_render_ms with min / max,
+    exchange_ms -- measured after the timed region through the library's sharded-frame calls on a ONE-rank communicator, and says whether that
+    frame equals the plain launch's.  Here: HIP double + RCCL double (librmdf_xcheck.so); with the real RCCL and no GPU the leg fails and the
+    line says so instead of dying (the first dry-run test sees that branch)."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    import rmdf_amd
+    from conftest import ROOT
+    from test_gpu_parity import _fake_rccl_lib
+    hdr = str(tmp_path / "probe.hdr")
+    shutil.copy(rmdf_amd.DEFAULT_ENV_HDR, hdr)
+    env = dict(os.environ, LD_PRELOAD=_fake_hip_lib(), RMDF_ENV_HDR=hdr, RMDF_BENCH_SHARE_GPU="1", RMDF_RCCL_LIB=_fake_rccl_lib(), FAKE_RCCL_TIMEOUT_S="60")
+    for k in ("RMDF_LIB", "RMDF_FLAGS", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_dry_run.py"), "--steps", "2", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline",
+                        "--width", "640", "--height", "360"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    c = json.loads(r.stdout.strip().splitlines()[-1])["config"]
+    assert "one_rank_exchange_error" not in c, c.get("one_rank_exchange_error")
+    assert c["rccl_ranks"] == 1 and c["sharded_frame_equals_plain_frame"] is True
+    for k in ("exchange_ms", "shard_render_ms", "shard_render_ms_min", "shard_render_ms_max", "sharded_frame_ms"):
+        assert c[k] is not None and c[k] >= 0, k
+
+
 @pytest.mark.parametrize("flags", ["--supersample 1 --width 960 --height 540", "--streams 1", "--animate 0.1 --streams 2",
                                    "--scene 0 --width 1280 --height 720 --max-steps 128", "--scene 3 --no-animated"])
 def test_bench_dry_run_of_the_other_modes(tmp_path, flags):
