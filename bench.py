@@ -254,6 +254,79 @@ def achievable_issue_roof():
         return None
 
 
+_LIVE_SCENE_PMC = {}       # scene name -> SQ_INSTS_VALU per launch, collected by this run (live_pmc_passes)
+
+
+def live_pmc_passes(lib_path, scenes=True, budget_s=240.0):
+    """The counter passes of tools/profile.sh + tools/prof_scene.sh, run NOW as child processes of this one -- `rocprofv3 --pmc <one group>
+    -- python3 bench.py ...`, never combined with tracing, one pass at a time, after the timed region -- for a build of the library that
+    profiles/ holds no passes of (round 5 ended without GPU access: the line the driver records would otherwise carry `traffic: null`).
+    Returns (record like profiles/pmc_traffic.json, source text) or (None, why not).  The raw output stays under gpurun_out/prof_live/."""
+    import shutil
+    import subprocess
+    rp = shutil.which("rocprofv3")
+    if not rp:
+        return None, "no rocprofv3 on PATH"
+    out = os.path.join(ROOT, "gpurun_out", "prof_live")
+    try:
+        shutil.rmtree(out, ignore_errors=True)
+        os.makedirs(out)
+    except OSError:
+        import tempfile
+        out = tempfile.mkdtemp(prefix="rmdf_prof_live_")
+    env = dict(os.environ, RMDF_BENCH_PMC_CHILD="1", RMDF_BENCH_MIN_WARM="0", TMPDIR="/tmp")
+    env.pop("RMDF_BENCH_MARK", None)
+    me = os.environ.get("RMDF_BENCH_SELF", os.path.abspath(__file__))      # (the CPU tier's dry run names its own harness)
+    common = ["--steps", "20", "--warmup", "2", "--repeats", "1", "--no-cpu-baseline", "--no-secondary", "--no-animated", "--streams", "1", "--pmc", "off"]
+    t0, notes = time.monotonic(), []
+
+    def one_pass(name, counters, extra):
+        left = budget_s - (time.monotonic() - t0)
+        if left < 20:
+            notes.append("%s skipped (time budget)" % name)
+            return False
+        cmd = [rp, "--pmc"] + counters + ["--output-format", "csv", "-d", os.path.join(out, name), "--", sys.executable, me] + common + extra
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=min(left, 120))
+            open(os.path.join(out, name + ".log"), "w").write(r.stderr[-4000:])
+            if r.returncode != 0:
+                notes.append("%s rc=%d" % (name, r.returncode))
+            return r.returncode == 0
+        except Exception as e:                                  # noqa: BLE001
+            notes.append("%s: %s" % (name, e))
+            return False
+
+    ok = one_pass("pmc_fetch", ["FETCH_SIZE"], [])
+    ok = one_pass("pmc_write", ["WRITE_SIZE"], []) and ok
+    one_pass("pmc_sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVES", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES"], [])
+    if scenes:
+        import csv
+        import glob
+        import statistics
+        for name, sc in (("config2_cornell_1280x720_m128", 0), ("scene1_detest_1280x720_m128", 1), ("scene3_mbgeneral_1280x720_m128", 3)):
+            d = "pmc_scene%d" % sc
+            if not one_pass(d, ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVES", "GRBM_GUI_ACTIVE"],
+                            ["--scene", str(sc), "--width", "1280", "--height", "720", "--max-steps", "128"] + (["--time", {1: "2.5", 3: "3.0"}[sc]] if sc else [])):
+                continue
+            per = {}
+            for f in glob.glob(os.path.join(out, d, "**", "*_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "k_render<%d" % sc in r["Kernel_Name"] and r["Counter_Name"] == "SQ_INSTS_VALU":
+                        per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+            if per:
+                _LIVE_SCENE_PMC[name] = statistics.median(per.values())
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), out, "live"], capture_output=True, text=True, timeout=120)
+        rec = json.load(open(os.path.join(out, "summary", "pmc_traffic.json")))
+    except Exception as e:                                      # noqa: BLE001
+        return None, "live counter passes: no summary (%s; %s)" % (e, "; ".join(notes))
+    if rec.get("lib_sha256") != sha256_file(lib_path) or "hbm_bytes_per_launch" not in rec and "valu" not in rec:
+        return None, "live counter passes: nothing usable (%s)" % "; ".join(notes)
+    rec["command"] = "bench.py --pmc auto: child runs `rocprofv3 --pmc <one group per run> -- python3 bench.py --steps 20 --warmup 2 --streams 1 ...` after the timed region"
+    return rec, ("collected LIVE by this run: child processes under rocprofv3 --pmc, one counter group per pass, after the timed region (%.0f s; librmdf.so sha256 %s...%s); "
+                 "raw output in gpurun_out/prof_live/" % (time.monotonic() - t0, sha256_file(lib_path)[:12], ("; " + "; ".join(notes)) if notes else ""))
+
+
 def pmc_record(lib_path, workload):
     """PMC figures of the dominant kernel from the committed counter passes (profiles/pmc_traffic.json, written by
     tools/pmc_summary.py on the GPU box).  They are measurements of ONE build: used only when the file names this very
@@ -362,6 +435,9 @@ def main():
     ap.add_argument("--no-animated", action="store_true", help="skip the extra animated block behind `value_animated` (profiling runs whose "
                     "per-kernel averages should cover the headline frame only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc", choices=("auto", "off"), default=os.environ.get("RMDF_BENCH_PMC", "auto"),
+                    help="auto: when profiles/ holds no counter passes of THIS build of librmdf.so, collect them now -- child runs of this script "
+                         "under `rocprofv3 --pmc <one group>` after the timed region (N = 1 only; about a minute); off: never")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (Cornell config 2, env prefilter config 5)")
     ap.add_argument("--check", action="store_true", help="also compare the frame with the oracle (slow)")
     a = ap.parse_args()
@@ -815,6 +891,18 @@ def main():
         pmc, pmc_src = (None, "not collected for this workload")
         if not sharded and L == 0:
             pmc, pmc_src = pmc_record(lib_path, [scene, w, h, ms])
+            if (pmc is None and headline and a.pmc == "auto" and world == 1 and not os.environ.get("RMDF_BENCH_PMC_CHILD")
+                    and not os.environ.get("RMDF_LIB") and not a.no_secondary):
+                # no counter passes of THIS build are committed: collect them now (the GPU is idle: the timed region is over)
+                # (every child has its own timeout and the passes share a 240 s budget: no watchdog needed, and none that could cost the line)
+                try:
+                    live, live_src = live_pmc_passes(lib_path)
+                except Exception as e:                              # noqa: BLE001
+                    live, live_src = None, "live counter passes failed: %s" % e
+                if live is not None:
+                    pmc, pmc_src = live, live_src
+                else:
+                    pmc_src = pmc_src + "; " + live_src
         kname = "k_render<%d, %s, OUT_RGBA8>" % (scene, "true" if scene != 0 and not (int(os.environ.get("RMDF_FLAGS", "0")) & 16) else "false")
         result = {
             "metric": "Mpixels/s, Mandelbulb power-8 1920x1080 @256 steps; 1/2/4/8 GPU",
@@ -1020,10 +1108,10 @@ def scene_pmc(name, lib_path=None):
         rec = json.load(open(os.path.join(ROOT, "profiles", "scene_pmc.json"))).get(name, {})
         import rmdf_amd
         if rec.get("lib_sha256") != sha256_file(lib_path or os.environ.get("RMDF_LIB", rmdf_amd.LIB_PATH)):
-            return None
+            return _LIVE_SCENE_PMC.get(name)                    # (collected by this very run, if it did: live_pmc_passes)
         return rec.get("SQ_INSTS_VALU_per_launch")
     except Exception:                                           # noqa: BLE001
-        return None
+        return _LIVE_SCENE_PMC.get(name)
 
 
 def one_rank_exchange_leg(sr, torch, dev, stream, event_ms, scene, w, h, ms, t, plain_frame, dog=None, xcheck=False):

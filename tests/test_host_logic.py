@@ -1102,3 +1102,63 @@ def test_march_loop_classes_of_the_shipped_sources(tmp_path):
     for k in ("pass_instr", "vslots", "full_slots", "t_spec_ms", "t_sust_ms", "ops"):
         assert abs(committed[k] - d[k]) <= 1e-9 * abs(d[k]), k
     assert 0.55 < d["t_as_written_ms"] / d["t_spec_ms"] < 0.65          # (B) = 0.59 of (A)
+
+
+def test_bench_collects_its_own_counter_passes_when_profiles_has_none_of_this_build(tmp_path):
+    """Round 6: profiles/pmc_traffic.json names the library it was measured with; for any other build bench.py used to print `traffic: null`.
+    Now (--pmc auto, N = 1, headline workload) it runs the counter passes itself after the timed region: children under `rocprofv3 --pmc <one
+    group>`, condensed by tools/pmc_summary.py.  Here the HIP double stands in for the GPU and a script for rocprofv3 (it runs the child
+    and writes a counter file in rocprofv3's CSV layout): the plumbing end to end -- traffic, issue block and the secondary scenes' instruction
+    counts arrive in the line, labelled as collected live."""
+    import json
+    import shutil
+    import stat
+    import subprocess
+    import sys
+    import rmdf_amd
+    from conftest import ROOT
+    fake = tmp_path / "bin"
+    fake.mkdir()
+    script = fake / "rocprofv3"
+    script.write_text('''#!%s
+import os, subprocess, sys
+a = sys.argv[1:]
+cmd = a[a.index("--") + 1:]
+d = a[a.index("-d") + 1]
+ctrs = []
+i = a.index("--pmc") + 1
+while not a[i].startswith("-"):
+    ctrs.append(a[i]); i += 1
+assert "--kernel-trace" not in a and "--sys-trace" not in a          # counters are never combined with tracing
+rc = subprocess.call(cmd)
+sc = cmd[cmd.index("--scene") + 1] if "--scene" in cmd else "2"
+os.makedirs(os.path.join(d, "host"), exist_ok=True)
+val = {"FETCH_SIZE": 9000.0, "WRITE_SIZE": 8200.0, "SQ_INSTS_VALU": 3.0e8, "SQ_ACTIVE_INST_VALU": 3.1e8, "SQ_THREAD_CYCLES_VALU": 1.5e10}
+with open(os.path.join(d, "host", "123_counter_collection.csv"), "w") as f:
+    f.write("Dispatch_Id,Kernel_Name,Grid_Size,Workgroup_Size,LDS_Block_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value\\n")
+    for disp in range(1, 6):
+        for c in ctrs:
+            f.write('%%d,"void rmdf::k_render<%%s, true, 0>(rmdf::FrameParams)",2073600,256,17920,56,0,80,%%s,%%f\\n' %% (disp, sc, c, val.get(c, 1000.0)))
+sys.exit(rc)
+''' % sys.executable)
+    script.chmod(script.stat().st_mode | stat.S_IXUSR)
+    hdr = str(tmp_path / "probe.hdr")
+    shutil.copy(rmdf_amd.DEFAULT_ENV_HDR, hdr)
+    env = dict(os.environ, LD_PRELOAD=_fake_hip_lib(), RMDF_ENV_HDR=hdr, PATH=str(fake) + os.pathsep + os.environ["PATH"],
+               RMDF_BENCH_SELF=os.path.join(ROOT, "tests", "bench_dry_run.py"))
+    for k in ("RMDF_LIB", "RMDF_FLAGS", "RANK", "WORLD_SIZE", "LOCAL_RANK", "RMDF_BENCH_PMC", "RMDF_BENCH_PMC_CHILD"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_dry_run.py"), "--steps", "2", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    rl = d["roofline"]
+    committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    import hashlib
+    if committed.get("lib_sha256") == hashlib.sha256(open(rmdf_amd.LIB_PATH, "rb").read()).hexdigest():
+        pytest.skip("profiles/pmc_traffic.json is of this build: nothing to collect")
+    assert rl["traffic"] == (9000.0 + 8200.0) * 1024.0 and "LIVE" in rl["traffic_source"], rl.get("traffic_source")
+    assert rl["issue"]["valu_instructions_per_launch"] == 3.0e8
+    for name in ("config2_cornell_1280x720_m128", "scene1_detest_1280x720_m128", "scene3_mbgeneral_1280x720_m128"):
+        assert d["secondary"][name]["roofline"].get("issue_g_wave_instr_s_simd") is not None, name
+    shutil.rmtree(os.path.join(ROOT, "gpurun_out", "prof_live"), ignore_errors=True)

@@ -4,7 +4,8 @@ export TMPDIR=/tmp
 sc=${1:-0}; w=${2:-1280}; h=${3:-720}; ms=${4:-128}
 out=gpurun_out/prof_scene$sc
 rm -rf $out; mkdir -p $out
-A="--scene $sc --width $w --height $h --max-steps $ms --no-cpu-baseline --no-secondary --repeats 1 --steps 20 --warmup 2 --streams 1"
+tm=0.0; [ "$sc" = 1 ] && tm=2.5; [ "$sc" = 3 ] && tm=3.0      # the committed views bench.py's secondary workloads time (tests/golden/full_size_digests.json)
+A="--scene $sc --time $tm --pmc off --width $w --height $h --max-steps $ms --no-cpu-baseline --no-secondary --repeats 1 --steps 20 --warmup 2 --streams 1"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES GRBM_GUI_ACTIVE SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $out/p1 -- python3 bench.py $A > /dev/null 2> $out/p1.log
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_LDS --output-format csv -d $out/p2 -- python3 bench.py $A > /dev/null 2> $out/p2.log
 python3 - $sc <<'PY'

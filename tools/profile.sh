@@ -13,7 +13,7 @@ out=gpurun_out/prof_$tag
 mkdir -p "$out"
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-args="--steps 100 --warmup 10 --no-cpu-baseline"
+args="--steps 100 --warmup 10 --no-cpu-baseline --pmc off"
 export RMDF_BENCH_MARK=1     # marker dispatches around the timed blocks (tools/pmc_summary.py cuts the trace there)
 # (--no-secondary --no-animated: k_render<2, true, 0> is then launched for the headline frame only, so its row of the stats file IS the
 #  headline kernel's average; Cornell, the prefilter and the animated block are in the default run's files)
@@ -21,7 +21,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_s1" -- pytho
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_default" -- python3 bench.py $args > "$out/bench_default.json" 2> "$out/trace_default.log"
 export RMDF_BENCH_MIN_WARM=0
 unset RMDF_BENCH_MARK
-pmc_args="--steps 20 --warmup 2 --repeats 1 --no-cpu-baseline --no-secondary --streams 1"
+pmc_args="--steps 20 --warmup 2 --repeats 1 --no-cpu-baseline --no-secondary --streams 1 --pmc off"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py $pmc_args > /dev/null 2> "$out/pmc_fetch.log"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py $pmc_args > /dev/null 2> "$out/pmc_write.log"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d "$out/pmc_sq" -- python3 bench.py $pmc_args > /dev/null 2> "$out/pmc_sq.log"
