@@ -41,6 +41,10 @@ int rmdf_debug_cornell_masks(int n, int brute_force, uint32_t *out);
  * plane and its three edge planes, four floats each from float CORNELL_BOUNDS on).  out: 32 * stride floats; *stride and *bounds
  * (either may be NULL) receive the two offsets.  tests/test_host_logic.py holds every plane to "a lower bound of the distance". */
 int rmdf_debug_cornell_table(float *out, int *stride, int *bounds);
+/* ... and the 32 x 8 floats that follow the rows in device memory: per triangle its plane (normal, offset) and a bounding sphere (centre,
+ * radius) -- the bounds of the wave-uniform pruned estimate (rmdf_device.hpp: de_cornell_box_table; cross-check schedules).
+ * tests/device_on_host.cpp runs that estimate on the CPU with them. */
+int rmdf_debug_cornell_bounds(float *out);
 
 /* Host-only check aids: the tables the env-map kernels only gather through, as the library builds them on the host with glibc's
  * acosf / atanf / cosf / sinf (the functions GHC's Float instances call in the reference).

@@ -59,7 +59,7 @@ ABI_SYMBOLS = (
     "rmdf_copy_to_host", "rmdf_probe_shader_clock", "rmdf_comm_selftest_loopback", "rmdf_get_cornell_vertices",
     "rmdf_get_shader_constants",
 )
-XCHECK_SYMBOLS = ("rmdf_debug_march_stats", "rmdf_debug_cornell_masks", "rmdf_debug_cornell_table", "rmdf_debug_cube_uv_table",
+XCHECK_SYMBOLS = ("rmdf_debug_march_stats", "rmdf_debug_cornell_masks", "rmdf_debug_cornell_table", "rmdf_debug_cornell_bounds", "rmdf_debug_cube_uv_table",
                   "rmdf_debug_lobe_tables", "rmdf_debug_camera", "rmdf_debug_hdr_decode", "rmdf_debug_hdr_encode")      # include/rmdf_xcheck.h
 
 

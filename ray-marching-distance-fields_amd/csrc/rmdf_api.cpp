@@ -2236,6 +2236,17 @@ int rmdf_debug_cornell_table(float *out, int *stride, int *bounds)
     return RMDF_OK;
 }
 
+int rmdf_debug_cornell_bounds(float *out)
+{
+    // host-only: the compact bounds table behind the rows (32 x 8 floats: plane, bounding sphere) that the wave-uniform pruned estimate reads
+    if (!out) return RMDF_E_INVALID;
+    float tri[96 * 3], tab[CORNELL_TAB_FLOATS];
+    cornell_triangles(tri);
+    cornell_table(tri, tab);
+    memcpy(out, tab + 32 * CORNELL_STRIDE, sizeof(float) * 32 * 8);
+    return RMDF_OK;
+}
+
 int rmdf_debug_camera(int scene, float time, float cam[12], float *fov_xs)
 {
     // host-only: the camera block every frame's kernel arguments carry (host_camera, host_fov_xs)

@@ -89,9 +89,13 @@ __device__ __forceinline__ bool root_needs_slow_rcp(float s) { return (uint16_t)
 // the hottest loop of the library (-2 % on the headline frame); rsqrt_ieee keeps the compiler's form, which measured 1 % better on the Cornell box.
 __device__ __forceinline__ unsigned long long root_needs_slow_rcp_lanes(float s)
 {
+#ifdef RMDF_HOST_EMULATION       // tests/device_on_host.cpp: this header compiled for the CPU, one lane at a time (no gfx950 assembly there)
+    return root_needs_slow_rcp(s) ? 1ull : 0ull;
+#else
     unsigned long long lanes;
     asm("v_cmp_eq_u16_e64 %0, %1, %2" : "=s"(lanes) : "v"(__float_as_uint(s)), "s"(0xffffu));
     return lanes;
+#endif
 }
 __device__ __forceinline__ float rcp_core(float x)         // |x| in [2^-100, 2^100]
 {
@@ -448,7 +452,9 @@ __device__ __forceinline__ float de_mandelbulb8(v3 pos, unsigned &iters, float f
     if (__builtin_expect(__ballot(redo) != 0ull, 0)) {
         if (redo) {
             v3 q = pos;
+#ifndef RMDF_HOST_EMULATION
             asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z));
+#endif
             n = 0u;
             dist = de_mandelbulb8_written_inl(q, n);
             if (n_redone) ++*n_redone;
@@ -903,9 +909,14 @@ __device__ __forceinline__ unsigned cornell_cell_mask_fast(v3 p, const unsigned 
 {
     const float s = (float)N / (2.0f * CORNELL_GRID_H), hs = CORNELL_GRID_H * s;
     int ix, iy, iz;
+#ifdef RMDF_HOST_EMULATION       // (v_cvt_flr_i32_f32 = floor, then a saturating conversion; NaN -> 0)
+    auto flr = [](float f) -> int { const float g = floorf(f); return !(g == g) ? 0 : (g >= 2147483648.0f ? 2147483647 : (g <= -2147483648.0f ? -2147483647 - 1 : (int)g)); };
+    ix = flr(__builtin_fmaf(p.x, s, hs)); iy = flr(__builtin_fmaf(p.y, s, hs)); iz = flr(__builtin_fmaf(p.z, s, hs));
+#else
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ix) : "v"(__builtin_fmaf(p.x, s, hs)));
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iy) : "v"(__builtin_fmaf(p.y, s, hs)));
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iz) : "v"(__builtin_fmaf(p.z, s, hs)));
+#endif
     if ((unsigned)ix >= (unsigned)N || (unsigned)iy >= (unsigned)N || (unsigned)iz >= (unsigned)N) return 0xffffffffu;
     return grid[(iz * N + iy) * N + ix];
 }
