@@ -40,6 +40,22 @@ RMDF_SHADER_CONSTANTS(RMDF_X)
 constexpr int mb_iterations_i = (int)mb_iterations;
 }  // namespace shk
 
+// Three wave operations under names of their own, because at these places their MEANING does not depend on which other lanes take part:
+// RMDF_LANES_HERE(x) is "does some lane that is here with me need the rare path" in front of a per-lane fix-up (`if (any) { if (mine) ... }`)
+// or the loop condition of per-lane work lists, RMDF_READLANE_HERE / RMDF_READFIRSTLANE_HERE pick an evaluation ORDER (a hint, a mask
+// that only has to be a superset), never a result.  On the device they are the plain instructions (pure text: same ISA).  The CPU tier
+// compiles this header one lane at a time (tests/device_on_host.cpp) and the render kernel under a SIMT emulator where __ballot is a true
+// 64-lane collective (tests/kernel_on_host.cpp): there these three act on the calling lane alone, which is what makes divergent callers legal.
+#ifdef RMDF_HOST_EMULATION
+#define RMDF_LANES_HERE(x) ((x) ? 1ull : 0ull)
+#define RMDF_READLANE_HERE(v, l) (v)
+#define RMDF_READFIRSTLANE_HERE(v) (v)
+#else
+#define RMDF_LANES_HERE(x) __ballot(x)
+#define RMDF_READLANE_HERE(v, l) __builtin_amdgcn_readlane((v), (l))
+#define RMDF_READFIRSTLANE_HERE(v) __builtin_amdgcn_readfirstlane(v)
+#endif
+
 struct v3 { float x, y, z; };
 
 __device__ __forceinline__ v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -110,14 +126,14 @@ __device__ __forceinline__ float sqrt_rn(float x)
     float s = sqrt_core(x);
     // one unsigned compare on the raw bits: negative numbers have the sign bit set and fall out of range too
     const bool bad = (__float_as_uint(x) - 0x0d800000u) > (0x71800000u - 0x0d800000u);
-    if (__builtin_expect(__ballot(bad) != 0ull, 0)) { if (bad) s = sqrtf(x); }
+    if (__builtin_expect(RMDF_LANES_HERE(bad) != 0ull, 0)) { if (bad) s = sqrtf(x); }
     return s;
 }
 __device__ __forceinline__ float rcp_rn(float x)
 {
     float y = rcp_core(x);
     const bool bad = !in_core_range(x);
-    if (__builtin_expect(__ballot(bad) != 0ull, 0)) { if (bad) y = 1.0f / x; }
+    if (__builtin_expect(RMDF_LANES_HERE(bad) != 0ull, 0)) { if (bad) y = 1.0f / x; }
     return y;
 }
 // a / b for operands whose range is known at the call site: |b| in [2^-40, 2^40], a = 0 or |a| in
@@ -162,7 +178,7 @@ __device__ __forceinline__ float rsqrt_ieee(float x)
     const float s = sqrt_core_y(x, y0);
     float y = rcp_of_root(s, y0);
     const bool bad = (int)((__float_as_uint(x) - 0x0d800000u) > (0x71800000u - 0x0d800000u)) | (int)root_needs_slow_rcp(s);
-    if (__builtin_expect(__ballot(bad) != 0ull, 0)) { if (bad) y = 1.0f / sqrtf(x); }
+    if (__builtin_expect(RMDF_LANES_HERE(bad) != 0ull, 0)) { if (bad) y = 1.0f / sqrtf(x); }
     return y;
 }
 __device__ __forceinline__ v3 normalize3(v3 a)
@@ -215,7 +231,7 @@ __device__ __forceinline__ float log_pinned(float x)
 {
     const bool special = (__float_as_uint(x) - 0x00800000u) >= (0x7f800000u - 0x00800000u);
     float r = log_core(x, 0);
-    if (__builtin_expect(__ballot(special) != 0ull, 0)) { if (special) r = log_special(x); }
+    if (__builtin_expect(RMDF_LANES_HERE(special) != 0ull, 0)) { if (special) r = log_special(x); }
     return r;
 }
 
@@ -270,7 +286,7 @@ __device__ __forceinline__ float exp_pinned(float x)
 {
     const bool special = !((x >= -87.0f) && (x <= 88.5f));
     float y = exp_core(special ? 0.0f : x);
-    if (__builtin_expect(__ballot(special) != 0ull, 0)) {
+    if (__builtin_expect(RMDF_LANES_HERE(special) != 0ull, 0)) {
         if (special) y = (x != x) ? x : ((x > 88.5f) ? __builtin_inff() : 0.0f);
     }
     return y;
@@ -315,7 +331,7 @@ __device__ __forceinline__ float div_by_dr(float a, float dr)
     const float q0 = a * y;
     float q = __builtin_fmaf(__builtin_fmaf(-dr, q0, a), y, q0);
     const bool bad = (int)!(dr <= 0x1p60f) | (int)!(fabsf(q) >= 0x1p-100f);
-    if (__builtin_expect(__ballot(bad) != 0ull, 0)) { if (bad) q = a / dr; }
+    if (__builtin_expect(RMDF_LANES_HERE(bad) != 0ull, 0)) { if (bad) q = a / dr; }
     return q;
 }
 
@@ -343,7 +359,7 @@ __device__ __forceinline__ void mb8_roots(float d, float k3, float q, float &r, 
     const float sq = sqrt_core_y(q, y0);
     k2 = rcp_of_root(sq, y0);
     const bool small = k3 < RMDF_MB8_K3MIN;
-    if (__builtin_expect((__ballot(small) | root_needs_slow_rcp_lanes(sq)) != 0ull, 0)) {
+    if (__builtin_expect((RMDF_LANES_HERE(small) | root_needs_slow_rcp_lanes(sq)) != 0ull, 0)) {
         if ((int)small | (int)root_needs_slow_rcp(sq)) { r = sqrtf(d); k2 = 1.0f / sqrtf(q); }
     }
 }
@@ -405,7 +421,7 @@ __device__ __forceinline__ void mb8_iterate_t(v3 &w, const v3 pos, float &dr, fl
             const float sq = sqrt_core_y(q, y0);
             float k2 = rcp_of_root(sq, y0);
             const bool small = k3 < RMDF_MB8_K3MIN;
-            if (__builtin_expect((__ballot(small) | root_needs_slow_rcp_lanes(sq)) != 0ull, 0)) {
+            if (__builtin_expect((RMDF_LANES_HERE(small) | root_needs_slow_rcp_lanes(sq)) != 0ull, 0)) {
                 if ((int)small | (int)root_needs_slow_rcp(sq)) { r = sqrtf(d); k2 = 1.0f / sqrtf(q); if (small) m = 0.0f; }
             }
             const float a = a_ * k2, b = b_ * k2;
@@ -449,7 +465,7 @@ __device__ __forceinline__ float de_mandelbulb8(v3 pos, unsigned &iters, float f
     mb8_iterate_t<true>(w, p, dr, r, d, 0, shk::mb_iterations_i, n, m);
     float dist = mb8_finish(dr, r, d);
     const bool redo = mb8_fold_failed(m, fold_min);
-    if (__builtin_expect(__ballot(redo) != 0ull, 0)) {
+    if (__builtin_expect(RMDF_LANES_HERE(redo) != 0ull, 0)) {
         if (redo) {
             v3 q = pos;
 #ifndef RMDF_HOST_EMULATION
@@ -588,7 +604,7 @@ __device__ __forceinline__ float acos_pinned(float x)
     const float wp = r * s + c;
     const float r_pos = 2.0f * (df + wp);
     float res = small ? r_small : ((x < 0.0f) ? r_neg : r_pos);
-    if (__builtin_expect(__ballot(special) != 0ull, 0)) { if (special) res = acos_full_inl(x); }
+    if (__builtin_expect(RMDF_LANES_HERE(special) != 0ull, 0)) { if (special) res = acos_full_inl(x); }
     return res;
 }
 __device__ __forceinline__ float atan_full_inl(float x)
@@ -652,7 +668,7 @@ __device__ __forceinline__ float atan_pinned(float x)
     const float r_small = t - t * (s1 + s2);
     const float zz = hi - ((t * (s1 + s2) - lo) - t);
     float res = small ? r_small : (neg ? -zz : zz);
-    if (__builtin_expect(__ballot(special) != 0ull, 0)) { if (special) res = atan_full_inl(x); }
+    if (__builtin_expect(RMDF_LANES_HERE(special) != 0ull, 0)) { if (special) res = atan_full_inl(x); }
     return res;
 }
 // GLSL atan(y, x), every special case
@@ -687,7 +703,7 @@ __device__ __forceinline__ float atan2_pinned(float y, float x)
     const int m = (int)((__float_as_uint(y) >> 31) | ((__float_as_uint(x) >> 30) & 2u));
     const float z = atan_pinned(special ? 1.0f : ay / ax);
     float res = (m == 0) ? z : (m == 1) ? -z : (m == 2) ? pi - (z - pi_lo) : (z - pi_lo) - pi;
-    if (__builtin_expect(__ballot(special) != 0ull, 0)) { if (special) res = atan2_full_inl(y, x); }
+    if (__builtin_expect(RMDF_LANES_HERE(special) != 0ull, 0)) { if (special) res = atan2_full_inl(y, x); }
     return res;
 }
 
@@ -825,7 +841,7 @@ __device__ __forceinline__ float div_by_table(float x, float len, float rlen)
     float q = __builtin_fmaf(r0, rlen, q0);
     const unsigned ax = __float_as_uint(x) & 0x7fffffffu;
     const bool bad = (ax - 0x21800000u) > (0x5d800000u - 0x21800000u);   // |x| outside 2^-60 .. 2^60 (zeros too: sign of -0/len)
-    if (__builtin_expect(__ballot(bad) != 0ull, 0)) { if (bad) q = x / len; }
+    if (__builtin_expect(RMDF_LANES_HERE(bad) != 0ull, 0)) { if (bad) q = x / len; }
     return q;
 }
 __device__ __forceinline__ float seg_dist_sq_table(v3 a, v3 ab, float len, float rlen, v3 pa, v3 p)
@@ -925,9 +941,9 @@ __device__ __forceinline__ unsigned wave_or_active(unsigned m)
 {
     unsigned acc = 0u;
     for (;;) {
-        const unsigned long long need = __ballot((m & ~acc) != 0u);
+        const unsigned long long need = RMDF_LANES_HERE((m & ~acc) != 0u);
         if (need == 0ull) break;
-        acc |= (unsigned)__builtin_amdgcn_readlane((int)m, (int)__builtin_ctzll(need));
+        acc |= (unsigned)RMDF_READLANE_HERE((int)m, (int)__builtin_ctzll(need));
     }
     return acc;
 }
@@ -957,7 +973,7 @@ __device__ __forceinline__ float de_cornell_box_lanes(v3 pos, const float *rows,
     // with the margin widened to 3e-5 (keep): (1.001 r + 3e-5)^2 = 1.002001 b + 6.006e-5 r + 9e-10 <= 1.0031 b + 8.3e-7  (6.006e-5 r <= 0.0011 b + 8.2e-7)
     const float dmax2 = __builtin_fmaf(best, 1.0031f, keep ? 8.3e-7f : 1.02e-7f);
     unsigned my = m & ~(1u << g), surv = 0u;
-    while (__ballot(my != 0u) != 0ull) {
+    while (RMDF_LANES_HERE(my != 0u) != 0ull) {
         if (my != 0u) {
             const int i = (int)__builtin_ctz(my);
             my &= my - 1u;
@@ -977,7 +993,7 @@ __device__ __forceinline__ float de_cornell_box_lanes(v3 pos, const float *rows,
         }
     }
     if (keep) *keep = surv | (1u << g);
-    while (__ballot(surv != 0u) != 0ull) {
+    while (RMDF_LANES_HERE(surv != 0u) != 0ull) {
         if (surv != 0u) {
             const int i = (int)__builtin_ctz(surv);
             surv &= surv - 1u;
@@ -992,7 +1008,7 @@ __device__ __forceinline__ float de_cornell_box_lanes(v3 pos, const float *rows,
 __device__ __forceinline__ float de_cornell_box_lanes_kept(v3 pos, const float *rows, unsigned kept)
 {
     float best = 998001.0f;
-    while (__ballot(kept != 0u) != 0ull) {
+    while (RMDF_LANES_HERE(kept != 0u) != 0ull) {
         if (kept != 0u) {
             const int i = (int)__builtin_ctz(kept);
             kept &= kept - 1u;
@@ -1099,7 +1115,7 @@ __device__ __forceinline__ float de_cornell_box_table(v3 pos, const float *__res
     unsigned cand = grid ? wave_or_active(cornell_cell_mask(pos, grid)) : 0xffffffffu;
     if (cand == 0u) cand = 0xffffffffu;                        // cannot happen with a well-formed grid (the nearest triangle is always in)
     // the triangle that was nearest last time first, unconditionally (if it is a candidate; else the first candidate)
-    int g = __builtin_amdgcn_readfirstlane(hint) & 31;
+    int g = RMDF_READFIRSTLANE_HERE(hint) & 31;
     if (!((cand >> g) & 1u)) g = (int)__builtin_ctz(cand);
     dist2 = cornell_tri_dist2(pos, ctab + g * CORNELL_STRIDE);
     float dmax = __builtin_amdgcn_sqrtf(dist2) * 1.001f + 1e-5f;

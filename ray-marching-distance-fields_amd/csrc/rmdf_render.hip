@@ -482,7 +482,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
                 unsigned n = 0u;
                 mb8_iterate_t<true>(w, pos, dr, r, d, 0, AO_CUT, n, m);
                 const bool redo = mb8_fold_failed(m, fold_min_of(p));   // rmdf_device.hpp: the folded passes need the written ones' range
-                if (__builtin_expect(__ballot(redo) != 0ull, 0)) {
+                if (__builtin_expect(RMDF_LANES_HERE(redo) != 0ull, 0)) {
                     if (redo) { w = pos; dr = 1.0f; r = 0.0f; d = 0.0f; n = 0u; mb8_iterate_t<false>(w, pos, dr, r, d, 0, AO_CUT, n, m); }
                 }
                 iters += n;
@@ -520,7 +520,7 @@ __device__ __forceinline__ void render_body(const FrameParams &p)
                 float m = 1.0f;
                 mb8_iterate_t<true>(w, pos, dr, r, d, AO_CUT, shk::mb_iterations_i, it2, m);
                 const bool redo = mb8_fold_failed(m, fold_min_of(p));
-                if (__builtin_expect(__ballot(redo) != 0ull, 0)) {
+                if (__builtin_expect(RMDF_LANES_HERE(redo) != 0ull, 0)) {
                     if (redo) { w = mk3(a.x, a.y, a.z); dr = a.w; r = b.w; d = 0.0f; it2 = 0u; mb8_iterate_t<false>(w, pos, dr, r, d, AO_CUT, shk::mb_iterations_i, it2, m); }
                 }
                 s_ao_out[tsk] = make_float2(mb8_finish(dr, r, d), __uint_as_float(it2));

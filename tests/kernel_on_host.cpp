@@ -1,0 +1,227 @@
+// kernel_on_host.cpp -- TEST INFRASTRUCTURE (CPU tier, round 6): the render kernel's SOURCE -- csrc/rmdf_render.hip as it is, render_body with its
+// march loops, the workgroup pooling of stragglers through LDS mailboxes, the AO queue, the eight-lanes-per-ray Cornell tail with its DPP
+// minima, the quad exchanges, the LDS-staged stores, the strip-cost reduction, and the library's own launch code (launch_render: grid,
+// variant choice, block order) -- compiled for the CPU and executed by the SIMT emulator of tests/koh_shim/hip/hip_runtime.h (one fiber per
+// lane, wave collectives and workgroup barriers with the hardware's meaning).  tests/test_kernel_source_on_host.py renders small frames
+// with it and holds every plane to the oracle's: step counts, hit mask and escape-iteration counts bit-exact, float colour and RGBA8
+// bit-exact too (same source arithmetic, correctly rounded seeds).  What it cannot see: the code generator, the hardware's memory model
+// (the mailbox protocol's acquire / release pairs are plain accesses here), timing.  Never part of the product.
+#include <ucontext.h>
+
+#include <atomic>
+#include <thread>
+#include <vector>
+
+#define RMDF_HOST_EMULATION 1
+#include "rmdf_render.hip"           // (-I csrc; <hip/hip_runtime.h>, <hip/hip_fp16.h> resolve to tests/koh_shim/)
+
+thread_local int doh_seed_mode = 0;
+thread_local unsigned doh_seed_rng = 12345u;
+
+namespace koh {
+
+thread_local Lane *cur = nullptr;
+thread_local Grid *grd = nullptr;
+
+namespace {
+
+constexpr size_t kStack = 256 * 1024;
+struct Fiber { ucontext_t ctx; Lane lane; bool done; };
+struct WaveState { int arrived = 0; unsigned gen = 0; uint64_t val[2][64]; const char *what[2] = { nullptr, nullptr }; };
+struct Block {
+    std::vector<Fiber> fib;
+    std::vector<WaveState> waves;
+    int sync_arrived = 0; unsigned sync_gen = 0;
+    ucontext_t sched;
+    void (*tramp)(void *) = nullptr; void *closure = nullptr;
+    char *stacks = nullptr; size_t nstacks = 0;
+    unsigned long long idle_spins = 0;
+};
+thread_local Block *blk = nullptr;
+std::atomic<unsigned long long> g_counts[6];
+std::atomic<int> g_seed_mode{ 0 };
+std::atomic<int> g_threads{ 1 };
+
+void fiber_main()
+{
+    blk->tramp(blk->closure);
+    Fiber *f = (Fiber *)((char *)cur - offsetof(Fiber, lane));
+    f->done = true;
+    swapcontext(&f->ctx, &blk->sched);
+}
+
+void run_block(Block &b, Grid &g, unsigned bx, unsigned by, unsigned bz)
+{
+    const unsigned nt = g.block.x * g.block.y * g.block.z;
+    if (nt % 64u) { fprintf(stderr, "koh: workgroup of %u threads is not whole waves\n", nt); abort(); }
+    g.bid = uint3{ bx, by, bz };
+    b.fib.resize(nt);
+    b.waves.assign(nt / 64u, WaveState());
+    b.sync_arrived = 0;
+    if (b.nstacks < nt) { free(b.stacks); b.stacks = (char *)malloc((size_t)nt * kStack); b.nstacks = nt; }
+    for (unsigned t = 0; t < nt; t++) {
+        Fiber &f = b.fib[t];
+        f.done = false;
+        f.lane.tid = uint3{ t % g.block.x, (t / g.block.x) % g.block.y, t / (g.block.x * g.block.y) };
+        f.lane.lane = (int)(t & 63u); f.lane.wave = (int)(t >> 6);
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = b.stacks + (size_t)t * kStack;
+        f.ctx.uc_stack.ss_size = kStack;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, fiber_main, 0);
+    }
+    blk = &b; grd = &g;
+    unsigned long long rounds = 0;
+    for (;;) {
+        bool any = false;
+        for (unsigned t = 0; t < nt; t++) {
+            Fiber &f = b.fib[t];
+            if (f.done) continue;
+            any = true;
+            cur = &f.lane;
+            swapcontext(&b.sched, &f.ctx);
+        }
+        if (!any) break;
+        if (++rounds > 20000000ull) {
+            fprintf(stderr, "koh: workgroup (%u, %u, %u) makes no progress: lanes wait in", bx, by, bz);
+            for (auto &w : b.waves) fprintf(stderr, " [%s: %d of 64 arrived]", w.what[w.gen & 1u] ? w.what[w.gen & 1u] : "-", w.arrived);
+            fprintf(stderr, " [__syncthreads: %d of %u]\n", b.sync_arrived, nt);
+            abort();
+        }
+    }
+    cur = nullptr;
+}
+
+}  // namespace
+
+void count(int kind) { g_counts[kind].fetch_add(1, std::memory_order_relaxed); }
+
+void yield_lane()
+{
+    Fiber *f = (Fiber *)((char *)cur - offsetof(Fiber, lane));
+    swapcontext(&f->ctx, &blk->sched);
+}
+
+const uint64_t *wave_gather(uint64_t v, const char *what)
+{
+    WaveState &w = blk->waves[(size_t)cur->wave];
+    const unsigned g = w.gen, slot = g & 1u;
+    if (w.arrived == 0) w.what[slot] = what;
+    else if (w.what[slot] != what) {
+        fprintf(stderr, "koh: lanes of one wave meet in DIFFERENT collectives (%s vs %s): a collective under divergent control flow\n", w.what[slot], what);
+        abort();
+    }
+    w.val[slot][cur->lane] = v;
+    if (++w.arrived == 64) { w.arrived = 0; w.gen = g + 1u; }
+    else while (w.gen == g) yield_lane();
+    return w.val[slot];
+}
+
+void block_barrier()
+{
+    Block &b = *blk;
+    const unsigned g = b.sync_gen;
+    if (++b.sync_arrived == (int)b.fib.size()) { b.sync_arrived = 0; b.sync_gen = g + 1u; }
+    else while (b.sync_gen == g) yield_lane();
+}
+
+void launch(dim3 grid, dim3 block, void (*tramp)(void *), void *closure)
+{
+    const unsigned long long nblk = (unsigned long long)grid.x * grid.y * grid.z;
+    if (nblk == 0) return;
+    std::atomic<unsigned long long> next{ 0 };
+    const int nthreads = (int)std::min<unsigned long long>((unsigned long long)std::max(1, g_threads.load()), nblk);
+    auto worker = [&] {
+        doh_seed_mode = g_seed_mode.load(); doh_seed_rng = 777u;
+        Block b; Grid g; g.grid = grid; g.block = block;
+        b.tramp = tramp; b.closure = closure;
+        for (;;) {
+            const unsigned long long i = next.fetch_add(1);
+            if (i >= nblk) break;
+            run_block(b, g, (unsigned)(i % grid.x), (unsigned)((i / grid.x) % grid.y), (unsigned)(i / ((unsigned long long)grid.x * grid.y)));
+        }
+        free(b.stacks);
+        blk = nullptr; grd = nullptr;
+    };
+    if (nthreads == 1) { worker(); return; }
+    std::vector<std::thread> ts;
+    for (int t = 0; t < nthreads; t++) ts.emplace_back(worker);
+    for (auto &t : ts) t.join();
+}
+
+}  // namespace koh
+
+extern "C" {
+
+struct KohFrame {          // mirrored in the Python test (ctypes)
+    int scene, w, h, x0, y0, x1, y1, max_steps;
+    float cam[12], fov_xs, time;
+    int no_merge, no_prune;
+    const void *env_refl, *env_cos1, *env_cos8;      // padded RGB16F texels (6 x (W+2)^2 x 4 halfs)
+    int w_refl, w_cos1, w_cos8;
+    const float *cornell_tri, *cornell_tab;
+    const unsigned *cornell_grid;
+    uint32_t *rgba8, *rgba8_mirror;
+    float *rgba_f32;
+    uint16_t *steps, *iters;
+    const unsigned *block_order;
+    unsigned *block_cost;
+    int n_shard_tiles;
+    unsigned char shard_tile[64];
+    int threads, seed_mode;
+};
+
+int koh_frame_size(void) { return (int)sizeof(KohFrame); }
+
+// lane-calls of every collective kind since the last call (ballot, shuffles, readfirstlane, DPP, polled loads, __syncthreads): a test can tell
+// that a frame DID go through the pooled march's mailboxes or the Cornell tail's DPP minima
+void koh_take_counts(unsigned long long out[6]) { for (int k = 0; k < 6; k++) out[k] = koh::g_counts[k].exchange(0); }
+
+// the frame parameters as rmdf_api.cpp's fill_params + its callers set them, then the library's own launch_render
+int koh_render(const KohFrame *f)
+{
+    using namespace rmdf;
+    FrameParams p;
+    memset(&p, 0, sizeof p);
+    memcpy(p.cam, f->cam, sizeof p.cam);
+    p.fov_xs = f->fov_xs;
+    {
+        const float a = f->time / 2.0f;                              // fragment.shd:116-119 (rmdf_api.cpp: fill_params)
+        float pow_offs = a - 9.0f * floorf(a / 9.0f);
+        if (pow_offs > 4.5f) pow_offs = 9.0f - pow_offs;
+        p.power = pow_offs + 2.0f;
+    }
+    p.wf = (float)f->w; p.hf = (float)f->h; p.aspect = p.wf / p.hf;
+    p.w = f->w; p.h = f->h;
+    p.max_steps = f->max_steps <= 0 ? (int)shk::march_max_steps_default : f->max_steps;
+    p.x0 = f->x0; p.y0 = f->y0; p.x1 = f->x1; p.y1 = f->y1;
+    p.n_shard_tiles = f->n_shard_tiles;
+    memcpy(p.shard_tile, f->shard_tile, 64);
+    p.env_refl = CubeDev{ (const uint2 *)f->env_refl, f->w_refl };
+    p.env_cos1 = CubeDev{ (const uint2 *)f->env_cos1, f->w_cos1 };
+    p.env_cos8 = CubeDev{ (const uint2 *)f->env_cos8, f->w_cos8 };
+    p.cornell = f->cornell_tri; p.cornell_tab = f->cornell_tab; p.cornell_grid = f->cornell_grid;
+    p.cornell_prune = f->no_prune ? 0 : 1;
+    p.merge_stragglers = (f->no_merge || f->scene == 0) ? 0 : 32;
+    p.rgba8 = f->rgba8; p.rgba8_mirror = f->rgba8_mirror; p.rgba_f32 = (float4 *)f->rgba_f32; p.steps = f->steps; p.iters = f->iters;
+    p.block_order = f->block_order; p.block_cost = f->block_cost;
+    koh::g_seed_mode = f->seed_mode; koh::g_threads = f->threads;
+    return (int)launch_render(f->scene, p, nullptr);
+}
+
+int koh_grid_blocks(const KohFrame *f)
+{
+    rmdf::FrameParams p;
+    memset(&p, 0, sizeof p);
+    p.w = f->w; p.h = f->h; p.x0 = f->x0; p.y0 = f->y0; p.x1 = f->x1; p.y1 = f->y1; p.n_shard_tiles = f->n_shard_tiles;
+    return rmdf::render_grid_blocks(p);
+}
+
+// k_order_blocks itself (1024 lanes, LDS histogram): the order it leaves for `cost`
+int koh_order_blocks(const unsigned *cost, int n, unsigned *order, int threads)
+{
+    koh::g_threads = threads;
+    return (int)rmdf::launch_order_blocks(cost, n, order, nullptr);
+}
+
+}  // extern "C"
