@@ -219,7 +219,11 @@ __global__ __launch_bounds__(64 * PREFILTER_WAVES) void k_prefilter(const float 
                                                   const float *__restrict__ lutT, const float2 *__restrict__ tcs,
                                                   float *__restrict__ out, int nbuf)
 {
-    extern __shared__ float lds_dyn[];                  // [nbuf][row_stride] source rows, then [w][64] cosine table when LUT_IN_LDS
+#ifdef RMDF_HOST_EMULATION
+    float *lds_dyn = (float *)koh::dyn_lds();
+#else
+    extern __shared__ float lds_dyn[];
+#endif                  // [nbuf][row_stride] source rows, then [w][64] cosine table when LUT_IN_LDS
     // nbuf = 2: the next row is written while this one is still being read by slower waves; nbuf = 1: one more barrier per row
     // separates the two.  The launcher takes one buffer as soon as two would exceed 80 KB (w > 3413), so that two workgroups
     // still fit a CU; tests/test_gpu_env.py runs a width on each side of that boundary
@@ -267,7 +271,11 @@ __global__ __launch_bounds__(64 * PREFILTER_WAVES) void k_prefilter(const float 
             auto texel = [&](float l, float r, float g, float b) {
                 const float cos_angle = lcpc + lsps * l;
                 unsigned ind;
+#ifdef RMDF_HOST_EMULATION
+                ind = __float_as_int(cos_angle) < 0 ? 0u : (__float_as_int(cos_angle) > 1 ? 1u : (unsigned)__float_as_int(cos_angle));   // (med3 of the bits as int32, 0, 1)
+#else
                 asm("v_med3_i32 %0, %1, 0, 1" : "=v"(ind) : "v"(__float_as_int(cos_angle)));
+#endif
                 ni += ind;
                 const float c0 = __builtin_fmaxf(cos_angle, 0.0f);
                 float cp = c0;
@@ -350,7 +358,11 @@ template <int K>
 __device__ __forceinline__ float mul_row_bcast(float row16, float f)       // (lane K of each 16-lane row of row16) * f
 {
     float r;
+#ifdef RMDF_HOST_EMULATION       // (tests/kernel_on_host.cpp: the broadcast is a wave collective of the emulator, the product the same IEEE multiply)
+    r = koh_row_newbcast(row16, K) * f;
+#else
     asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(row16), "v"(f), "n"(K));
+#endif
     return r;
 }
 // texel T of a chunk (static): its three floats sit at 3T .. 3T+2 of the chunk's floats, held sixteen per register
@@ -402,7 +414,11 @@ __global__ __launch_bounds__(64 * (4 + F4_PROD), 6) void k_prefilter_fused4(cons
     // LDS: the four rings and two staged source rows, 78 KB -- two workgroups per CU.  The cosine table stays out of it: a producer
     // meets the same 32 entries (its group of each of the row's <= 8 chunks, for its lane's destination column) in every source row
     // and keeps them in registers; the chunk loop is unrolled so that every index into them is static.
+#ifdef RMDF_HOST_EMULATION
+    float *lds_dyn = (float *)koh::dyn_lds();
+#else
     extern __shared__ float lds_dyn[];
+#endif
     const int nch = (w + F4_CHUNK - 1) / F4_CHUNK;                      // chunks per source row
     const int row_stride = nch * F4_CHUNK * 3;                           // floats per staged row, zero beyond w * 3
     float *lds_row = lds_dyn;                                            // [2][row_stride]
@@ -472,7 +488,11 @@ __global__ __launch_bounds__(64 * (4 + F4_PROD), 6) void k_prefilter_fused4(cons
                         for (int t = 0; t < 4; t++) {
                             const float cos_angle = lcpc + lsps * lutreg[j][t];
                             unsigned ind;
+#ifdef RMDF_HOST_EMULATION
+                            ind = __float_as_int(cos_angle) < 0 ? 0u : (__float_as_int(cos_angle) > 1 ? 1u : (unsigned)__float_as_int(cos_angle));   // (med3 of the bits as int32, 0, 1)
+#else
                             asm("v_med3_i32 %0, %1, 0, 1" : "=v"(ind) : "v"(__float_as_int(cos_angle)));
+#endif
                             ni += ind;
                             c0[t] = __builtin_fmaxf(cos_angle, 0.0f);
                         }
@@ -580,7 +600,11 @@ template <int LOG2P>
 __global__ __launch_bounds__(64 * (3 + CH_PROD), 6) void k_prefilter_chan(const float *__restrict__ src, int w, int h,
         const float *__restrict__ lutT, const float2 *__restrict__ tcs, float *__restrict__ out)
 {
+#ifdef RMDF_HOST_EMULATION
+    float *lds_dyn = (float *)koh::dyn_lds();
+#else
     extern __shared__ float lds_dyn[];
+#endif
     const int nch = (w + CH_CHUNK - 1) / CH_CHUNK;                      // chunks per source row
     const int row_stride = nch * CH_CHUNK * 3;                           // floats per staged row, zero beyond w * 3
     float *lds_row = lds_dyn;                                            // [2][row_stride]
@@ -648,7 +672,11 @@ __global__ __launch_bounds__(64 * (3 + CH_PROD), 6) void k_prefilter_chan(const 
                             for (int t = 0; t < 4; t++) {
                                 const float cos_angle = lcpc + lsps * lutreg[j][k][t];
                                 unsigned ind;
+#ifdef RMDF_HOST_EMULATION
+                                ind = __float_as_int(cos_angle) < 0 ? 0u : (__float_as_int(cos_angle) > 1 ? 1u : (unsigned)__float_as_int(cos_angle));   // (med3 of the bits as int32, 0, 1)
+#else
                                 asm("v_med3_i32 %0, %1, 0, 1" : "=v"(ind) : "v"(__float_as_int(cos_angle)));
+#endif
                                 ni += ind;
                                 c0[t] = __builtin_fmaxf(cos_angle, 0.0f);
                             }
@@ -762,7 +790,11 @@ template <int LOG2P>
 __global__ __launch_bounds__(64 * (3 + RING_PROD), 6) void k_prefilter_ring(const float *__restrict__ src, int w, int h,
         const float *__restrict__ lutT, const float2 *__restrict__ tcs, float *__restrict__ out)
 {
+#ifdef RMDF_HOST_EMULATION
+    float *lds_dyn = (float *)koh::dyn_lds();
+#else
     extern __shared__ float lds_dyn[];
+#endif
     const int nch = (w + RING_CHUNK - 1) / RING_CHUNK;                   // chunks per source row, >= RING_SLOTS (launcher)
     const int row_stride = nch * RING_CHUNK * 3;                          // floats per staged row, zero beyond w * 3
     float *lds_row = lds_dyn;                                             // [2][row_stride]
@@ -828,7 +860,11 @@ __global__ __launch_bounds__(64 * (3 + RING_PROD), 6) void k_prefilter_ring(cons
                     for (int t = 0; t < 4; t++) {
                         const float cos_angle = lcpc + lsps * lutreg[j][t];
                         unsigned ind;
+#ifdef RMDF_HOST_EMULATION
+                        ind = __float_as_int(cos_angle) < 0 ? 0u : (__float_as_int(cos_angle) > 1 ? 1u : (unsigned)__float_as_int(cos_angle));   // (med3 of the bits as int32, 0, 1)
+#else
                         asm("v_med3_i32 %0, %1, 0, 1" : "=v"(ind) : "v"(__float_as_int(cos_angle)));
+#endif
                         ni += ind;
                         c0[t] = __builtin_fmaxf(cos_angle, 0.0f);
                     }
@@ -879,7 +915,9 @@ __global__ __launch_bounds__(64 * (3 + RING_PROD), 6) void k_prefilter_ring(cons
                 for (int k = 0; k < RING_CHUNK / 4; k++) f[k] = *(const float4 *)(fsrc + 4 * k);      // (dead groups: stale, unused)
                 // everything this wave needs of the slot is in registers (the compiler waits for the reads before their first use; the
                 // release below is ordered behind them): hand the slot back before the sums
+#ifndef RMDF_HOST_EMULATION
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
                 if (lane == 0) __hip_atomic_fetch_add(&lds_drained[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (g == 0)      ring_sum_chunk<0>(rr, f, live, acc);
                 else if (g == 1) ring_sum_chunk<1>(rr, f, live, acc);

@@ -14,6 +14,8 @@
 
 #define RMDF_HOST_EMULATION 1
 #include "rmdf_render.hip"           // (-I csrc; <hip/hip_runtime.h>, <hip/hip_fp16.h> resolve to tests/koh_shim/)
+#include "rmdf_env.hip"              // ... and the env-map kernels (cube upload, lat/long -> cube, resize, the lobe prefilter's forms)
+#include "rmdf_util.hip"             // ... and the small ones (box resolve, shard assembly, fill; the GPU self-tests of the exact arithmetic)
 
 thread_local int doh_seed_mode = 0;
 thread_local unsigned doh_seed_rng = 12345u;
@@ -35,6 +37,7 @@ struct Block {
     ucontext_t sched;
     void (*tramp)(void *) = nullptr; void *closure = nullptr;
     char *stacks = nullptr; size_t nstacks = 0;
+    void *dyn = nullptr;
     unsigned long long idle_spins = 0;
 };
 thread_local Block *blk = nullptr;
@@ -125,7 +128,9 @@ void block_barrier()
     else while (b.sync_gen == g) yield_lane();
 }
 
-void launch(dim3 grid, dim3 block, void (*tramp)(void *), void *closure)
+void *dyn_lds() { return blk->dyn; }
+
+void launch(dim3 grid, dim3 block, size_t dyn_lds_bytes, void (*tramp)(void *), void *closure)
 {
     const unsigned long long nblk = (unsigned long long)grid.x * grid.y * grid.z;
     if (nblk == 0) return;
@@ -135,12 +140,13 @@ void launch(dim3 grid, dim3 block, void (*tramp)(void *), void *closure)
         doh_seed_mode = g_seed_mode.load(); doh_seed_rng = 777u;
         Block b; Grid g; g.grid = grid; g.block = block;
         b.tramp = tramp; b.closure = closure;
+        b.dyn = dyn_lds_bytes ? calloc(1, dyn_lds_bytes + 64) : nullptr;
         for (;;) {
             const unsigned long long i = next.fetch_add(1);
             if (i >= nblk) break;
             run_block(b, g, (unsigned)(i % grid.x), (unsigned)((i / grid.x) % grid.y), (unsigned)(i / ((unsigned long long)grid.x * grid.y)));
         }
-        free(b.stacks);
+        free(b.stacks); free(b.dyn);
         blk = nullptr; grd = nullptr;
     };
     if (nthreads == 1) { worker(); return; }
@@ -224,4 +230,36 @@ int koh_order_blocks(const unsigned *cost, int n, unsigned *order, int threads)
     return (int)rmdf::launch_order_blocks(cost, n, order, nullptr);
 }
 
+// ---- the env-map and utility kernels through the library's own launchers ----
+int koh_cube_upload(const float *faces, int W, void *padded, int threads) { koh::g_threads = threads; return (int)rmdf::launch_cube_upload(faces, W, (uint2 *)padded, nullptr); }
+int koh_latlong_to_cube(const float *latlong, int w, int h, const float *uv, float *faces, int threads)
+{
+    koh::g_threads = threads;
+    return (int)rmdf::launch_latlong_to_cube(latlong, w, h, (const float2 *)uv, faces, nullptr);
+}
+int koh_resize_latlong(const float *src, int sw, int sh, int dstw, int dsth, float *out, int threads)
+{
+    koh::g_threads = threads;
+    return (int)rmdf::launch_resize_latlong(src, sw, sh, dstw, dsth, out, nullptr);
+}
+int koh_prefilter(const float *src, int w, int h, float power, const float *lutT, const float *tcs, float *out, int split_ok, int threads)
+{
+    koh::g_threads = threads;
+    return (int)rmdf::launch_prefilter(src, w, h, power, lutT, (const float2 *)tcs, out, nullptr, split_ok != 0);
+}
+int koh_prefilter_fused4(const float *src, int w, int h, const float *lutT, const float *tcs, float *o0, float *o1, float *o2, float *o3, int threads)
+{
+    koh::g_threads = threads;
+    float *const outs[4] = { o0, o1, o2, o3 };
+    return (int)rmdf::launch_prefilter_fused4(src, w, h, lutT, (const float2 *)tcs, outs, nullptr);
+}
+int koh_resolve_box2(const uint32_t *src, int sw, int sh, uint32_t *dst, int threads) { koh::g_threads = threads; return (int)rmdf::launch_resolve_box2(src, sw, sh, dst, nullptr); }
+int koh_fill_u32(uint32_t *dst, uint32_t value, size_t n, int threads) { koh::g_threads = threads; return (int)rmdf::launch_fill_u32(dst, value, n, nullptr); }
+int koh_assemble_shards(const uint32_t *gathered, uint32_t *frame, int w, int h, int nranks, const unsigned short *where64, int threads)
+{
+    koh::g_threads = threads;
+    rmdf::ShardWhere wh;
+    for (int i = 0; i < 64; i++) wh.v[i] = where64[i];
+    return (int)rmdf::launch_assemble_shards(gathered, frame, w, h, nranks, wh, nullptr);
+}
 }  // extern "C"

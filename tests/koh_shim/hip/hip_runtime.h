@@ -57,8 +57,9 @@ void yield_lane();
 const uint64_t *wave_gather(uint64_t v, const char *what);      // every lane of the wave calls; returns the 64 contributed values
 void count(int kind);                                           // 0 ballot, 1 shfl, 2 readfirstlane, 3 DPP, 4 polled load, 5 __syncthreads (per lane-call)
 void block_barrier();
-void launch(dim3 grid, dim3 block, void (*tramp)(void *), void *closure);
-template <typename F> void launch(dim3 grid, dim3 block, F fn) { launch(grid, block, [](void *c) { (*(F *)c)(); }, &fn); }
+void launch(dim3 grid, dim3 block, size_t dyn_lds_bytes, void (*tramp)(void *), void *closure);
+template <typename F> void launch(dim3 grid, dim3 block, size_t dyn_lds_bytes, F fn) { launch(grid, block, dyn_lds_bytes, [](void *c) { (*(F *)c)(); }, &fn); }
+void *dyn_lds();                                                // the workgroup's dynamic LDS (`extern __shared__`), sized by the launch
 template <typename T> inline uint64_t pack(T v) { uint64_t u = 0; static_assert(sizeof(T) <= 8, ""); memcpy(&u, &v, sizeof v); return u; }
 template <typename T> inline T unpack(uint64_t u) { T v; memcpy(&v, &u, sizeof v); return v; }
 }  // namespace koh
@@ -67,7 +68,10 @@ template <typename T> inline T unpack(uint64_t u) { T v; memcpy(&v, &u, sizeof v
 #define blockIdx (koh::grd->bid)
 #define gridDim (koh::grd->grid)
 #define blockDim (koh::grd->block)
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) koh::launch((grid), (block), [&] { kernel(__VA_ARGS__); })
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) koh::launch((grid), (block), (size_t)(shmem), [&] { kernel(__VA_ARGS__); })
+typedef int hipFuncAttribute;
+#define hipFuncAttributeMaxDynamicSharedMemorySize 8
+static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int bytes) { return bytes <= 160 * 1024 ? hipSuccess : hipErrorInvalidValue; }   /* 160 KB of LDS per CU */
 
 static inline void __syncthreads() { koh::count(5); koh::block_barrier(); }
 static inline unsigned long long __ballot(int pred)
@@ -93,6 +97,15 @@ static inline int koh_update_dpp(int old, int src, int ctrl)
     else { fprintf(stderr, "koh: DPP control 0x%x not emulated\n", ctrl); abort(); }
     return koh::unpack<int>(koh::wave_gather(koh::pack(src), "update_dpp")[from]);
 }
+/* v_mul_f32_dpp ... row_newbcast:K -- lane K of the caller's 16-lane row (csrc/rmdf_env.hip: mul_row_bcast) */
+static inline float koh_row_newbcast(float v, int k)
+{
+    koh::count(3);
+    return koh::unpack<float>(koh::wave_gather(koh::pack(v), "row_newbcast")[(koh::cur->lane & ~15) | (k & 15)]);
+}
+static inline unsigned long long koh_ticks() { static thread_local unsigned long long t = 0; return t += 100; }
+#define __builtin_amdgcn_s_memrealtime() koh_ticks()
+#define __builtin_amdgcn_s_memtime() koh_ticks()
 #define __builtin_amdgcn_readfirstlane(v) koh_readfirstlane(v)
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rmask, bmask, bc) koh_update_dpp((old), (src), (ctrl))
 static inline int koh_mbcnt_lo(unsigned m, int base) { const int l = koh::cur->lane; return base + __builtin_popcount(l >= 32 ? m : (m & ((1u << l) - 1u))); }
@@ -101,10 +114,10 @@ static inline int koh_mbcnt_hi(unsigned m, int base) { const int l = koh::cur->l
 #define __builtin_amdgcn_mbcnt_hi(m, b) koh_mbcnt_hi((m), (b))
 #define __builtin_amdgcn_s_sleep(n) koh::yield_lane()
 
-/* atomics: the fibers of a workgroup never run concurrently, and workgroups on other OS threads touch other addresses */
-static inline int atomicCAS(int *p, int cmp, int val) { const int o = *p; if (o == cmp) *p = val; return o; }
-static inline unsigned atomicAdd(unsigned *p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
-static inline unsigned atomicMax(unsigned *p, unsigned v) { const unsigned o = *p; if (v > o) *p = v; return o; }
+/* atomics: real ones (workgroups of one launch run on several OS threads and may meet in global counters) */
+static inline int atomicCAS(int *p, int cmp, int val) { __atomic_compare_exchange_n(p, &cmp, val, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); return cmp; }
+template <typename T, typename V> static inline T atomicAdd(T *p, V v) { return __atomic_fetch_add(p, (T)v, __ATOMIC_SEQ_CST); }
+static inline unsigned atomicMax(unsigned *p, unsigned v) { unsigned o = __atomic_load_n(p, __ATOMIC_SEQ_CST); while (v > o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) { } return o; }
 /* (__hip_atomic_fetch_add / _store are clang builtins on every target: the kernel's scoped atomics compile as they are.)
  * __hip_atomic_load is the exception: the kernel polls workgroup state with it from wave-uniform code, and on the hardware ONE load
  * instruction gives all 64 lanes the same answer.  Fibers run one after the other, so each lane would see the flag at its own moment and

@@ -49,8 +49,14 @@ class Emulated:
             fma = ["-mfma"] if " fma " in open("/proc/cpuinfo").read() else []
             subprocess.check_call([CLANG, "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-pthread", "-Wall", "-Wno-unused-function",
                                    "-Wno-unknown-attributes", "-Wno-unused-variable"] + fma + ["-x", "c++", "-I", os.path.join(tdir, "koh_shim"), "-I", csrc, src, "-o", so])
-        self.K = C.CDLL(so)
+        self.K = K = C.CDLL(so)
         assert self.K.koh_frame_size() == C.sizeof(Frame)
+        vp, i = C.c_void_p, C.c_int
+        K.koh_cube_upload.argtypes = [vp, i, vp, i]
+        K.koh_latlong_to_cube.argtypes = [vp, i, i, vp, vp, i]
+        K.koh_resize_latlong.argtypes = [vp, i, i, i, i, vp, i]
+        K.koh_resolve_box2.argtypes = [vp, i, i, vp, i]
+        K.koh_order_blocks.argtypes = [vp, i, vp, i]
         rmdf.build()
         X = rmdf.load_library(xcheck=True)
         self.X = X
@@ -262,3 +268,105 @@ def test_frames_under_perturbed_hardware_seeds(emu, orc, env_oracle):
         assert (got["steps"] != ref["steps"]).mean() < 0.01 and (got["iters"] != ref["iters"]).mean() < 0.01
         d = np.abs(got["rgba8"].view(np.uint8).astype(int) - ref["rgba8"].view(np.uint8).astype(int))
         assert d.max() <= 1 and (d > 0).mean() < 0.01
+
+
+# ---- the env-map kernels (csrc/rmdf_env.hip) and the small ones (csrc/rmdf_util.hip), through the library's own launchers ---------------------
+
+def _synthetic_latlong(w, h, seed):
+    rng = np.random.RandomState(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.empty((h, w, 3), np.float32)
+    for k in range(3):
+        lobes = sum(a * np.exp(-(((x - cx) / sx) ** 2 + ((y - cy) / sy) ** 2))
+                    for a, cx, cy, sx, sy in zip(rng.uniform(2, 40, 5), rng.uniform(0, w, 5), rng.uniform(0, h, 5), rng.uniform(3, max(4, w / 8), 5), rng.uniform(3, max(4, h / 8), 5)))
+        img[..., k] = 0.2 + 0.8 * (1.0 - y / h) ** (k + 1) + lobes + rng.uniform(0, 0.05, (h, w))
+    return img.astype(np.float32)
+
+
+def test_latlong_to_cube_and_rgb16f_upload_kernels_equal_the_oracle(emu, orc, env_latlongs):
+    """k_latlong_to_cube on the host-built (u, v) table (rmdf_debug_cube_uv_table: what rmdf_set_env_latlong uploads) and k_cube_upload (RNE
+    to RGB16F + the seamless border): every texel of the 512-wide reflection map's cube, of a 256-wide lobe map's, and of two odd sizes"""
+    X, K = emu.X, emu.K
+    X.rmdf_debug_cube_uv_table.argtypes = [C.c_int, C.c_void_p]
+    for ll in (env_latlongs["refl"], env_latlongs["cos8"], _synthetic_latlong(100, 37, 1), orc.build_test_latlong()):
+        ll = np.ascontiguousarray(ll, np.float32)
+        h, w, _ = ll.shape
+        cw = w // 3
+        uv = np.zeros(6 * cw * cw * 2, np.float32)
+        assert X.rmdf_debug_cube_uv_table(cw, uv.ctypes.data) == 0
+        faces = np.zeros((6, cw, cw, 3), np.float32)
+        assert K.koh_latlong_to_cube(ll.ctypes.data, w, h, uv.ctypes.data, faces.ctypes.data, THREADS) == 0
+        ref = orc.latlong_to_cube(ll)
+        assert np.array_equal(faces.view(np.uint32), ref.view(np.uint32)), (w, h)
+        padded = np.zeros((6, cw + 2, cw + 2, 4), np.uint16)
+        assert K.koh_cube_upload(faces.ctypes.data, cw, padded.ctypes.data, THREADS) == 0
+        assert np.array_equal(padded, orc.cube_pad_f16(ref)), (w, h)
+
+
+def test_resize_kernel_equals_the_oracle(emu, orc, env_latlongs):
+    """k_resize_latlong (resizeHDRImage): the probe to the reference's 256, to other widths, from a map that is not 2:1"""
+    for src, dstw in ((env_latlongs["refl"], 256), (env_latlongs["refl"], 128), (env_latlongs["refl"], 100), (_synthetic_latlong(100, 37, 2), 32)):
+        src = np.ascontiguousarray(src, np.float32)
+        ref = orc.resize_hdr(src, dstw)
+        out = np.zeros_like(ref)
+        assert emu.K.koh_resize_latlong(src.ctypes.data, src.shape[1], src.shape[0], dstw, ref.shape[0], out.ctypes.data, THREADS) == 0
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), dstw
+
+
+@pytest.mark.parametrize("w,h", [(32, 16), (36, 10), (17, 6), (8, 3), (4, 2), (252, 5), (300, 4)])
+def test_lobe_prefilter_kernels_equal_the_oracle(emu, orc, env_latlongs, w, h):
+    """cosineConvolveHDREnvMap's kernels on the host-built lobe tables (rmdf_debug_lobe_tables): a reference power alone as the launcher picks
+    the form (k_prefilter_chan -- producer waves, three summing waves, DPP row broadcasts -- for widths 4 divides up to 256, the one-wave
+    k_prefilter with the table in LDS or read through global memory otherwise), side by side with others (split_ok = 0: the one-wave form),
+    and the four powers in ONE launch (k_prefilter_fused4): bit-equal to the oracle's pinned form"""
+    X, K = emu.X, emu.K
+    X.rmdf_debug_lobe_tables.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    src = np.ascontiguousarray(orc.resize_hdr(env_latlongs["refl"], w) if (w, h) == (32, 16) else _synthetic_latlong(w, h, 7), np.float32)
+    assert src.shape == (h, w, 3)
+    lut = np.zeros(((w + 63) // 64) * w * 64, np.float32)
+    tcs = np.zeros(2 * h, np.float32)
+    assert X.rmdf_debug_lobe_tables(w, h, lut.ctypes.data, tcs.ctypes.data) == 0
+    K.koh_prefilter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    refs = {p: orc.cosine_convolve(src, p, pow_mode=1) for p in (1.0, 8.0, 64.0, 512.0)}
+    for p, ref in refs.items():
+        for split_ok in (1, 0):
+            out = np.zeros_like(src)
+            assert K.koh_prefilter(src.ctypes.data, w, h, p, lut.ctypes.data, tcs.ctypes.data, out.ctypes.data, split_ok, THREADS) == 0
+            assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (p, split_ok, float(np.abs(out - ref).max()))
+    if w <= 256 and w % 4 == 0:
+        outs = [np.zeros_like(src) for _ in range(4)]
+        K.koh_prefilter_fused4.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p] + [C.c_void_p] * 4 + [C.c_int]
+        assert K.koh_prefilter_fused4(src.ctypes.data, w, h, lut.ctypes.data, tcs.ctypes.data, *[o.ctypes.data for o in outs], THREADS) == 0
+        for o, p in zip(outs, (1.0, 8.0, 64.0, 512.0)):
+            assert np.array_equal(o.view(np.uint32), refs[p].view(np.uint32)), ("fused", p)
+    c = emu.counts()
+    if w <= 256 and w % 4 == 0 and w >= 16:
+        assert c["dpp"] > 0, c                                    # the producer / summing-wave forms DID run (row broadcasts)
+
+
+def test_resolve_assemble_and_fill_kernels(emu, orc, rmdf):
+    """k_resolve_box2 (the super-sampling resolve) against the oracle's; k_assemble_shards (both forms: 16-byte and 4-byte) against the
+    package's host assembly for 1, 2, 3 and 8 ranks; k_fill_u32"""
+    K = emu.K
+    rng = np.random.RandomState(5)
+    for sw, sh in ((64, 36), (130, 6), (2, 2)):
+        src = rng.randint(0, 2 ** 32, (sh, sw), dtype=np.uint64).astype(np.uint32)
+        dst = np.zeros((sh // 2, sw // 2), np.uint32)
+        assert K.koh_resolve_box2(src.ctypes.data, sw, sh, dst.ctypes.data, THREADS) == 0
+        assert np.array_equal(dst, orc.resolve_box2(src))
+    K.koh_fill_u32.argtypes = [C.c_void_p, C.c_uint, C.c_size_t, C.c_int]
+    buf = np.zeros(100003, np.uint32)
+    assert K.koh_fill_u32(buf.ctypes.data, 0xFF203040, buf.size - 3, THREADS) == 0
+    assert (buf[:-3] == 0xFF203040).all() and not buf[-3:].any()
+    K.koh_assemble_shards.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    for (w, h) in ((128, 72), (104, 40)):                         # tile widths 16 (the uint4 form) and 13 (the scalar form)
+        for n in (1, 2, 3, 8):
+            slots = rmdf.shard_slots(n)
+            gathered = rng.randint(0, 2 ** 32, (n, slots, h // 8, w // 8), dtype=np.uint64).astype(np.uint32)
+            where = np.zeros(64, np.uint16)
+            for r in range(n):
+                for s, t in enumerate(rmdf.shard_tiles(r, n)):
+                    where[t] = (r << 8) | s
+            frame = np.zeros((h, w), np.uint32)
+            assert K.koh_assemble_shards(gathered.ctypes.data, frame.ctypes.data, w, h, n, where.ctypes.data, THREADS) == 0
+            assert np.array_equal(frame, rmdf.assemble_shards_host(gathered, w, h, n)), (w, h, n)
