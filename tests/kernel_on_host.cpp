@@ -14,8 +14,10 @@
 
 #define RMDF_HOST_EMULATION 1
 #include "rmdf_render.hip"           // (-I csrc; <hip/hip_runtime.h>, <hip/hip_fp16.h> resolve to tests/koh_shim/)
+#ifndef KOH_RENDER_ONLY               // (the A/B builds of the render kernel compile the render source alone: a third of the time)
 #include "rmdf_env.hip"              // ... and the env-map kernels (cube upload, lat/long -> cube, resize, the lobe prefilter's forms)
 #include "rmdf_util.hip"             // ... and the small ones (box resolve, shard assembly, fill; the GPU self-tests of the exact arithmetic)
+#endif
 
 thread_local int doh_seed_mode = 0;
 thread_local unsigned doh_seed_rng = 12345u;
@@ -175,6 +177,10 @@ struct KohFrame {          // mirrored in the Python test (ctypes)
     int n_shard_tiles;
     unsigned char shard_tile[64];
     int threads, seed_mode;
+    // librmdf_xcheck.so's one-launch band hand-over (FrameParams' band fields: -DRMDF_XCHECK builds of this harness only)
+    unsigned *band_count, *band_flag;
+    unsigned band_seq;
+    int band_strip_rows;
 };
 
 int koh_frame_size(void) { return (int)sizeof(KohFrame); }
@@ -211,6 +217,10 @@ int koh_render(const KohFrame *f)
     p.merge_stragglers = (f->no_merge || f->scene == 0) ? 0 : 32;
     p.rgba8 = f->rgba8; p.rgba8_mirror = f->rgba8_mirror; p.rgba_f32 = (float4 *)f->rgba_f32; p.steps = f->steps; p.iters = f->iters;
     p.block_order = f->block_order; p.block_cost = f->block_cost;
+#ifdef RMDF_XCHECK
+    p.band_count = f->band_count; p.band_flag = f->band_flag; p.band_seq = f->band_seq; p.band_strip_rows = f->band_strip_rows;
+    p.fold_min = RMDF_MB8_FOLD_MIN;
+#endif
     koh::g_seed_mode = f->seed_mode; koh::g_threads = f->threads;
     return (int)launch_render(f->scene, p, nullptr);
 }
@@ -229,7 +239,14 @@ int koh_order_blocks(const unsigned *cost, int n, unsigned *order, int threads)
     koh::g_threads = threads;
     return (int)rmdf::launch_order_blocks(cost, n, order, nullptr);
 }
+// (-DRMDF_XCHECK builds: k_order_blocks_bands when nbands > 0)
+int koh_order_blocks_bands(const unsigned *cost, int n, unsigned *order, int gx, int band_strip_rows, int nbands, int threads)
+{
+    koh::g_threads = threads;
+    return (int)rmdf::launch_order_blocks(cost, n, order, nullptr, gx, band_strip_rows, nbands);
+}
 
+#ifndef KOH_RENDER_ONLY
 // ---- the env-map and utility kernels through the library's own launchers ----
 int koh_cube_upload(const float *faces, int W, void *padded, int threads) { koh::g_threads = threads; return (int)rmdf::launch_cube_upload(faces, W, (uint2 *)padded, nullptr); }
 int koh_latlong_to_cube(const float *latlong, int w, int h, const float *uv, float *faces, int threads)
@@ -262,4 +279,6 @@ int koh_assemble_shards(const uint32_t *gathered, uint32_t *frame, int w, int h,
     for (int i = 0; i < 64; i++) wh.v[i] = where64[i];
     return (int)rmdf::launch_assemble_shards(gathered, frame, w, h, nranks, wh, nullptr);
 }
+#endif
+
 }  // extern "C"

@@ -73,6 +73,7 @@ typedef int hipFuncAttribute;
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
 static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int bytes) { return bytes <= 160 * 1024 ? hipSuccess : hipErrorInvalidValue; }   /* 160 KB of LDS per CU */
 
+static inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline void __syncthreads() { koh::count(5); koh::block_barrier(); }
 static inline unsigned long long __ballot(int pred)
 {

@@ -33,30 +33,47 @@ class Frame(C.Structure):
                 ("cornell_tri", C.c_void_p), ("cornell_tab", C.c_void_p), ("cornell_grid", C.c_void_p),
                 ("rgba8", C.c_void_p), ("rgba8_mirror", C.c_void_p), ("rgba_f32", C.c_void_p), ("steps", C.c_void_p), ("iters", C.c_void_p),
                 ("block_order", C.c_void_p), ("block_cost", C.c_void_p), ("n_shard_tiles", C.c_int), ("shard_tile", C.c_ubyte * 64),
-                ("threads", C.c_int), ("seed_mode", C.c_int)]
+                ("threads", C.c_int), ("seed_mode", C.c_int),
+                ("band_count", C.c_void_p), ("band_flag", C.c_void_p), ("band_seq", C.c_uint), ("band_strip_rows", C.c_int)]
 
 
 class Emulated:
     """the kernel source + the inputs rmdf_create / fill_params would give it (all host-built: librmdf_xcheck.so's host-only accessors)"""
 
-    def __init__(self, rmdf, env_oracle):
+    @staticmethod
+    def build(variants):
+        """compile the harness for every (defines, tag) that is missing or older than its sources -- all at once (each takes ~30 s)"""
         tdir = os.path.join(ROOT, "tests")
-        so, src = os.path.join(tdir, "libkernel_on_host.so"), os.path.join(tdir, "kernel_on_host.cpp")
+        src = os.path.join(tdir, "kernel_on_host.cpp")
         csrc = os.path.join(ROOT, "ray-marching-distance-fields_amd", "csrc")
-        deps = [src] + [os.path.join(csrc, f) for f in ("rmdf_render.hip", "rmdf_device.hpp", "rmdf_internal.hpp")] + \
+        deps = [src] + [os.path.join(csrc, f) for f in ("rmdf_render.hip", "rmdf_env.hip", "rmdf_util.hip", "rmdf_device.hpp", "rmdf_internal.hpp")] + \
                [os.path.join(tdir, "koh_shim", "hip", f) for f in ("hip_runtime.h", "hip_fp16.h")]
-        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
-            fma = ["-mfma"] if " fma " in open("/proc/cpuinfo").read() else []
-            subprocess.check_call([CLANG, "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-pthread", "-Wall", "-Wno-unused-function",
-                                   "-Wno-unknown-attributes", "-Wno-unused-variable"] + fma + ["-x", "c++", "-I", os.path.join(tdir, "koh_shim"), "-I", csrc, src, "-o", so])
+        newest = max(os.path.getmtime(d) for d in deps)
+        fma = ["-mfma"] if " fma " in open("/proc/cpuinfo").read() else []
+        procs = []
+        for defines, tag in variants:
+            so = os.path.join(tdir, "libkernel_on_host%s.so" % tag)
+            if os.path.exists(so) and os.path.getmtime(so) >= newest:
+                continue
+            cmd = [CLANG, "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-pthread", "-Wall", "-Wno-unused-function",
+                   "-Wno-unknown-attributes", "-Wno-unused-variable"] + fma + list(defines) + ["-x", "c++", "-I", os.path.join(tdir, "koh_shim"), "-I", csrc, src, "-o", so]
+            procs.append((tag, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        for tag, pr in procs:
+            out = pr.communicate()[0]
+            assert pr.returncode == 0, "kernel_on_host%s: %s" % (tag, out[-3000:])
+
+    def __init__(self, rmdf, env_oracle, defines=(), tag=""):
+        Emulated.build([(defines, tag)])
+        so = os.path.join(ROOT, "tests", "libkernel_on_host%s.so" % tag)
         self.K = K = C.CDLL(so)
         assert self.K.koh_frame_size() == C.sizeof(Frame)
         vp, i = C.c_void_p, C.c_int
-        K.koh_cube_upload.argtypes = [vp, i, vp, i]
-        K.koh_latlong_to_cube.argtypes = [vp, i, i, vp, vp, i]
-        K.koh_resize_latlong.argtypes = [vp, i, i, i, i, vp, i]
-        K.koh_resolve_box2.argtypes = [vp, i, i, vp, i]
         K.koh_order_blocks.argtypes = [vp, i, vp, i]
+        if "-DKOH_RENDER_ONLY" not in defines:
+            K.koh_cube_upload.argtypes = [vp, i, vp, i]
+            K.koh_latlong_to_cube.argtypes = [vp, i, i, vp, vp, i]
+            K.koh_resize_latlong.argtypes = [vp, i, i, i, i, vp, i]
+            K.koh_resolve_box2.argtypes = [vp, i, i, vp, i]
         rmdf.build()
         X = rmdf.load_library(xcheck=True)
         self.X = X
@@ -108,10 +125,17 @@ class Emulated:
         return dict(zip(("ballot", "shfl", "readfirstlane", "dpp", "polled_load", "syncthreads"), [int(x) for x in c]))
 
 
+AB_BUILDS = [("-DRMDF_AB_XL_G=4", "_xl4", "four lanes per ray in the Cornell tail (sixteen rays per wave, two DPP steps)"),
+             ("-DRMDF_AB_SHARED_BOUNDS", "_sharedb", "one pass of bound tests serves the normal's four sample points"),
+             ("-DRMDF_AB_NO_XL", "_noxl", "the Cornell march without the lanes-per-ray tail"),
+             ("-DRMDF_AB_MIRROR16", "_mirror16", "mirror stores as one wave's 16-byte stores")]
+
+
 @pytest.fixture(scope="module")
 def emu(rmdf, env_oracle):
     if not os.path.exists(CLANG):
         pytest.skip("no clang++")
+    Emulated.build([((), ""), (("-DRMDF_XCHECK",), "_xcheck")] + [((d, "-DKOH_RENDER_ONLY"), t) for d, t, _ in AB_BUILDS])       # every build this module needs, side by side
     return Emulated(rmdf, env_oracle)
 
 
@@ -370,3 +394,108 @@ def test_resolve_assemble_and_fill_kernels(emu, orc, rmdf):
             frame = np.zeros((h, w), np.uint32)
             assert K.koh_assemble_shards(gathered.ctypes.data, frame.ctypes.data, w, h, n, where.ctypes.data, THREADS) == 0
             assert np.array_equal(frame, rmdf.assemble_shards_host(gathered, w, h, n)), (w, h, n)
+
+
+# ---- the A/B builds of the render kernel (tools/abtest/*.so on the GPU): written in round 5, never run on hardware -- here: do they render the same frames? ----
+
+@pytest.mark.parametrize("define,tag,what", AB_BUILDS, ids=[t[1:] for _, t, _ in AB_BUILDS])
+def test_ab_builds_of_the_render_kernel_render_the_same_frames(emu, rmdf, orc, env_oracle, define, tag, what):
+    """Each A/B build claims "bit-identical frames, maybe faster".  The second half needs a GPU; the first is checked here, before any
+    GPU minute is spent on timing it: Cornell frames at four times + a 256 x 144 one, a Mandelbulb frame, tile rectangles with the mirror
+    output (a variant whose frame differs from the oracle's is wrong, whatever its speed)."""
+    if not os.path.exists(CLANG):
+        pytest.skip("no clang++")
+    e = Emulated(rmdf, env_oracle, defines=(define, "-DKOH_RENDER_ONLY"), tag=tag)
+    e.counts()
+    for t in (0.0, 1.0, 2.5, 7.0):
+        assert_same_frame(e.render(0, 64, 36, t, 128), orc.render(0, 64, 36, t, 128, env_oracle), "%s: Cornell t %.1f" % (what, t))
+    assert_same_frame(e.render(0, 256, 144, 0.0, 128), orc.render(0, 256, 144, 0.0, 128, env_oracle), what + ": Cornell 256 x 144")
+    assert_same_frame(e.render(2, 64, 36, 0.0, 256), orc.render(2, 64, 36, 0.0, 256, env_oracle), what + ": Mandelbulb")
+    c = e.counts()
+    assert (c["dpp"] > 0) == (tag != "_noxl"), c
+    w, h = 100, 52
+    for scene in (0, 2):
+        ref = orc.render(scene, w, h, 0.7, 64, env_oracle)["rgba8"]
+        whole = e.render(scene, w, h, 0.7, 64, planes=False, mirror=True)
+        assert np.array_equal(whole["rgba8"], ref) and np.array_equal(whole["mirror"], ref), (what, scene)
+        for tile in (0, 27, 63):
+            x0, y0, x1, y1 = rmdf.tile_rect(tile, w, h)
+            got = e.render(scene, w, h, 0.7, 64, planes=False, mirror=True, rect=(x0, y0, x1, y1))
+            outside = np.ones((h, w), bool)
+            outside[y0:y1, x0:x1] = False
+            for k in ("rgba8", "mirror"):
+                assert np.array_equal(got[k][y0:y1, x0:x1], ref[y0:y1, x0:x1]) and (got[k][outside] == 0xDEADBEEF).all(), (what, scene, tile, k)
+
+
+# ---- what lives in librmdf_xcheck.so because no GPU has run it: does it at least compute the right thing? ------------------------------------
+
+@pytest.fixture(scope="module")
+def xemu(emu, rmdf, env_oracle):
+    os.environ["RMDF_PREFILTER_RING"] = "1"          # read once per process by the cross-check build's launcher: the ring form where it applies
+    return Emulated(rmdf, env_oracle, defines=("-DRMDF_XCHECK",), tag="_xcheck")
+
+
+def test_one_launch_band_handover_of_the_cross_check_build(xemu, orc, env_oracle):
+    """rmdf_config.reserved[3] = 2, 3 (round 5, never run on hardware): ONE launch whose OUT_MIRROR kernels count their workgroups in per band
+    and flag a band when its last strip's stores are out; the strips ordered costliest first, then band by band from the outside in
+    (k_order_blocks_bands).  Emulated: every band's flag carries the frame's sequence number afterwards, the counters are back at zero for the
+    next frame, frame and mirror equal the oracle's -- in raster order and in the band-aware order, which is a permutation that does put the
+    costly strips first and the outer bands before the inner ones."""
+    scene, w, h, ms = 2, 128, 72, 128
+    ref = orc.render(scene, w, h, 0.0, ms, env_oracle)["rgba8"]
+    f = xemu.frame(scene, w, h, 0.0, ms)
+    n, gx, rows = xemu.K.koh_grid_blocks(C.byref(f)), 4, 9
+    assert n == gx * rows
+    bsr, nb = 2, 5                                                        # bands of two strip rows: five bands, the last one a single row
+    count, flag = np.zeros(16, np.uint32), np.zeros(16, np.uint32)
+    frame, mirror, cost = np.zeros((h, w), np.uint32), np.zeros((h, w), np.uint32), np.zeros(n, np.uint32)
+    f.rgba8, f.rgba8_mirror, f.block_cost = frame.ctypes.data, mirror.ctypes.data, cost.ctypes.data
+    f.band_count, f.band_flag, f.band_seq, f.band_strip_rows = count.ctypes.data, flag.ctypes.data, 7, bsr
+    assert xemu.K.koh_render(C.byref(f)) == 0
+    assert np.array_equal(frame, ref) and np.array_equal(mirror, ref)
+    assert (flag[:nb] == 7).all() and not flag[nb:].any() and not count.any(), (flag, count)
+    order = np.zeros(n, np.uint32)
+    xemu.K.koh_order_blocks_bands.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    assert xemu.K.koh_order_blocks_bands(cost.ctypes.data, n, order.ctypes.data, gx, bsr, nb, 1) == 0
+    assert sorted(order.tolist()) == list(range(n))
+    def bin_of(c):
+        if c < 8:
+            return c
+        e = int(c).bit_length() - 1
+        return min(255, (e - 2) * 8 + ((int(c) >> (e - 3)) & 7))
+    maxbin = max(bin_of(int(c)) for c in cost)
+    assert maxbin > 16, "a frame whose strips differ in cost"
+
+    def key(i):                                                            # the kernel's sort key, restated: descending
+        b = bin_of(int(cost[i]))
+        if b >= maxbin - 8:
+            return 128 + (b >> 1)                                          # within a factor two of the costliest strip: first, by cost
+        band = (int(i) // gx) // bsr
+        from_edge = 2 * band if band < nb - 1 - band else 2 * (nb - 1 - band) + 1
+        return 127 - from_edge                                             # then band by band, outer bands first
+    keys = [key(i) for i in order]
+    assert keys == sorted(keys, reverse=True) and len(set(keys)) > 2, keys
+    frame[...] = 0; mirror[...] = 0; flag[...] = 0
+    f.block_order, f.band_seq = order.ctypes.data, 8
+    assert xemu.K.koh_render(C.byref(f)) == 0
+    assert np.array_equal(frame, ref) and np.array_equal(mirror, ref) and (flag[:nb] == 8).all() and not count.any()
+
+
+@pytest.mark.parametrize("w,h", [(128, 4), (252, 5), (256, 3), (132, 9)])
+def test_ring_form_of_the_prefilter_in_the_cross_check_build(xemu, orc, w, h):
+    """k_prefilter_ring (RMDF_PREFILTER_RING=1, librmdf_xcheck.so; round 5, never run on hardware): producers and summing waves that never meet
+    at a barrier -- factors through a ring of four chunk buffers with `filled` / `drained` counters in LDS.  Emulated (the counters are
+    polled with the wave-uniform load, the waves really do run ahead of each other): every reference power bit-equal to the oracle's."""
+    X, K = xemu.X, xemu.K
+    X.rmdf_debug_lobe_tables.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    src = _synthetic_latlong(w, h, 9)
+    lut, tcs = np.zeros(((w + 63) // 64) * w * 64, np.float32), np.zeros(2 * h, np.float32)
+    assert X.rmdf_debug_lobe_tables(w, h, lut.ctypes.data, tcs.ctypes.data) == 0
+    K.koh_prefilter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    xemu.counts()
+    for p in (1.0, 8.0, 64.0, 512.0):
+        out = np.zeros_like(src)
+        assert K.koh_prefilter(src.ctypes.data, w, h, p, lut.ctypes.data, tcs.ctypes.data, out.ctypes.data, 1, THREADS) == 0
+        ref = orc.cosine_convolve(src, p, pow_mode=1)
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (p, float(np.abs(out - ref).max()))
+    assert xemu.counts()["polled_load"] > 0, "the ring form did not run (no counter was polled)"
