@@ -70,6 +70,14 @@ _real_to = torch.Tensor.to
 torch.Tensor.to = lambda self, *a, **k: self if (a and str(a[0]).startswith("cuda")) or str(k.get("device", "")).startswith("cuda") else _real_to(self, *a, **k)
 torch.Tensor.cuda = lambda self, *a, **k: self
 
+if os.environ.get("DRY_RUN_SCRIPT"):
+    # any other GPU-side tool of the repository (tools/*.py) under the same stand-ins: DRY_RUN_SCRIPT=<path> bench_dry_run.py <its arguments>
+    import runpy
+    script = os.environ["DRY_RUN_SCRIPT"]
+    sys.argv = [script] + sys.argv[1:]
+    runpy.run_path(script, run_name="__main__")
+    sys.exit(0)
+
 sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[1:]
 import bench                                                 # noqa: E402
 

@@ -1162,3 +1162,37 @@ sys.exit(rc)
     for name in ("config2_cornell_1280x720_m128", "scene1_detest_1280x720_m128", "scene3_mbgeneral_1280x720_m128"):
         assert d["secondary"][name]["roofline"].get("issue_g_wave_instr_s_simd") is not None, name
     shutil.rmtree(os.path.join(ROOT, "gpurun_out", "prof_live"), ignore_errors=True)
+
+
+def test_the_tools_gpu_measure_runs_do_run(tmp_path):
+    """tools/gpu_measure.sh is what the first GPU call of a round executes, and GPU minutes are scarce: every Python tool it calls is run here
+    to completion against the doubles (tests/bench_dry_run.py with DRY_RUN_SCRIPT: the same torch stand-ins bench.py's dry run uses), the
+    shell scripts are syntax-checked, and the steps the script names exist.  The numbers mean nothing; a typo, a renamed keyword argument
+    or a hand-over mode the product library no longer has would show here instead of on the GPU box."""
+    import shutil
+    import subprocess
+    import sys
+    import rmdf_amd
+    from conftest import ROOT
+    for sh in ("tools/gpu_measure.sh", "tools/profile.sh", "tools/prof_scene.sh", "tools/pmc_prefilter.sh", "tools/abtest/rebuild_all.sh", "tools/abtest/build_variant.sh"):
+        r = subprocess.run(["bash", "-n", os.path.join(ROOT, sh)], capture_output=True, text=True)
+        assert r.returncode == 0, (sh, r.stderr)
+    script = open(os.path.join(ROOT, "tools", "gpu_measure.sh")).read()
+    for step in ("tier", "bench", "prof", "scenes", "sweep", "mirror16", "copynt", "prefilter", "unverified"):
+        assert ("\n%s)" % step) in script, step
+    assert "--faults" in script and script.index("faults = 1") > script.index("unverified)") if "faults = 1" in script else True
+    hdr = str(tmp_path / "probe.hdr")
+    shutil.copy(rmdf_amd.DEFAULT_ENV_HDR, hdr)
+    env = dict(os.environ, LD_PRELOAD=_fake_hip_lib(), RMDF_ENV_HDR=hdr)
+    for k in ("RMDF_LIB", "RMDF_FLAGS", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    for tool, args, expect in (("tools/scene_times.py", ["2"], "headline mb8"), ("tools/prefilter_time.py", [], "four powers on four streams"),
+                               ("tools/whole_frame_sweep.py", ["1"], "bands mirror threads"), ("tools/tile_mode_time.py", [], "")):
+        if not os.path.exists(os.path.join(ROOT, tool)):
+            continue
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_dry_run.py")] + args, cwd=ROOT, capture_output=True, text=True, timeout=900,
+                           env=dict(env, DRY_RUN_SCRIPT=os.path.join(ROOT, tool)))
+        assert r.returncode == 0 and "Traceback" not in r.stderr and expect in r.stdout, (tool, r.stdout[-800:], r.stderr[-2000:])
+        if tool.endswith("whole_frame_sweep.py"):
+            rows = [l.split() for l in r.stdout.splitlines() if l[:6].strip().isdigit()]
+            assert {int(x[1]) for x in rows} == {0, 1, 2, 3}, "the sweep lost a hand-over mode"        # 2 and 3 run on librmdf_xcheck.so
