@@ -17,6 +17,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
+ENV_CACHE = os.path.join(GOLD, "env_cache")        # the ORACLE's pre-convolved maps of uffizi_512 (make_fixtures.py --caches)
 
 
 def pytest_configure(config):
@@ -27,6 +28,9 @@ def pytest_configure(config):
 # never run on hardware are kept, but only run when asked for (RMDF_TEST_UNVERIFIED=1): a test that has never been seen green must not
 # stand in the tier the driver runs -- it would stop the tier (-x) for a reason nobody has looked at.  DESIGN.md section 5 lists them.
 ON_HIP_DOUBLE = "libfake_hip" in os.environ.get("LD_PRELOAD", "")       # the process runs against the HIP test double (no GPU)
+# ... and with FAKE_HIP_EMULATE=1 the double RUNS the library's kernels (tests/kernel_on_host.cpp: their source under a SIMT emulator): the pixels
+# are the real ones, so the GPU tier's tests hold as written -- as far as their frame sizes allow (the emulator is ~10^4 x slower than the GPU)
+ON_HIP_EMULATOR = ON_HIP_DOUBLE and os.environ.get("FAKE_HIP_EMULATE", "0") not in ("", "0")
 unverified = pytest.mark.skipif(os.environ.get("RMDF_TEST_UNVERIFIED") != "1",
                                 reason="code written after GPU access closed in round 5: never run on hardware (RMDF_TEST_UNVERIFIED=1 runs it)")
 
@@ -45,6 +49,11 @@ def _no_stand_in_cache_files_in_the_tree():
     real = rmdf_amd.DEFAULT_ENV_HDR
     rmdf_amd.DEFAULT_ENV_HDR = os.path.join(d, os.path.basename(real))
     shutil.copy(real, rmdf_amd.DEFAULT_ENV_HDR)
+    if ON_HIP_EMULATOR:
+        # the emulated prefilter of the 256 x 128 probe would take an hour: the private copy comes with the ORACLE's cache files (the
+        # product's are byte-identical: tests/test_gpu_env.py), so rmdf_load_env_hdr finds its caches as it does on every run but the first
+        for f in os.listdir(ENV_CACHE):
+            shutil.copy(os.path.join(ENV_CACHE, f), d)
     os.environ["RMDF_ENV_HDR"] = rmdf_amd.DEFAULT_ENV_HDR        # child processes (tools/tile_mode_fuzz.py, the C hosts) as well
     yield
     os.environ.pop("RMDF_ENV_HDR", None)
@@ -66,7 +75,6 @@ def rmdf():
     return rmdf_amd
 
 
-ENV_CACHE = os.path.join(GOLD, "env_cache")        # the ORACLE's pre-convolved maps of uffizi_512 (make_fixtures.py --caches)
 
 
 @pytest.fixture(scope="session")
@@ -97,7 +105,7 @@ def _renderer_with_product_env(rmdf, env_oracle, **kw):
     to the oracle-built maps every parity test compares against."""
     rmdf.build()
     r = rmdf.ShaderRenderer(0, **kw)
-    if ON_HIP_DOUBLE:
+    if ON_HIP_DOUBLE and not ON_HIP_EMULATOR:
         # dry run of GPU-tier tests against tests/fake_hip.cpp (tests/test_host_logic.py: test_gpu_tier_tests_that_need_no_oracle_...): the
         # double's env kernels are stand-ins -- no cache files into the tree, no comparison with the oracle's maps
         for slot, ref in ((rmdf.ENV_REFLECTION, env_oracle.reflection), (rmdf.ENV_COS_1, env_oracle.cos_1), (rmdf.ENV_COS_8, env_oracle.cos_8)):

@@ -150,8 +150,49 @@ float src_checksum(const float *src, size_t n)                  // reads every e
 }
 
 // the arguments are decoded NOW (the args array belongs to the caller's stack frame); what is returned runs when the stream gets to it
-std::function<void()> make_task(const std::string &name, dim3 grid, dim3 block, void **args, bool from_xcheck)
+// FAKE_HIP_EMULATE=1: instead of the stand-ins below, every kernel the emulator holds (tests/kernel_on_host.cpp: the library's kernel SOURCE
+// compiled for the CPU, one fiber per lane) is RUN -- the double then is a functional model of the device, the pixels are the real ones,
+// and the GPU tier's own tests can be run through the C ABI without a GPU (small frames: the emulator is ~10^4 x slower than the GPU).
+// libkernel_on_host.so serves librmdf.so's launches, libkernel_on_host_xcheck.so librmdf_xcheck.so's (its FrameParams is longer).
+struct Emulator {
+    void *(*prepare)(const char *, void **) = nullptr;
+    void (*run)(void *, const unsigned *, const unsigned *, size_t, int) = nullptr;
+};
+Emulator *emulator_for(bool from_xcheck)
 {
+    static const bool on = getenv("FAKE_HIP_EMULATE") && atoi(getenv("FAKE_HIP_EMULATE")) != 0;
+    if (!on) return nullptr;
+    static Emulator emu[2];
+    static std::once_flag once[2];
+    const int k = from_xcheck ? 1 : 0;
+    std::call_once(once[k], [k] {
+        Dl_info di;
+        std::string dir = ".";
+        if (dladdr((void *)&emulator_for, &di) && di.dli_fname) { dir = di.dli_fname; const size_t sl = dir.rfind('/'); dir = sl == std::string::npos ? "." : dir.substr(0, sl); }
+        const std::string path = dir + (k ? "/libkernel_on_host_xcheck.so" : "/libkernel_on_host.so");
+        void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) { fprintf(stderr, "fake_hip: FAKE_HIP_EMULATE: cannot load %s: %s\n", path.c_str(), dlerror()); abort(); }
+        emu[k].prepare = (void *(*)(const char *, void **))dlsym(h, "koh_prepare");
+        emu[k].run = (void (*)(void *, const unsigned *, const unsigned *, size_t, int))dlsym(h, "koh_run");
+        if (!emu[k].prepare || !emu[k].run) { fprintf(stderr, "fake_hip: %s lacks koh_prepare / koh_run\n", path.c_str()); abort(); }
+    });
+    return &emu[k];
+}
+std::atomic<unsigned long long> g_emulated{ 0 };
+
+std::function<void()> make_task(const std::string &name, dim3 grid, dim3 block, void **args, bool from_xcheck, size_t shmem)
+{
+    if (Emulator *e = emulator_for(from_xcheck)) {
+        if (void *closure = e->prepare(name.c_str(), args)) {
+            static const int threads = getenv("FAKE_HIP_EMULATE_THREADS") ? atoi(getenv("FAKE_HIP_EMULATE_THREADS")) : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+            g_emulated++;
+            return [=] { const unsigned g[3] = { grid.x, grid.y, grid.z }, b[3] = { block.x, block.y, block.z }; e->run(closure, g, b, shmem, threads); };
+        }
+        // (a kernel the emulator does not hold -- the cross-check build's alternative schedules -- keeps its stand-in: say so, once per name)
+        static std::mutex mu; static std::set<std::string> told;
+        std::lock_guard<std::mutex> lk(mu);
+        if (told.insert(name).second) fprintf(stderr, "fake_hip: FAKE_HIP_EMULATE: no emulated kernel %s (stand-in used)\n", name.c_str());
+    }
     (void)block;
     auto has = [&](const char *s) { return name.find(s) != std::string::npos; };
     if (has("k_renderILi")) {
@@ -423,7 +464,7 @@ hipError_t __hipPopCallConfiguration(dim3 *grid, dim3 *block, size_t *shmem, hip
     *grid = c.grid; *block = c.block; *shmem = c.shmem; *stream = c.stream;
     return hipSuccess;
 }
-hipError_t hipLaunchKernel(const void *fn, dim3 grid, dim3 block, void **args, size_t, hipStream_t stream)
+hipError_t hipLaunchKernel(const void *fn, dim3 grid, dim3 block, void **args, size_t shmem, hipStream_t stream)
 { COUNT();
     std::string name;
     { std::lock_guard<std::mutex> lk(g_mu); auto it = g_kernels.find(fn); if (it == g_kernels.end()) return hipErrorInvalidDeviceFunction; name = it->second; }
@@ -431,7 +472,7 @@ hipError_t hipLaunchKernel(const void *fn, dim3 grid, dim3 block, void **args, s
     if (grid.x == 0 || grid.y == 0 || grid.z == 0 || block.x == 0) return hipErrorInvalidConfiguration;
     Dl_info di;                                   // which build launches: the cross-check library's FrameParams is longer (BandTail)
     const bool from_xcheck = dladdr(fn, &di) && di.dli_fname && strstr(di.dli_fname, "xcheck");
-    submit(stream, make_task(name, grid, block, args, from_xcheck));
+    submit(stream, make_task(name, grid, block, args, from_xcheck, shmem));
     return hipSuccess;
 }
 hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }

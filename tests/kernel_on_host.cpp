@@ -282,3 +282,83 @@ int koh_assemble_shards(const uint32_t *gathered, uint32_t *frame, int w, int h,
 #endif
 
 }  // extern "C"
+
+// ---- launches by NAME: the HIP double (tests/fake_hip.cpp, FAKE_HIP_EMULATE=1) hands every hipLaunchKernel of librmdf here, so that the library's
+// own host code drives the emulated kernels through the C ABI -- the GPU tier's tests then run on a box without a GPU.  The table is keyed by the
+// kernels' mangled names, which are the same on both sides (Itanium ABI): dladdr of the host-compiled kernel gives the name the device code
+// object registered.
+#include <dlfcn.h>
+#include <functional>
+#include <map>
+#include <string>
+#include <tuple>
+
+namespace {
+
+typedef std::function<std::function<void()> *(void **)> Prepare;
+std::map<std::string, Prepare> &table() { static std::map<std::string, Prepare> t; return t; }
+
+template <typename... A, size_t... I>
+std::function<void()> *bind_args(void (*k)(A...), void **args, std::index_sequence<I...>)
+{
+    auto tup = std::make_tuple(*(typename std::decay<A>::type *)args[I]...);          // copied NOW: the array belongs to the caller's frame
+    return new std::function<void()>([k, tup] { std::apply(k, tup); });
+}
+template <typename... A>
+void reg(void (*k)(A...))
+{
+    Dl_info di;
+    if (!dladdr((void *)k, &di) || !di.dli_sname) { fprintf(stderr, "koh: a kernel without a dynamic symbol\n"); abort(); }
+    table()[di.dli_sname] = [k](void **args) { return bind_args(k, args, std::index_sequence_for<A...>{}); };
+}
+template <int S> void reg_render()
+{
+    reg(&rmdf::k_render<S, false, 0>); reg(&rmdf::k_render<S, false, 1>); reg(&rmdf::k_render<S, false, 2>);
+    reg(&rmdf::k_render<S, true, 0>); reg(&rmdf::k_render<S, true, 1>); reg(&rmdf::k_render<S, true, 2>);
+}
+template <int L> void reg_prefilter() { reg(&rmdf::k_prefilter<L, false>); reg(&rmdf::k_prefilter<L, true>); }
+
+void build_table()
+{
+    using namespace rmdf;
+    reg_render<0>(); reg_render<1>(); reg_render<2>(); reg_render<3>();
+    reg(&k_order_blocks);
+#ifdef RMDF_XCHECK
+    reg(&k_order_blocks_bands);
+#endif
+#ifndef KOH_RENDER_ONLY
+    reg(&k_cube_upload); reg(&k_latlong_to_cube); reg(&k_resize_latlong);
+    reg_prefilter<-1>(); reg_prefilter<0>(); reg_prefilter<3>(); reg_prefilter<6>(); reg_prefilter<9>();
+    reg(&k_prefilter_chan<0>); reg(&k_prefilter_chan<3>); reg(&k_prefilter_chan<6>); reg(&k_prefilter_chan<9>);
+    reg(&k_prefilter_fused4);
+#ifdef RMDF_XCHECK
+    reg(&k_prefilter_ring<0>); reg(&k_prefilter_ring<3>); reg(&k_prefilter_ring<6>); reg(&k_prefilter_ring<9>);
+#endif
+    reg(&k_resolve_box2); reg(&k_assemble_shards); reg(&k_assemble_shards_x4); reg(&k_fill_u32); reg(&k_clock_probe);
+    reg(&k_selftest_cornell_div); reg(&k_selftest_exact_math); reg(&k_selftest_mb8_folds); reg(&k_selftest_pinned_math);
+    reg(&k_selftest_shading_math); reg(&k_selftest_fill_cube); reg(&k_selftest_frame_quotients);
+#endif
+}
+
+}  // namespace
+
+extern "C" {
+
+// closure for one launch of the kernel registered under `mangled_name` with its arguments copied, or NULL (a kernel this build does not hold)
+void *koh_prepare(const char *mangled_name, void **args)
+{
+    static const bool once = (build_table(), true);
+    (void)once;
+    auto it = table().find(mangled_name);
+    return it == table().end() ? nullptr : (void *)it->second(args);
+}
+void koh_run(void *closure, const unsigned grid[3], const unsigned block[3], size_t dyn_lds_bytes, int threads)
+{
+    std::function<void()> *fn = (std::function<void()> *)closure;
+    koh::g_threads = threads;
+    koh::launch(dim3(grid[0], grid[1], grid[2]), dim3(block[0], block[1], block[2]), dyn_lds_bytes, [](void *c) { (*(std::function<void()> *)c)(); }, fn);
+    delete fn;
+}
+int koh_kernels(void) { (void)koh_prepare("", nullptr); return (int)table().size(); }
+
+}  // extern "C"

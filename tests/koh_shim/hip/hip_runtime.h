@@ -26,11 +26,16 @@
 #define __launch_bounds__(...)
 #define __shared__ static thread_local
 
-struct float2 { float x, y; };
-struct float4 { float x, y, z, w; };
-struct uint2 { unsigned x, y; };
-struct uint3 { unsigned x, y, z; };
-struct uint4 { unsigned x, y, z, w; };
+/* the vector types under HIP's own names: a kernel's mangled name (what the HIP double looks the emulated kernel up by) spells its parameter types */
+template <typename T, unsigned N> struct HIP_vector_type;
+template <typename T> struct HIP_vector_type<T, 2u> { T x, y; };
+template <typename T> struct HIP_vector_type<T, 3u> { T x, y, z; };
+template <typename T> struct HIP_vector_type<T, 4u> { T x, y, z, w; };
+typedef HIP_vector_type<float, 2u> float2;
+typedef HIP_vector_type<float, 4u> float4;
+typedef HIP_vector_type<unsigned, 2u> uint2;
+typedef HIP_vector_type<unsigned, 3u> uint3;
+typedef HIP_vector_type<unsigned, 4u> uint4;
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) { } };
 static inline float2 make_float2(float x, float y) { float2 r = { x, y }; return r; }
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r = { x, y, z, w }; return r; }
