@@ -316,7 +316,9 @@ template <int S> void reg_render()
     reg(&rmdf::k_render<S, false, 0>); reg(&rmdf::k_render<S, false, 1>); reg(&rmdf::k_render<S, false, 2>);
     reg(&rmdf::k_render<S, true, 0>); reg(&rmdf::k_render<S, true, 1>); reg(&rmdf::k_render<S, true, 2>);
 }
+#ifndef KOH_RENDER_ONLY
 template <int L> void reg_prefilter() { reg(&rmdf::k_prefilter<L, false>); reg(&rmdf::k_prefilter<L, true>); }
+#endif
 
 void build_table()
 {
