@@ -6,8 +6,6 @@
 // with it and holds every plane to the oracle's: step counts, hit mask and escape-iteration counts bit-exact, float colour and RGBA8
 // bit-exact too (same source arithmetic, correctly rounded seeds).  What it cannot see: the code generator, the hardware's memory model
 // (the mailbox protocol's acquire / release pairs are plain accesses here), timing.  Never part of the product.
-#include <ucontext.h>
-
 #include <atomic>
 #include <thread>
 #include <vector>
@@ -29,14 +27,50 @@ thread_local Grid *grd = nullptr;
 
 namespace {
 
+// Context switch between fibers: callee-saved registers, stack pointer, MXCSR and the x87 control word -- glibc's swapcontext does the same
+// plus a signal-mask system call per switch, which was half of the emulator's run time.
+struct Ctx { void *sp; };
+extern "C" void koh_ctx_switch(Ctx *from, Ctx *to);
+#if !defined(__x86_64__)
+#error "tests/kernel_on_host.cpp: the fiber switch is written for x86-64"
+#endif
+asm(R"(
+    .text
+    .globl koh_ctx_switch
+    .type koh_ctx_switch,@function
+koh_ctx_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    subq $8, %rsp
+    stmxcsr (%rsp)
+    fnstcw 4(%rsp)
+    movq %rsp, (%rdi)
+    movq (%rsi), %rsp
+    ldmxcsr (%rsp)
+    fldcw 4(%rsp)
+    addq $8, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size koh_ctx_switch, .-koh_ctx_switch
+)");
+
 constexpr size_t kStack = 256 * 1024;
-struct Fiber { ucontext_t ctx; Lane lane; bool done; };
+struct Fiber { Ctx ctx; Lane lane; bool done; };
 struct WaveState { int arrived = 0; unsigned gen = 0; uint64_t val[2][64]; const char *what[2] = { nullptr, nullptr }; };
 struct Block {
     std::vector<Fiber> fib;
     std::vector<WaveState> waves;
     int sync_arrived = 0; unsigned sync_gen = 0;
-    ucontext_t sched;
+    Ctx sched;
     void (*tramp)(void *) = nullptr; void *closure = nullptr;
     char *stacks = nullptr; size_t nstacks = 0;
     void *dyn = nullptr;
@@ -52,7 +86,20 @@ void fiber_main()
     blk->tramp(blk->closure);
     Fiber *f = (Fiber *)((char *)cur - offsetof(Fiber, lane));
     f->done = true;
-    swapcontext(&f->ctx, &blk->sched);
+    koh_ctx_switch(&f->ctx, &blk->sched);
+    abort();                                                        // a finished fiber is never resumed
+}
+
+// a new fiber's stack, as koh_ctx_switch expects to find a suspended one: control words, six callee-saved registers, the address to "return" to
+void fiber_init(Fiber &f, char *stack_base)
+{
+    uintptr_t top = ((uintptr_t)stack_base + kStack) & ~(uintptr_t)15;
+    uint64_t *sp = (uint64_t *)top;
+    *--sp = 0;                                                      // (entry is reached by `ret`: the stack looks as after a call)
+    *--sp = (uint64_t)(uintptr_t)&fiber_main;
+    for (int i = 0; i < 6; i++) *--sp = 0;                          // rbp, rbx, r12 .. r15
+    *--sp = 0x037f00001f80ull;                                      // MXCSR 0x1f80 (round to nearest, exceptions masked), x87 control word 0x037f
+    f.ctx.sp = sp;
 }
 
 void run_block(Block &b, Grid &g, unsigned bx, unsigned by, unsigned bz)
@@ -69,11 +116,7 @@ void run_block(Block &b, Grid &g, unsigned bx, unsigned by, unsigned bz)
         f.done = false;
         f.lane.tid = uint3{ t % g.block.x, (t / g.block.x) % g.block.y, t / (g.block.x * g.block.y) };
         f.lane.lane = (int)(t & 63u); f.lane.wave = (int)(t >> 6);
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = b.stacks + (size_t)t * kStack;
-        f.ctx.uc_stack.ss_size = kStack;
-        f.ctx.uc_link = nullptr;
-        makecontext(&f.ctx, fiber_main, 0);
+        fiber_init(f, b.stacks + (size_t)t * kStack);
     }
     blk = &b; grd = &g;
     unsigned long long rounds = 0;
@@ -84,7 +127,7 @@ void run_block(Block &b, Grid &g, unsigned bx, unsigned by, unsigned bz)
             if (f.done) continue;
             any = true;
             cur = &f.lane;
-            swapcontext(&b.sched, &f.ctx);
+            koh_ctx_switch(&b.sched, &f.ctx);
         }
         if (!any) break;
         if (++rounds > 20000000ull) {
@@ -104,7 +147,7 @@ void count(int kind) { g_counts[kind].fetch_add(1, std::memory_order_relaxed); }
 void yield_lane()
 {
     Fiber *f = (Fiber *)((char *)cur - offsetof(Fiber, lane));
-    swapcontext(&f->ctx, &blk->sched);
+    koh_ctx_switch(&f->ctx, &blk->sched);
 }
 
 const uint64_t *wave_gather(uint64_t v, const char *what)

@@ -1,6 +1,6 @@
 /* tests/koh_shim/hip/hip_runtime.h -- TEST INFRASTRUCTURE.  <hip/hip_runtime.h> for tests/kernel_on_host.cpp: csrc/rmdf_render.hip -- the
  * render kernel's SOURCE, launch code included -- compiled for the CPU and executed by a small SIMT emulator:
- *   * one FIBER per lane (ucontext), 64 lanes per wave, all waves of a workgroup on one OS thread, scheduled round-robin;
+ *   * one FIBER per lane (a hand-written context switch: callee-saved registers and the stack pointer), 64 lanes per wave, all waves of a workgroup on one OS thread, scheduled round-robin;
  *   * __ballot / __shfl / __shfl_xor / readfirstlane / DPP are true 64-lane collectives: a lane that calls one yields until all 64 lanes
  *     of its wave have called the same kind of collective, then everyone reads the exchanged values.  That is the hardware's meaning for
  *     wave-UNIFORM call sites, which is what the kernel's own collectives are; the per-lane "is anyone here in trouble" tests of divergent

@@ -63,3 +63,66 @@ def test_the_gpu_tiers_parity_tests_pass_on_the_emulated_device(rmdf):
     n = int(tail[-1].split(" passed")[0].split()[-1])
     assert n >= 86, tail[-1]
     assert "stand-in used" not in r.stderr and "stand-in used" not in r.stdout, "a launch fell back to a stand-in: the pixels compared were not the kernels'"
+
+
+def _probe_with_caches(rmdf, tmp_path):
+    import shutil
+    from conftest import ENV_CACHE
+    probe = str(tmp_path / os.path.basename(rmdf.DEFAULT_ENV_HDR))
+    shutil.copy(rmdf.DEFAULT_ENV_HDR, probe)
+    for f in os.listdir(ENV_CACHE):
+        shutil.copy(os.path.join(ENV_CACHE, f), str(tmp_path))
+    return probe
+
+
+def test_the_bench_renders_the_oracles_frame_on_the_emulated_device(rmdf, tmp_path):
+    """bench.py --check on the emulated device (tests/bench_dry_run.py's torch stand-ins over the emulating double): the frames of the TIMED
+    path -- several frames in flight on their own streams, strips in cost order from the second frame on -- equal the oracle's RGBA8 frame"""
+    import json
+    _emulator_builds(rmdf)
+    env = dict(os.environ, LD_PRELOAD=_fake_hip_lib(), FAKE_HIP_EMULATE="1", RMDF_ENV_HDR=_probe_with_caches(rmdf, tmp_path), RMDF_BENCH_MIN_WARM="0.02")
+    for k in ("RMDF_LIB", "RMDF_FLAGS", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    for extra in ([], ["--scene", "0", "--max-steps", "128"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_dry_run.py"), "--width", "64", "--height", "40", "--steps", "3", "--warmup", "1",
+                            "--repeats", "1", "--check", "--no-secondary", "--pmc", "off"] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["check_rgba8_equal"] is True and d["n_gpus"] == 1, extra
+
+
+SLOW = os.environ.get("RMDF_TEST_SLOW") == "1"       # the 8- and 3-rank runs take minutes each on eight cores: RMDF_TEST_SLOW=1 (both green when last run)
+
+
+@pytest.mark.parametrize("nranks", [2, pytest.param(8, marks=pytest.mark.skipif(not SLOW, reason="minutes: RMDF_TEST_SLOW=1")),
+                                    pytest.param(3, marks=pytest.mark.skipif(not SLOW, reason="minutes: RMDF_TEST_SLOW=1"))])
+def test_n_rank_frames_equal_the_oracles_on_emulated_devices(rmdf, tmp_path, nranks):
+    """bench.py as the driver launches N > 1, every rank on an emulated device, the exchange the library's own over the RCCL double: the frame
+    rank 0 assembles from N ranks' shards (cost-aware deal, verified by the library; two frames in flight on one communicator) EQUALS THE
+    ORACLE'S frame.  The double-based runs of round 5 could only say "equals the single launch's stand-in pixels"; this says the 2-, 8- and
+    3-rank render + exchange + assembly computes the right picture.  Not a scaling number."""
+    import json
+    import socket
+    from test_gpu_parity import _fake_rccl_lib
+    _emulator_builds(rmdf)
+    env = dict(os.environ, LD_PRELOAD=_fake_hip_lib(), FAKE_HIP_EMULATE="1", FAKE_HIP_EMULATE_THREADS="1", RMDF_ENV_HDR=_probe_with_caches(rmdf, tmp_path),
+               RMDF_BENCH_SHARE_GPU="1", RMDF_RCCL_LIB=_fake_rccl_lib(), FAKE_RCCL_TIMEOUT_S="300", RMDF_BENCH_MIN_WARM="0.02", RMDF_BENCH_WATCHDOG_S="900",
+               OMP_NUM_THREADS="1")
+    for k in ("RMDF_LIB", "RMDF_FLAGS", "RANK", "WORLD_SIZE", "LOCAL_RANK", "RMDF_BENCH_TORCH_GATHER"):
+        env.pop(k, None)
+    for attempt in range(3):
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), os.path.join(ROOT, "tests", "bench_dry_run.py"), "--gpus", str(nranks), "--width", "64", "--height", "40",
+                            "--steps", "2", "--warmup", "1", "--repeats", "1", "--check", "--no-secondary", "--streams", "2"],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=2400)
+        if r.returncode == 0 or "EADDRINUSE" not in r.stderr:
+            break
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == nranks and d["config"]["rccl_ranks"] == nranks and d["check_rgba8_equal"] is True
+    assert d["config"]["tile_deal"].startswith("cost-aware") and "verified by the library" in d["config"]["tile_deal"]
+    assert "falling back" not in r.stderr and "stand-in used" not in r.stderr
