@@ -12,63 +12,12 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 assert "libfake_hip" in os.environ.get("LD_PRELOAD", ""), "run with LD_PRELOAD=tests/libfake_hip.so"
 import torch                                                 # noqa: E402
 
-FAKE = C.CDLL(os.environ.get("FAKE_HIP_LIB", os.path.join(ROOT, "tests", "libfake_hip.so")))
-FAKE.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
-FAKE.hipStreamSynchronize.argtypes = [C.c_void_p]
-
-
-class Stream:
-    def __init__(self, device=None, priority=0):
-        h = C.c_void_p()
-        assert FAKE.hipStreamCreateWithFlags(C.byref(h), 1) == 0
-        self.cuda_stream = h.value
-
-    def synchronize(self):
-        FAKE.hipStreamSynchronize(self.cuda_stream)
-
-    def wait_stream(self, other): pass
-    def wait_event(self, ev): pass
-    def query(self): return True
-
-
-class Event:
-    def __init__(self, enable_timing=False): self.t = None
-    def record(self, stream=None): self.t = time.perf_counter()
-    def synchronize(self): pass
-    def query(self): return True
-    def elapsed_time(self, other): return max((other.t - self.t) * 1e3, 1e-3)
-
-
-class _StreamCtx:
-    def __init__(self, s): pass
-    def __enter__(self): return self
-    def __exit__(self, *a): return False
-
-
-def _cpu(fn):
-    def f(*a, **k):
-        if k.get("device") is not None and str(k["device"]).startswith("cuda"):
-            k["device"] = "cpu"
-        return fn(*a, **k)
-    return f
-
-
-torch.cuda.is_available = lambda: True
-torch.cuda.device_count = lambda: 1
-torch.cuda.set_device = lambda d: None
-torch.cuda.synchronize = lambda d=None: FAKE.hipDeviceSynchronize()
-torch.cuda.Stream = Stream
-torch.cuda.Event = Event
-torch.cuda.stream = _StreamCtx
-torch.cuda.set_stream = lambda s: None
-for name in ("empty", "zeros", "tensor", "ones", "full"):
-    setattr(torch, name, _cpu(getattr(torch, name)))
-_real_to = torch.Tensor.to
-torch.Tensor.to = lambda self, *a, **k: self if (a and str(a[0]).startswith("cuda")) or str(k.get("device", "")).startswith("cuda") else _real_to(self, *a, **k)
-torch.Tensor.cuda = lambda self, *a, **k: self
+import torch_cuda_standins                                   # noqa: E402
+torch_cuda_standins.install()
 
 if os.environ.get("DRY_RUN_SCRIPT"):
     # any other GPU-side tool of the repository (tools/*.py) under the same stand-ins: DRY_RUN_SCRIPT=<path> bench_dry_run.py <its arguments>

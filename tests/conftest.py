@@ -31,6 +31,12 @@ ON_HIP_DOUBLE = "libfake_hip" in os.environ.get("LD_PRELOAD", "")       # the pr
 # ... and with FAKE_HIP_EMULATE=1 the double RUNS the library's kernels (tests/kernel_on_host.cpp: their source under a SIMT emulator): the pixels
 # are the real ones, so the GPU tier's tests hold as written -- as far as their frame sizes allow (the emulator is ~10^4 x slower than the GPU)
 ON_HIP_EMULATOR = ON_HIP_DOUBLE and os.environ.get("FAKE_HIP_EMULATE", "0") not in ("", "0")
+if ON_HIP_EMULATOR:
+    # tests that hold torch device buffers and streams: the same stand-ins bench.py's dry run uses ("device" tensors are CPU tensors: the
+    # double's device memory IS host memory, and the emulated kernels write where the pointer says)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch_cuda_standins
+    torch_cuda_standins.install()
 unverified = pytest.mark.skipif(os.environ.get("RMDF_TEST_UNVERIFIED") != "1",
                                 reason="code written after GPU access closed in round 5: never run on hardware (RMDF_TEST_UNVERIFIED=1 runs it)")
 

@@ -4,8 +4,10 @@ With FAKE_HIP_EMULATE=1 the HIP test double (tests/fake_hip.cpp) no longer write
 by its mangled name in tests/libkernel_on_host.so -- the library's kernel SOURCE compiled for the CPU and executed by the SIMT emulator
 (tests/kernel_on_host.cpp, tests/koh_shim/) -- and RUN.  The process then is: the product's shared library as shipped (host code: contexts,
 staging, tile jobs, env pipeline, cache files), its kernels' source executed lane by lane, and the `-m gpu` tests as they are written, calling
-through the C ABI and comparing with the oracle.  88 of the tier's tests fit the emulator's speed (frames up to 480 x 270); the others
-need full-size frames, torch device buffers or RCCL and stay the GPU's.  The selection below runs in a child process, four workers wide."""
+through the C ABI and comparing with the oracle.  119 of the tier's tests pass that way (profiles/r06_emulated_gpu_tier.txt: the builder's full
+run, incl. every full-size digest and BASELINE config 5 as written); the 22 others need a real RCCL, start GPU programs of their own, or take
+longer than a quarter of an hour.  This file runs the quick ones on every CPU-tier run (four workers wide), BASELINE config 2 and config 3 at FULL
+size, and -- with RMDF_TEST_SLOW=1 -- the rest of the 119."""
 import os
 import subprocess
 import sys
@@ -125,3 +127,34 @@ def test_n_rank_frames_equal_the_oracles_on_emulated_devices(rmdf, tmp_path, nra
     assert d["n_gpus"] == nranks and d["config"]["rccl_ranks"] == nranks and d["check_rgba8_equal"] is True
     assert d["config"]["tile_deal"].startswith("cost-aware") and "verified by the library" in d["config"]["tile_deal"]
     assert "falling back" not in r.stderr and "stand-in used" not in r.stderr
+
+
+def _run_tier(rmdf, selection, workers, threads, timeout):
+    _emulator_builds(rmdf)
+    env = dict(os.environ, LD_PRELOAD=_fake_hip_lib(), FAKE_HIP_EMULATE="1", FAKE_HIP_EMULATE_THREADS=str(threads))
+    for k in ("RMDF_LIB", "RMDF_TEST_UNVERIFIED"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_env.py"),
+                        "-q", "-m", "gpu", "-p", "no:cacheprovider", "--timeout=%d" % timeout, "-k", selection] + (["-n", str(workers)] if workers > 1 else []),
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout * 8)
+    tail = [l for l in r.stdout.strip().splitlines() if " passed" in l or " failed" in l or " error" in l]
+    assert r.returncode == 0 and tail and "failed" not in tail[-1] and "error" not in tail[-1], (r.stdout[-4000:], r.stderr[-1500:])
+    assert "stand-in used" not in r.stderr and "stand-in used" not in r.stdout
+    return int(tail[-1].split(" passed")[0].split()[-1])
+
+
+def test_baseline_configs_2_and_3_at_full_size_on_the_emulated_device(rmdf):
+    """BASELINE config 2 (CornellBox 1280 x 720, 128 steps) and config 3 (Mandelbulb power-8 1920 x 1080, 256 steps, uffizi env -- the headline
+    metric's frame) rendered at FULL size through the C ABI by the kernels' source on the emulated device: the sha256 of every plane -- RGBA8,
+    float colour, steps + hit mask, escape-iteration counts -- equals the committed oracle digest (tests/golden/full_size_digests.json).
+    About 11 s and 31 s of emulation on eight cores."""
+    n = _run_tier(rmdf, "test_full_size_frames_match_the_committed_oracle_digests and (config2_cornell or config3_mandelbulb8)", 1, min(8, os.cpu_count() or 1), 1500)
+    assert n == 2
+
+
+@pytest.mark.skipif(not SLOW, reason="a quarter of an hour on eight cores: RMDF_TEST_SLOW=1 (119 green in the builder's run: profiles/r06_emulated_gpu_tier.txt)")
+def test_everything_of_the_gpu_tier_that_can_run_on_the_emulated_device(rmdf):
+    sel = ("not (test_comm_selftest_loopback or test_exchange_behind_the_c_abi or test_exchange_with_n_ranks or test_bench_ or test_multirank_bench "
+           "or test_shader_clock_probe or test_alternative_schedule or test_both_mandelbulb_schedules or test_config4 or test_the_product_library_ignores "
+           "or (test_lobe_prefilter_is_bit_exact and 256-128))")
+    assert _run_tier(rmdf, sel, 2, 4, 1500) >= 115
