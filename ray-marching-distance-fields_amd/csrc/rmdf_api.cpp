@@ -619,10 +619,15 @@ int fill_params(rmdf_ctx *ctx, int scene, int w, int h, float time, int max_step
     p.cornell = ctx->d_cornell;
     // pooling the last rays of a workgroup pays for both Mandelbulbs (+5 %, +8 %) and the test scene (+8 %);
     // it costs 6 % for the Cornell box, whose distance estimate has the same cost for every ray
-#ifdef RMDF_AB_CORNELL_MERGE
-    p.merge_stragglers = (ctx->flags & RMDF_FLAG_NO_MERGE) ? 0 : (scene == RMDF_FS_DE_CORNELL_BOX ? RMDF_AB_CORNELL_MERGE : 32);
+#ifdef RMDF_AB_MERGE_T              // (A/B builds: the pooling threshold, with the kernel's mailbox size of the same name in rmdf_render.hip)
+    const int merge_t = RMDF_AB_MERGE_T;
 #else
-    p.merge_stragglers = ((ctx->flags & RMDF_FLAG_NO_MERGE) || scene == RMDF_FS_DE_CORNELL_BOX) ? 0 : 32;
+    const int merge_t = 32;
+#endif
+#ifdef RMDF_AB_CORNELL_MERGE
+    p.merge_stragglers = (ctx->flags & RMDF_FLAG_NO_MERGE) ? 0 : (scene == RMDF_FS_DE_CORNELL_BOX ? RMDF_AB_CORNELL_MERGE : merge_t);
+#else
+    p.merge_stragglers = ((ctx->flags & RMDF_FLAG_NO_MERGE) || scene == RMDF_FS_DE_CORNELL_BOX) ? 0 : merge_t;
 #endif
     p.cornell_tab = ctx->d_cornell_tab;
     p.cornell_grid = ctx->d_cornell_grid;

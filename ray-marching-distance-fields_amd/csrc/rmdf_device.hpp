@@ -50,7 +50,13 @@ constexpr int mb_iterations_i = (int)mb_iterations;
 #define RMDF_LANES_HERE(x) ((x) ? 1ull : 0ull)
 #define RMDF_READLANE_HERE(v, l) (v)
 #define RMDF_READFIRSTLANE_HERE(v) (v)
+#ifndef RMDF_EMU_PASS                 // (tests/koh_shim counts iteration passes per lane and per wave: the lane utilisation of a schedule, tools/emulated_schedule.py)
+#define RMDF_EMU_PASS()
+#define RMDF_EMU_SEGMENT_END(i0)
+#endif
 #else
+#define RMDF_EMU_PASS()
+#define RMDF_EMU_SEGMENT_END(i0)
 #define RMDF_LANES_HERE(x) __ballot(x)
 #define RMDF_READLANE_HERE(v, l) __builtin_amdgcn_readlane((v), (l))
 #define RMDF_READFIRSTLANE_HERE(v) __builtin_amdgcn_readfirstlane(v)
@@ -432,7 +438,9 @@ __device__ __forceinline__ void mb8_iterate_t(v3 &w, const v3 pos, float &dr, fl
             w = mk3(__builtin_fmaf(-8.0f, a, pos.x), __builtin_fmaf(64.0f, b, pos.y), wz + pos.z);
         }
         iters++;
+        RMDF_EMU_PASS();
     }
+    RMDF_EMU_SEGMENT_END(i0);
 }
 // does the folded call have to be run again in written form (any lane of the wave decides for itself; the branch is wave-uniform)
 __device__ __forceinline__ bool mb8_fold_failed(float m, float fold_min = RMDF_MB8_FOLD_MIN) { return !(m >= fold_min); }

@@ -71,7 +71,11 @@ __device__ __forceinline__ float bsphere_r() { return SCENE == 2 ? shk::bsphere_
 // they march in their own wave until handed over, then in the host.  Handed-over rays are all late, near-surface
 // rays with similar escape-iteration counts, so the packet coherence the nested loop lives on is kept.  Results go
 // through an LDS table indexed by strip pixel; ray arithmetic is untouched (bit-identical output).
+#ifdef RMDF_AB_MERGE_T              // A/B switch (tools/abtest/mt48.so; tools/emulated_schedule.py PREDICTS -2.8 % issued instructions for 48: not yet timed)
+#define MERGE_T RMDF_AB_MERGE_T
+#else
 #define MERGE_T 32
+#endif
 // Distance-AO estimates of the power-8 Mandelbulb (MERGE variant): a sample point 0.016 / 0.081 off the surface lands INSIDE another
 // part of the set for 0.7 % / 4.2 % of the hit pixels and then runs all 25 iterations, while the mean is 3.8 -- so nearly every
 // wave's two AO estimates ran ~21 passes for ~7.5 lanes' worth of work (tools/ubench/surface_k.hip).  Every lane therefore

@@ -78,8 +78,14 @@ struct Block {
 };
 thread_local Block *blk = nullptr;
 std::atomic<unsigned long long> g_counts[6];
+// lane utilisation of the Mandelbulb estimates under the schedule being emulated, in the cost model of tools/ubench/sched_sim (round 4): an
+// estimate segment costs 87 vector instructions per iteration pass + 100; a wave pays the MAXIMUM over its lanes, 64 lanes wide
+std::atomic<unsigned long long> g_useful{ 0 }, g_slots{ 0 }, g_wave_passes{ 0 }, g_lane_passes{ 0 };
+constexpr unsigned kPassCost = 87, kEstimateCost = 100;
 std::atomic<int> g_seed_mode{ 0 };
 std::atomic<int> g_threads{ 1 };
+
+void flush_wave(Block &b, int wave);
 
 void fiber_main()
 {
@@ -115,7 +121,7 @@ void run_block(Block &b, Grid &g, unsigned bx, unsigned by, unsigned bz)
         Fiber &f = b.fib[t];
         f.done = false;
         f.lane.tid = uint3{ t % g.block.x, (t / g.block.x) % g.block.y, t / (g.block.x * g.block.y) };
-        f.lane.lane = (int)(t & 63u); f.lane.wave = (int)(t >> 6);
+        f.lane.lane = (int)(t & 63u); f.lane.wave = (int)(t >> 6); f.lane.nseg = 0; f.lane.cur_passes = 0;
         fiber_init(f, b.stacks + (size_t)t * kStack);
     }
     blk = &b; grd = &g;
@@ -129,7 +135,7 @@ void run_block(Block &b, Grid &g, unsigned bx, unsigned by, unsigned bz)
             cur = &f.lane;
             koh_ctx_switch(&b.sched, &f.ctx);
         }
-        if (!any) break;
+        if (!any) { for (int wv = 0; wv < (int)b.waves.size(); wv++) flush_wave(b, wv); break; }
         if (++rounds > 20000000ull) {
             fprintf(stderr, "koh: workgroup (%u, %u, %u) makes no progress: lanes wait in", bx, by, bz);
             for (auto &w : b.waves) fprintf(stderr, " [%s: %d of 64 arrived]", w.what[w.gen & 1u] ? w.what[w.gen & 1u] : "-", w.arrived);
@@ -143,6 +149,31 @@ void run_block(Block &b, Grid &g, unsigned bx, unsigned by, unsigned bz)
 }  // namespace
 
 void count(int kind) { g_counts[kind].fetch_add(1, std::memory_order_relaxed); }
+
+// the wave's lanes have all arrived at a collective (or the workgroup at a barrier, or the fibers at their end): price what they did since the last one
+namespace {
+void flush_wave(Block &b, int wave)
+{
+    unsigned long long useful = 0, slots = 0, wp = 0, lp = 0;
+    int maxseg = 0;
+    for (int l = 0; l < 64; l++) { const Lane &L = b.fib[(size_t)wave * 64 + l].lane; if (L.nseg > maxseg) maxseg = L.nseg; }
+    for (int k = 0; k < maxseg; k++) {
+        unsigned mx = 0, mxp = 0;
+        for (int l = 0; l < 64; l++) {
+            const Lane &L = b.fib[(size_t)wave * 64 + l].lane;
+            if (L.nseg <= k) continue;
+            const unsigned np = L.seg[k] & 0x7fffu;
+            const unsigned c = kPassCost * np + ((L.seg[k] & 0x8000u) ? 0u : kEstimateCost);
+            useful += c; lp += np;
+            if (c > mx) mx = c;
+            if (np > mxp) mxp = np;
+        }
+        slots += 64ull * mx; wp += mxp;
+    }
+    for (int l = 0; l < 64; l++) b.fib[(size_t)wave * 64 + l].lane.nseg = 0;
+    if (slots) { g_useful += useful; g_slots += slots; g_wave_passes += wp; g_lane_passes += lp; }
+}
+}  // namespace
 
 void yield_lane()
 {
@@ -160,7 +191,7 @@ const uint64_t *wave_gather(uint64_t v, const char *what)
         abort();
     }
     w.val[slot][cur->lane] = v;
-    if (++w.arrived == 64) { w.arrived = 0; w.gen = g + 1u; }
+    if (++w.arrived == 64) { flush_wave(*blk, cur->wave); w.arrived = 0; w.gen = g + 1u; }
     else while (w.gen == g) yield_lane();
     return w.val[slot];
 }
@@ -169,7 +200,7 @@ void block_barrier()
 {
     Block &b = *blk;
     const unsigned g = b.sync_gen;
-    if (++b.sync_arrived == (int)b.fib.size()) { b.sync_arrived = 0; b.sync_gen = g + 1u; }
+    if (++b.sync_arrived == (int)b.fib.size()) { for (int wv = 0; wv < (int)b.waves.size(); wv++) flush_wave(b, wv); b.sync_arrived = 0; b.sync_gen = g + 1u; }
     else while (b.sync_gen == g) yield_lane();
 }
 
@@ -231,6 +262,12 @@ int koh_frame_size(void) { return (int)sizeof(KohFrame); }
 // lane-calls of every collective kind since the last call (ballot, shuffles, readfirstlane, DPP, polled loads, __syncthreads): a test can tell
 // that a frame DID go through the pooled march's mailboxes or the Cornell tail's DPP minima
 void koh_take_counts(unsigned long long out[6]) { for (int k = 0; k < 6; k++) out[k] = koh::g_counts[k].exchange(0); }
+// since the last call: useful lane-slots and issued lane-slots of the Mandelbulb estimates (87 per pass + 100 per estimate, a wave pays its slowest
+// lane 64 wide), wave-level iteration passes, lane-level iteration passes
+void koh_take_schedule(unsigned long long out[4])
+{
+    out[0] = koh::g_useful.exchange(0); out[1] = koh::g_slots.exchange(0); out[2] = koh::g_wave_passes.exchange(0); out[3] = koh::g_lane_passes.exchange(0);
+}
 
 // the frame parameters as rmdf_api.cpp's fill_params + its callers set them, then the library's own launch_render
 int koh_render(const KohFrame *f)
@@ -257,7 +294,7 @@ int koh_render(const KohFrame *f)
     p.env_cos8 = CubeDev{ (const uint2 *)f->env_cos8, f->w_cos8 };
     p.cornell = f->cornell_tri; p.cornell_tab = f->cornell_tab; p.cornell_grid = f->cornell_grid;
     p.cornell_prune = f->no_prune ? 0 : 1;
-    p.merge_stragglers = (f->no_merge || f->scene == 0) ? 0 : 32;
+    p.merge_stragglers = f->scene == 0 ? 0 : (f->no_merge == 0 ? MERGE_T : (f->no_merge == 1 ? 0 : f->no_merge));       // (no_merge >= 2: that pooling threshold, <= MERGE_T)
     p.rgba8 = f->rgba8; p.rgba8_mirror = f->rgba8_mirror; p.rgba_f32 = (float4 *)f->rgba_f32; p.steps = f->steps; p.iters = f->iters;
     p.block_order = f->block_order; p.block_cost = f->block_cost;
 #ifdef RMDF_XCHECK

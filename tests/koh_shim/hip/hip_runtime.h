@@ -54,7 +54,9 @@ typedef void *hipStream_t;
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 
 namespace koh {
-struct Lane { uint3 tid; int lane, wave; };
+/* per lane: the Mandelbulb iteration passes of every mb8_iterate_t call ("segment") since the wave's last collective -- the emulator turns them
+ * into the wave's lock-step cost there (max over lanes per segment) and the lanes' useful work (their own): rmdf_device.hpp RMDF_EMU_PASS */
+struct Lane { uint3 tid; int lane, wave; unsigned short seg[24]; int nseg; unsigned short cur_passes; };
 struct Grid { uint3 bid; dim3 grid, block; };
 extern thread_local Lane *cur;
 extern thread_local Grid *grd;
@@ -69,6 +71,10 @@ template <typename T> inline uint64_t pack(T v) { uint64_t u = 0; static_assert(
 template <typename T> inline T unpack(uint64_t u) { T v; memcpy(&v, &u, sizeof v); return v; }
 }  // namespace koh
 
+#define RMDF_EMU_PASS() (koh::cur->cur_passes++)
+/* (bit 15 of an entry: the segment continues an estimate begun earlier -- the AO queue's second half -- and pays no second per-estimate overhead) */
+#define RMDF_EMU_SEGMENT_END(i0) do { koh::Lane *l_ = koh::cur; const unsigned short e_ = (unsigned short)(l_->cur_passes | ((i0) != 0 ? 0x8000u : 0u)); \
+                                       if (l_->nseg < 24) l_->seg[l_->nseg++] = e_; else l_->seg[23] = (unsigned short)(l_->seg[23] + l_->cur_passes); l_->cur_passes = 0; } while (0)
 #define threadIdx (koh::cur->tid)
 #define blockIdx (koh::grd->bid)
 #define gridDim (koh::grd->grid)

@@ -128,7 +128,8 @@ class Emulated:
 AB_BUILDS = [("-DRMDF_AB_XL_G=4", "_xl4", "four lanes per ray in the Cornell tail (sixteen rays per wave, two DPP steps)"),
              ("-DRMDF_AB_SHARED_BOUNDS", "_sharedb", "one pass of bound tests serves the normal's four sample points"),
              ("-DRMDF_AB_NO_XL", "_noxl", "the Cornell march without the lanes-per-ray tail"),
-             ("-DRMDF_AB_MIRROR16", "_mirror16", "mirror stores as one wave's 16-byte stores")]
+             ("-DRMDF_AB_MIRROR16", "_mirror16", "mirror stores as one wave's 16-byte stores"),
+             ("-DRMDF_AB_MERGE_T=48", "_mt48", "workgroup pooling of the last rays at <= 48 live rays (tools/emulated_schedule.py predicts -2.8 % instructions)")]
 
 
 @pytest.fixture(scope="module")
@@ -413,6 +414,11 @@ def test_ab_builds_of_the_render_kernel_render_the_same_frames(emu, rmdf, orc, e
     assert_same_frame(e.render(2, 64, 36, 0.0, 256), orc.render(2, 64, 36, 0.0, 256, env_oracle), what + ": Mandelbulb")
     c = e.counts()
     assert (c["dpp"] > 0) == (tag != "_noxl"), c
+    if tag == "_mt48":
+        for scene, ms in ((2, 256), (1, 128), (3, 128)):          # the scenes that pool: every time, and one larger frame
+            for t in (1.0, 2.5, 7.0):
+                assert_same_frame(e.render(scene, 64, 36, t, ms), orc.render(scene, 64, 36, t, ms, env_oracle), "%s: scene %d t %.1f" % (what, scene, t))
+        assert_same_frame(e.render(2, 256, 144, 0.0, 256), orc.render(2, 256, 144, 0.0, 256, env_oracle), what + ": Mandelbulb 256 x 144")
     w, h = 100, 52
     for scene in (0, 2):
         ref = orc.render(scene, w, h, 0.7, 64, env_oracle)["rgba8"]

@@ -6,5 +6,6 @@ cd "$(dirname "$0")" || exit 1
 ./build_variant.sh xl4      -DRMDF_AB_XL_G=4 &
 ./build_variant.sh sharedb  -DRMDF_AB_SHARED_BOUNDS &
 ./build_variant.sh mirror16 -DRMDF_AB_MIRROR16 &
+./build_variant.sh mt48     -DRMDF_AB_MERGE_T=48 &
 wait
 ls -la *.so
