@@ -82,7 +82,11 @@ __device__ __forceinline__ float bsphere_r() { return SCENE == 2 ? shk::bsphere_
 // iterates at most AO_CUT passes in place; estimates still iterating then are set aside in an LDS queue (their state: w, pos,
 // dr, r) and the workgroup finishes them together, 64 per wave, with the same code (mb8_iterate resumes anywhere: bit-identical).
 // A full queue is not an error: those lanes finish in place.
+#ifdef RMDF_AB_AO_CUT               // A/B switch: passes an AO estimate runs in place before it is queued (tools/emulated_schedule.py sweeps it)
+#define AO_CUT RMDF_AB_AO_CUT
+#else
 #define AO_CUT 6
+#endif
 #define AO_CAP 256
 
 // OUT selects the planes an instantiation writes: OUT_RGBA8 = the product path (RGBA8 frame only), OUT_MIRROR = RGBA8 +

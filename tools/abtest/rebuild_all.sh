@@ -7,5 +7,6 @@ cd "$(dirname "$0")" || exit 1
 ./build_variant.sh sharedb  -DRMDF_AB_SHARED_BOUNDS &
 ./build_variant.sh mirror16 -DRMDF_AB_MIRROR16 &
 ./build_variant.sh mt48     -DRMDF_AB_MERGE_T=48 &
+./build_variant.sh mt56     -DRMDF_AB_MERGE_T=56 &
 wait
 ls -la *.so
