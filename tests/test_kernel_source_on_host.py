@@ -505,3 +505,43 @@ def test_ring_form_of_the_prefilter_in_the_cross_check_build(xemu, orc, w, h):
         ref = orc.cosine_convolve(src, p, pow_mode=1)
         assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (p, float(np.abs(out - ref).max()))
     assert xemu.counts()["polled_load"] > 0, "the ring form did not run (no counter was polled)"
+
+
+@pytest.mark.skipif(os.environ.get("RMDF_TEST_SLOW") != "1", reason="a build of its own (a minute): RMDF_TEST_SLOW=1 (clean when last run)")
+def test_kernel_source_under_the_undefined_behaviour_sanitizer(rmdf, orc, env_oracle, tmp_path):
+    """The same kernel source built with -fsanitize=undefined (minimal runtime: it prints `ubsan: <kind>` on stderr) and executed by the emulator: every scene,
+    pooled and not, the env kernels through the launchers -- no shift, signed-overflow, misaligned-access, float-cast or bounds report, and the frames still
+    equal the oracle's.  (GPU AddressSanitizer is not available on this pool; this is what a sanitizer can say about the kernels on the CPU.)"""
+    import subprocess
+    import sys
+    rt = "/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.ubsan_minimal-x86_64.a"
+    if not (os.path.exists(CLANG) and os.path.exists(rt)):
+        pytest.skip("no clang++ / ubsan runtime")
+    tdir = os.path.join(ROOT, "tests")
+    so = os.path.join(tdir, "libkernel_on_host_ubsan.so")
+    subprocess.check_call([CLANG, "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-pthread", "-fsanitize=undefined",
+                           "-fsanitize-minimal-runtime", "-fno-sanitize=vptr,function", "-Wno-unused-function", "-Wno-unknown-attributes", "-Wno-unused-variable",
+                           "-x", "c++", "-I", os.path.join(tdir, "koh_shim"), "-I", os.path.join(ROOT, "ray-marching-distance-fields_amd", "csrc"),
+                           os.path.join(tdir, "kernel_on_host.cpp"), "-x", "none", rt, "-o", so, "-ldl", "-lpthread"])
+    code = '''
+import sys, os
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, rmdf_amd
+from oracle import orc
+import test_kernel_source_on_host as T
+orc.build()
+rd = lambda fn: orc.hdr_decode(open(fn, "rb").read())
+cache = os.path.join(%r, "tests", "golden", "env_cache")
+ll = {"refl": rd(rmdf_amd.DEFAULT_ENV_HDR), "cos1": rd(cache + "/uffizi_512_cache_pow_1.0.hdr"), "cos8": rd(cache + "/uffizi_512_cache_pow_8.0.hdr")}
+env = orc.EnvSet(*(orc.cube_pad_f16(orc.latlong_to_cube(ll[k])) for k in ("refl", "cos1", "cos8")))
+os.utime(%r, None)
+e = T.Emulated(rmdf_amd, env, defines=("-DUBSAN",), tag="_ubsan")
+for scene, ms in ((2, 256), (0, 128), (1, 128), (3, 128)):
+    for nm in (0, 1):
+        got, ref = e.render(scene, 96, 54, 2.5, ms, no_merge=nm), orc.render(scene, 96, 54, 2.5, ms, env)
+        assert np.array_equal(got["rgba8"], ref["rgba8"]) and np.array_equal(got["iters"], ref["iters"]) and np.array_equal(got["steps"], ref["steps"]), (scene, nm)
+print("frames ok")
+''' % (ROOT, tdir, ROOT, so)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500)
+    os.remove(so)
+    assert r.returncode == 0 and "frames ok" in r.stdout and "ubsan:" not in r.stderr, (r.stdout[-1000:], r.stderr[-3000:])
