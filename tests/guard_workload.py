@@ -20,14 +20,22 @@ def main():
     # mmap / mprotect, so the fence is real there too -- it then checks the HOST's buffer sizes against what the kernels' stand-ins write
     # and read, and the allocator's own bookkeeping (tests/test_host_logic.py: test_guarded_allocations_against_the_hip_double).
     double = "libfake_hip" in os.environ.get("LD_PRELOAD", "")
+    # ... and with FAKE_HIP_EMULATE=1 the double RUNS the kernels' source (tests/kernel_on_host.cpp): then the fence checks what it was built to
+    # check -- the KERNELS' own global accesses, every one of them, against the exact size of every device buffer -- on the CPU.  The emulator
+    # is slow: the 256 x 128 prefilters are left to the cache files and to smaller maps of the same shapes.
+    emulated = double and os.environ.get("FAKE_HIP_EMULATE", "0") not in ("", "0")
     import ctypes as C
     import shutil
     import tempfile
     tmpdir = tempfile.mkdtemp() if double else None
     hdr = rmdf_amd.DEFAULT_ENV_HDR
     if double:                                               # (the double's prefilter is a stand-in: its cache files must not land in the tree)
-        hdr = os.path.join(tmpdir, "probe.hdr")
+        hdr = os.path.join(tmpdir, os.path.basename(rmdf_amd.DEFAULT_ENV_HDR) if emulated else "probe.hdr")
         shutil.copy(rmdf_amd.DEFAULT_ENV_HDR, hdr)
+        if emulated:
+            cache = os.path.join(ROOT, "tests", "golden", "env_cache")
+            for f in os.listdir(cache):
+                shutil.copy(os.path.join(cache, f), tmpdir)
     rng = np.random.RandomState(7)
     sr = rmdf_amd.ShaderRenderer(0, xcheck=True)
     L = rmdf_amd.load_library(True)
@@ -42,7 +50,7 @@ def main():
     # the whole env pipeline: decode, resize (k_resize_latlong), the fused four-power prefilter, RGBE caches, k_latlong_to_cube, k_cube_upload
     sr.load_env_hdr(hdr)
     # prefilter kernels: the channel-split form, the one-wave form (odd width, wide map reading its table through L2), other powers
-    for (w, h) in ((256, 128), (100, 37), (252, 5), (8, 3), (260, 20), (1100, 6)):
+    for (w, h) in (((36, 10), (100, 3), (252, 5), (8, 3), (260, 4), (1100, 2)) if emulated else ((256, 128), (100, 37), (252, 5), (8, 3), (260, 20), (1100, 6))):
         src = rng.uniform(0.0, 4.0, (h, w, 3)).astype(np.float32)
         for pw in ((1.0, 8.0, 64.0, 512.0), (8.0,), (2.5, 64.0), (1.0, 8.0, 64.0, 512.0, 3.0)):
             sr.prefilter_env_powers(src, pw)
@@ -57,17 +65,17 @@ def main():
         sr.get_env_cube_padded(rmdf_amd.ENV_COS_64)
     # every scene, every output variant: planes, RGBA8 only (row bands, every way the rows reach the host), tiles, a registered buffer
     for scene, ms in ((0, 40), (1, 40), (2, 64), (3, 24)):
-        for (w, h) in ((333, 187), (64, 64), (33, 17), (1, 1), (250, 9)):
+        for (w, h) in (((133, 87), (33, 17), (1, 1), (250, 9)) if emulated else ((333, 187), (64, 64), (33, 17), (1, 1), (250, 9))):
             sr.render(scene, w, h, 0.4, max_steps=ms)
             fb = np.zeros(w * h, np.uint32)
             sr.draw_shader_tile(scene, None, w, h, 0.4, fb, max_steps=ms)
-            for idx in range(0, 64, 5):
+            for idx in range(0, 64, 13 if emulated else 5):
                 sr.draw_shader_tile(scene, idx, w, h, 0.4, fb, max_steps=ms)
     for bands, mode in ((3, 0), (4, 1), (5, 2), (16, 3)):
         r2 = rmdf_amd.ShaderRenderer(0, xcheck=True, frame_bands=bands, frame_mirror=mode)
         for slot in (rmdf_amd.ENV_REFLECTION, rmdf_amd.ENV_COS_1, rmdf_amd.ENV_COS_8):
             r2.set_env_cube(slot, rng.uniform(0.0, 2.0, (6, 9, 9, 3)).astype(np.float32))
-        for (w, h) in ((1283, 721), (1920, 1080)):
+        for (w, h) in (((323, 181),) if emulated else ((1283, 721), (1920, 1080))):
             fb = np.zeros(w * h, np.uint32)
             for _ in range(2):
                 r2.draw_shader_tile(2, None, w, h, 0.1, fb, max_steps=32)
@@ -95,12 +103,13 @@ def main():
         sr.assemble_shards_device(w, h, n, gath, frame)
         sr.synchronize()
     sr.render_supersampled(2, 160, 90, 2, 0.0, max_steps=32)
-    sr.probe_tile_costs(2, 1920, 1080, 0.0, 64)
+    sr.probe_tile_costs(2, 1920, 1080, 0.0, 64)                  # (renders its own 256 x 144 probe frame)
     rect = dmalloc(187 * 333 * 4)
     sr.render_rect_device(0, 333, 187, 0.0, 32, (5, 3, 301, 180), d_rgba8=rect)
     sr.synchronize()
     # the self-tests' kernels (their own cube map, the Cornell table)
-    assert sum(sr.selftest_shading_math()) == 0
+    if not emulated or os.environ.get("RMDF_TEST_SLOW") == "1":  # (100 s on the emulator: exhaustive over the shading functions' inputs)
+        assert sum(sr.selftest_shading_math()) == 0
     for p in held:
         assert L.rmdf_device_free(sr.handle, p) == 0
     sr.close()

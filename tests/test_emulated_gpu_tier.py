@@ -158,3 +158,38 @@ def test_everything_of_the_gpu_tier_that_can_run_on_the_emulated_device(rmdf):
            "or test_shader_clock_probe or test_alternative_schedule or test_both_mandelbulb_schedules or test_config4 or test_the_product_library_ignores "
            "or (test_lobe_prefilter_is_bit_exact and 256-128))")
     assert _run_tier(rmdf, sel, 2, 4, 1500) >= 115
+
+
+@pytest.mark.parametrize("mode", ["end", "start"])
+def test_no_kernel_touches_memory_outside_its_buffers_on_the_emulated_device(rmdf, mode):
+    """Round 4 asked for "a bounds-checked build, 0 violations over the tier"; round 5 wrote an electric-fence device allocator for the GPU
+    (RMDF_GUARD_ALLOC, librmdf_xcheck.so) that never ran.  Here it runs for real, on the CPU: the HIP double's virtual-memory calls are
+    mmap / mprotect, so every device buffer of the library ends (or starts) at an inaccessible page, and the kernels are the library's
+    own source on the emulator -- every global load and store of every kernel in tests/guard_workload.py (the env pipeline, the
+    prefilter's forms, every scene and output variant at ragged sizes, tiles, bands, shards, resolve, the cost probe) against the exact
+    size of its buffer.  One element outside is SIGSEGV; the workload completes."""
+    _emulator_builds(rmdf)
+    env = dict(os.environ, LD_PRELOAD=_fake_hip_lib(), FAKE_HIP_EMULATE="1", RMDF_GUARD_ALLOC=mode)
+    env.pop("RMDF_LIB", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "guard_workload.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0 and "guard workload ok" in r.stdout, (r.returncode, r.stdout[-800:], r.stderr[-3000:])
+    unknown = [l for l in r.stderr.splitlines() if "stand-in used" in l and "k_march_mb8" not in l and "k_shade" not in l and "k_march_" not in l]
+    assert not unknown, unknown                                   # (only the cross-check build's alternative schedule is not emulated)
+
+
+def test_the_fence_catches_a_real_kernels_overrun_on_the_emulated_device(rmdf):
+    """... and the instrument works with real kernels: k_resolve_box2 (the library's source, emulated), told that its source frame is two rows
+    taller than the fenced buffer it is given, dies of SIGSEGV; with the true height it completes."""
+    _emulator_builds(rmdf)
+    code = ("import os, sys; sys.path.insert(0, %r); import rmdf_amd, ctypes as C\n"
+            "sr = rmdf_amd.ShaderRenderer(0, xcheck=True)\n"
+            "L = rmdf_amd.load_library(True); p = C.c_void_p(); q = C.c_void_p()\n"
+            "assert L.rmdf_device_malloc(sr.handle, 256 * 64 * 4, C.byref(p)) == 0 and L.rmdf_device_malloc(sr.handle, 128 * 33 * 4, C.byref(q)) == 0\n"
+            "sr.resolve_box2_device(p.value, 256, 64, q.value); sr.synchronize(); print('before', flush=True)\n"
+            "sr.resolve_box2_device(p.value, 256, int(sys.argv[1]), q.value)\n"
+            "sr.synchronize(); print('survived', flush=True)\n" % ROOT)
+    env = dict(os.environ, LD_PRELOAD=_fake_hip_lib(), FAKE_HIP_EMULATE="1", RMDF_GUARD_ALLOC="end")
+    ok = subprocess.run([sys.executable, "-c", code, "64"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert ok.returncode == 0 and "survived" in ok.stdout and "stand-in used" not in ok.stderr, (ok.returncode, ok.stdout, ok.stderr[-1500:])
+    r = subprocess.run([sys.executable, "-c", code, "66"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert "before" in r.stdout and "survived" not in r.stdout and r.returncode < 0, (r.returncode, r.stdout, r.stderr[-1500:])
