@@ -53,10 +53,12 @@ constexpr int mb_iterations_i = (int)mb_iterations;
 #ifndef RMDF_EMU_PASS                 // (tests/koh_shim counts iteration passes per lane and per wave: the lane utilisation of a schedule, tools/emulated_schedule.py)
 #define RMDF_EMU_PASS()
 #define RMDF_EMU_SEGMENT_END(i0)
+#define RMDF_EMU_COST(n)
 #endif
 #else
 #define RMDF_EMU_PASS()
 #define RMDF_EMU_SEGMENT_END(i0)
+#define RMDF_EMU_COST(n)
 #define RMDF_LANES_HERE(x) __ballot(x)
 #define RMDF_READLANE_HERE(v, l) __builtin_amdgcn_readlane((v), (l))
 #define RMDF_READFIRSTLANE_HERE(v) __builtin_amdgcn_readfirstlane(v)
@@ -883,6 +885,7 @@ typedef const float __attribute__((address_space(4))) cfloat;     // constant ad
 template <typename PTR>
 __device__ __forceinline__ float cornell_tri_dist2(v3 pos, PTR t)
 {
+    RMDF_EMU_COST(130);                 // (emulator only: ~130 vector instructions per point-triangle distance, tools/emulated_schedule.py)
     const v3 v0 = mk3(t[0], t[1], t[2]), v1 = mk3(t[3], t[4], t[5]), v2 = mk3(t[6], t[7], t[8]);
     const v3 e0 = mk3(t[9], t[10], t[11]), e1 = mk3(t[12], t[13], t[14]);
     const float dot00 = t[15], dot01 = t[16], dot11 = t[17], inv_denom = t[18];
@@ -991,6 +994,7 @@ __device__ __forceinline__ float de_cornell_box_lanes(v3 pos, const float *rows,
             const float4 pl = b[0], ea = b[1], eb = b[2], ec = b[3];
             // The plane distance and the in-plane distance are orthogonal components of the true distance, and the in-plane distance
             // to the triangle is at least the largest of the three edge-plane distances: d^2 >= pd^2 + max(0, sa, sb, sc)^2.
+            RMDF_EMU_COST(13);          // (emulator only: the bound test)
             const float pd = __builtin_fmaf(pl.z, pos.z, __builtin_fmaf(pl.y, pos.y, pl.x * pos.x)) - pl.w;
             const float sa = __builtin_fmaf(ea.z, pos.z, __builtin_fmaf(ea.y, pos.y, ea.x * pos.x)) - ea.w;
             const float sb = __builtin_fmaf(eb.z, pos.z, __builtin_fmaf(eb.y, pos.y, eb.x * pos.x)) - eb.w;

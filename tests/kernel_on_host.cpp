@@ -65,7 +65,7 @@ koh_ctx_switch:
 
 constexpr size_t kStack = 256 * 1024;
 struct Fiber { Ctx ctx; Lane lane; bool done; };
-struct WaveState { int arrived = 0; unsigned gen = 0; uint64_t val[2][64]; const char *what[2] = { nullptr, nullptr }; };
+struct WaveState { int arrived = 0; unsigned gen = 0; uint64_t val[2][64]; const char *what[2] = { nullptr, nullptr }; unsigned long long chain = 0; };
 struct Block {
     std::vector<Fiber> fib;
     std::vector<WaveState> waves;
@@ -81,6 +81,9 @@ std::atomic<unsigned long long> g_counts[6];
 // lane utilisation of the Mandelbulb estimates under the schedule being emulated, in the cost model of tools/ubench/sched_sim (round 4): an
 // estimate segment costs 87 vector instructions per iteration pass + 100; a wave pays the MAXIMUM over its lanes, 64 lanes wide
 std::atomic<unsigned long long> g_useful{ 0 }, g_slots{ 0 }, g_wave_passes{ 0 }, g_lane_passes{ 0 };
+// the Cornell box's cost hooks (RMDF_EMU_COST): per wave the serial chain -- the slowest lane between collectives, summed -- and over the launch the
+// longest wave's chain (what one frame at a time waits for), the sum of all chains (what the issue ports see) and the lanes' own work
+std::atomic<unsigned long long> g_chain_max{ 0 }, g_chain_sum{ 0 }, g_chain_useful{ 0 };
 constexpr unsigned kPassCost = 87, kEstimateCost = 100;
 std::atomic<int> g_seed_mode{ 0 };
 std::atomic<int> g_threads{ 1 };
@@ -121,7 +124,7 @@ void run_block(Block &b, Grid &g, unsigned bx, unsigned by, unsigned bz)
         Fiber &f = b.fib[t];
         f.done = false;
         f.lane.tid = uint3{ t % g.block.x, (t / g.block.x) % g.block.y, t / (g.block.x * g.block.y) };
-        f.lane.lane = (int)(t & 63u); f.lane.wave = (int)(t >> 6); f.lane.nseg = 0; f.lane.cur_passes = 0;
+        f.lane.lane = (int)(t & 63u); f.lane.wave = (int)(t >> 6); f.lane.nseg = 0; f.lane.cur_passes = 0; f.lane.cost = 0;
         fiber_init(f, b.stacks + (size_t)t * kStack);
     }
     blk = &b; grd = &g;
@@ -135,7 +138,16 @@ void run_block(Block &b, Grid &g, unsigned bx, unsigned by, unsigned bz)
             cur = &f.lane;
             koh_ctx_switch(&b.sched, &f.ctx);
         }
-        if (!any) { for (int wv = 0; wv < (int)b.waves.size(); wv++) flush_wave(b, wv); break; }
+        if (!any) {
+            for (int wv = 0; wv < (int)b.waves.size(); wv++) {
+                flush_wave(b, wv);
+                const unsigned long long c = b.waves[(size_t)wv].chain;
+                g_chain_sum += c;
+                unsigned long long m = g_chain_max.load();
+                while (c > m && !g_chain_max.compare_exchange_weak(m, c)) { }
+            }
+            break;
+        }
         if (++rounds > 20000000ull) {
             fprintf(stderr, "koh: workgroup (%u, %u, %u) makes no progress: lanes wait in", bx, by, bz);
             for (auto &w : b.waves) fprintf(stderr, " [%s: %d of 64 arrived]", w.what[w.gen & 1u] ? w.what[w.gen & 1u] : "-", w.arrived);
@@ -170,7 +182,9 @@ void flush_wave(Block &b, int wave)
         }
         slots += 64ull * mx; wp += mxp;
     }
-    for (int l = 0; l < 64; l++) b.fib[(size_t)wave * 64 + l].lane.nseg = 0;
+    unsigned cmax = 0; unsigned long long csum = 0;
+    for (int l = 0; l < 64; l++) { Lane &L = b.fib[(size_t)wave * 64 + l].lane; if (L.cost > cmax) cmax = L.cost; csum += L.cost; L.cost = 0; L.nseg = 0; }
+    if (cmax) { b.waves[(size_t)wave].chain += cmax; g_chain_useful += csum; }
     if (slots) { g_useful += useful; g_slots += slots; g_wave_passes += wp; g_lane_passes += lp; }
 }
 }  // namespace
@@ -264,6 +278,8 @@ int koh_frame_size(void) { return (int)sizeof(KohFrame); }
 void koh_take_counts(unsigned long long out[6]) { for (int k = 0; k < 6; k++) out[k] = koh::g_counts[k].exchange(0); }
 // since the last call: useful lane-slots and issued lane-slots of the Mandelbulb estimates (87 per pass + 100 per estimate, a wave pays its slowest
 // lane 64 wide), wave-level iteration passes, lane-level iteration passes
+// the Cornell box's chains since the last call: longest wave's, sum over waves, the lanes' own instructions (RMDF_EMU_COST units)
+void koh_take_chains(unsigned long long out[3]) { out[0] = koh::g_chain_max.exchange(0); out[1] = koh::g_chain_sum.exchange(0); out[2] = koh::g_chain_useful.exchange(0); }
 void koh_take_schedule(unsigned long long out[4])
 {
     out[0] = koh::g_useful.exchange(0); out[1] = koh::g_slots.exchange(0); out[2] = koh::g_wave_passes.exchange(0); out[3] = koh::g_lane_passes.exchange(0);

@@ -56,7 +56,7 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 namespace koh {
 /* per lane: the Mandelbulb iteration passes of every mb8_iterate_t call ("segment") since the wave's last collective -- the emulator turns them
  * into the wave's lock-step cost there (max over lanes per segment) and the lanes' useful work (their own): rmdf_device.hpp RMDF_EMU_PASS */
-struct Lane { uint3 tid; int lane, wave; unsigned short seg[24]; int nseg; unsigned short cur_passes; };
+struct Lane { uint3 tid; int lane, wave; unsigned short seg[24]; int nseg; unsigned short cur_passes; unsigned cost; };
 struct Grid { uint3 bid; dim3 grid, block; };
 extern thread_local Lane *cur;
 extern thread_local Grid *grd;
@@ -72,6 +72,7 @@ template <typename T> inline T unpack(uint64_t u) { T v; memcpy(&v, &u, sizeof v
 }  // namespace koh
 
 #define RMDF_EMU_PASS() (koh::cur->cur_passes++)
+#define RMDF_EMU_COST(n) (koh::cur->cost += (n))      /* instructions of a lane's serial chain since the wave's last collective (Cornell box) */
 /* (bit 15 of an entry: the segment continues an estimate begun earlier -- the AO queue's second half -- and pays no second per-estimate overhead) */
 #define RMDF_EMU_SEGMENT_END(i0) do { koh::Lane *l_ = koh::cur; const unsigned short e_ = (unsigned short)(l_->cur_passes | ((i0) != 0 ? 0x8000u : 0u)); \
                                        if (l_->nseg < 24) l_->seg[l_->nseg++] = e_; else l_->seg[23] = (unsigned short)(l_->seg[23] + l_->cur_passes); l_->cur_passes = 0; } while (0)
