@@ -891,8 +891,9 @@ def main():
         pmc, pmc_src = (None, "not collected for this workload")
         if not sharded and L == 0:
             pmc, pmc_src = pmc_record(lib_path, [scene, w, h, ms])
+            under_profiler = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
             if (pmc is None and headline and a.pmc == "auto" and world == 1 and not os.environ.get("RMDF_BENCH_PMC_CHILD")
-                    and not os.environ.get("RMDF_LIB") and not a.no_secondary):
+                    and not os.environ.get("RMDF_LIB") and not a.no_secondary and not under_profiler):      # (never a profiler inside a profiler)
                 # no counter passes of THIS build are committed: collect them now (the GPU is idle: the timed region is over)
                 # (every child has its own timeout and the passes share a 240 s budget: no watchdog needed, and none that could cost the line)
                 try:
