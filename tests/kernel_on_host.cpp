@@ -16,6 +16,10 @@
 #include "rmdf_env.hip"              // ... and the env-map kernels (cube upload, lat/long -> cube, resize, the lobe prefilter's forms)
 #include "rmdf_util.hip"             // ... and the small ones (box resolve, shard assembly, fill; the GPU self-tests of the exact arithmetic)
 #endif
+#if defined(RMDF_XCHECK) && !defined(KOH_RENDER_ONLY)
+#include "xcheck/rmdf_march.hip"     // librmdf_xcheck.so's alternative schedule of the power-8 Mandelbulb (persistent waves fed from a global counter, G-buffer,
+#include "xcheck/rmdf_stats.hip"     //   separate shade kernel) and its march statistics: the cross-check of the product's schedule, emulated as well
+#endif
 
 thread_local int doh_seed_mode = 0;
 thread_local unsigned doh_seed_rng = 12345u;
@@ -430,6 +434,7 @@ void build_table()
     reg(&k_prefilter_chan<0>); reg(&k_prefilter_chan<3>); reg(&k_prefilter_chan<6>); reg(&k_prefilter_chan<9>);
     reg(&k_prefilter_fused4);
 #ifdef RMDF_XCHECK
+    reg(&k_march_mb8); reg(&k_shade); reg(&k_march_stats);
     reg(&k_prefilter_ring<0>); reg(&k_prefilter_ring<3>); reg(&k_prefilter_ring<6>); reg(&k_prefilter_ring<9>);
 #endif
     reg(&k_resolve_box2); reg(&k_assemble_shards); reg(&k_assemble_shards_x4); reg(&k_fill_u32); reg(&k_clock_probe);

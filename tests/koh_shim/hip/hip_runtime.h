@@ -52,6 +52,7 @@ typedef void *hipStream_t;
 #define hipSuccess 0
 #define hipErrorInvalidValue 1
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }   /* (launchers of the cross-check schedule) */
 
 namespace koh {
 /* per lane: the Mandelbulb iteration passes of every mb8_iterate_t call ("segment") since the wave's last collective -- the emulator turns them
