@@ -162,22 +162,27 @@ Emulator *emulator_for(bool from_xcheck)
 {
     static const bool on = getenv("FAKE_HIP_EMULATE") && atoi(getenv("FAKE_HIP_EMULATE")) != 0;
     if (!on) return nullptr;
-    static Emulator emu[2];
-    static std::once_flag once[2];
-    const int k = from_xcheck ? 1 : 0;
-    std::call_once(once[k], [k] {
+    // (function-local statics, not std::call_once: in a plain C host that does not link libpthread itself, call_once's gthread probe fails)
+    auto load = [](int k) {
+        Emulator e;
         Dl_info di;
         std::string dir = ".";
         if (dladdr((void *)&emulator_for, &di) && di.dli_fname) { dir = di.dli_fname; const size_t sl = dir.rfind('/'); dir = sl == std::string::npos ? "." : dir.substr(0, sl); }
         const std::string path = dir + (k ? "/libkernel_on_host_xcheck.so" : "/libkernel_on_host.so");
         void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (!h) { fprintf(stderr, "fake_hip: FAKE_HIP_EMULATE: cannot load %s: %s\n", path.c_str(), dlerror()); abort(); }
-        emu[k].prepare = (void *(*)(const char *, void **))dlsym(h, "koh_prepare");
-        emu[k].run = (void (*)(void *, const unsigned *, const unsigned *, size_t, int))dlsym(h, "koh_run");
-        if (!emu[k].prepare || !emu[k].run) { fprintf(stderr, "fake_hip: %s lacks koh_prepare / koh_run\n", path.c_str()); abort(); }
-    });
-    return &emu[k];
+        e.prepare = (void *(*)(const char *, void **))dlsym(h, "koh_prepare");
+        e.run = (void (*)(void *, const unsigned *, const unsigned *, size_t, int))dlsym(h, "koh_run");
+        if (!e.prepare || !e.run) { fprintf(stderr, "fake_hip: %s lacks koh_prepare / koh_run\n", path.c_str()); abort(); }
+        return e;
+    };
+    const int k = from_xcheck ? 1 : 0;
+    static Emulator emu0 = load(0);
+    if (k == 0) return &emu0;
+    static Emulator emu1 = load(1);
+    return &emu1;
 }
+
 std::atomic<unsigned long long> g_emulated{ 0 };
 
 std::function<void()> make_task(const std::string &name, dim3 grid, dim3 block, void **args, bool from_xcheck, size_t shmem)

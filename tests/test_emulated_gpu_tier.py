@@ -22,7 +22,8 @@ SELECTION = ("test_small_frames_vs_oracle or test_vs_committed_golden or test_fi
              "or test_tile_jobs_issued_ahead or test_random_views_vs_oracle or test_max_steps_edge_cases or test_fresh_frame_is_cleared_to_opaque_black "
              "or test_error_convention or test_env_upload_matches_oracle_padding or test_determinism or test_argument_limits "
              "or test_resize_of_a_map_that_is_not_2_to_1 or test_malformed_hdr_files_fail_cleanly or test_latlong_to_cube_is_bit_exact "
-             "or (test_lobe_prefilter_is_bit_exact and (32-16 or 8-3 or 4-2)) or test_both_mandelbulb_schedules_agree or test_alternative_schedule_lives")
+             "or (test_lobe_prefilter_is_bit_exact and (32-16 or 8-3 or 4-2)) or test_both_mandelbulb_schedules_agree or test_alternative_schedule_lives "
+             "or test_c_host_runs")                # (the plain-C host of examples/, LINKED against librmdf.so, on the emulated device)
 
 
 def _emulator_builds(rmdf):
@@ -58,12 +59,12 @@ def test_the_gpu_tiers_parity_tests_pass_on_the_emulated_device(rmdf):
     for k in ("RMDF_LIB", "RMDF_TEST_UNVERIFIED"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_env.py"),
-                        "-q", "-m", "gpu", "-p", "no:cacheprovider", "-n", "4", "--timeout=300", "-k", SELECTION],
+                        os.path.join(ROOT, "tests", "test_abi.py"), "-q", "-m", "gpu", "-p", "no:cacheprovider", "-n", "4", "--timeout=300", "-k", SELECTION],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=3000)
     tail = [l for l in r.stdout.strip().splitlines() if " passed" in l or " failed" in l or " error" in l]
     assert r.returncode == 0 and tail and "failed" not in tail[-1] and "error" not in tail[-1], (r.stdout[-4000:], r.stderr[-1500:])
     n = int(tail[-1].split(" passed")[0].split()[-1])
-    assert n >= 88, tail[-1]
+    assert n >= 89, tail[-1]
     assert "stand-in used" not in r.stderr and "stand-in used" not in r.stdout, "a launch fell back to a stand-in: the pixels compared were not the kernels'"
 
 

@@ -56,7 +56,9 @@ class Emulated:
             if os.path.exists(so) and os.path.getmtime(so) >= newest:
                 continue
             cmd = [CLANG, "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-pthread", "-Wall", "-Wno-unused-function",
-                   "-Wno-unknown-attributes", "-Wno-unused-variable"] + fma + list(defines) + ["-x", "c++", "-I", os.path.join(tdir, "koh_shim"), "-I", csrc, src, "-o", so]
+                   "-Wno-unknown-attributes", "-Wno-unused-variable", "-Wl,-Bsymbolic"] + fma + list(defines) + ["-x", "c++", "-I", os.path.join(tdir, "koh_shim"), "-I", csrc, src, "-o", so]
+            # (-Bsymbolic: the emulated kernels carry the names of librmdf.so's kernel stubs -- that is how launches find them; in a host that LINKS
+            #  librmdf.so the stubs sit in the global scope and would capture the emulator's own calls to its kernels)
             procs.append((tag, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         for tag, pr in procs:
             out = pr.communicate()[0]
