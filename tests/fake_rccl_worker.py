@@ -14,6 +14,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch                                                # noqa: E402  (before librmdf: one HIP runtime per process)
+if "libfake_hip" in os.environ.get("LD_PRELOAD", "") and os.environ.get("FAKE_HIP_EMULATE", "0") not in ("", "0"):
+    # the N ranks on EMULATED devices (the HIP double running the kernels' source: tests/test_emulated_gpu_tier.py): torch's device buffers and
+    # streams are the stand-ins over the double
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch_cuda_standins                              # noqa: E402
+    torch_cuda_standins.install()
 import rmdf_amd                                             # noqa: E402
 
 
