@@ -160,8 +160,8 @@ def test_baseline_configs_2_and_3_at_full_size_on_the_emulated_device(rmdf):
 def test_everything_of_the_gpu_tier_that_can_run_on_the_emulated_device(rmdf):
     sel = ("not (test_comm_selftest_loopback or test_exchange_behind_the_c_abi or test_bench_ or test_multirank_bench "
            "or test_shader_clock_probe or test_config4 or test_the_product_library_ignores "
-           "or (test_lobe_prefilter_is_bit_exact and 256-128))")
-    assert _run_tier(rmdf, sel, 2, 4, 1500) >= 120
+           "or (test_lobe_prefilter_is_bit_exact and 256-128) or test_load_env_hdr_in_a_read_only_directory)")      # (the last two: the 256 x 128 prefilter, hours)
+    assert _run_tier(rmdf, sel, 2, 4, 1500) >= 125               # (the builder's run: 127 passed, 9 skipped, 52 minutes)
 
 
 @pytest.mark.parametrize("mode", ["end", "start"])
