@@ -131,7 +131,8 @@ AB_BUILDS = [("-DRMDF_AB_XL_G=4", "_xl4", "four lanes per ray in the Cornell tai
              ("-DRMDF_AB_SHARED_BOUNDS", "_sharedb", "one pass of bound tests serves the normal's four sample points"),
              ("-DRMDF_AB_NO_XL", "_noxl", "the Cornell march without the lanes-per-ray tail"),
              ("-DRMDF_AB_MIRROR16", "_mirror16", "mirror stores as one wave's 16-byte stores"),
-             ("-DRMDF_AB_MERGE_T=48", "_mt48", "workgroup pooling of the last rays at <= 48 live rays (tools/emulated_schedule.py predicts -2.8 % instructions)")]
+             ("-DRMDF_AB_MERGE_T=48", "_mt48", "workgroup pooling of the last rays at <= 48 live rays (tools/emulated_schedule.py predicts -2.8 % instructions)"),
+             ("-DRMDF_AB_MERGE_T=56", "_mt56", "workgroup pooling of the last rays at <= 56 live rays (predicted -3.6 %)")]
 
 
 @pytest.fixture(scope="module")
@@ -416,7 +417,12 @@ def test_ab_builds_of_the_render_kernel_render_the_same_frames(emu, rmdf, orc, e
     assert_same_frame(e.render(2, 64, 36, 0.0, 256), orc.render(2, 64, 36, 0.0, 256, env_oracle), what + ": Mandelbulb")
     c = e.counts()
     assert (c["dpp"] > 0) == (tag != "_noxl"), c
-    if tag == "_mt48":
+    if tag in ("_mt48", "_mt56"):
+        # ... and BASELINE config 3 at FULL size: the sha256 of the RGBA8 frame == the committed oracle digest
+        import hashlib
+        import json
+        want = json.load(open(os.path.join(GOLD, "full_size_digests.json")))["config3_mandelbulb8_1920x1080_m256"]["sha256"]["rgba8"]
+        assert hashlib.sha256(e.render(2, 1920, 1080, 0.0, 256, planes=False)["rgba8"].tobytes()).hexdigest() == want, what
         for scene, ms in ((2, 256), (1, 128), (3, 128)):          # the scenes that pool: every time, and one larger frame
             for t in (1.0, 2.5, 7.0):
                 assert_same_frame(e.render(scene, 64, 36, t, ms), orc.render(scene, 64, 36, t, ms, env_oracle), "%s: scene %d t %.1f" % (what, scene, t))
