@@ -206,3 +206,28 @@ def test_the_tests_of_code_no_gpu_has_run_pass_on_the_emulated_device(rmdf):
     sel = ("test_cornell_eight_lane_tail_with_long_step_limits or (test_whole_frame_host_call_in_row_bands and (4-2 or 7-3 or 16-3)) "
            "or test_no_kernel_touches_memory_outside_its_buffers")
     assert _run_tier(rmdf, sel, 1, min(8, os.cpu_count() or 1), 3000, unverified=True) == 6
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_the_multi_rank_c_host_writes_the_oracles_picture_on_emulated_devices(rmdf, orc, env_oracle, tmp_path, nranks):
+    """examples/c_host_multi.c -- plain C, one forked process per device, the unique id through a shared page, rmdf_comm_init, the cost-aware deal, one
+    rmdf_render_frame_sharded_device per frame; linked against the cross-check library, whose exchange runs over the RCCL double -- on N emulated
+    devices: the PNG rank 0 writes decodes to the ORACLE's 640 x 360 frame.  No Python between the host program and the C ABI."""
+    import numpy as np
+    from PIL import Image
+    from test_gpu_parity import _fake_rccl_lib
+    _emulator_builds(rmdf)
+    libdir = os.path.dirname(rmdf.XCHECK_LIB_PATH)
+    exe = str(tmp_path / "c_host_multi")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-std=c99", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_host_multi.c"),
+                           "-o", exe, "-L", libdir, "-lrmdf_xcheck", "-Wl,-rpath," + libdir])
+    probe = _probe_with_caches(rmdf, tmp_path)
+    png = str(tmp_path / "multi.png")
+    env = dict(os.environ, LD_PRELOAD=_fake_hip_lib(), FAKE_HIP_EMULATE="1", FAKE_HIP_EMULATE_THREADS="2", FAKE_HIP_DEVICES=str(nranks),
+               RMDF_RCCL_LIB=_fake_rccl_lib(), FAKE_RCCL_TIMEOUT_S="300")
+    out = subprocess.run([exe, probe, png, str(nranks), "640", "360", "3"], capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0 and "sharded == single launch: yes" in out.stdout and "stand-in used" not in out.stderr, out.stdout + out.stderr
+    ref = orc.render(2, 640, 360, 0.0, 256, env_oracle, want_f32=False)["rgba8"]
+    want = np.ascontiguousarray(ref[::-1]).view(np.uint8).reshape(360, 640, 4)          # (the oracle's row 0 is the bottom row; a PNG's the top)
+    got = np.asarray(Image.open(png).convert("RGBA"))
+    assert got.shape == want.shape and np.array_equal(got[..., :3], want[..., :3]), "the C host's picture differs from the oracle's"
