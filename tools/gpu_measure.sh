@@ -34,6 +34,7 @@ prof)  step "3 rocprofv3 kernel trace + PMC passes of the shipped library"
        timeout 1500 tools/profile.sh $tag > $o/profile.log 2>&1; tail -8 $o/profile.log
        for sc in 0 1 3; do timeout 300 tools/prof_scene.sh $sc > $o/prof_scene$sc.txt 2>&1; tail -1 $o/prof_scene$sc.txt; done ;;
 scenes) step "4 scene kernels one frame at a time: shipped library, then the A/B builds"
+       [ -f tools/abtest/mt56.so ] || tools/abtest/rebuild_all.sh > $o/abtest_build.log 2>&1      # (git-ignored binaries: a fresh checkout builds them here, ~1 min)
        for l in default tools/abtest/mt48.so tools/abtest/mt56.so tools/abtest/noxl.so tools/abtest/xl4.so tools/abtest/sharedb.so tools/abtest/r04.so; do
          [ $l = default ] || [ -f $l ] || continue
          if [ $l = default ]; then unset RMDF_LIB; else export RMDF_LIB=$PWD/$l; fi; timeout 200 python tools/scene_times.py 60; done > $o/scene_times.txt 2>&1; unset RMDF_LIB; cat $o/scene_times.txt ;;
