@@ -475,8 +475,22 @@ hipError_t hipLaunchKernel(const void *fn, dim3 grid, dim3 block, void **args, s
     { std::lock_guard<std::mutex> lk(g_mu); auto it = g_kernels.find(fn); if (it == g_kernels.end()) return hipErrorInvalidDeviceFunction; name = it->second; }
     g_launches++;
     if (grid.x == 0 || grid.y == 0 || grid.z == 0 || block.x == 0) return hipErrorInvalidConfiguration;
-    Dl_info di;                                   // which build launches: the cross-check library's FrameParams is longer (BandTail)
-    const bool from_xcheck = dladdr(fn, &di) && di.dli_fname && strstr(di.dli_fname, "xcheck");
+    // which build launches: the cross-check library's FrameParams is longer (BandTail).  Told by a symbol only that build exports, not by the
+    // file's name (tools/asan_host.sh builds it as librmdf_asan.so)
+    Dl_info di;
+    bool from_xcheck = false;
+    if (dladdr(fn, &di) && di.dli_fname) {
+        static std::mutex mu; static std::map<std::string, bool> known;
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = known.find(di.dli_fname);
+        if (it == known.end()) {
+            void *h = dlopen(di.dli_fname, RTLD_NOW | RTLD_NOLOAD);
+            const bool x = h && dlsym(h, "rmdf_debug_cornell_table") != nullptr;
+            if (h) dlclose(h);
+            it = known.emplace(di.dli_fname, x).first;
+        }
+        from_xcheck = it->second;
+    }
     submit(stream, make_task(name, grid, block, args, from_xcheck, shmem));
     return hipSuccess;
 }
